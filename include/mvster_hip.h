@@ -1,0 +1,95 @@
+/* C ABI of libmvster_hip.so -- the gfx950 kernels of the MVSTER cost-volume hot path.
+ *
+ * The reference (JeffWang987/MVSTER) is pure Python/PyTorch and has no FFI of its own; the
+ * drop-in boundary is its Python module API (models/__init__.py:2, models/MVS4Net.py:9-111),
+ * mirrored by the `mvster_amd` package, which calls the entry points below through ctypes
+ * with raw device pointers (mvster_amd/_lib.py).  Each entry point names the reference code it
+ * replaces (file:line under the reference tree).
+ *
+ * Conventions: every pointer is a DEVICE pointer to contiguous fp32 unless stated otherwise;
+ * buffers are caller-owned; nothing is allocated, copied to the host or synchronised inside;
+ * `stream` is a hipStream_t (NULL = default stream); the return value is 0 or a negative
+ * MVSTER_ERR_* code.  All functions are stateless and re-entrant.
+ */
+#ifndef MVSTER_HIP_H
+#define MVSTER_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVSTER_OK 0
+#define MVSTER_ERR_NULL (-1)        /* a required pointer is NULL */
+#define MVSTER_ERR_SHAPE (-2)       /* inconsistent or out-of-range sizes */
+#define MVSTER_ERR_UNSUPPORTED (-3) /* no kernel instance for this channel / tile combination */
+#define MVSTER_ERR_LAUNCH (-4)      /* hipGetLastError() != hipSuccess after the launch */
+
+/* proj_matrices [B,N,2,4,4] (extrinsic, intrinsic) -> rt [B,N-1,12]: rows 0..2 of
+ * src_P @ inverse(ref_P) as rot(9)+trans(3), with X_P = K[:3,:3] @ E[:3,:4] (row 3 from E).
+ * Replaces models/mvs4net_utils.py:1032-1035 (K@[R|t]) and :24-26 (inverse + matmul). */
+int mvster_relative_projection(const float* proj_matrices, float* rt, int B, int N, void* stream);
+
+/* Fused homography warp + group-wise (or squared-difference) correlation + epipolar attention
+ * aggregation over all NV source views.  Channels-last features:
+ *   ref_feat [B,h,w,C] (batch stride given), src_feat view v / batch b at
+ *   src_feat + v*src_view_stride + b*src_batch_stride as [Hs,Ws,C];
+ *   rt [B,NV,12]; hypo [B,D,h,w]; out [B,D,h,w,G]; wsum_out optional [B,D,h,w].
+ * group_cor=0 requires G == C.  Replaces models/mvs4net_utils.py:13-59 (homo_warping),
+ * :1037-1042 (correlation), :1048-1060 (attention aggregation). */
+int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat, const float* rt, const float* hypo,
+                        float* out, float* wsum_out, int B, int NV, int C, int G, int D, int h, int w, int Hs,
+                        int Ws, long ref_batch_stride, long src_view_stride, long src_batch_stride, int group_cor,
+                        int attn_fuse_d, float attn_temp, void* stream);
+
+/* Backward of mvster_warp_agg_fwd w.r.t. the features (the sampling grid carries no gradient,
+ * models/mvs4net_utils.py:23).  grad_out/out [B,D,h,w,G], wsum [B,D,h,w] from the forward;
+ * grad_ref [B,h,w,C] and grad_src [NV][B,Hs,Ws,C] must be zero-initialised (atomic accumulate).
+ * Autograd of models/mvs4net_utils.py:1036-1060. */
+int mvster_warp_agg_bwd(const float* ref_feat, const float* src_feat, const float* rt, const float* hypo,
+                        const float* out, const float* wsum, const float* grad_out, float* grad_ref,
+                        float* grad_src, int B, int NV, int C, int G, int D, int h, int w, int Hs, int Ws,
+                        long ref_batch_stride, long src_view_stride, long src_batch_stride, int group_cor,
+                        int attn_fuse_d, float attn_temp, void* stream);
+
+/* depth_values [B,ndv] (columns 0 and ndv-1 used) -> out [B,D,h,w].
+ * inverse=1: models/mvs4net_utils.py:71-77 (init_inverse_range); inverse=0: :61-69 (init_range). */
+int mvster_init_range(const float* depth_values, int ndv, float* out, int B, int D, int h, int w, int inverse,
+                      void* stream);
+
+/* inv_min, inv_max [B,h/2,w/2] -> out [B,D,h,w].  models/mvs4net_utils.py:79-86. */
+int mvster_schedule_inverse_range(const float* inv_min, const float* inv_max, float* out, int B, int D, int h,
+                                  int w, void* stream);
+
+/* cur_depth [B,h/2,w/2], interval [B] (device) -> out [B,D,h,w].  models/mvs4net_utils.py:88-99. */
+int mvster_schedule_range(const float* cur_depth, const float* interval, float* out, int B, int D, int h, int w,
+                          void* stream);
+
+/* (optional 1x1x1 `prob` head) + softmax over D + first-max argmax + gather + max-prob confidence
+ * + inverse-depth bounds.  Either logits [B,D,h,w] or feat [B,D,h,w,CF] (+ prob_w [CF], prob_b [1]).
+ * attn [B,D,h,w], depth/conf/inv_min/inv_max [B,h,w] (conf, inv_* optional; inv_* need D >= 3),
+ * logits_out optional [B,D,h,w].  models/mvs4net_utils.py:900 and :1068-1088. */
+int mvster_select_depth(const float* logits, const float* feat, const float* prob_w, const float* prob_b, int CF,
+                        const float* hypo, float* attn, float* depth, float* conf, float* inv_min, float* inv_max,
+                        float* logits_out, int B, int D, int h, int w, float split_itv, void* stream);
+
+/* in [B,hi,wi] -> out [B,ho,wo], bilinear, align_corners=True.  models/mvs4net_utils.py:1077. */
+int mvster_upsample_bilinear(const float* in, float* out, int B, int hi, int wi, int ho, int wo, void* stream);
+
+/* Channels-last implicit-GEMM convolution on the fp32 matrix cores with a fused
+ * scale/shift (+ReLU, +skip) epilogue.  in [B,Di,Hi,Wi,cin]; wpk = weights packed by
+ * mvster_amd/conv_plan.py; scale/shift [16*ntiles]; skip optional; zeros = >=16 B of zeros;
+ * geom = HOST int32 array (layout: conv_plan.GEOM), woff = HOST int64 per-class weight offsets.
+ * Conv3d/ConvTranspose3d/BatchNorm3d/ReLU of reg2d/reg3d (models/mvs4net_utils.py:870-965) and
+ * Conv2d/BatchNorm2d/ReLU/upsample-add of FPN4 (:419-502). */
+int mvster_conv_mfma(const float* in, const float* wpk, const float* scale, const float* shift, const float* skip,
+                     const float* zeros, float* out, const int* geom, int ngeom, const long* woff, int cin, int mt,
+                     int nt, void* stream);
+
+/* One v_mfma_f32_16x16x4_f32: A [16,4], B [4,16] -> D [16,16] (row major).  Test hook that pins the
+ * fragment layout the convolution kernels assume. */
+int mvster_mfma_probe(const float* A, const float* B, float* D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,54 @@
+"""ctypes binding of libmvster_hip.so (C ABI: include/mvster_hip.h).
+
+There is deliberately no fallback: if the shared library is missing, importing
+`mvster_amd.ops` on a GPU box fails loudly instead of silently running PyTorch ops.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmvster_hip.so")
+
+ERRORS = {-1: "NULL pointer", -2: "bad shape", -3: "unsupported channel/tile combination", -4: "kernel launch failed"}
+
+_f = ctypes.c_void_p     # device pointers are passed as integers
+_i = ctypes.c_int
+_l = ctypes.c_long
+_fl = ctypes.c_float
+
+SIGNATURES = {
+    "mvster_relative_projection": [_f, _f, _i, _i, _f],
+    "mvster_warp_agg_fwd": [_f, _f, _f, _f, _f, _f] + [_i] * 9 + [_l] * 3 + [_i, _i, _fl, _f],
+    "mvster_warp_agg_bwd": [_f] * 9 + [_i] * 9 + [_l] * 3 + [_i, _i, _fl, _f],
+    "mvster_init_range": [_f, _i, _f, _i, _i, _i, _i, _i, _f],
+    "mvster_schedule_inverse_range": [_f, _f, _f, _i, _i, _i, _i, _f],
+    "mvster_schedule_range": [_f, _f, _f, _i, _i, _i, _i, _f],
+    "mvster_select_depth": [_f, _f, _f, _f, _i, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _f],
+    "mvster_upsample_bilinear": [_f, _f, _i, _i, _i, _i, _i, _f],
+    "mvster_conv_mfma": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _f, _i, _i, _i, _f],
+    "mvster_mfma_probe": [_f, _f, _f, _f],
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise with build instructions if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "mvster_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no PyTorch fallback for the HIP path." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)        # AttributeError if the library does not export it
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s (code %d)" % (what, ERRORS.get(rc, "unknown error"), rc))

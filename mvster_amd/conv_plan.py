@@ -1,0 +1,321 @@
+"""Host side of the MFMA convolution kernels (mvster_amd/csrc/conv_mfma.hip).
+
+A ``ConvLayer`` owns what one fused layer needs on the device: weights packed into
+MFMA fragment order, BatchNorm folded into per-channel scale/shift (eval mode), the
+geometry record and the tile shape.  ``Reg2dPlan`` / ``Reg3dPlan`` / ``FpnPlan`` chain
+layers exactly like the reference modules (models/mvs4net_utils.py:870-965, :419-502)
+on channels-last activations.  Plans are built from the nn.Module tree of
+``mvster_amd.modules`` and are rebuilt when its parameters change.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# geometry record shared with mvster_conv_mfma (int32, host memory)
+GEOM = ("B", "Di", "Hi", "Wi", "Do", "Ho", "Wo", "DoF", "HoF", "WoF", "sd", "sh", "sw", "cout", "ntile_total", "relu",
+        "skip_mode", "osd", "osh", "osw", "nclass")
+GEOM_CLASS = ("kd", "kh", "kw", "pd", "ph", "pw", "od", "oh", "ow", "nsteps")
+
+SKIP_NONE, SKIP_ADD, SKIP_UPSAMPLE_ADD = 0, 1, 2
+
+
+def _pack_gemm(wk):
+    """[K, N] -> fragment order [K/16, N/16, 64 lanes, 4] (K and N zero-padded to multiples of 16).
+    Lane (q = lane >> 4, n = lane & 15) of K-step s and N-tile t holds wk[s*16 + q*4 + j, t*16 + n], j=0..3."""
+    K, N = wk.shape
+    Kp, Np = (K + 15) // 16 * 16, (N + 15) // 16 * 16
+    full = wk.new_zeros(Kp, Np)
+    full[:K, :N] = wk
+    return full.view(Kp // 16, 4, 4, Np // 16, 16).permute(0, 3, 1, 4, 2).contiguous().view(-1), Kp // 16
+
+
+def fold_bn(bn, cout, device):
+    """eval BatchNorm -> (scale, shift); None -> identity."""
+    if bn is None:
+        return torch.ones(cout, device=device), torch.zeros(cout, device=device)
+    scale = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+    shift = bn.bias.detach() - bn.running_mean.detach() * scale
+    return scale.float(), shift.float()
+
+
+def _tiles(M, ntile_total, nclass):
+    """(MT, NT): biggest register tile that still fills the chip (>= 2048 waves), else the most waves."""
+    best = None
+    for nt in (4, 2, 1):
+        if nt > ntile_total or ntile_total % nt:
+            continue
+        for mt in (4, 2, 1):
+            waves = -(-M // (16 * mt)) * (ntile_total // nt) * nclass
+            if waves >= 2048:
+                return mt, nt
+            if best is None or waves > best[0]:
+                best = (waves, mt, nt)
+    return best[1], best[2]
+
+
+class ConvLayer:
+    """One fused conv (+scale/shift, +ReLU, +skip) layer on channels-last tensors."""
+
+    def __init__(self, weight, transposed, stride, padding, bn=None, bias=None, relu=False, cin_pad=None):
+        w = weight.detach().float()
+        dev = w.device
+        if w.dim() == 4:  # 2-D conv -> depth 1
+            w = w.unsqueeze(2)
+            stride = (1,) + tuple(stride)
+            padding = (0,) + tuple(padding)
+        self.transposed = transposed
+        self.stride = tuple(stride)
+        self.padding = tuple(padding)
+        if transposed:
+            cin, cout = w.shape[0], w.shape[1]
+        else:
+            cout, cin = w.shape[0], w.shape[1]
+        self.cin = cin_pad or cin
+        if self.cin not in (4, 8, 16, 32, 64):
+            raise RuntimeError("conv_mfma: unsupported input channel count %d" % self.cin)
+        self.cout = cout
+        self.relu = relu
+        kd, kh, kw = w.shape[2:]
+        self.kernel = (kd, kh, kw)
+        classes = []
+        packed = []
+        woff = []
+        off = 0
+        if not transposed:
+            wk = w.permute(2, 3, 4, 1, 0)  # [kd,kh,kw,cin,cout]
+            if self.cin != cin:
+                wk = torch.nn.functional.pad(wk, (0, 0, 0, self.cin - cin))
+            flat, nsteps = _pack_gemm(wk.reshape(kd * kh * kw * self.cin, cout))
+            classes.append(dict(kd=kd, kh=kh, kw=kw, pd=padding[0], ph=padding[1], pw=padding[2], od=0, oh=0, ow=0,
+                                nsteps=nsteps))
+            packed.append(flat)
+            woff.append(0)
+        else:
+            # stride-2 transposed conv (k=3, pad=1, output_padding=1) or stride 1 along a size-1 kernel axis:
+            # output parity p gets taps {(k=1, d=0)} (p=0) or {(k=2, d=0), (k=0, d=1)} (p=1); in = lattice + d
+            def axis_classes(k, s, p):
+                if s == 1:
+                    if k != 1 or p != 0:
+                        raise RuntimeError("conv_mfma: transposed stride-1 axis must have kernel 1")
+                    return [(0, [0])]
+                if (k, s, p) != (3, 2, 1):
+                    raise RuntimeError("conv_mfma: transposed conv must be k=3, s=2, p=1")
+                return [(0, [1]), (1, [2, 0])]
+            for pz, kzs in axis_classes(kd, stride[0], padding[0]):
+                for py, kys in axis_classes(kh, stride[1], padding[1]):
+                    for px, kxs in axis_classes(kw, stride[2], padding[2]):
+                        sub = w[:, :, kzs][:, :, :, kys][:, :, :, :, kxs]  # [cin,cout,|kz|,|ky|,|kx|]
+                        wk = sub.permute(2, 3, 4, 0, 1).reshape(-1, cout)
+                        flat, nsteps = _pack_gemm(wk)
+                        classes.append(dict(kd=len(kzs), kh=len(kys), kw=len(kxs), pd=0, ph=0, pw=0, od=pz, oh=py,
+                                            ow=px, nsteps=nsteps))
+                        packed.append(flat)
+                        woff.append(off)
+                        off += flat.numel()
+        self.classes = classes
+        self.wpk = torch.cat(packed).to(dev).contiguous()
+        self.woff = np.asarray(woff, dtype=np.int64)
+        self.ntile_total = (cout + 15) // 16
+        npad = self.ntile_total * 16
+        scale, shift = fold_bn(bn, cout, dev)
+        if bias is not None:
+            shift = shift + bias.detach().float() * scale
+        self.scale = torch.zeros(npad, device=dev)
+        self.shift = torch.zeros(npad, device=dev)
+        self.scale[:cout] = scale
+        self.shift[:cout] = shift
+        self.zeros = torch.zeros(64, device=dev)
+        self._geom_cache = {}
+
+    def out_shape(self, B, Di, Hi, Wi):
+        kd, kh, kw = self.kernel
+        s, p = self.stride, self.padding
+        if self.transposed:
+            return (B, Di * s[0], Hi * s[1], Wi * s[2])
+        return (B, (Di + 2 * p[0] - kd) // s[0] + 1, (Hi + 2 * p[1] - kh) // s[1] + 1, (Wi + 2 * p[2] - kw) // s[2] + 1)
+
+    def _geom(self, B, Di, Hi, Wi, skip_mode):
+        key = (B, Di, Hi, Wi, skip_mode)
+        g = self._geom_cache.get(key)
+        if g is None:
+            _, DoF, HoF, WoF = self.out_shape(B, Di, Hi, Wi)
+            s = self.stride
+            if self.transposed:
+                Do, Ho, Wo = Di, Hi, Wi
+                sd = sh = sw = 1
+                osd, osh, osw = s
+            else:
+                Do, Ho, Wo = DoF, HoF, WoF
+                sd, sh, sw = s
+                osd = osh = osw = 1
+            vals = dict(B=B, Di=Di, Hi=Hi, Wi=Wi, Do=Do, Ho=Ho, Wo=Wo, DoF=DoF, HoF=HoF, WoF=WoF, sd=sd, sh=sh, sw=sw,
+                        cout=self.cout, ntile_total=self.ntile_total, relu=int(self.relu), skip_mode=skip_mode,
+                        osd=osd, osh=osh, osw=osw, nclass=len(self.classes))
+            arr = [vals[k] for k in GEOM]
+            for c in self.classes:
+                arr += [c[k] for k in GEOM_CLASS]
+            mt, nt = _tiles(B * Do * Ho * Wo, self.ntile_total, len(self.classes))
+            g = (np.asarray(arr, dtype=np.int32), mt, nt, (B, DoF, HoF, WoF))
+            self._geom_cache[key] = g
+        return g
+
+    def __call__(self, x, skip=None, skip_mode=SKIP_NONE, tiles=None):
+        """x [B,Di,Hi,Wi,cin] channels-last -> [B,Do,Ho,Wo,cout]."""
+        B, Di, Hi, Wi, C = x.shape
+        if C != self.cin or not x.is_contiguous() or x.dtype != torch.float32 or not x.is_cuda:
+            raise RuntimeError("conv_mfma: bad input (shape %s, cin %d)" % (tuple(x.shape), self.cin))
+        if skip is None:
+            skip_mode = SKIP_NONE
+        geom, mt, nt, oshape = self._geom(B, Di, Hi, Wi, skip_mode)
+        if tiles is not None:
+            mt, nt = tiles
+        out = torch.empty(oshape + (self.cout,), device=x.device, dtype=torch.float32)
+        if skip is not None:
+            if not skip.is_contiguous():
+                raise RuntimeError("conv_mfma: skip must be contiguous")
+            want = out.shape if skip_mode == SKIP_ADD else (B, 1, oshape[2] // 2, oshape[3] // 2, self.cout)
+            if tuple(skip.shape) != tuple(want):
+                raise RuntimeError("conv_mfma: skip shape %s, expected %s" % (tuple(skip.shape), tuple(want)))
+        rc = _lib.load().mvster_conv_mfma(
+            x.data_ptr(), self.wpk.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+            None if skip is None else skip.data_ptr(), self.zeros.data_ptr(), out.data_ptr(),
+            geom.ctypes.data_as(ctypes.c_void_p), int(geom.size), self.woff.ctypes.data_as(ctypes.c_void_p), self.cin,
+            mt, nt, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "conv_mfma")
+        return out
+
+    def flops(self, B, Di, Hi, Wi):
+        """Algorithmic FLOPs (2*MACs) of one call, as torch.utils.flop_counter counts them."""
+        _, Do, Ho, Wo = self.out_shape(B, Di, Hi, Wi)
+        kd, kh, kw = self.kernel
+        if self.transposed:
+            return 2 * B * Di * Hi * Wi * kd * kh * kw * self.cin * self.cout
+        return 2 * B * Do * Ho * Wo * kd * kh * kw * self.cin * self.cout
+
+
+def _cbr3d(m, **kw):
+    """ConvBnReLU3D module -> ConvLayer."""
+    return ConvLayer(m.conv.weight, False, m.conv.stride, m.conv.padding, bn=m.bn, relu=True, **kw)
+
+
+def _up3d(seq):
+    """Sequential(ConvTranspose3d, BatchNorm3d, ReLU) -> ConvLayer."""
+    ct, bn = seq[0], seq[1]
+    return ConvLayer(ct.weight, True, ct.stride, ct.padding, bn=bn, relu=True)
+
+
+class Reg2dPlan:
+    """reg2d U-Net (models/mvs4net_utils.py:870-912) on channels-last volumes; the 1x1x1 ``prob``
+    head is left to the selection kernel (fused with the softmax)."""
+
+    def __init__(self, m):
+        self.conv0, self.conv1, self.conv2 = _cbr3d(m.conv0), _cbr3d(m.conv1), _cbr3d(m.conv2)
+        self.conv3, self.conv4 = _cbr3d(m.conv3), _cbr3d(m.conv4)
+        self.conv5, self.conv6 = _cbr3d(m.conv5), _cbr3d(m.conv6)
+        self.conv7, self.conv9, self.conv11 = _up3d(m.conv7), _up3d(m.conv9), _up3d(m.conv11)
+        self.prob_w = m.prob.weight.detach().float().reshape(-1).contiguous()
+        self.prob_b = m.prob.bias.detach().float().reshape(-1).contiguous()
+        self.fused_prob = True
+
+    def layers(self):
+        return [self.conv0, self.conv1, self.conv2, self.conv3, self.conv4, self.conv5, self.conv6, self.conv7,
+                self.conv9, self.conv11]
+
+    def __call__(self, x):
+        """x [B,D,h,w,G] -> last feature volume [B,D,h,w,8] (before ``prob``)."""
+        c0 = self.conv0(x)
+        c2 = self.conv2(self.conv1(c0))
+        c4 = self.conv4(self.conv3(c2))
+        t = self.conv6(self.conv5(c4))
+        t = self.conv7(t, skip=c4, skip_mode=SKIP_ADD)
+        t = self.conv9(t, skip=c2, skip_mode=SKIP_ADD)
+        return self.conv11(t, skip=c0, skip_mode=SKIP_ADD)
+
+    def flops(self, B, D, h, w):
+        tot, shp = 0, None
+        dims = {"conv0": (D, h, w), "conv1": (D, h, w), "conv2": (D, h // 2, w // 2), "conv3": (D, h // 2, w // 2),
+                "conv4": (D, h // 4, w // 4), "conv5": (D, h // 4, w // 4), "conv6": (D, h // 8, w // 8),
+                "conv7": (D, h // 8, w // 8), "conv9": (D, h // 4, w // 4), "conv11": (D, h // 2, w // 2)}
+        for k, (d_, h_, w_) in dims.items():
+            tot += getattr(self, k).flops(B, d_, h_, w_)
+        return tot + 2 * B * D * h * w * 8
+
+
+class Reg3dPlan:
+    """reg3d U-Net (models/mvs4net_utils.py:914-965); ``prob`` is a 3x3x3 conv -> logits."""
+
+    def __init__(self, m):
+        self.down_size = m.down_size
+        self.conv0, self.conv1, self.conv2 = _cbr3d(m.conv0), _cbr3d(m.conv1), _cbr3d(m.conv2)
+        if m.down_size >= 2:
+            self.conv3, self.conv4 = _cbr3d(m.conv3), _cbr3d(m.conv4)
+            self.conv9 = _up3d(m.conv9)
+        if m.down_size >= 3:
+            self.conv5, self.conv6 = _cbr3d(m.conv5), _cbr3d(m.conv6)
+            self.conv7 = _up3d(m.conv7)
+        self.conv11 = _up3d(m.conv11)
+        self.prob = ConvLayer(m.prob.weight, False, m.prob.stride, m.prob.padding)
+        self.fused_prob = False
+
+    def __call__(self, x):
+        """x [B,D,h,w,G] -> logits [B,D,h,w]."""
+        c0 = self.conv0(x)
+        c2 = self.conv2(self.conv1(c0))
+        if self.down_size == 3:
+            c4 = self.conv4(self.conv3(c2))
+            t = self.conv6(self.conv5(c4))
+            t = self.conv7(t, skip=c4, skip_mode=SKIP_ADD)
+            t = self.conv9(t, skip=c2, skip_mode=SKIP_ADD)
+        elif self.down_size == 2:
+            t = self.conv4(self.conv3(c2))
+            t = self.conv9(t, skip=c2, skip_mode=SKIP_ADD)
+        else:
+            t = c2
+        t = self.conv11(t, skip=c0, skip_mode=SKIP_ADD)
+        return self.prob(t).squeeze(-1)
+
+
+def _cbr2d(m, **kw):
+    c = m.conv
+    return ConvLayer(c.weight, False, c.stride, c.padding, bn=m.bn, relu=m.relu, **kw)
+
+
+def _plain2d(c):
+    return ConvLayer(c.weight, False, c.stride, c.padding, bias=c.bias)
+
+
+class FpnPlan:
+    """FPN4 (models/mvs4net_utils.py:419-502) for all views at once; input [N*B,1,H,W,4] (RGB0),
+    outputs four channels-last maps [N*B,1,h,w,C]."""
+
+    def __init__(self, m):
+        self.conv0 = [_cbr2d(m.conv0[0], cin_pad=4), _cbr2d(m.conv0[1])]
+        self.conv1 = [_cbr2d(l) for l in m.conv1]
+        self.conv2 = [_cbr2d(l) for l in m.conv2]
+        self.conv3 = [_cbr2d(l) for l in m.conv3]
+        self.inner1, self.inner2, self.inner3 = _plain2d(m.inner1), _plain2d(m.inner2), _plain2d(m.inner3)
+        self.out1, self.out2, self.out3, self.out4 = (_plain2d(m.out1), _plain2d(m.out2), _plain2d(m.out3),
+                                                      _plain2d(m.out4))
+
+    @staticmethod
+    def _seq(layers, x):
+        for l in layers:
+            x = l(x)
+        return x
+
+    def __call__(self, x):
+        c0 = self._seq(self.conv0, x)
+        c1 = self._seq(self.conv1, c0)
+        c2 = self._seq(self.conv2, c1)
+        c3 = self._seq(self.conv3, c2)
+        o1 = self.out1(c3)
+        f = self.inner1(c2, skip=c3, skip_mode=SKIP_UPSAMPLE_ADD)
+        o2 = self.out2(f)
+        f = self.inner2(c1, skip=f, skip_mode=SKIP_UPSAMPLE_ADD)
+        o3 = self.out3(f)
+        f = self.inner3(c0, skip=f, skip_mode=SKIP_UPSAMPLE_ADD)
+        o4 = self.out4(f)
+        return [o1, o2, o3, o4]

@@ -1,0 +1,288 @@
+// Channels-last implicit-GEMM convolution on the gfx950 fp32 matrix cores.
+//
+// One kernel family covers every dense contraction of the path (eval mode, BatchNorm
+// folded into a per-channel scale/shift):
+//   reg2d / reg3d   Conv3d (1,3,3) s1/s2, 3x3x3, ConvTranspose3d (1,3,3)|3x3x3 s2
+//                   models/mvs4net_utils.py:870-965 (+ ConvBnReLU3D :116-123)
+//   FPN4            Conv2d 3x3, 5x5 s2, 1x1 (+bias), bilinear x2 upsample-add
+//                   models/mvs4net_utils.py:419-502 (+ Conv2d :224-251)
+//
+// GEMM view:  M = output voxels (b,z,y,x flattened), N = Cout, K = taps x Cin.
+//   D[m][n] += sum_k A[m][k] * B[k][n]   with v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered FMA chain)
+//   A[m][k] : lane (m = lane&15, q = lane>>4) reads ONE float4 = 4 consecutive input channels of its
+//             voxel for the tap that K-slot belongs to -> feeds 4 MFMAs (the K order inside a 16-wide
+//             K step is a fixed permutation shared with the packed weights, so it cancels out)
+//   B[k][n] : weights pre-packed on the host in exactly the fragment order -> one coalesced float4 per lane
+//   D       : lane holds rows 4*(lane>>4)+r, column lane&15  (r = 0..3)
+// A wave owns MT x NT tiles of 16x16; there is no LDS staging and no barrier in the K loop: the
+// activations of one stage are L2/MALL resident (<= 42 MB), every tap re-read is a cache hit, and
+// zero padding is a per-lane select.  Transposed stride-2 layers run as 2^k parity classes
+// (blockIdx.z), each an ordinary small-kernel convolution on the input lattice.
+//
+// Epilogue (fused): y = acc*scale[n] + shift[n]; optional ReLU; optional skip add (same-resolution
+// tensor, or bilinear x2 align_corners upsample of a half-resolution tensor); channels-last store.
+//
+// Roofline: the 3x3x3 layers are MFMA-bound (157.3 TFLOP/s fp32 matrix peak), the full-resolution
+// (1,3,3) layers are HBM/L2-bound.  FLOPs per launch = 2 * M * Cout * taps * Cin.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxTaps = 128;
+constexpr int kMaxClasses = 8;
+
+struct ConvArgs {
+    const float* in;      // [B, Di, Hi, Wi, CIN]
+    const float* wpk;     // packed weights, all classes
+    const float* scale;   // [Np]
+    const float* shift;   // [Np]
+    const float* skip;    // optional
+    const float* zeros;   // >= 16 bytes of zeros: the "address" of every padded tap
+    float* out;           // [B, DoF, HoF, WoF, COUT]
+    int B, Di, Hi, Wi;
+    int Do, Ho, Wo;       // output lattice walked by M (per class)
+    int DoF, HoF, WoF;    // full output dims
+    int sd, sh, sw;       // input step per lattice step
+    int cout;             // real output channels
+    int ntile_total;      // Np / 16
+    int relu;
+    int skip_mode;        // 0 none, 1 same-resolution add, 2 bilinear x2 upsample-add (2-D, half resolution)
+    int nclass;
+    // per class
+    int kd[kMaxClasses], kh[kMaxClasses], kw[kMaxClasses];   // sub-kernel extent
+    int pd[kMaxClasses], ph[kMaxClasses], pw[kMaxClasses];   // input offset: i = o*s - p + k
+    int od[kMaxClasses], oh[kMaxClasses], ow[kMaxClasses];   // output phase
+    int osd, osh, osw;                                       // output lattice stride
+    int nsteps[kMaxClasses];
+    long woff[kMaxClasses];                                  // float offset of the class's packed weights
+};
+
+template <int CIN, int MT, int NT>
+__global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
+    static_assert(CIN % 4 == 0 && (CIN >= 16 ? CIN % 16 == 0 : 16 % CIN == 0), "channel packing");
+    __shared__ int lut_ofs[kMaxTaps];   // linear input offset (voxels) of a tap
+    __shared__ int lut_zyx[kMaxTaps];   // kz | ky << 8 | kx << 16
+
+    const int cls = blockIdx.z;
+    const int KD = a.kd[cls], KH = a.kh[cls], KW = a.kw[cls];
+    const int ntaps = KD * KH * KW;
+    for (int t = threadIdx.x; t < ntaps; t += blockDim.x) {
+        const int kx = t % KW, ky = (t / KW) % KH, kz = t / (KW * KH);
+        lut_ofs[t] = (kz * a.Hi + ky) * a.Wi + kx;
+        lut_zyx[t] = kz | (ky << 8) | (kx << 16);
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int lm = lane & 15;   // A row / B,D column
+    const int lq = lane >> 4;   // K slot
+    // all voxel counts fit 32 bits (checked on the host side of the ABI)
+    const unsigned Mtot = (unsigned)(a.B * a.Do * a.Ho * a.Wo);
+    const unsigned tile0 = (blockIdx.x * 4u + wave) * MT;   // first 16-voxel tile of this wave
+    if (tile0 * 16u >= Mtot) return;
+    const int nt0 = blockIdx.y * NT;
+
+    // A-role voxel of this lane in each M tile
+    int iz0[MT], iy0[MT], ix0[MT];
+    int pin0[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        unsigned m = (tile0 + mt) * 16u + lm;
+        const bool ok = m < Mtot;
+        if (!ok) m = 0;
+        const unsigned x = m % (unsigned)a.Wo;
+        unsigned r = m / (unsigned)a.Wo;
+        const unsigned y = r % (unsigned)a.Ho;
+        r /= (unsigned)a.Ho;
+        const unsigned z = r % (unsigned)a.Do;
+        const unsigned b = r / (unsigned)a.Do;
+        iz0[mt] = ok ? (int)z * a.sd - a.pd[cls] : -(1 << 20);
+        iy0[mt] = (int)y * a.sh - a.ph[cls];
+        ix0[mt] = (int)x * a.sw - a.pw[cls];
+        pin0[mt] = (((int)b * a.Di + (ok ? iz0[mt] : 0)) * a.Hi + iy0[mt]) * a.Wi + ix0[mt];
+    }
+
+    f32x4v acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    const float* wp = a.wpk + a.woff[cls] + ((long)nt0 * 64 + lane) * 4;
+    const long wstep = (long)a.ntile_total * 256;
+    const int nsteps = a.nsteps[cls];
+
+    const long zero_off = a.zeros - a.in;   // element offset of the zero page relative to `in`
+    f32x4v af[MT], bf[NT];
+    auto load_step = [&](int s, f32x4v (&A)[MT], f32x4v (&Bv)[NT]) {
+        const int kk = s * 16 + lq * 4;
+        const int tap = kk / CIN;
+        const int c = kk % CIN;
+        const bool tap_ok = tap < ntaps;
+        const int tt = tap_ok ? tap : 0;
+        const int ofs = lut_ofs[tt];
+        const int zyx = lut_zyx[tt];
+        const int kz = zyx & 255, ky = (zyx >> 8) & 255, kx = zyx >> 16;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bool ok = tap_ok && (unsigned)(iz0[mt] + kz) < (unsigned)a.Di &&
+                            (unsigned)(iy0[mt] + ky) < (unsigned)a.Hi && (unsigned)(ix0[mt] + kx) < (unsigned)a.Wi;
+            // padded taps read a zero page: one unconditional load, no exec-masked branch per tap
+            const long off = ok ? ((long)(pin0[mt] + ofs) * CIN + c) : zero_off;
+            A[mt] = *reinterpret_cast<const f32x4v*>(a.in + off);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            Bv[nt] = *reinterpret_cast<const f32x4v*>(wp + (long)s * wstep + (long)nt * 256);
+    };
+
+    auto mma_step = [&](const f32x4v (&A)[MT], const f32x4v (&Bv)[NT]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[mt][j], Bv[nt][j], acc[mt][nt], 0, 0, 0);
+    };
+
+    // Two register sets, ping-pong: the loads of step s+1 are in flight under the MFMAs of step s.
+    // Every prefetch is unconditional (the last one re-reads the final step) so that hipcc can
+    // count the outstanding loads exactly (a conditional prefetch makes it wait vmcnt(0)).
+    f32x4v ag[MT], bg[NT];
+    load_step(0, af, bf);
+    int s = 0;
+    for (; s + 2 <= nsteps; s += 2) {
+        load_step(s + 1, ag, bg);
+        mma_step(af, bf);
+        load_step(s + 2 < nsteps ? s + 2 : nsteps - 1, af, bf);
+        mma_step(ag, bg);
+    }
+    if (s < nsteps) mma_step(af, bf);
+
+    // epilogue
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        // rows 4*lq .. 4*lq+3 are consecutive lattice voxels: decompose the first, then carry
+        const unsigned m0 = (tile0 + mt) * 16u + lq * 4u;
+        int x = (int)(m0 % (unsigned)a.Wo);
+        unsigned q0 = m0 / (unsigned)a.Wo;
+        int y = (int)(q0 % (unsigned)a.Ho);
+        q0 /= (unsigned)a.Ho;
+        int z = (int)(q0 % (unsigned)a.Do);
+        int b = (int)(q0 / (unsigned)a.Do);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r > 0) {
+                if (++x == a.Wo) { x = 0; if (++y == a.Ho) { y = 0; if (++z == a.Do) { z = 0; ++b; } } }
+            }
+            if (m0 + r >= Mtot) continue;
+            const int oz = z * a.osd + a.od[cls], oy = y * a.osh + a.oh[cls], ox = x * a.osw + a.ow[cls];
+            const long opix = (((long)b * a.DoF + oz) * a.HoF + oy) * a.WoF + ox;
+            mv::Lerp ly, lx;
+            const float* sk = a.skip;
+            if (a.skip_mode == 2) {
+                const int hh = a.HoF / 2, wh = a.WoF / 2;
+                ly = mv::make_lerp(oy, hh, a.HoF);
+                lx = mv::make_lerp(ox, wh, a.WoF);
+                sk = a.skip + (long)b * hh * wh * a.cout;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = (nt0 + nt) * 16 + lm;
+                if (n >= a.cout) continue;
+                float v = fmaf(acc[mt][nt][r], a.scale[n], a.shift[n]);
+                if (a.relu) v = fmaxf(v, 0.0f);
+                if (a.skip_mode == 1) {
+                    v += a.skip[opix * a.cout + n];
+                } else if (a.skip_mode == 2) {
+                    const int wh = a.WoF / 2;
+                    const float up = mv::bilerp(ly, lx, sk[((long)ly.i0 * wh + lx.i0) * a.cout + n],
+                                                sk[((long)ly.i0 * wh + lx.i1) * a.cout + n],
+                                                sk[((long)ly.i1 * wh + lx.i0) * a.cout + n],
+                                                sk[((long)ly.i1 * wh + lx.i1) * a.cout + n]);
+                    v = up + v;   // F.interpolate(prev) + inner(conv)   (mvs4net_utils.py:482-488)
+                }
+                a.out[opix * a.cout + n] = v;
+            }
+        }
+    }
+}
+
+template <int CIN, int MT, int NT>
+int launch(const ConvArgs& a, hipStream_t s) {
+    const long Mtot = (long)a.B * a.Do * a.Ho * a.Wo;
+    if (Mtot >= (1L << 31) || (long)a.B * a.Di * a.Hi * a.Wi >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    const long tiles = (Mtot + 15) / 16;
+    dim3 grid((unsigned)((tiles + 4 * MT - 1) / (4 * MT)), a.ntile_total / NT, a.nclass);
+    hipLaunchKernelGGL((conv_mfma_kernel<CIN, MT, NT>), grid, dim3(256), 0, s, a);
+    return mv_check_launch();
+}
+
+template <int CIN>
+int dispatch_tiles(const ConvArgs& a, int MT, int NT, hipStream_t s) {
+#define MV_T(M_, N_) if (MT == M_ && NT == N_) return launch<CIN, M_, N_>(a, s);
+    MV_T(1, 1) MV_T(2, 1) MV_T(4, 1) MV_T(1, 2) MV_T(2, 2) MV_T(4, 2) MV_T(1, 4) MV_T(2, 4) MV_T(4, 4)
+#undef MV_T
+    return MVSTER_ERR_UNSUPPORTED;
+}
+
+// one raw MFMA, to pin the fragment layout this file assumes (tests/test_gpu_conv.py)
+__global__ void mfma_probe_kernel(const float* A, const float* Bm, float* Dm) {
+    const int lane = threadIdx.x;
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    const float av = A[(lane & 15) * 4 + (lane >> 4)];    // A[m][k], 16x4 row major
+    const float bv = Bm[(lane >> 4) * 16 + (lane & 15)];  // B[k][n], 4x16 row major
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) Dm[((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[r];
+}
+
+}  // namespace
+
+// geom: int32 array, see mvster_amd/conv_plan.py (GEOM_* layout); woff: per-class offsets (floats)
+extern "C" int mvster_conv_mfma(const float* in, const float* wpk, const float* scale, const float* shift,
+                                const float* skip, const float* zeros, float* out, const int* geom, int ngeom, const long* woff,
+                                int cin, int mt, int nt, void* stream) {
+    if (!in || !wpk || !scale || !shift || !zeros || !out || !geom || !woff) return MVSTER_ERR_NULL;
+    if (ngeom < 22) return MVSTER_ERR_SHAPE;
+    ConvArgs a;
+    a.in = in; a.wpk = wpk; a.scale = scale; a.shift = shift; a.skip = skip; a.zeros = zeros; a.out = out;
+    int i = 0;
+    a.B = geom[i++]; a.Di = geom[i++]; a.Hi = geom[i++]; a.Wi = geom[i++];
+    a.Do = geom[i++]; a.Ho = geom[i++]; a.Wo = geom[i++];
+    a.DoF = geom[i++]; a.HoF = geom[i++]; a.WoF = geom[i++];
+    a.sd = geom[i++]; a.sh = geom[i++]; a.sw = geom[i++];
+    a.cout = geom[i++]; a.ntile_total = geom[i++]; a.relu = geom[i++]; a.skip_mode = geom[i++];
+    a.osd = geom[i++]; a.osh = geom[i++]; a.osw = geom[i++];
+    a.nclass = geom[i++];
+    if (a.nclass < 1 || a.nclass > kMaxClasses || ngeom < i + a.nclass * 10) return MVSTER_ERR_SHAPE;
+    for (int c = 0; c < a.nclass; ++c) {
+        a.kd[c] = geom[i++]; a.kh[c] = geom[i++]; a.kw[c] = geom[i++];
+        a.pd[c] = geom[i++]; a.ph[c] = geom[i++]; a.pw[c] = geom[i++];
+        a.od[c] = geom[i++]; a.oh[c] = geom[i++]; a.ow[c] = geom[i++];
+        a.nsteps[c] = geom[i++];
+        a.woff[c] = woff[c];
+        if (a.kd[c] * a.kh[c] * a.kw[c] > kMaxTaps || a.nsteps[c] < 1) return MVSTER_ERR_SHAPE;
+    }
+    if (a.B <= 0 || a.Do <= 0 || a.Ho <= 0 || a.Wo <= 0 || a.cout <= 0 || a.ntile_total <= 0) return MVSTER_ERR_SHAPE;
+    if (a.skip_mode != 0 && !skip) return MVSTER_ERR_NULL;
+    if (a.ntile_total % nt != 0) return MVSTER_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    switch (cin) {
+        case 4: return dispatch_tiles<4>(a, mt, nt, s);
+        case 8: return dispatch_tiles<8>(a, mt, nt, s);
+        case 16: return dispatch_tiles<16>(a, mt, nt, s);
+        case 32: return dispatch_tiles<32>(a, mt, nt, s);
+        case 64: return dispatch_tiles<64>(a, mt, nt, s);
+        default: return MVSTER_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int mvster_mfma_probe(const float* A, const float* B, float* D, void* stream) {
+    if (!A || !B || !D) return MVSTER_ERR_NULL;
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, D);
+    return mv_check_launch();
+}

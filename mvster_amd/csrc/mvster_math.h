@@ -1,0 +1,344 @@
+// Per-element arithmetic of the MVSTER cost-volume path, shared by every kernel.
+//
+// Everything here is a small inline function over scalars so that (a) the HIP
+// kernels in this directory and (b) a host build used only by the tests
+// (tests/hostmath) execute the *same* expression trees.  The op order mirrors the
+// reference's PyTorch expressions so that fp32 results agree to rounding:
+//   projection   models/mvs4net_utils.py:34-45   (rot*xyz, *depth, +trans, z==0 fix, /z, normalise)
+//   sampling     F.grid_sample(bilinear, zeros, align_corners=True)  (mvs4net_utils.py:51)
+//   correlation  models/mvs4net_utils.py:1038-1042
+//   attention    models/mvs4net_utils.py:1053-1060
+//   upsample     F.interpolate(..., align_corners=True)  (mvs4net_utils.py:85, :1077)
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define MV_HD __host__ __device__ __forceinline__
+#else
+#define MV_HD inline
+#endif
+
+namespace mv {
+
+// fp32 ops that must not be contracted into FMAs (the reference materialises the
+// intermediate tensors, so every product and sum is rounded on its own).  hipcc's
+// __fmul_rn/__fadd_rn are plain `*`/`+` and WOULD be contracted; the pragma removes the
+// `contract` flag from the instruction itself, which survives inlining (hipcc's default is
+// -ffp-contract=fast-honor-pragmas).  The host test build uses -ffp-contract=off.
+MV_HD float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+MV_HD float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+MV_HD float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+MV_HD float div_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a / b;
+}
+
+// 3x4 homography of one (batch, source view): p_src ~ R * (x, y, 1) * depth + t.
+struct RT {
+    float r[9];
+    float t[3];
+};
+
+// Normalised->pixel round trip of the reference: the grid is normalised with
+// (size-1)/2 (mvs4net_utils.py:43-44) and ATen un-normalises it with
+// ((g + 1) / 2) * (size - 1) (GridSampler.h, align_corners=True).
+MV_HD float grid_roundtrip(float pix, int size) {
+    float half = (float)(size - 1) / 2.0f;          // exact in fp32 for any feature-map size
+    float g = sub_rn(div_rn(pix, half), 1.0f);
+    return mul_rn(div_rn(add_rn(g, 1.0f), 2.0f), (float)(size - 1));
+}
+
+// Source-view sampling position (in source pixels, after the round trip) of
+// reference pixel (x, y) at hypothesis `depth`.
+MV_HD void project(const RT& m, float x, float y, float depth, int Hs, int Ws, float& sx, float& sy) {
+    // rot @ (x, y, 1) is a GEMM in the reference: an FMA chain over k (bit-identical to
+    // torch's CPU sgemm on the golden vectors, tests/test_hostmath.py)
+    float rx = add_rn(fmaf(m.r[1], y, mul_rn(m.r[0], x)), m.r[2]);
+    float ry = add_rn(fmaf(m.r[4], y, mul_rn(m.r[3], x)), m.r[5]);
+    float rz = add_rn(fmaf(m.r[7], y, mul_rn(m.r[6], x)), m.r[8]);
+    float px = add_rn(mul_rn(rx, depth), m.t[0]);
+    float py = add_rn(mul_rn(ry, depth), m.t[1]);
+    float pz = add_rn(mul_rn(rz, depth), m.t[2]);
+    if (pz == 0.0f) pz = 1e-9f;
+    sx = grid_roundtrip(div_rn(px, pz), Ws);
+    sy = grid_roundtrip(div_rn(py, pz), Hs);
+}
+
+// Bilinear footprint: integer corner, the four weights, and which taps are in bounds
+// (zeros padding is applied per tap, like ATen's within_bounds_2d).
+struct Taps {
+    int x0, y0;            // north-west corner
+    float nw, ne, sw, se;  // weights
+    bool vx0, vx1, vy0, vy1;
+};
+
+MV_HD Taps make_taps(float sx, float sy, int Hs, int Ws) {
+    Taps t;
+    // clamp far-away / non-finite positions so that the int conversion is defined;
+    // anything beyond one pixel outside samples only zeros anyway
+    float cx = (sx > -4.0f) ? ((sx < (float)(Ws + 4)) ? sx : (float)(Ws + 4)) : -4.0f;   // NaN -> -4
+    float cy = (sy > -4.0f) ? ((sy < (float)(Hs + 4)) ? sy : (float)(Hs + 4)) : -4.0f;
+    float fx = floorf(cx), fy = floorf(cy);
+    t.x0 = (int)fx;
+    t.y0 = (int)fy;
+    float wx1 = sub_rn(cx, fx), wy1 = sub_rn(cy, fy);   // east / south
+    float wx0 = sub_rn(1.0f, wx1), wy0 = sub_rn(1.0f, wy1);
+    t.nw = mul_rn(wy0, wx0);
+    t.ne = mul_rn(wy0, wx1);
+    t.sw = mul_rn(wy1, wx0);
+    t.se = mul_rn(wy1, wx1);
+    t.vx0 = (t.x0 >= 0) && (t.x0 < Ws);
+    t.vx1 = (t.x0 + 1 >= 0) && (t.x0 + 1 < Ws);
+    t.vy0 = (t.y0 >= 0) && (t.y0 < Hs);
+    t.vy1 = (t.y0 + 1 >= 0) && (t.y0 + 1 < Hs);
+    return t;
+}
+
+// Branch-free form for the kernels: out-of-bounds taps get weight 0 and a clamped (always
+// readable) address instead of a predicated load.  0 * finite == 0, so the blend is the
+// same value as with a zero-padded tap.
+struct TapsClamped {
+    int xa, xb, ya, yb;  // clamped west/east column, north/south row
+};
+
+MV_HD TapsClamped clamp_taps(Taps& t, int Hs, int Ws) {
+    TapsClamped c;
+    if (!(t.vy0 && t.vx0)) t.nw = 0.0f;
+    if (!(t.vy0 && t.vx1)) t.ne = 0.0f;
+    if (!(t.vy1 && t.vx0)) t.sw = 0.0f;
+    if (!(t.vy1 && t.vx1)) t.se = 0.0f;
+    c.xa = t.x0 < 0 ? 0 : (t.x0 > Ws - 1 ? Ws - 1 : t.x0);
+    c.xb = t.x0 + 1 < 0 ? 0 : (t.x0 + 1 > Ws - 1 ? Ws - 1 : t.x0 + 1);
+    c.ya = t.y0 < 0 ? 0 : (t.y0 > Hs - 1 ? Hs - 1 : t.y0);
+    c.yb = t.y0 + 1 < 0 ? 0 : (t.y0 + 1 > Hs - 1 ? Hs - 1 : t.y0 + 1);
+    return c;
+}
+
+// ((nw*a + ne*b) + sw*c) + se*d, each product rounded (ATen CPU/CUDA order).
+MV_HD float blend(const Taps& t, float a, float b, float c, float d) {
+    return add_rn(add_rn(add_rn(mul_rn(a, t.nw), mul_rn(b, t.ne)), mul_rn(c, t.sw)), mul_rn(d, t.se));
+}
+
+// 1-D linear upsampling coefficient, align_corners=True (ATen area_pixel_compute_source_index
+// + guard_index_and_lambda): src = dst * (in-1)/(out-1).
+struct Lerp {
+    int i0, i1;
+    float w0, w1;
+};
+
+MV_HD Lerp make_lerp(int dst, int in_size, int out_size) {
+    Lerp l;
+    float scale = (out_size > 1) ? (float)(in_size - 1) / (float)(out_size - 1) : 0.0f;
+    float src = mul_rn(scale, (float)dst);
+    int i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    float lam = sub_rn(src, (float)i0);
+    lam = lam < 0.0f ? 0.0f : (lam > 1.0f ? 1.0f : lam);
+    l.i0 = i0;
+    l.i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+    l.w1 = lam;
+    l.w0 = sub_rn(1.0f, lam);
+    return l;
+}
+
+// h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
+MV_HD float bilerp(const Lerp& ly, const Lerp& lx, float v00, float v01, float v10, float v11) {
+    float top = add_rn(mul_rn(lx.w0, v00), mul_rn(lx.w1, v01));
+    float bot = add_rn(mul_rn(lx.w0, v10), mul_rn(lx.w1, v11));
+    return add_rn(mul_rn(ly.w0, top), mul_rn(ly.w1, bot));
+}
+
+// double-precision 4x4 inverse (Gauss-Jordan, partial pivoting); returns false if singular
+MV_HD bool inverse4(const double* a, double* inv) {
+    double m[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            m[i][j] = a[i * 4 + j];
+            m[i][j + 4] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 4; ++c) {
+        int p = c;
+        double best = fabs(m[c][c]);
+        for (int r = c + 1; r < 4; ++r)
+            if (fabs(m[r][c]) > best) { best = fabs(m[r][c]); p = r; }
+        if (best == 0.0) return false;
+        if (p != c)
+            for (int j = 0; j < 8; ++j) { double tmp = m[c][j]; m[c][j] = m[p][j]; m[p][j] = tmp; }
+        double d = 1.0 / m[c][c];
+        for (int j = 0; j < 8; ++j) m[c][j] *= d;
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            double f = m[r][c];
+            if (f != 0.0)
+                for (int j = 0; j < 8; ++j) m[r][j] -= f * m[c][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) inv[i * 4 + j] = m[i][j + 4];
+    return true;
+}
+
+// Compose K @ [R|t] for one camera: pm = {extrinsic 4x4, intrinsic 4x4} (fp32, row major).
+// Rows 0..2 of the result are K[:3,:3] @ E[:3,:4] rounded to fp32 like the reference's fp32
+// matmul (mvs4net_utils.py:1033), row 3 is the extrinsic's.
+MV_HD void compose_camera(const float* pm, double* P) {
+    const float* E = pm;
+    const float* K = pm + 16;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0.0f;
+            for (int k = 0; k < 3; ++k) acc = fmaf(K[i * 4 + k], E[k * 4 + j], acc);
+            P[i * 4 + j] = (double)acc;
+        }
+    for (int j = 0; j < 4; ++j) P[12 + j] = (double)E[12 + j];
+}
+
+// src_P @ inv(ref_P), top 3x4 rounded to fp32 (mvs4net_utils.py:24-26).
+MV_HD bool relative_projection(const float* ref_pm, const float* src_pm, RT& out) {
+    double Pr[16], Ps[16], Pi[16];
+    compose_camera(ref_pm, Pr);
+    compose_camera(src_pm, Ps);
+    bool ok = inverse4(Pr, Pi);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) acc += Ps[i * 4 + k] * Pi[k * 4 + j];
+            if (j < 3) out.r[i * 3 + j] = (float)acc;
+            else out.t[i] = (float)acc;
+        }
+    return ok;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Per-pixel bodies of the small stage kernels (stage_ops.hip); `p` is the linear pixel index.
+// ---------------------------------------------------------------------------------------
+
+// init_inverse_range / init_range (mvs4net_utils.py:61-77): out[d*hw + p] for one batch item
+MV_HD void init_range_pixel(float dmin, float dmax, float* out, int D, long hw, long p, int inverse) {
+    if (inverse) {
+        const float inv_near = div_rn(1.0f, dmin), inv_far = div_rn(1.0f, dmax);
+        const float span = sub_rn(inv_near, inv_far);
+        for (int d = 0; d < D; ++d) {
+            const float itv = div_rn((float)d, (float)(D - 1));
+            out[d * hw + p] = div_rn(1.0f, add_rn(inv_far, mul_rn(span, itv)));
+        }
+    } else {
+        const float step = div_rn(sub_rn(dmax, dmin), (float)(D - 1));
+        for (int d = 0; d < D; ++d) out[d * hw + p] = add_rn(dmin, mul_rn((float)d, step));
+    }
+}
+
+// schedule_inverse_range (mvs4net_utils.py:79-86): inv_min/inv_max are one batch item's
+// [hi, wi] maps; trilinear with the depth size unchanged is bilinear per slice.
+MV_HD void schedule_inverse_pixel(const float* inv_min, const float* inv_max, float* out, int D, int h, int w,
+                                  int hi, int wi, int p) {
+    const int y = p / w, x = p - y * w;
+    const Lerp ly = make_lerp(y, hi, h), lx = make_lerp(x, wi, w);
+    const int i00 = ly.i0 * wi + lx.i0, i01 = ly.i0 * wi + lx.i1, i10 = ly.i1 * wi + lx.i0, i11 = ly.i1 * wi + lx.i1;
+    const float mx00 = inv_max[i00], mx01 = inv_max[i01], mx10 = inv_max[i10], mx11 = inv_max[i11];
+    const float sp00 = sub_rn(inv_min[i00], mx00), sp01 = sub_rn(inv_min[i01], mx01);
+    const float sp10 = sub_rn(inv_min[i10], mx10), sp11 = sub_rn(inv_min[i11], mx11);
+    for (int d = 0; d < D; ++d) {
+        const float itv = div_rn((float)d, (float)(D - 1));
+        const float v00 = add_rn(mx00, mul_rn(sp00, itv)), v01 = add_rn(mx01, mul_rn(sp01, itv));
+        const float v10 = add_rn(mx10, mul_rn(sp10, itv)), v11 = add_rn(mx11, mul_rn(sp11, itv));
+        out[(long)d * h * w + p] = div_rn(1.0f, bilerp(ly, lx, v00, v01, v10, v11));
+    }
+}
+
+// schedule_range (mvs4net_utils.py:88-99)
+MV_HD void schedule_linear_pixel(const float* cur, float interval, float* out, int D, int h, int w, int hi, int wi,
+                                 int p) {
+    const int y = p / w, x = p - y * w;
+    const Lerp ly = make_lerp(y, hi, h), lx = make_lerp(x, wi, w);
+    const int idx[4] = {ly.i0 * wi + lx.i0, ly.i0 * wi + lx.i1, ly.i1 * wi + lx.i0, ly.i1 * wi + lx.i1};
+    const float half = mul_rn((float)D / 2.0f, interval);  // ndepth / 2 * interval
+    float lo[4], st[4];
+    for (int k = 0; k < 4; ++k) {
+        const float c = cur[idx[k]];
+        lo[k] = sub_rn(c, half);
+        st[k] = div_rn(sub_rn(add_rn(c, half), lo[k]), (float)(D - 1));
+    }
+    for (int d = 0; d < D; ++d) {
+        float v[4];
+        for (int k = 0; k < 4; ++k) v[k] = add_rn(lo[k], mul_rn((float)d, st[k]));
+        out[(long)d * h * w + p] = bilerp(ly, lx, v[0], v[1], v[2], v[3]);
+    }
+}
+
+constexpr int kSelMaxD = 16;
+
+// prob 1x1x1 (optional) + softmax over D + first-max argmax + gather + inverse bounds
+// (mvs4net_utils.py:900, :1068-1088).  All pointers are one batch item's; plane stride = hw.
+// feat: [D, hw, CF] channels-last or null (then logits [D, hw] is read).
+MV_HD void select_pixel(const float* logits, const float* feat, const float* prob_w, const float* prob_b, int CF,
+                        const float* hypo, float* attn, float* depth, float* conf, float* inv_min, float* inv_max,
+                        float* logits_out, int D, long hw, long p, float split_itv) {
+    float lg[kSelMaxD];  // fully unrolled + guarded so that it stays in registers on the GPU
+    float mx = -INFINITY;
+#pragma unroll
+    for (int d = 0; d < kSelMaxD; ++d) {
+        if (d >= D) break;
+        const long o = d * hw + p;
+        float v;
+        if (feat) {
+            const float* f = feat + o * CF;
+            v = 0.0f;
+            for (int c = 0; c < CF; ++c) v = fmaf(f[c], prob_w[c], v);
+            v = add_rn(v, prob_b[0]);
+            if (logits_out) logits_out[o] = v;
+        } else {
+            v = logits[o];
+        }
+        lg[d] = v;
+        mx = fmaxf(mx, v);
+    }
+    float den = 0.0f;
+#pragma unroll
+    for (int d = 0; d < kSelMaxD; ++d) {
+        if (d >= D) break;
+        lg[d] = expf(sub_rn(lg[d], mx));
+        den = add_rn(den, lg[d]);
+    }
+    float best = -1.0f, hb = 0.f, h1 = 0.f, h2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < kSelMaxD; ++d) {
+        if (d >= D) break;
+        const long o = d * hw + p;
+        const float pr = div_rn(lg[d], den);
+        attn[o] = pr;
+        const float hd = hypo[o];
+        if (d == 1) h1 = hd;
+        if (d == 2) h2 = hd;
+        if (pr > best) { best = pr; hb = hd; }  // strict '>' : the first maximum wins ties (ATen max)
+    }
+    depth[p] = hb;
+    if (conf) conf[p] = best;
+    if (inv_min) {
+        const float itv = sub_rn(div_rn(1.0f, h2), div_rn(1.0f, h1));
+        const float inv_d = div_rn(1.0f, hb);
+        const float delta = mul_rn(split_itv, itv);
+        inv_min[p] = add_rn(inv_d, delta);
+        inv_max[p] = sub_rn(inv_d, delta);
+    }
+}
+
+// F.interpolate(bilinear, align_corners=True) of one [hi, wi] map at output pixel p
+MV_HD float upsample_pixel(const float* in, int hi, int wi, int ho, int wo, int p) {
+    const int y = p / wo, x = p - y * wo;
+    const Lerp ly = make_lerp(y, hi, ho), lx = make_lerp(x, wi, wo);
+    return bilerp(ly, lx, in[ly.i0 * wi + lx.i0], in[ly.i0 * wi + lx.i1], in[ly.i1 * wi + lx.i0],
+                  in[ly.i1 * wi + lx.i1]);
+}
+
+}  // namespace mv

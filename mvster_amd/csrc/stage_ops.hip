@@ -1,0 +1,160 @@
+// Small per-stage kernels of the cascade: camera composition, depth-hypothesis
+// schedulers, depth selection, confidence upsampling.  All HBM/latency-bound,
+// one thread per output pixel, D (<= 16) handled in registers.
+//
+// Reference counterparts (models/mvs4net_utils.py):
+//   relative projection  :24-26 + :1032-1035      mvster_relative_projection
+//   init_inverse_range   :71-77                   mvster_init_range(inverse=1)
+//   init_range           :61-69                   mvster_init_range(inverse=0)
+//   schedule_inverse_range :79-86                 mvster_schedule_inverse_range
+//   schedule_range       :88-99                   mvster_schedule_range
+//   prob 1x1x1 + softmax + argmax + gather + confidence + inverse bounds  :900,:1068-1088
+//                                                 mvster_select_depth
+//   F.interpolate(bilinear, align_corners=True)   :1077   mvster_upsample_bilinear
+#include "common.hpp"
+
+namespace {
+
+constexpr int kMaxD = mv::kSelMaxD;
+
+__global__ void relative_projection_kernel(const float* __restrict__ pm, float* __restrict__ rt, int B, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int NV = N - 1;
+    if (i >= B * NV) return;
+    const int b = i / NV, v = i - b * NV;
+    const float* ref = pm + ((long)b * N) * 32;
+    const float* src = pm + ((long)b * N + v + 1) * 32;
+    mv::RT m;
+    mv::relative_projection(ref, src, m);
+    float* o = rt + (long)i * 12;
+    for (int k = 0; k < 9; ++k) o[k] = m.r[k];
+    for (int k = 0; k < 3; ++k) o[9 + k] = m.t[k];
+}
+
+// depth_values [B, ndv] (first and last column used) -> out [B, D, h, w]
+__global__ void init_range_kernel(const float* __restrict__ dv, int ndv, float* __restrict__ out, int B, int D,
+                                  int hw, int inverse) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (p >= hw) return;
+    mv::init_range_pixel(dv[b * ndv], dv[b * ndv + ndv - 1], out + (long)b * D * hw, D, hw, p, inverse);
+}
+
+// inv_min / inv_max [B, h/2, w/2] -> out [B, D, h, w]
+__global__ void schedule_inverse_kernel(const float* __restrict__ inv_min, const float* __restrict__ inv_max,
+                                        float* __restrict__ out, int B, int D, int h, int w, int hi, int wi) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (p >= h * w) return;
+    const long base = (long)b * hi * wi;
+    mv::schedule_inverse_pixel(inv_min + base, inv_max + base, out + (long)b * D * h * w, D, h, w, hi, wi, p);
+}
+
+// cur_depth [B, h/2, w/2], interval [B] -> out [B, D, h, w]
+__global__ void schedule_linear_kernel(const float* __restrict__ cur, const float* __restrict__ interval,
+                                       float* __restrict__ out, int B, int D, int h, int w, int hi, int wi) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (p >= h * w) return;
+    mv::schedule_linear_pixel(cur + (long)b * hi * wi, interval[b], out + (long)b * D * h * w, D, h, w, hi, wi, p);
+}
+
+struct SelectArgs {
+    const float* logits;  // [B, D, h, w] or null
+    const float* feat;    // [B, D, h, w, CF] channels-last (output of the last reg layer) or null
+    const float* prob_w;  // [CF]
+    const float* prob_b;  // [1]
+    const float* hypo;    // [B, D, h, w]
+    float* attn;          // [B, D, h, w]
+    float* depth;         // [B, h, w]
+    float* conf;          // [B, h, w] or null
+    float* inv_min;       // [B, h, w] or null
+    float* inv_max;
+    float* logits_out;    // optional [B, D, h, w]
+    int B, D, hw, CF;
+    float split_itv;
+};
+
+__global__ void select_depth_kernel(SelectArgs a) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (p >= a.hw) return;
+    const long vol = (long)b * a.D * a.hw, img = (long)b * a.hw;
+    mv::select_pixel(a.logits ? a.logits + vol : nullptr, a.feat ? a.feat + vol * a.CF : nullptr, a.prob_w, a.prob_b,
+                     a.CF, a.hypo + vol, a.attn + vol, a.depth + img, a.conf ? a.conf + img : nullptr,
+                     a.inv_min ? a.inv_min + img : nullptr, a.inv_max ? a.inv_max + img : nullptr,
+                     a.logits_out ? a.logits_out + vol : nullptr, a.D, a.hw, p, a.split_itv);
+}
+
+__global__ void upsample_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int hi, int wi,
+                                         int ho, int wo) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (p >= ho * wo) return;
+    out[(long)b * ho * wo + p] = mv::upsample_pixel(in + (long)b * hi * wi, hi, wi, ho, wo, p);
+}
+
+}  // namespace
+
+extern "C" int mvster_relative_projection(const float* proj_matrices, float* rt, int B, int N, void* stream) {
+    if (!proj_matrices || !rt) return MVSTER_ERR_NULL;
+    if (B <= 0 || N < 2) return MVSTER_ERR_SHAPE;
+    const int n = B * (N - 1);
+    hipLaunchKernelGGL(relative_projection_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       proj_matrices, rt, B, N);
+    return mv_check_launch();
+}
+
+extern "C" int mvster_init_range(const float* depth_values, int ndv, float* out, int B, int D, int h, int w,
+                                 int inverse, void* stream) {
+    if (!depth_values || !out) return MVSTER_ERR_NULL;
+    if (B <= 0 || D < 2 || h <= 0 || w <= 0 || ndv < 1) return MVSTER_ERR_SHAPE;
+    hipLaunchKernelGGL(init_range_kernel, dim3((h * w + 255) / 256, B), dim3(256), 0, (hipStream_t)stream,
+                       depth_values, ndv, out, B, D, h * w, inverse);
+    return mv_check_launch();
+}
+
+extern "C" int mvster_schedule_inverse_range(const float* inv_min, const float* inv_max, float* out, int B, int D,
+                                             int h, int w, void* stream) {
+    if (!inv_min || !inv_max || !out) return MVSTER_ERR_NULL;
+    if (B <= 0 || D < 2 || h < 2 || w < 2) return MVSTER_ERR_SHAPE;
+    hipLaunchKernelGGL(schedule_inverse_kernel, dim3((h * w + 255) / 256, B), dim3(256), 0, (hipStream_t)stream,
+                       inv_min, inv_max, out, B, D, h, w, h / 2, w / 2);
+    return mv_check_launch();
+}
+
+extern "C" int mvster_schedule_range(const float* cur_depth, const float* interval, float* out, int B, int D, int h,
+                                     int w, void* stream) {
+    if (!cur_depth || !interval || !out) return MVSTER_ERR_NULL;
+    if (B <= 0 || D < 2 || h < 2 || w < 2) return MVSTER_ERR_SHAPE;
+    hipLaunchKernelGGL(schedule_linear_kernel, dim3((h * w + 255) / 256, B), dim3(256), 0, (hipStream_t)stream,
+                       cur_depth, interval, out, B, D, h, w, h / 2, w / 2);
+    return mv_check_launch();
+}
+
+extern "C" int mvster_select_depth(const float* logits, const float* feat, const float* prob_w, const float* prob_b,
+                                   int CF, const float* hypo, float* attn, float* depth, float* conf, float* inv_min,
+                                   float* inv_max, float* logits_out, int B, int D, int h, int w, float split_itv,
+                                   void* stream) {
+    if ((!logits && !feat) || !hypo || !attn || !depth) return MVSTER_ERR_NULL;
+    if (feat && (!prob_w || !prob_b)) return MVSTER_ERR_NULL;
+    if ((inv_min == nullptr) != (inv_max == nullptr)) return MVSTER_ERR_NULL;
+    if (B <= 0 || D < 1 || D > kMaxD || h <= 0 || w <= 0) return MVSTER_ERR_SHAPE;
+    if (inv_min && D < 3) return MVSTER_ERR_SHAPE;
+    if (feat && (CF <= 0 || CF % 4 != 0)) return MVSTER_ERR_SHAPE;
+    SelectArgs a;
+    a.logits = logits; a.feat = feat; a.prob_w = prob_w; a.prob_b = prob_b; a.hypo = hypo; a.attn = attn;
+    a.depth = depth; a.conf = conf; a.inv_min = inv_min; a.inv_max = inv_max; a.logits_out = logits_out;
+    a.B = B; a.D = D; a.hw = h * w; a.CF = CF; a.split_itv = split_itv;
+    hipLaunchKernelGGL(select_depth_kernel, dim3((h * w + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, a);
+    return mv_check_launch();
+}
+
+extern "C" int mvster_upsample_bilinear(const float* in, float* out, int B, int hi, int wi, int ho, int wo,
+                                        void* stream) {
+    if (!in || !out) return MVSTER_ERR_NULL;
+    if (B <= 0 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0) return MVSTER_ERR_SHAPE;
+    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3((ho * wo + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, in,
+                       out, B, hi, wi, ho, wo);
+    return mv_check_launch();
+}

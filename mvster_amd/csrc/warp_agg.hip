@@ -1,0 +1,408 @@
+// Fused homography warp + group correlation + epipolar attention aggregation (forward).
+//
+// Replaces, for one cascade stage and ALL source views in one launch, the reference's
+//   homo_warping            models/mvs4net_utils.py:13-59
+//   group / squared corr    models/mvs4net_utils.py:1037-1042
+//   attention aggregation   models/mvs4net_utils.py:1048-1060
+// without ever materialising the [B,C,D,h,w] warped volumes.
+//
+// Data layout (HBM):
+//   ref feature  [B, h, w, C]        channels-last fp32
+//   src features [NV][B, Hs, Ws, C]  channels-last fp32 (view / batch strides are arguments)
+//   rt           [B, NV, 12]         relative projection rot(9) + trans(3)
+//   hypo         [B, D, h, w]        depth hypotheses (API layout of `hypo_depth`)
+//   out          [B, D, h, w, G]     aggregated correlation, channels-last (feeds conv0 of reg2d)
+//
+// Mapping: a workgroup is 64 consecutive reference pixels x D hypotheses; wave d handles
+// hypothesis d for the 64 pixels (lane = pixel, so a wave's four bilinear taps fall on a
+// short, contiguous run of source texels: one channels-last tap is C*4 bytes per lane and
+// neighbouring lanes hit neighbouring texels).  The softmax over the depth axis is the
+// only cross-wave step: each wave publishes its 64 scores in LDS (double-buffered by
+// view parity, one barrier per view) and every lane reduces the D scores of its pixel.
+//
+// Roofline: HBM-bound.  Algorithmic bytes per launch = 4*[(NV+1)*C*hw + D*hw + G*D*hw]*B.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kMaxD = 16;
+
+struct WarpAggArgs {
+    const float* ref;
+    const float* src;
+    const float* rt;
+    const float* hypo;
+    float* out;
+    float* wsum_out;  // optional [B, D, h, w] (saved for the backward pass)
+    long ref_bs;      // batch stride of ref (elements)
+    long src_vs;      // view stride of src
+    long src_bs;      // batch stride of src
+    int B, NV, D, h, w, Hs, Ws;
+    float attn_temp;
+    float sqrt_c;
+    int fuse_d;
+};
+
+template <int C, int G, bool GROUP, int DMAX>
+__global__ void __launch_bounds__(64 * DMAX) warp_agg_fwd_kernel(WarpAggArgs a) {
+    static_assert(C % 8 == 0, "channels-last taps are read as float4 pairs");
+    static_assert(GROUP ? (C % G == 0) : (C == G), "group layout");
+    constexpr int CG = C / G;                // channels per correlation group
+    constexpr int CB = CG > 8 ? CG : 8;      // channels gathered per loop iteration
+    constexpr int GB = CB / CG;              // groups completed per iteration
+    static_assert(C % CB == 0, "channel block");
+    // per-view correlations live in LDS (G floats per thread) so that the gather loop can
+    // stay rolled: ~45 VGPRs for every C instead of 4*C registers of in-flight taps
+    __shared__ float sc[2][DMAX][64];
+    __shared__ float corL[G][DMAX * 64];
+
+    const int tx = threadIdx.x;
+    const int d = threadIdx.y;
+    const int tid = d * 64 + tx;
+    const int b = blockIdx.y;
+    const int hw = a.h * a.w;
+    const int p = blockIdx.x * 64 + tx;
+    const bool valid = p < hw;
+    const int pc = valid ? p : hw - 1;  // clamped: every lane takes part in the barriers
+    const int y = pc / a.w;
+    const int x = pc - y * a.w;
+    const float depth = a.hypo[((long)b * a.D + d) * hw + pc];
+    const float* rp = a.ref + (long)b * a.ref_bs + (long)pc * C;
+
+    float acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = 0.0f;
+    float wsum = 1e-8f;
+
+    for (int v = 0; v < a.NV; ++v) {
+        mv::RT m;
+        {
+            const float* r = a.rt + ((long)b * a.NV + v) * 12;  // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 9; ++i) m.r[i] = r[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) m.t[i] = r[9 + i];
+        }
+        float sx, sy;
+        mv::project(m, (float)x, (float)y, depth, a.Hs, a.Ws, sx, sy);
+        mv::Taps t = mv::make_taps(sx, sy, a.Hs, a.Ws);
+        const mv::TapsClamped tc = mv::clamp_taps(t, a.Hs, a.Ws);
+        const float* sp = a.src + (long)v * a.src_vs + (long)b * a.src_bs;
+        const float* p00 = sp + ((long)tc.ya * a.Ws + tc.xa) * C;
+        const float* p01 = sp + ((long)tc.ya * a.Ws + tc.xb) * C;
+        const float* p10 = sp + ((long)tc.yb * a.Ws + tc.xa) * C;
+        const float* p11 = sp + ((long)tc.yb * a.Ws + tc.xb) * C;
+
+        float score = 0.0f;
+#pragma unroll 2
+        for (int cb = 0; cb < C / CB; ++cb) {
+            const int cbase = cb * CB;
+            float part[GB];
+#pragma unroll
+            for (int c0 = 0; c0 < CB; c0 += 4) {
+                const f32x4 R = ld4(rp + cbase + c0);
+                const f32x4 A = ld4(p00 + cbase + c0);
+                const f32x4 Bq = ld4(p01 + cbase + c0);
+                const f32x4 Cq = ld4(p10 + cbase + c0);
+                const f32x4 Dq = ld4(p11 + cbase + c0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = c0 + j;  // channel within the block
+                    const float wv = mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
+                    if (GROUP) {
+                        const float pr = mv::mul_rn(wv, R[j]);
+                        part[c / CG] = (c % CG == 0) ? pr : mv::add_rn(part[c / CG], pr);
+                    } else {
+                        const float df = mv::sub_rn(R[j], wv);
+                        part[c] = mv::mul_rn(df, df);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                const float cg = GROUP ? mv::div_rn(part[k], (float)CG) : part[k];  // .mean(2)
+                corL[cb * GB + k][tid] = cg;
+                score = (cb == 0 && k == 0) ? cg : mv::add_rn(score, cg);           // .sum(1)
+            }
+        }
+        if (a.fuse_d) score = mv::div_rn(score, a.attn_temp);
+
+        float (*buf)[64] = sc[v & 1];
+        buf[d][tx] = score;
+        __syncthreads();
+        float mx = buf[0][tx];
+        for (int j = 1; j < a.D; ++j) mx = fmaxf(mx, buf[j][tx]);
+        float den = 0.0f;
+        for (int j = 0; j < a.D; ++j) den = mv::add_rn(den, expf(mv::sub_rn(buf[j][tx], mx)));
+        float wgt;
+        if (a.fuse_d)
+            wgt = mv::div_rn(mv::div_rn(expf(mv::sub_rn(score, mx)), den), a.sqrt_c);
+        else
+            wgt = mv::div_rn(1.0f, den);  // max_d softmax = exp(0) / sum
+        wsum = mv::add_rn(wsum, wgt);
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] = mv::add_rn(acc[g], mv::mul_rn(wgt, corL[g][tid]));
+    }
+
+    if (valid) {
+        const long o = (((long)b * a.D + d) * hw + p);
+        float* op = a.out + o * G;
+#pragma unroll
+        for (int g = 0; g < G; g += 4) {
+            f32x4 r;
+            r[0] = mv::div_rn(acc[g], wsum);
+            r[1] = mv::div_rn(acc[g + 1], wsum);
+            r[2] = mv::div_rn(acc[g + 2], wsum);
+            r[3] = mv::div_rn(acc[g + 3], wsum);
+            st4(op + g, r);
+        }
+        if (a.wsum_out) a.wsum_out[o] = wsum;
+    }
+}
+
+template <int C, int G, bool GROUP>
+int launch_fwd(const WarpAggArgs& a, hipStream_t stream) {
+    dim3 block(64, a.D);
+    dim3 grid((a.h * a.w + 63) / 64, a.B);
+    if (a.D <= 8) {
+        hipLaunchKernelGGL((warp_agg_fwd_kernel<C, G, GROUP, 8>), grid, block, 0, stream, a);
+    } else {
+        // 1024-thread blocks; the per-thread correlations of the widest ungrouped case do not fit LDS
+        if constexpr (G * kMaxD * 64 * 4 > 120 * 1024) return MVSTER_ERR_UNSUPPORTED;
+        else hipLaunchKernelGGL((warp_agg_fwd_kernel<C, G, GROUP, kMaxD>), grid, block, 0, stream, a);
+    }
+    return mv_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward w.r.t. the features (training; autograd of mvs4net_utils.py:1036-1060).  The grid is
+// not differentiated (torch.no_grad at :23).  Per (pixel, d) thread and per view: re-gather the
+// taps, redo the depth softmax, form dL/dcor, then re-gather once more to scatter
+//   d src[tap][c] += w_tap * dwarp[c]      (atomic, 4 taps x C)
+//   d ref[c]      += ...                   (atomic, summed over d and views)
+// Uses `out` and `wsum` saved by the forward.  attn_fuse_d only.
+// ------------------------------------------------------------------------------------------
+struct WarpAggBwdArgs {
+    WarpAggArgs f;
+    const float* fwd_out;   // [B, D, h, w, G]
+    const float* wsum;      // [B, D, h, w]
+    const float* grad_out;  // [B, D, h, w, G]
+    float* grad_ref;        // [B, h, w, C]
+    float* grad_src;        // [NV][B, Hs, Ws, C]  (same strides as src)
+};
+
+template <int C, int G, bool GROUP, int DMAX>
+__global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs ba) {
+    const WarpAggArgs& a = ba.f;
+    constexpr int CG = C / G;
+    constexpr int CB = CG > 8 ? CG : 8;
+    constexpr int GB = CB / CG;
+    __shared__ float sc[2][DMAX][64];
+    __shared__ float sd[2][DMAX][64];
+    __shared__ float corL[G][DMAX * 64];
+
+    const int tx = threadIdx.x;
+    const int d = threadIdx.y;
+    const int tid = d * 64 + tx;
+    const int b = blockIdx.y;
+    const int hw = a.h * a.w;
+    const int p = blockIdx.x * 64 + tx;
+    const bool valid = p < hw;
+    const int pc = valid ? p : hw - 1;
+    const int y = pc / a.w;
+    const int x = pc - y * a.w;
+    const long o = ((long)b * a.D + d) * hw + pc;
+    const float depth = a.hypo[o];
+    const float* rp = a.ref + (long)b * a.ref_bs + (long)pc * C;
+    float* grp = ba.grad_ref + (long)b * a.ref_bs + (long)pc * C;
+    const float W = ba.wsum[o];
+    const float invW = 1.0f / W;
+
+    float go[G];
+    float common = 0.0f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        go[g] = valid ? ba.grad_out[o * G + g] : 0.0f;
+        common = fmaf(go[g], ba.fwd_out[o * G + g], common);
+    }
+
+    for (int v = 0; v < a.NV; ++v) {
+        mv::RT m;
+        {
+            const float* r = a.rt + ((long)b * a.NV + v) * 12;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) m.r[i] = r[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) m.t[i] = r[9 + i];
+        }
+        float sx, sy;
+        mv::project(m, (float)x, (float)y, depth, a.Hs, a.Ws, sx, sy);
+        mv::Taps t = mv::make_taps(sx, sy, a.Hs, a.Ws);
+        const mv::TapsClamped tc = mv::clamp_taps(t, a.Hs, a.Ws);
+        const long voff = (long)v * a.src_vs + (long)b * a.src_bs;
+        const long o00 = ((long)tc.ya * a.Ws + tc.xa) * C, o01 = ((long)tc.ya * a.Ws + tc.xb) * C;
+        const long o10 = ((long)tc.yb * a.Ws + tc.xa) * C, o11 = ((long)tc.yb * a.Ws + tc.xb) * C;
+        const float* sp = a.src + voff;
+        float* gsp = ba.grad_src + voff;
+
+        // pass 1: correlations and score (same arithmetic as the forward)
+        float score = 0.0f;
+        for (int cb = 0; cb < C / CB; ++cb) {
+            const int cbase = cb * CB;
+            float part[GB];
+#pragma unroll
+            for (int c0 = 0; c0 < CB; c0 += 4) {
+                const f32x4 R = ld4(rp + cbase + c0);
+                const f32x4 A = ld4(sp + o00 + cbase + c0), Bq = ld4(sp + o01 + cbase + c0);
+                const f32x4 Cq = ld4(sp + o10 + cbase + c0), Dq = ld4(sp + o11 + cbase + c0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = c0 + j;
+                    const float wv = mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
+                    if (GROUP) {
+                        const float pr = mv::mul_rn(wv, R[j]);
+                        part[c / CG] = (c % CG == 0) ? pr : mv::add_rn(part[c / CG], pr);
+                    } else {
+                        const float df = mv::sub_rn(R[j], wv);
+                        part[c] = mv::mul_rn(df, df);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                const float cg = GROUP ? mv::div_rn(part[k], (float)CG) : part[k];
+                corL[cb * GB + k][tid] = cg;
+                score = (cb == 0 && k == 0) ? cg : mv::add_rn(score, cg);
+            }
+        }
+        score = mv::div_rn(score, a.attn_temp);
+        sc[v & 1][d][tx] = score;
+        __syncthreads();
+        float mx = sc[v & 1][0][tx];
+        for (int j = 1; j < a.D; ++j) mx = fmaxf(mx, sc[v & 1][j][tx]);
+        float den = 0.0f;
+        for (int j = 0; j < a.D; ++j) den += expf(sc[v & 1][j][tx] - mx);
+        const float sig = expf(score - mx) / den;
+        const float wgt = sig / a.sqrt_c;
+        // dL/dw_v = (sum_g go[g]*cor[g] - sum_g go[g]*out[g]) / W
+        float dw = -common;
+#pragma unroll
+        for (int g = 0; g < G; ++g) dw = fmaf(go[g], corL[g][tid], dw);
+        dw *= invW;
+        const float dsig = dw / a.sqrt_c;
+        sd[v & 1][d][tx] = sig * dsig;
+        __syncthreads();
+        float dot = 0.0f;
+        for (int j = 0; j < a.D; ++j) dot += sd[v & 1][j][tx];
+        const float dscore = sig * (dsig - dot) / a.attn_temp;   // d/d(sum_g cor[g])
+
+        // pass 2: re-gather, scatter the feature gradients
+        if (valid) {
+            for (int cb = 0; cb < C / CB; ++cb) {
+                const int cbase = cb * CB;
+#pragma unroll
+                for (int c0 = 0; c0 < CB; c0 += 4) {
+                    const f32x4 R = ld4(rp + cbase + c0);
+                    const f32x4 A = ld4(sp + o00 + cbase + c0), Bq = ld4(sp + o01 + cbase + c0);
+                    const f32x4 Cq = ld4(sp + o10 + cbase + c0), Dq = ld4(sp + o11 + cbase + c0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = cbase + c0 + j;
+                        const int g = GROUP ? c / CG : c;
+                        const float dcor = fmaf(go[g] * invW, wgt, dscore);   // direct + through the softmax
+                        const float wv = mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
+                        float dwv, dref;
+                        if (GROUP) {
+                            dwv = dcor * (1.0f / CG) * R[j];
+                            dref = dcor * (1.0f / CG) * wv;
+                        } else {
+                            const float df = R[j] - wv;
+                            dref = 2.0f * df * dcor;
+                            dwv = -dref;
+                        }
+                        unsafeAtomicAdd(grp + c, dref);
+                        if (t.nw != 0.0f) unsafeAtomicAdd(gsp + o00 + c, t.nw * dwv);
+                        if (t.ne != 0.0f) unsafeAtomicAdd(gsp + o01 + c, t.ne * dwv);
+                        if (t.sw != 0.0f) unsafeAtomicAdd(gsp + o10 + c, t.sw * dwv);
+                        if (t.se != 0.0f) unsafeAtomicAdd(gsp + o11 + c, t.se * dwv);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int C, int G, bool GROUP>
+int launch_bwd(const WarpAggBwdArgs& ba, hipStream_t stream) {
+    const WarpAggArgs& a = ba.f;
+    if (a.D > 8) return MVSTER_ERR_UNSUPPORTED;
+    dim3 block(64, a.D);
+    dim3 grid((a.h * a.w + 63) / 64, a.B);
+    hipLaunchKernelGGL((warp_agg_bwd_kernel<C, G, GROUP, 8>), grid, block, 0, stream, ba);
+    return mv_check_launch();
+}
+
+}  // namespace
+
+extern "C" int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat, const float* rt, const float* hypo,
+                                   float* out, float* wsum_out, int B, int NV, int C, int G, int D, int h, int w,
+                                   int Hs, int Ws, long ref_batch_stride, long src_view_stride, long src_batch_stride,
+                                   int group_cor, int attn_fuse_d, float attn_temp, void* stream) {
+    if (!ref_feat || !src_feat || !rt || !hypo || !out) return MVSTER_ERR_NULL;
+    if (B <= 0 || NV <= 0 || D <= 0 || D > kMaxD || h <= 0 || w <= 0 || Hs <= 0 || Ws <= 0) return MVSTER_ERR_SHAPE;
+    if (!group_cor && G != C) return MVSTER_ERR_SHAPE;
+    WarpAggArgs a;
+    a.ref = ref_feat; a.src = src_feat; a.rt = rt; a.hypo = hypo; a.out = out; a.wsum_out = wsum_out;
+    a.ref_bs = ref_batch_stride; a.src_vs = src_view_stride; a.src_bs = src_batch_stride;
+    a.B = B; a.NV = NV; a.D = D; a.h = h; a.w = w; a.Hs = Hs; a.Ws = Ws;
+    a.attn_temp = attn_temp; a.sqrt_c = sqrtf((float)C); a.fuse_d = attn_fuse_d;
+    hipStream_t s = (hipStream_t)stream;
+#define MV_CASE(CC, GG, GR) \
+    if (C == CC && G == GG && (group_cor != 0) == GR) return launch_fwd<CC, GG, GR>(a, s);
+    MV_CASE(64, 8, true)
+    MV_CASE(32, 8, true)
+    MV_CASE(16, 4, true)
+    MV_CASE(8, 4, true)
+    MV_CASE(16, 8, true)
+    MV_CASE(8, 8, true)
+    MV_CASE(64, 4, true)
+    MV_CASE(32, 4, true)
+    MV_CASE(8, 8, false)
+    MV_CASE(16, 16, false)
+    MV_CASE(32, 32, false)
+    MV_CASE(64, 64, false)
+#undef MV_CASE
+    return MVSTER_ERR_UNSUPPORTED;
+}
+
+extern "C" int mvster_warp_agg_bwd(const float* ref_feat, const float* src_feat, const float* rt, const float* hypo,
+                                   const float* out, const float* wsum, const float* grad_out, float* grad_ref,
+                                   float* grad_src, int B, int NV, int C, int G, int D, int h, int w, int Hs, int Ws,
+                                   long ref_batch_stride, long src_view_stride, long src_batch_stride, int group_cor,
+                                   int attn_fuse_d, float attn_temp, void* stream) {
+    if (!ref_feat || !src_feat || !rt || !hypo || !out || !wsum || !grad_out || !grad_ref || !grad_src)
+        return MVSTER_ERR_NULL;
+    if (B <= 0 || NV <= 0 || D <= 0 || D > 8 || h <= 0 || w <= 0 || Hs <= 0 || Ws <= 0) return MVSTER_ERR_SHAPE;
+    if (!group_cor && G != C) return MVSTER_ERR_SHAPE;
+    if (!attn_fuse_d) return MVSTER_ERR_UNSUPPORTED;
+    WarpAggBwdArgs ba;
+    WarpAggArgs& a = ba.f;
+    a.ref = ref_feat; a.src = src_feat; a.rt = rt; a.hypo = hypo; a.out = nullptr; a.wsum_out = nullptr;
+    a.ref_bs = ref_batch_stride; a.src_vs = src_view_stride; a.src_bs = src_batch_stride;
+    a.B = B; a.NV = NV; a.D = D; a.h = h; a.w = w; a.Hs = Hs; a.Ws = Ws;
+    a.attn_temp = attn_temp; a.sqrt_c = sqrtf((float)C); a.fuse_d = attn_fuse_d;
+    ba.fwd_out = out; ba.wsum = wsum; ba.grad_out = grad_out; ba.grad_ref = grad_ref; ba.grad_src = grad_src;
+    hipStream_t s = (hipStream_t)stream;
+#define MV_CASE(CC, GG, GR) \
+    if (C == CC && G == GG && (group_cor != 0) == GR) return launch_bwd<CC, GG, GR>(ba, s);
+    MV_CASE(64, 8, true)
+    MV_CASE(32, 8, true)
+    MV_CASE(16, 4, true)
+    MV_CASE(8, 4, true)
+    MV_CASE(16, 8, true)
+    MV_CASE(8, 8, true)
+    MV_CASE(8, 8, false)
+    MV_CASE(16, 16, false)
+#undef MV_CASE
+    return MVSTER_ERR_UNSUPPORTED;
+}

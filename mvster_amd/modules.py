@@ -1,0 +1,175 @@
+"""Parameter containers of the MVS4net module tree.
+
+These modules own the learnable state with exactly the reference's ``state_dict`` keys
+(348 tensors for the shipped configuration: ``feature.*`` 76, ``reg.{0..3}.*`` 62 each,
+``mono_depth_decoder.*`` 24 -- SURVEY.md section 5), so reference checkpoints load with
+``strict=True``.  Their ``forward`` is the differentiable PyTorch-ROCm (MIOpen) form used in
+training mode, where BatchNorm runs on batch statistics and cannot be folded; in eval mode
+``mvster_amd.net.MVS4net`` bypasses it and runs the hand-written gfx950 kernels through
+``mvster_amd.conv_plan``.
+
+Reference: models/mvs4net_utils.py:116-123 (ConvBnReLU3D), :224-251 (Conv2d), :419-502 (FPN4),
+:833-868 (mono_depth_decoder), :870-912 (reg2d), :914-965 (reg3d).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class ConvBnReLU3D(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1):
+        super().__init__()
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
+        self.bn = nn.BatchNorm3d(out_channels)
+
+    def forward(self, x):
+        return F.relu(self.bn(self.conv(x)), inplace=True)
+
+
+def _deconv_bn_relu(cin, cout, kernel, pad, out_pad, stride):
+    return nn.Sequential(
+        nn.ConvTranspose3d(cin, cout, kernel_size=kernel, padding=pad, output_padding=out_pad, stride=stride, bias=False),
+        nn.BatchNorm3d(cout), nn.ReLU(inplace=True))
+
+
+class reg2d(nn.Module):
+    def __init__(self, input_channel=128, base_channel=32, conv_name="ConvBnReLU3D"):
+        super().__init__()
+        if conv_name != "ConvBnReLU3D":
+            raise NotImplementedError("agg_type %r: only the shipped ConvBnReLU3D blocks are built" % conv_name)
+        c = base_channel
+        flat = dict(kernel_size=(1, 3, 3), pad=(0, 1, 1))
+        down = dict(kernel_size=(1, 3, 3), stride=(1, 2, 2), pad=(0, 1, 1))
+        self.conv0 = ConvBnReLU3D(input_channel, c, **flat)
+        self.conv1 = ConvBnReLU3D(c, c * 2, **down)
+        self.conv2 = ConvBnReLU3D(c * 2, c * 2)
+        self.conv3 = ConvBnReLU3D(c * 2, c * 4, **down)
+        self.conv4 = ConvBnReLU3D(c * 4, c * 4)
+        self.conv5 = ConvBnReLU3D(c * 4, c * 8, **down)
+        self.conv6 = ConvBnReLU3D(c * 8, c * 8)
+        up = ((1, 3, 3), (0, 1, 1), (0, 1, 1), (1, 2, 2))
+        self.conv7 = _deconv_bn_relu(c * 8, c * 4, *up)
+        self.conv9 = _deconv_bn_relu(c * 4, c * 2, *up)
+        self.conv11 = _deconv_bn_relu(c * 2, c, *up)
+        self.prob = nn.Conv3d(8, 1, 1, stride=1, padding=0)   # hard-coded 8 inputs, with bias (reference :900)
+
+    def forward(self, x):
+        c0 = self.conv0(x)
+        c2 = self.conv2(self.conv1(c0))
+        c4 = self.conv4(self.conv3(c2))
+        x = self.conv6(self.conv5(c4))
+        x = c4 + self.conv7(x)
+        x = c2 + self.conv9(x)
+        x = c0 + self.conv11(x)
+        return self.prob(x).squeeze(1)
+
+
+class reg3d(nn.Module):
+    def __init__(self, in_channels, base_channels, down_size=3):
+        super().__init__()
+        c = base_channels
+        self.down_size = down_size
+        self.conv0 = ConvBnReLU3D(in_channels, c, kernel_size=3, pad=1)
+        self.conv1 = ConvBnReLU3D(c, c * 2, kernel_size=3, stride=2, pad=1)
+        self.conv2 = ConvBnReLU3D(c * 2, c * 2)
+        if down_size >= 2:
+            self.conv3 = ConvBnReLU3D(c * 2, c * 4, kernel_size=3, stride=2, pad=1)
+            self.conv4 = ConvBnReLU3D(c * 4, c * 4)
+        if down_size >= 3:
+            self.conv5 = ConvBnReLU3D(c * 4, c * 8, kernel_size=3, stride=2, pad=1)
+            self.conv6 = ConvBnReLU3D(c * 8, c * 8)
+            self.conv7 = _deconv_bn_relu(c * 8, c * 4, 3, 1, 1, 2)
+        if down_size >= 2:
+            self.conv9 = _deconv_bn_relu(c * 4, c * 2, 3, 1, 1, 2)
+        self.conv11 = _deconv_bn_relu(c * 2, c, 3, 1, 1, 2)
+        self.prob = nn.Conv3d(c, 1, 3, stride=1, padding=1, bias=False)
+
+    def forward(self, x):
+        c0 = self.conv0(x)
+        c2 = self.conv2(self.conv1(c0))
+        if self.down_size == 3:
+            c4 = self.conv4(self.conv3(c2))
+            x = self.conv6(self.conv5(c4))
+            x = c4 + self.conv7(x)
+            x = c2 + self.conv9(x)
+        elif self.down_size == 2:
+            x = self.conv4(self.conv3(c2))
+            x = c2 + self.conv9(x)
+        else:
+            x = c2
+        x = c0 + self.conv11(x)
+        return self.prob(x).squeeze(1)
+
+
+class Conv2d(nn.Module):
+    """conv (no bias) + BatchNorm2d + optional ReLU (reference Conv2d with gn=False)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, relu=True, bn_momentum=0.1, **kwargs):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, bias=False, **kwargs)
+        self.bn = nn.BatchNorm2d(out_channels, momentum=bn_momentum)
+        self.relu = relu
+
+    def forward(self, x):
+        x = self.bn(self.conv(x))
+        return F.relu(x, inplace=True) if self.relu else x
+
+
+class FPN4(nn.Module):
+    def __init__(self, base_channels, gn=False, dcn=False):
+        super().__init__()
+        if gn or dcn:
+            raise NotImplementedError("FPN4: GroupNorm / deformable-conv variants are out of scope (SURVEY.md section 2, #10)")
+        c = base_channels
+        self.base_channels = c
+        self.conv0 = nn.Sequential(Conv2d(3, c, 3, 1, padding=1), Conv2d(c, c, 3, 1, padding=1))
+        self.conv1 = nn.Sequential(Conv2d(c, c * 2, 5, stride=2, padding=2), Conv2d(c * 2, c * 2, 3, 1, padding=1),
+                                   Conv2d(c * 2, c * 2, 3, 1, padding=1))
+        self.conv2 = nn.Sequential(Conv2d(c * 2, c * 4, 5, stride=2, padding=2), Conv2d(c * 4, c * 4, 3, 1, padding=1),
+                                   Conv2d(c * 4, c * 4, 3, 1, padding=1))
+        self.conv3 = nn.Sequential(Conv2d(c * 4, c * 8, 5, stride=2, padding=2), Conv2d(c * 8, c * 8, 3, 1, padding=1),
+                                   Conv2d(c * 8, c * 8, 3, 1, padding=1))
+        f = c * 8
+        self.inner1 = nn.Conv2d(c * 4, f, 1, bias=True)
+        self.inner2 = nn.Conv2d(c * 2, f, 1, bias=True)
+        self.inner3 = nn.Conv2d(c, f, 1, bias=True)
+        self.out1 = nn.Conv2d(f, c * 8, 1, bias=False)
+        self.out2 = nn.Conv2d(f, c * 4, 3, padding=1, bias=False)
+        self.out3 = nn.Conv2d(f, c * 2, 3, padding=1, bias=False)
+        self.out4 = nn.Conv2d(f, c, 3, padding=1, bias=False)
+        self.out_channels = [c * 8, c * 4, c * 2, c]
+
+    def forward(self, x):
+        c0 = self.conv0(x)
+        c1 = self.conv1(c0)
+        c2 = self.conv2(c1)
+        c3 = self.conv3(c2)
+        out = {"stage1": self.out1(c3)}
+        f = F.interpolate(c3, scale_factor=2, mode="bilinear", align_corners=True) + self.inner1(c2)
+        out["stage2"] = self.out2(f)
+        f = F.interpolate(f, scale_factor=2, mode="bilinear", align_corners=True) + self.inner2(c1)
+        out["stage3"] = self.out3(f)
+        f = F.interpolate(f, scale_factor=2, mode="bilinear", align_corners=True) + self.inner3(c0)
+        out["stage4"] = self.out4(f)
+        return out
+
+
+class mono_depth_decoder(nn.Module):
+    """Training-only auxiliary monocular head."""
+
+    def __init__(self):
+        super().__init__()
+        self.convblocks = nn.ModuleList([Conv2d(64, 32, 3, 1, padding=1), Conv2d(32, 16, 3, 1, padding=1),
+                                         Conv2d(16, 8, 3, 1, padding=1)])
+        self.conv3x3 = nn.ModuleList([nn.Conv2d(64, 1, 3, 1, 1), nn.Conv2d(32, 1, 3, 1, 1), nn.Conv2d(16, 1, 3, 1, 1)])
+
+    def forward(self, outputs, d_min, d_max):
+        for i in range(1, 4):
+            coarse = outputs["stage%d" % i]["mono_feat"]
+            fine = outputs["stage%d" % (i + 1)]["mono_feat"]
+            coarse = F.interpolate(self.convblocks[i - 1](coarse), scale_factor=2, mode="nearest")
+            disp = torch.sigmoid(self.conv3x3[i - 1](torch.cat([coarse, fine], 1)))
+            lo = (1 / d_max)[:, None, None, None]
+            hi = (1 / d_min)[:, None, None, None]
+            outputs["stage%d" % (i + 1)]["mono_depth"] = (1 / (lo + (hi - lo) * disp)).squeeze(1)
+        return outputs

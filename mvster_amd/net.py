@@ -1,0 +1,234 @@
+"""``MVS4net`` -- the reference's model API on hand-written gfx950 kernels.
+
+Drop-in for ``models.MVS4Net.MVS4net`` (reference models/MVS4Net.py:9-111): same constructor
+keywords (including the ``depth_interals_ratio`` spelling), same
+``forward(imgs, proj_matrices, depth_values, filename=None)``, same output dict (``stage1..4``
+sub-dicts plus the last stage flattened at top level) and the same ``state_dict`` keys.
+
+Execution:
+* eval  -- every op of the cascade runs in libmvster_hip.so: FPN4 and the regularisation U-Nets on
+  the fp32 MFMA convolution kernel (BatchNorm folded), one fused warp+correlation+attention launch
+  per stage, fused prob+softmax+argmax+gather selection, hypothesis schedulers, confidence
+  upsampling.  No host synchronisation inside ``forward`` (the reference's ``.cpu().numpy()``
+  at MVS4Net.py:61-62 is gone), so the whole forward can be captured in a HIP graph
+  (``mvster_amd.graph.GraphedForward``).
+* train -- BatchNorm needs batch statistics, so the convolutions run through PyTorch-ROCm
+  autograd; the fused warp/aggregation kernel is wrapped in an ``autograd.Function`` with a
+  hand-written HIP backward.
+There is no CPU path: CPU tensors raise.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .conv_plan import FpnPlan, Reg2dPlan, Reg3dPlan
+from .modules import FPN4, mono_depth_decoder, reg2d, reg3d
+
+
+class _WarpAgg(torch.autograd.Function):
+    """cor_feats [B,G,D,h,w] from NCHW features; HIP forward + HIP backward."""
+
+    @staticmethod
+    def forward(ctx, ref_fea, src_feas, rt, hypo, G, group_cor, attn_fuse_d, attn_temp):
+        ref_cl = ops.to_channels_last(ref_fea)
+        src_cl = src_feas.permute(0, 1, 3, 4, 2).contiguous()          # [NV,B,C,Hs,Ws] -> [NV,B,Hs,Ws,C]
+        out, wsum = ops.warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, group_cor, attn_fuse_d, attn_temp, want_wsum=True)
+        ctx.save_for_backward(ref_cl, src_cl, rt, hypo, out, wsum)
+        ctx.cfg = (G, group_cor, attn_fuse_d, attn_temp)
+        return out.permute(0, 4, 1, 2, 3)                              # [B,G,D,h,w] view
+
+    @staticmethod
+    def backward(ctx, grad):
+        ref_cl, src_cl, rt, hypo, out, wsum = ctx.saved_tensors
+        G, group_cor, attn_fuse_d, attn_temp = ctx.cfg
+        g_cl = grad.permute(0, 2, 3, 4, 1).contiguous()                # [B,D,h,w,G]
+        g_ref, g_src = ops.warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, g_cl, G, group_cor, attn_fuse_d,
+                                           attn_temp)
+        return g_ref.permute(0, 3, 1, 2), g_src.permute(0, 1, 4, 2, 3), None, None, None, None, None, None
+
+
+class MVS4net(nn.Module):
+    def __init__(self, arch_mode="fpn", reg_net="reg2d", num_stage=4, fpn_base_channel=8, reg_channel=8,
+                 stage_splits=[8, 8, 4, 4], depth_interals_ratio=[0.5, 0.5, 0.5, 1], group_cor=False,
+                 group_cor_dim=[8, 8, 8, 8], inverse_depth=False, agg_type="ConvBnReLU3D", dcn=False, pos_enc=0,
+                 mono=False, asff=False, attn_temp=2, attn_fuse_d=True, vis_ETA=False, vis_mono=False):
+        super().__init__()
+        if arch_mode != "fpn":
+            raise NotImplementedError("arch_mode %r (only 'fpn' exists in the reference too)" % arch_mode)
+        if dcn or asff or pos_enc or vis_ETA or vis_mono:
+            raise NotImplementedError("dcn / asff / pos_enc / vis_* ablation switches are out of scope "
+                                      "(SURVEY.md section 2, #10): not enabled by the shipped scripts")
+        self.arch_mode = arch_mode
+        self.num_stage = num_stage
+        self.depth_interals_ratio = list(depth_interals_ratio)
+        self.group_cor = group_cor
+        self.group_cor_dim = list(group_cor_dim)
+        self.inverse_depth = inverse_depth
+        self.stage_splits = list(stage_splits)
+        self.mono = mono
+        self.attn_temp = attn_temp
+        self.attn_fuse_d = attn_fuse_d
+        self.reg_net = reg_net
+        self.feature = FPN4(base_channels=fpn_base_channel)
+        # empty lists kept for state_dict / attribute parity with the reference (MVS4Net.py:35,43)
+        self.attn_ob = nn.ModuleList()
+        self.pos_enc_func = nn.ModuleList()
+        self.reg = nn.ModuleList()
+        if self.mono:
+            self.mono_depth_decoder = mono_depth_decoder()
+        down_size = [3, 3, 2, 2]
+        for idx in range(num_stage):
+            in_dim = self.group_cor_dim[idx] if group_cor else self.feature.out_channels[idx]
+            if reg_net == "reg2d":
+                self.reg.append(reg2d(input_channel=in_dim, base_channel=reg_channel, conv_name=agg_type))
+            elif reg_net == "reg3d":
+                self.reg.append(reg3d(in_channels=in_dim, base_channels=reg_channel, down_size=down_size[idx]))
+            else:
+                raise NotImplementedError("reg_net %r" % reg_net)
+        self._plans = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_plans())
+
+    # ------------------------------------------------------------------ plan cache
+    def invalidate_plans(self):
+        """Drop the packed-weight plans; they are rebuilt on the next eval forward.  Called
+        automatically by load_state_dict(), train()/eval() and .to()/.cuda(); call it by hand
+        after modifying parameters in place while in eval mode."""
+        self._plans = None
+
+    def train(self, mode=True):
+        self._plans = None
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._plans = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def _get_plans(self):
+        if self._plans is None:
+            with torch.no_grad():
+                fpn = FpnPlan(self.feature)
+                regs = [Reg2dPlan(m) if isinstance(m, reg2d) else Reg3dPlan(m) for m in self.reg]
+            self._plans = (fpn, regs)
+        return self._plans
+
+    # ------------------------------------------------------------------ pieces
+    def _hypotheses(self, stage_idx, depth_values, depth_interval, prev, H, W):
+        D = self.stage_splits[stage_idx]
+        if stage_idx == 0:
+            return ops.init_range(depth_values, D, H, W, inverse=self.inverse_depth)
+        if self.inverse_depth:
+            return ops.schedule_inverse_range(prev["inverse_min_depth"].detach(), prev["inverse_max_depth"].detach(), D,
+                                              H, W)
+        return ops.schedule_range(prev["depth"].detach(), D, self.depth_interals_ratio[stage_idx] * depth_interval, H, W)
+
+    def _check_inputs(self, imgs, proj_matrices, depth_values):
+        if not imgs[0].is_cuda:
+            raise RuntimeError("mvster_amd.MVS4net runs on MI355X only: move the model and inputs to the GPU "
+                               "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests)")
+        if imgs[0].dtype != torch.float32:
+            raise RuntimeError("mvster_amd.MVS4net is fp32-only, like the reference path")
+        H, W = imgs[0].shape[-2:]
+        if H % 64 or W % 64:
+            raise RuntimeError("image size %dx%d: H and W must be multiples of 64 (stage-1 is H/8 and reg2d "
+                               "halves three more times)" % (H, W))
+
+    # ------------------------------------------------------------------ eval: all-HIP
+    @torch.no_grad()
+    def _forward_eval(self, imgs, proj_matrices, depth_values, teacher=None, capture=None):
+        N = len(imgs)
+        B, _, H, W = imgs[0].shape
+        dev = imgs[0].device
+        fpn, regs = self._get_plans()
+        depth_values = depth_values.to(dev, torch.float32)
+        depth_interval = (depth_values[:, -1] - depth_values[:, 0]) / depth_values.size(1)
+
+        x = torch.zeros(N * B, 1, H, W, 4, device=dev, dtype=torch.float32)       # RGB0, channels-last
+        x[:, 0, :, :, :3] = torch.stack(imgs, 0).reshape(N * B, 3, H, W).permute(0, 2, 3, 1)
+        pyramid = fpn(x)                                                         # 4 x [N*B,1,h,w,C]
+
+        outputs = {}
+        prev = None
+        for s in range(self.num_stage):
+            name = "stage%d" % (s + 1)
+            f = pyramid[s]
+            h, w, C = f.shape[2], f.shape[3], f.shape[4]
+            f = f.view(N, B, h, w, C)
+            ref_cl, src_cl = f[0], f[1:]
+            G = self.group_cor_dim[s] if self.group_cor else C
+            rt = ops.relative_projection(proj_matrices[name].to(dev, torch.float32))
+            if teacher is not None and name in teacher:
+                hypo = teacher[name].contiguous()
+            else:
+                hypo = self._hypotheses(s, depth_values, depth_interval, prev, h, w)
+            cor = ops.warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, self.group_cor, self.attn_fuse_d,
+                                      float(self.attn_temp))
+            plan = regs[s]
+            want_logits = capture is not None
+            if plan.fused_prob:
+                sel = ops.select_depth(hypo, self.depth_interals_ratio[s], self.inverse_depth, feat_cl=plan(cor),
+                                       prob_w=plan.prob_w, prob_b=plan.prob_b, want_logits=want_logits)
+            else:
+                sel = ops.select_depth(hypo, self.depth_interals_ratio[s], self.inverse_depth, logits=plan(cor),
+                                       want_logits=want_logits)
+            if capture is not None:
+                capture[name] = {"cor_feats": cor.permute(0, 4, 1, 2, 3), "logits": sel["logits"]}
+            conf = ops.upsample_bilinear(sel["conf"], 2 ** (3 - s))
+            st = {"depth": sel["depth"], "photometric_confidence": conf, "hypo_depth": hypo,
+                  "attn_weight": sel["attn_weight"]}
+            if self.inverse_depth:
+                st["inverse_min_depth"] = sel["inverse_min_depth"]
+                st["inverse_max_depth"] = sel["inverse_max_depth"]
+            if self.mono:
+                st["mono_feat"] = ref_cl.permute(0, 3, 1, 2)                     # [B,C,h,w] view, channels-last memory
+            prev = st
+            outputs[name] = st
+            outputs.update(st)
+        return outputs
+
+    # ------------------------------------------------------------------ train: autograd
+    def _forward_train(self, imgs, proj_matrices, depth_values):
+        dev = imgs[0].device
+        depth_values = depth_values.to(dev, torch.float32)
+        depth_interval = (depth_values[:, -1] - depth_values[:, 0]) / depth_values.size(1)
+        pyramids = [self.feature(img) for img in imgs]     # per view, like the reference (BN batch stats per view)
+        outputs = {}
+        prev = None
+        for s in range(self.num_stage):
+            name = "stage%d" % (s + 1)
+            feats = [p[name] for p in pyramids]
+            ref_fea = feats[0]
+            B, C, h, w = ref_fea.shape
+            G = self.group_cor_dim[s] if self.group_cor else C
+            with torch.no_grad():
+                rt = ops.relative_projection(proj_matrices[name].to(dev, torch.float32))
+                hypo = self._hypotheses(s, depth_values, depth_interval, prev, h, w)
+            cor = _WarpAgg.apply(ref_fea, torch.stack(feats[1:], 0), rt, hypo, G, self.group_cor, self.attn_fuse_d,
+                                 float(self.attn_temp))
+            attn = F.softmax(self.reg[s](cor.contiguous()), dim=1)
+            idx = attn.max(1, keepdim=True)[1]
+            depth = torch.gather(hypo, 1, idx).squeeze(1)
+            if self.training:
+                conf = torch.tensor(0.0, dtype=torch.float32, device=dev, requires_grad=False)
+            else:
+                with torch.no_grad():
+                    conf = ops.upsample_bilinear(attn.max(1)[0].contiguous(), 2 ** (3 - s))
+            st = {"depth": depth, "photometric_confidence": conf, "hypo_depth": hypo, "attn_weight": attn}
+            if self.inverse_depth:
+                itv = 1.0 / hypo[:, 2] - 1.0 / hypo[:, 1]
+                st["inverse_min_depth"] = 1 / depth + self.depth_interals_ratio[s] * itv
+                st["inverse_max_depth"] = 1 / depth - self.depth_interals_ratio[s] * itv
+            if self.mono:
+                st["mono_feat"] = ref_fea
+            prev = st
+            outputs[name] = st
+            outputs.update(st)
+        if self.mono and self.training:
+            outputs = self.mono_depth_decoder(outputs, depth_values[:, 0], depth_values[:, 1])
+        return outputs
+
+    def forward(self, imgs, proj_matrices, depth_values, filename=None):
+        self._check_inputs(imgs, proj_matrices, depth_values)
+        if self.training:
+            return self._forward_train(imgs, proj_matrices, depth_values)
+        return self._forward_eval(imgs, proj_matrices, depth_values)

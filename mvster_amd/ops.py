@@ -1,0 +1,175 @@
+"""Thin tensor-level wrappers over the C ABI (include/mvster_hip.h).
+
+Every function takes CUDA (=HIP) fp32 tensors, launches on torch's current stream and
+returns freshly allocated outputs.  Names and argument meaning follow the reference's
+functions in models/mvs4net_utils.py; shapes at this level use the reference's layouts
+(NCHW / NCDHW) unless the name says ``_cl`` (channels-last).
+"""
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError("mvster_amd.ops.%s: expected a GPU tensor (the HIP path has no CPU fallback)" % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError("mvster_amd.ops.%s: the path is fp32-only, got %s" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("mvster_amd.ops.%s: tensor must be contiguous" % name)
+
+
+def relative_projection(proj_matrices):
+    """[B,N,2,4,4] -> rt [B,N-1,12] (rot 9 + trans 3).  mvs4net_utils.py:24-26, :1032-1035."""
+    pm = proj_matrices.contiguous()
+    _chk(pm, "relative_projection")
+    B, N = pm.shape[:2]
+    rt = torch.empty(B, N - 1, 12, device=pm.device, dtype=torch.float32)
+    _lib.check(_lib.load().mvster_relative_projection(_ptr(pm), _ptr(rt), B, N, _stream()), "relative_projection")
+    return rt
+
+
+def to_channels_last(feat_nchw):
+    """[B,C,H,W] -> [B,H,W,C] contiguous."""
+    return feat_nchw.permute(0, 2, 3, 1).contiguous()
+
+
+def warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, group_cor=True, attn_fuse_d=True, attn_temp=2.0, want_wsum=False):
+    """ref_cl [B,h,w,C], src_cl [NV,B,Hs,Ws,C], rt [B,NV,12], hypo [B,D,h,w] ->
+    cor_feats channels-last [B,D,h,w,G] (and wsum [B,D,h,w]).  mvs4net_utils.py:1025-1060."""
+    for t, n in ((ref_cl, "ref"), (src_cl, "src"), (rt, "rt"), (hypo, "hypo")):
+        _chk(t, "warp_agg_fwd:" + n)
+    B, h, w, C = ref_cl.shape
+    NV, B2, Hs, Ws, C2 = src_cl.shape
+    D = hypo.shape[1]
+    if B2 != B or C2 != C or tuple(hypo.shape) != (B, D, h, w) or tuple(rt.shape) != (B, NV, 12):
+        raise RuntimeError("warp_agg_fwd: inconsistent shapes")
+    out = torch.empty(B, D, h, w, G, device=ref_cl.device, dtype=torch.float32)
+    wsum = torch.empty(B, D, h, w, device=ref_cl.device, dtype=torch.float32) if want_wsum else None
+    rc = _lib.load().mvster_warp_agg_fwd(_ptr(ref_cl), _ptr(src_cl), _ptr(rt), _ptr(hypo), _ptr(out), _ptr(wsum), B, NV,
+                                         C, G, D, h, w, Hs, Ws, h * w * C, B * Hs * Ws * C, Hs * Ws * C,
+                                         int(group_cor), int(attn_fuse_d), float(attn_temp), _stream())
+    _lib.check(rc, "warp_agg_fwd")
+    return (out, wsum) if want_wsum else out
+
+
+def warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad_out, G, group_cor=True, attn_fuse_d=True, attn_temp=2.0):
+    """Gradients of warp_agg_fwd_cl w.r.t. ref_cl and src_cl."""
+    grad_out = grad_out.contiguous()
+    for t, n in ((ref_cl, "ref"), (src_cl, "src"), (rt, "rt"), (hypo, "hypo"), (out, "out"), (wsum, "wsum"),
+                 (grad_out, "grad_out")):
+        _chk(t, "warp_agg_bwd:" + n)
+    B, h, w, C = ref_cl.shape
+    NV, _, Hs, Ws, _ = src_cl.shape
+    D = hypo.shape[1]
+    g_ref = torch.zeros_like(ref_cl)
+    g_src = torch.zeros_like(src_cl)
+    rc = _lib.load().mvster_warp_agg_bwd(_ptr(ref_cl), _ptr(src_cl), _ptr(rt), _ptr(hypo), _ptr(out), _ptr(wsum),
+                                         _ptr(grad_out), _ptr(g_ref), _ptr(g_src), B, NV, C, G, D, h, w, Hs, Ws,
+                                         h * w * C, B * Hs * Ws * C, Hs * Ws * C, int(group_cor), int(attn_fuse_d),
+                                         float(attn_temp), _stream())
+    _lib.check(rc, "warp_agg_bwd")
+    return g_ref, g_src
+
+
+def init_range(depth_values, ndepths, H, W, inverse):
+    """mvs4net_utils.py:61-77 -> [B,D,H,W]."""
+    dv = depth_values.contiguous()
+    _chk(dv, "init_range")
+    B, ndv = dv.shape
+    out = torch.empty(B, ndepths, H, W, device=dv.device, dtype=torch.float32)
+    _lib.check(_lib.load().mvster_init_range(_ptr(dv), ndv, _ptr(out), B, ndepths, H, W, int(inverse), _stream()),
+               "init_range")
+    return out
+
+
+def schedule_inverse_range(inverse_min_depth, inverse_max_depth, ndepths, H, W):
+    """mvs4net_utils.py:79-86: [B,H/2,W/2] x2 -> [B,D,H,W]."""
+    a, b = inverse_min_depth.contiguous(), inverse_max_depth.contiguous()
+    _chk(a, "schedule_inverse_range")
+    _chk(b, "schedule_inverse_range")
+    B, hi, wi = a.shape
+    if hi != H // 2 or wi != W // 2:
+        raise RuntimeError("schedule_inverse_range: previous stage must be at half resolution")
+    out = torch.empty(B, ndepths, H, W, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.load().mvster_schedule_inverse_range(_ptr(a), _ptr(b), _ptr(out), B, ndepths, H, W, _stream()),
+               "schedule_inverse_range")
+    return out
+
+
+def schedule_range(cur_depth, ndepth, depth_interval_pixel, H, W):
+    """mvs4net_utils.py:88-99; ``depth_interval_pixel`` is a [B] device tensor."""
+    a = cur_depth.contiguous()
+    itv = depth_interval_pixel.to(device=a.device, dtype=torch.float32).contiguous()
+    _chk(a, "schedule_range")
+    B, hi, wi = a.shape
+    if hi != H // 2 or wi != W // 2:
+        raise RuntimeError("schedule_range: previous stage must be at half resolution")
+    out = torch.empty(B, ndepth, H, W, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.load().mvster_schedule_range(_ptr(a), _ptr(itv), _ptr(out), B, ndepth, H, W, _stream()),
+               "schedule_range")
+    return out
+
+
+def select_depth(hypo, split_itv, inverse_depth, logits=None, feat_cl=None, prob_w=None, prob_b=None,
+                 want_logits=False):
+    """softmax / argmax / gather / confidence / inverse bounds (mvs4net_utils.py:1068-1088), with the
+    1x1x1 ``prob`` head (:900) fused when ``feat_cl`` [B,D,h,w,CF] is given instead of ``logits``."""
+    _chk(hypo, "select_depth:hypo")
+    B, D, h, w = hypo.shape
+    dev = hypo.device
+    CF = 0
+    if feat_cl is not None:
+        _chk(feat_cl, "select_depth:feat")
+        CF = feat_cl.shape[-1]
+        prob_w = prob_w.reshape(-1).contiguous()
+        prob_b = prob_b.reshape(-1).contiguous()
+    else:
+        logits = logits.contiguous()
+        _chk(logits, "select_depth:logits")
+    attn = torch.empty(B, D, h, w, device=dev, dtype=torch.float32)
+    depth = torch.empty(B, h, w, device=dev, dtype=torch.float32)
+    conf = torch.empty(B, h, w, device=dev, dtype=torch.float32)
+    imin = torch.empty(B, h, w, device=dev, dtype=torch.float32) if inverse_depth else None
+    imax = torch.empty(B, h, w, device=dev, dtype=torch.float32) if inverse_depth else None
+    lo = torch.empty(B, D, h, w, device=dev, dtype=torch.float32) if (want_logits and feat_cl is not None) else None
+    rc = _lib.load().mvster_select_depth(_ptr(logits), _ptr(feat_cl), _ptr(prob_w), _ptr(prob_b), CF, _ptr(hypo),
+                                         _ptr(attn), _ptr(depth), _ptr(conf), _ptr(imin), _ptr(imax), _ptr(lo), B, D, h,
+                                         w, float(split_itv), _stream())
+    _lib.check(rc, "select_depth")
+    out = {"attn_weight": attn, "depth": depth, "conf": conf}
+    if inverse_depth:
+        out["inverse_min_depth"] = imin
+        out["inverse_max_depth"] = imax
+    if want_logits:
+        out["logits"] = lo if lo is not None else logits
+    return out
+
+
+def upsample_bilinear(x, scale):
+    """[B,h,w] -> [B,h*scale,w*scale], align_corners=True (mvs4net_utils.py:1077)."""
+    x = x.contiguous()
+    _chk(x, "upsample_bilinear")
+    B, h, w = x.shape
+    out = torch.empty(B, h * scale, w * scale, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().mvster_upsample_bilinear(_ptr(x), _ptr(out), B, h, w, h * scale, w * scale, _stream()),
+               "upsample_bilinear")
+    return out
+
+
+def mfma_probe(A, Bm):
+    """A [16,4] @ B [4,16] on one v_mfma_f32_16x16x4_f32 (layout test hook)."""
+    A, Bm = A.contiguous(), Bm.contiguous()
+    D = torch.empty(16, 16, device=A.device, dtype=torch.float32)
+    _lib.check(_lib.load().mvster_mfma_probe(_ptr(A), _ptr(Bm), _ptr(D), _stream()), "mfma_probe")
+    return D

@@ -1,0 +1,103 @@
+"""NumPy emulation of mvster_amd/csrc/conv_mfma.hip -- TEST INFRASTRUCTURE.
+
+Walks the packed weights, the geometry record and the parity classes exactly the way the
+kernel does (K-step -> lane K-slot -> tap/channel -> input voxel, zero page for padded taps,
+fused epilogue), vectorised over the output voxels.  It lets the CPU-only suite validate
+``mvster_amd.conv_plan`` (weight packing, BatchNorm folding, geometry, transposed-conv parity
+classes, skip modes) against PyTorch's own convolutions; the GPU suite then only has to prove
+that the kernel agrees with this description.
+"""
+import numpy as np
+import torch
+
+from mvster_amd.conv_plan import GEOM, GEOM_CLASS, SKIP_ADD, SKIP_NONE, SKIP_UPSAMPLE_ADD
+
+
+def _lerp(dst, insz, outsz):
+    scale = np.float32(insz - 1) / np.float32(outsz - 1) if outsz > 1 else np.float32(0)
+    src = (scale * dst.astype(np.float32)).astype(np.float32)
+    i0 = np.minimum(src.astype(np.int64), insz - 1)
+    lam = np.clip(src - i0.astype(np.float32), 0, 1).astype(np.float32)
+    i1 = i0 + (i0 < insz - 1)
+    return i0, i1, (np.float32(1) - lam), lam
+
+
+def run_layer(layer, x, skip=None, skip_mode=SKIP_NONE):
+    """x: torch CPU tensor [B,Di,Hi,Wi,cin] -> torch tensor [B,DoF,HoF,WoF,cout]."""
+    x = x.detach().cpu().numpy().astype(np.float32)
+    B, Di, Hi, Wi, C = x.shape
+    assert C == layer.cin
+    if skip is None:
+        skip_mode = SKIP_NONE
+    geom, mt, nt, oshape = layer._geom(B, Di, Hi, Wi, skip_mode)
+    g = dict(zip(GEOM, geom[:len(GEOM)].tolist()))
+    ncls = g["nclass"]
+    cls = [dict(zip(GEOM_CLASS, geom[len(GEOM) + i * len(GEOM_CLASS):len(GEOM) + (i + 1) * len(GEOM_CLASS)].tolist()))
+           for i in range(ncls)]
+    wpk = layer.wpk.detach().cpu().numpy()
+    scale = layer.scale.detach().cpu().numpy()
+    shift = layer.shift.detach().cpu().numpy()
+    cout, NTt, CIN = g["cout"], g["ntile_total"], layer.cin
+    out = np.full((B, g["DoF"], g["HoF"], g["WoF"], cout), np.nan, np.float32)
+    M = B * g["Do"] * g["Ho"] * g["Wo"]
+    m = np.arange(M)
+    xo = m % g["Wo"]
+    r = m // g["Wo"]
+    yo = r % g["Ho"]
+    r //= g["Ho"]
+    zo = r % g["Do"]
+    bo = r // g["Do"]
+    xf = x.reshape(-1, CIN)
+    for ci, c in enumerate(cls):
+        ntaps = c["kd"] * c["kh"] * c["kw"]
+        iz0, iy0, ix0 = zo * g["sd"] - c["pd"], yo * g["sh"] - c["ph"], xo * g["sw"] - c["pw"]
+        acc = np.zeros((M, NTt * 16), np.float32)
+        wc = wpk[layer.woff[ci]:]
+        for s in range(c["nsteps"]):
+            for q in range(4):
+                kk = s * 16 + q * 4
+                tap, ch = kk // CIN, kk % CIN
+                if tap >= ntaps:
+                    continue
+                kx, ky, kz = tap % c["kw"], (tap // c["kw"]) % c["kh"], tap // (c["kw"] * c["kh"])
+                iz, iy, ix = iz0 + kz, iy0 + ky, ix0 + kx
+                ok = (iz >= 0) & (iz < Di) & (iy >= 0) & (iy < Hi) & (ix >= 0) & (ix < Wi)
+                lin = ((bo * Di + np.where(ok, iz, 0)) * Hi + np.where(ok, iy, 0)) * Wi + np.where(ok, ix, 0)
+                A = np.where(ok[:, None], xf[lin, ch:ch + 4], 0.0)                    # [M,4]
+                for t in range(NTt):
+                    base = ((s * NTt + t) * 64 + q * 16) * 4
+                    Bw = wc[base:base + 64].reshape(16, 4)                             # [n, j]
+                    acc[:, t * 16:(t + 1) * 16] += A @ Bw.T
+        v = acc[:, :cout] * scale[:cout] + shift[:cout]
+        if g["relu"]:
+            v = np.maximum(v, 0)
+        oz, oy, ox = zo * g["osd"] + c["od"], yo * g["osh"] + c["oh"], xo * g["osw"] + c["ow"]
+        if skip_mode == SKIP_ADD:
+            v = v + skip.detach().cpu().numpy()[bo, oz, oy, ox]
+        elif skip_mode == SKIP_UPSAMPLE_ADD:
+            sk = skip.detach().cpu().numpy()[:, 0]
+            hh, wh = g["HoF"] // 2, g["WoF"] // 2
+            y0, y1, wy0, wy1 = _lerp(oy, hh, g["HoF"])
+            x0, x1, wx0, wx1 = _lerp(ox, wh, g["WoF"])
+            top = wx0[:, None] * sk[bo, y0, x0] + wx1[:, None] * sk[bo, y0, x1]
+            bot = wx0[:, None] * sk[bo, y1, x0] + wx1[:, None] * sk[bo, y1, x1]
+            v = (wy0[:, None] * top + wy1[:, None] * bot) + v
+        out[bo, oz, oy, ox] = v
+    assert not np.isnan(out).any(), "some output voxel was never written"
+    return torch.from_numpy(out)
+
+
+class Emulated:
+    """Wraps a plan so that every ConvLayer call goes through run_layer()."""
+
+    def __init__(self, plan):
+        self.plan = plan
+
+    def __call__(self, x):
+        import mvster_amd.conv_plan as cp
+        orig = cp.ConvLayer.__call__
+        cp.ConvLayer.__call__ = lambda self_, x_, skip=None, skip_mode=SKIP_NONE, tiles=None: run_layer(self_, x_, skip, skip_mode)
+        try:
+            return self.plan(x)
+        finally:
+            cp.ConvLayer.__call__ = orig

@@ -1,0 +1,127 @@
+"""conv_plan (weight packing, BN folding, geometry, parity classes) checked on CPU through a
+NumPy emulation of the HIP kernel's indexing, against the oracle's PyTorch modules."""
+import numpy as np
+import pytest
+import torch
+
+from mvster_amd import conv_plan as cp
+from mvster_amd import modules as M
+from mvster_amd.synthetic import randomize_state
+from oracle import mvs4_oracle as O
+from tests.conv_emulator import Emulated, run_layer
+
+
+def cl(x):   # NCDHW -> NDHWC
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def test_pack_gemm_layout():
+    wk = torch.arange(40 * 24, dtype=torch.float32).reshape(40, 24)
+    flat, nsteps = cp._pack_gemm(wk)
+    assert nsteps == 3 and flat.numel() == 48 * 32
+    f = flat.reshape(3, 2, 64, 4)
+    for s, t, lane, j in [(0, 0, 0, 0), (1, 1, 37, 2), (2, 0, 63, 3), (2, 1, 5, 1)]:
+        k, n = s * 16 + (lane >> 4) * 4 + j, t * 16 + (lane & 15)
+        want = wk[k, n].item() if (k < 40 and n < 24) else 0.0
+        assert f[s, t, lane, j].item() == want
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p", [(8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1)), (4, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+                                            (8, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1)), (16, 16, 3, 1, 1),
+                                            (32, 64, (1, 3, 3), (1, 2, 2), (0, 1, 1)), (16, 32, 3, 2, 1)])
+def test_conv_bn_relu_layer(cin, cout, k, s, p):
+    torch.manual_seed(cin * 100 + cout)
+    m = M.ConvBnReLU3D(cin, cout, kernel_size=k, stride=s, pad=p)
+    m.load_state_dict(randomize_state(m.state_dict(), seed=3))
+    m.eval()
+    x = torch.randn(2, cin, 4, 10, 12)
+    with torch.no_grad():
+        want = m(x)
+    got = run_layer(cp._cbr3d(m), cl(x))
+    assert got.shape == cl(want).shape
+    assert (got - cl(want)).abs().max() <= 2e-5 * want.abs().max()
+
+
+@pytest.mark.parametrize("cin,cout,k,pad,op,s", [(64, 32, (1, 3, 3), (0, 1, 1), (0, 1, 1), (1, 2, 2)),
+                                                 (16, 8, (1, 3, 3), (0, 1, 1), (0, 1, 1), (1, 2, 2)),
+                                                 (16, 8, 3, 1, 1, 2)])
+def test_transposed_layer_with_skip(cin, cout, k, pad, op, s):
+    torch.manual_seed(cin + cout)
+    seq = M._deconv_bn_relu(cin, cout, k, pad, op, s)
+    seq.load_state_dict(randomize_state(seq.state_dict(), seed=4))
+    seq.eval()
+    x = torch.randn(2, cin, 3, 5, 6)
+    with torch.no_grad():
+        y = seq(x)
+        skip = torch.randn_like(y)
+        want = skip + y
+    got = run_layer(cp._up3d(seq), cl(x), skip=cl(skip), skip_mode=cp.SKIP_ADD)
+    assert (got - cl(want)).abs().max() <= 2e-5 * want.abs().max()
+
+
+@pytest.mark.parametrize("G,D", [(8, 8), (4, 4)])
+def test_reg2d_plan(G, D):
+    torch.manual_seed(G)
+    m = M.reg2d(input_channel=G, base_channel=8)
+    m.load_state_dict(randomize_state(m.state_dict(), seed=5, prob_gain=1.0))
+    m.eval()
+    x = torch.randn(1, G, D, 16, 24)
+    with torch.no_grad():
+        want = m(x)
+    feat = Emulated(cp.Reg2dPlan(m))(cl(x))                      # [B,D,h,w,8]
+    plan = cp.Reg2dPlan(m)
+    logits = feat @ plan.prob_w + plan.prob_b
+    assert (logits - want).abs().max() <= 5e-5 * want.abs().max()
+    # same weights in the oracle's module tree give the same answer (state_dict compatibility)
+    o = O.Reg2d(input_channel=G, base_channel=8)
+    o.load_state_dict(m.state_dict(), strict=True)
+    o.eval()
+    with torch.no_grad():
+        assert torch.equal(o(x), want)
+
+
+@pytest.mark.parametrize("down", [3, 2, 1])
+def test_reg3d_plan(down):
+    torch.manual_seed(down)
+    m = M.reg3d(in_channels=8, base_channels=8, down_size=down)
+    m.load_state_dict(randomize_state(m.state_dict(), seed=6, prob_gain=1.0))
+    m.eval()
+    x = torch.randn(1, 8, 8, 8, 16)
+    with torch.no_grad():
+        want = m(x)
+    got = Emulated(cp.Reg3dPlan(m))(cl(x))
+    assert (got - want).abs().max() <= 5e-5 * want.abs().max()
+
+
+def test_fpn_plan():
+    torch.manual_seed(0)
+    m = M.FPN4(base_channels=8)
+    m.load_state_dict(randomize_state(m.state_dict(), seed=7))
+    m.eval()
+    img = torch.rand(2, 3, 32, 48)
+    with torch.no_grad():
+        want = m(img)
+    x = torch.zeros(2, 1, 32, 48, 4)
+    x[:, 0, :, :, :3] = img.permute(0, 2, 3, 1)
+    got = Emulated(cp.FpnPlan(m))(x)
+    for s in range(4):
+        w = want["stage%d" % (s + 1)].permute(0, 2, 3, 1)
+        assert got[s][:, 0].shape == w.shape
+        assert (got[s][:, 0] - w).abs().max() <= 5e-5 * w.abs().max(), s
+    o = O.FPN4(base_channels=8)
+    o.load_state_dict(m.state_dict(), strict=True)
+    o.eval()
+    with torch.no_grad():
+        assert torch.equal(o(img)["stage4"], want["stage4"])
+
+
+def test_tile_heuristic_and_flops():
+    assert cp._tiles(4 * 512 * 640, 1, 1) == (4, 1)
+    mt, nt = cp._tiles(8 * 8 * 10, 4, 1)
+    assert (mt, nt) == (1, 1)
+    m = M.reg2d(input_channel=4, base_channel=8).eval()
+    plan = cp.Reg2dPlan(m)
+    # 14,416 conv FLOPs per D*h*w voxel for G=4
+    assert plan.flops(1, 4, 64, 64) == 14416 * 4 * 64 * 64
+    m8 = M.reg2d(input_channel=8, base_channel=8).eval()
+    assert cp.Reg2dPlan(m8).flops(1, 8, 64, 64) == 14992 * 8 * 64 * 64
