@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""depth-maps/sec of the MVSTER cost-volume path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one ``MVS4net.forward`` (B=1, eval, fp32) = one depth map of the workload
+"DTU 512x640, 5 views, 4-stage cascade (8/8/4/4 hypotheses)" (BASELINE.json configs[1]) on seeded
+synthetic inputs already resident in HBM.  Multi-GPU = independent replicas on disjoint depth maps
+(weak scaling, no data-path collective).  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      the dominant kernel instance of the forward, timed with HIP events on the launch
+                stream in an instrumented eager pass inside this script (same inputs, same kernels)
+  cpu_baseline  the CPU oracle (pure PyTorch restatement of the reference, oracle/) timed on the
+                host cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+SHIPPED = dict(arch_mode="fpn", reg_net="reg2d", num_stage=4, fpn_base_channel=8, reg_channel=8,
+               stage_splits=[8, 8, 4, 4], depth_interals_ratio=[0.5, 0.5, 0.5, 1], group_cor=True,
+               group_cor_dim=[8, 8, 4, 4], inverse_depth=True, mono=True, attn_temp=2, attn_fuse_d=True)
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (matrix), dense
+HBM_PEAK_GBS = 8000.0             # same guide: HBM3E peak
+
+
+def load_weights():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g7_checkpoint.npz"))
+    return {k: torch.from_numpy(z[k]) for k in z.keys()}
+
+
+class KernelTimer:
+    """HIP-event timing of every conv_mfma / warp_agg launch (instrumented eager pass)."""
+
+    def __init__(self):
+        self.records = []
+
+    def install(self):
+        import mvster_amd.conv_plan as cp
+        import mvster_amd.ops as ops
+        timer = self
+        self._orig_conv = cp.ConvLayer.__call__
+        self._orig_warp = ops.warp_agg_fwd_cl
+
+        def conv_call(layer, x, skip=None, skip_mode=0, tiles=None):
+            B, Di, Hi, Wi, _ = x.shape
+            _, mt, nt, _ = layer._geom(B, Di, Hi, Wi, skip_mode if skip is not None else 0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = timer._orig_conv(layer, x, skip, skip_mode, tiles)
+            e1.record()
+            bytes_ = 4 * (x.numel() + out.numel() + layer.wpk.numel() + (skip.numel() if skip is not None else 0))
+            timer.records.append(("conv_mfma_kernel<%d,%d,%d>" % (layer.cin, mt, nt), e0, e1,
+                                  layer.flops(B, Di, Hi, Wi), bytes_))
+            return out
+
+        def warp_call(ref_cl, src_cl, rt, hypo, G, *a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = timer._orig_warp(ref_cl, src_cl, rt, hypo, G, *a, **k)
+            e1.record()
+            C = ref_cl.shape[-1]
+            bytes_ = 4 * (ref_cl.numel() + src_cl.numel() + hypo.numel() + hypo.numel() * G)
+            timer.records.append(("warp_agg_fwd_kernel<%d,%d>" % (C, G), e0, e1, 0, bytes_))
+            return out
+
+        cp.ConvLayer.__call__ = conv_call
+        ops.warp_agg_fwd_cl = warp_call
+
+    def remove(self):
+        import mvster_amd.conv_plan as cp
+        import mvster_amd.ops as ops
+        cp.ConvLayer.__call__ = self._orig_conv
+        ops.warp_agg_fwd_cl = self._orig_warp
+
+    def summary(self):
+        agg = {}
+        for name, e0, e1, flops, bytes_ in self.records:
+            a = agg.setdefault(name, dict(ms=0.0, n=0, flops=0, bytes=0))
+            a["ms"] += e0.elapsed_time(e1)
+            a["n"] += 1
+            a["flops"] += flops
+            a["bytes"] += bytes_
+        return agg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--views", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    from mvster_amd import MVS4net, shard
+    from mvster_amd.graph import GraphedForward
+    from mvster_amd.synthetic import make_inputs
+
+    rank, local_rank, world = shard.init_distributed()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    model = MVS4net(**SHIPPED)
+    model.load_state_dict(load_weights(), strict=True)
+    model.to(dev).eval()
+    # every rank works on its own depth maps: disjoint seeds = disjoint units of the shard
+    units = shard.shard_units(world * (args.steps + args.warmup), rank, world)
+    imgs, proj, dv = make_inputs(nviews=args.views, H=args.height, W=args.width, seed=units[0], device=dev)
+
+    if args.no_graph:
+        step = lambda: model(imgs, proj, dv)   # noqa: E731
+    else:
+        graphed = GraphedForward(model, imgs, proj, dv)
+        step = lambda: graphed()               # noqa: E731
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    shard.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    shard.barrier()
+    torch.cuda.synchronize()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0)
+
+    # ---- instrumented eager pass: per-kernel HIP-event timing (rank 0 only) -------------------
+    roofline = None
+    table = None
+    if rank == 0:
+        timer = KernelTimer()
+        timer.install()
+        try:
+            for _ in range(3):
+                model(imgs, proj, dv)
+            timer.records.clear()
+            for _ in range(min(args.steps, 20)):
+                model(imgs, proj, dv)
+            torch.cuda.synchronize()
+            table = timer.summary()
+        finally:
+            timer.remove()
+        name, a = max(table.items(), key=lambda kv: kv[1]["ms"])
+        avg_ms = a["ms"] / a["n"]
+        if a["flops"] > 0 and name.startswith("conv"):
+            achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
+            roofline = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": a["n"] // min(args.steps, 20),
+                        "flops_per_launch": a["flops"] // a["n"]}
+        else:
+            achieved = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+            roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": a["n"] // min(args.steps, 20),
+                        "bytes_per_launch": a["bytes"] // a["n"]}
+        if args.kernel_table:
+            tot = sum(v["ms"] for v in table.values())
+            for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
+                print("%-34s n=%4d  avg %8.2f us  %5.1f%%  %7.2f TFLOP/s  %8.1f GB/s" % (
+                    k, v["n"], v["ms"] / v["n"] * 1e3, 100 * v["ms"] / tot, v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                    v["bytes"] / (v["ms"] * 1e-3) / 1e9), file=sys.stderr)
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample ----------------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import mvs4_oracle as O
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        oracle = O.OracleMVS4net(**SHIPPED)
+        oracle.load_state_dict(load_weights(), strict=True)
+        oracle.eval()
+        cimgs, cproj, cdv = make_inputs(nviews=args.views, H=args.height, W=args.width, seed=units[0])
+        with torch.no_grad():
+            oracle(cimgs, cproj, cdv)                       # warm-up
+            n, c0 = 0, time.perf_counter()
+            while n < 8 and (time.perf_counter() - c0) < 12.0:
+                oracle(cimgs, cproj, cdv)
+                n += 1
+            ct = time.perf_counter() - c0
+        cpu = {"value": round(n / ct, 4), "unit": "depth-maps/s", "cores": cores, "kind": "port",
+               "sample": "%d forwards of the same %dx%d %d-view 4-stage workload after 1 warm-up (torch %d threads)"
+                         % (n, args.height, args.width, args.views, cores)}
+
+    if rank == 0:
+        total_maps = args.steps * world
+        line = {
+            "metric": "depth-maps/sec (DTU 512x640, 5-view, 4-stage)", "value": round(total_maps / elapsed, 3),
+            "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DTU mid %dx%d, %d views, 4-stage cascade 8/8/4/4 hyp, B=1 eval, 1 depth map per step per GPU"
+                                   % (args.height, args.width, args.views),
+                       "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "replicas x%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if cpu:
+            line["vs_cpu_baseline"] = round(line["value"] / cpu["value"], 2)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,81 @@
+"""Multi-GPU: independent replicas over disjoint depth maps (inference) and DDP (training).
+
+The path shards naturally: each depth map (one reference view and its
+source views) is an independent unit, so inference uses one process per GPU, weights replicated
+(4 MB), round-robin assignment of units to ranks and NO data-path collective -- exactly what the
+reference's scan loop does on one GPU (test_mvs4.py:161-164).  Training is the reference's DDP
+(train_mvs4.py:321-326, :389-392): one all-reduce of 4.04 MB of fp32 gradients per step, which
+``torch.distributed`` backend "nccl" runs on RCCL over xGMI; a single default 25 MB bucket.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def dist_env():
+    """(rank, local_rank, world_size) from the torchrun environment (defaults: single process)."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_distributed(backend=None):
+    """Join the process group described by the environment; returns (rank, local_rank, world)."""
+    rank, local_rank, world = dist_env()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_units(num_units, rank, world):
+    """Round-robin partition of unit indices (depth maps / reference views) for one rank."""
+    return list(range(rank, num_units, world))
+
+
+def shard_scans(scans, views_per_scan, rank, world):
+    """Flatten (scan, ref_view) units in the reference's iteration order (test_mvs4.py:161-164,
+    datasets/general_eval4.py:111) and keep this rank's share."""
+    units = [(s, v) for s in scans for v in range(views_per_scan)]
+    return [units[i] for i in shard_units(len(units), rank, world)]
+
+
+def max_over_ranks(value, device=None):
+    """MAX all-reduce of a python float (timing protocol of bench.py)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device=None):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def wrap_ddp(model, local_rank=None):
+    """DistributedDataParallel exactly as the reference wraps it (train_mvs4.py:389-392).
+    No SyncBN: BatchNorm statistics stay per rank, as in the reference."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return model
+    if next(model.parameters()).is_cuda:
+        lr = torch.cuda.current_device() if local_rank is None else local_rank
+        return torch.nn.parallel.DistributedDataParallel(model, device_ids=[lr], output_device=lr)
+    return torch.nn.parallel.DistributedDataParallel(model)

@@ -1,0 +1,294 @@
+"""HIP kernels (through the C ABI) against the CPU oracle / golden vectors.  Needs an MI355X."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mvster_amd import conv_plan as cp
+from mvster_amd import modules as M
+from mvster_amd import ops
+from mvster_amd.synthetic import make_inputs, randomize_state
+from oracle import mvs4_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+REPORT = {}
+
+
+def note(name, **kv):
+    REPORT[name] = {k: (float(v) if not isinstance(v, (list, str)) else v) for k, v in kv.items()}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_kernels.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def cl5(x):   # NCDHW -> NDHWC
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def test_library_is_loaded_from_the_tree():
+    from mvster_amd import _lib
+    lib = _lib.load()
+    assert os.path.samefile(_lib.LIB_PATH, os.path.join(os.path.dirname(_lib.__file__), "csrc", "libmvster_hip.so"))
+    assert lib.mvster_warp_agg_fwd is not None
+
+
+def test_mfma_fragment_layout():
+    """Asymmetric operands: a transposed A, B or D mapping cannot pass."""
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(16, 4, generator=g)
+    B = torch.randn(4, 16, generator=g)
+    D = ops.mfma_probe(A.to(DEV), B.to(DEV)).cpu()
+    want = (A.double() @ B.double()).float()
+    err = (D - want).abs().max().item()
+    note("mfma_probe", max_abs=err)
+    assert err <= 1e-6
+
+
+def test_relative_projection():
+    _, proj, _ = make_inputs(5, 512, 640, seed=0, batch=2)
+    for stage in ("stage1", "stage4"):
+        pm = proj[stage]
+        rt = ops.relative_projection(pm.to(DEV)).cpu()
+        Pr = O.compose_projection(pm[:, 0]).double()
+        for v in range(1, 5):
+            P = torch.matmul(O.compose_projection(pm[:, v]).double(), torch.inverse(Pr))
+            want = torch.cat([P[:, :3, :3].reshape(2, 9), P[:, :3, 3]], 1)
+            got = rt[:, v - 1].double()
+            assert torch.all((got - want).abs() <= 5e-7 * want.abs().clamp(min=1.0)), (stage, v)
+
+
+def test_schedulers(golden):
+    g = golden("g5_sched")
+    dv = g.t("dv", DEV)
+    assert torch.equal(ops.init_range(dv, 8, 6, 10, inverse=True).cpu(), g.t("init_inverse_8"))
+    assert torch.equal(ops.init_range(dv, 8, 6, 10, inverse=False).cpu(), g.t("init_range_8"))
+    worst = 0.0
+    for D in (8, 4):
+        out = ops.schedule_inverse_range(g.t("inv_min", DEV), g.t("inv_max", DEV), D, 24, 40).cpu()
+        want = g.t("sched_inverse_%d" % D)
+        worst = max(worst, ((out - want).abs() / want.abs()).max().item())
+    out = ops.schedule_range(g.t("cur_depth", DEV), 4, g.t("itv", DEV), 24, 40).cpu()
+    want = g.t("sched_range_4")
+    worst = max(worst, ((out - want).abs() / want.abs()).max().item())
+    note("schedulers", max_rel=worst)
+    assert worst <= 5e-7          # <= 3 ulp: ATen contracts its lerp into FMAs differently
+
+
+@pytest.mark.parametrize("name", ["d8_s0", "d4_s2", "d4_s3_ties", "d8_s1_b2"])
+def test_select_depth(golden, name):
+    g = golden("g4_select")
+    s = int(g.np(name + "_stage_idx"))
+    r = ops.select_depth(g.t(name + "_hypo", DEV), 0.5, True, logits=g.t(name + "_logits", DEV))
+    attn = r["attn_weight"].cpu()
+    want_attn = g.t(name + "_attn_weight")
+    assert (attn - want_attn).abs().max() <= 3e-7
+    top2 = want_attn.topk(2, dim=1)[0]
+    clear = ((top2[:, 0] - top2[:, 1]) > 1e-6) | (top2[:, 0] == top2[:, 1])     # exact ties must agree too
+    assert torch.equal(r["depth"].cpu()[clear], g.t(name + "_depth")[clear])
+    assert (r["inverse_min_depth"].cpu() - g.t(name + "_inverse_min_depth"))[clear].abs().max() <= 1e-9
+    assert (r["inverse_max_depth"].cpu() - g.t(name + "_inverse_max_depth"))[clear].abs().max() <= 1e-9
+    conf = ops.upsample_bilinear(r["conf"], 2 ** (3 - s)).cpu()
+    assert (conf - g.t(name + "_photometric_confidence")).abs().max() <= 5e-7
+
+
+def test_select_depth_fused_prob():
+    g = torch.Generator().manual_seed(1)
+    B, D, h, w, CF = 2, 4, 9, 13, 8
+    feat = torch.randn(B, D, h, w, CF, generator=g)
+    pw, pb = torch.randn(CF, generator=g), torch.randn(1, generator=g)
+    hypo = 500 + 100 * torch.rand(B, D, h, w, generator=g)
+    r = ops.select_depth(hypo.to(DEV), 1.0, True, feat_cl=feat.to(DEV), prob_w=pw.to(DEV), prob_b=pb.to(DEV),
+                         want_logits=True)
+    logits = feat @ pw + pb
+    assert (r["logits"].cpu() - logits).abs().max() <= 1e-5
+    want = O.select_depth(r["logits"].cpu(), hypo, 3, True, 1.0)
+    assert (r["attn_weight"].cpu() - want["attn_weight"]).abs().max() <= 3e-7
+    assert torch.equal(r["depth"].cpu(), want["depth"])
+
+
+def _oracle_rt(pm):
+    ref_p = O.compose_projection(pm[:, 0])
+    rts = []
+    for v in range(1, pm.shape[1]):
+        P = torch.matmul(O.compose_projection(pm[:, v]), torch.inverse(ref_p))
+        rts.append(torch.cat([P[:, :3, :3].reshape(-1, 9), P[:, :3, 3]], 1))
+    return torch.stack(rts, 1).contiguous()
+
+
+@pytest.mark.parametrize("name", ["gc_t2", "gc_t1", "sq_t2", "gc_nofuse", "gc_b2"])
+def test_warp_agg_forward(golden, name):
+    """Fused warp + correlation + attention aggregation vs the reference's captured cor_feats."""
+    g = golden("g2_aggregate")
+    n, C, G, D, gc, fuse, temp = g.np(name + "_cfg").tolist()
+    C, G, gc, fuse = int(C), int(G), bool(gc), bool(fuse)
+    feats = g.t(name + "_feats")                      # [N,B,C,h,w]
+    pm, hypo, want = g.t(name + "_proj"), g.t(name + "_hypo"), g.t(name + "_cor")
+    f_cl = feats.permute(0, 1, 3, 4, 2).contiguous().to(DEV)
+    Gk = G if gc else C
+    # (1) with the reference's own fp32 relative projection: pure per-pixel arithmetic
+    out = ops.warp_agg_fwd_cl(f_cl[0], f_cl[1:], _oracle_rt(pm).to(DEV), hypo.to(DEV), Gk, gc, fuse, temp)
+    got = out.permute(0, 4, 1, 2, 3).cpu()
+    tight = (got - want).abs().max().item()
+    # (2) with the kernel-computed (fp64-inverse) projection: differs by the fp32 LAPACK noise of the reference
+    out2 = ops.warp_agg_fwd_cl(f_cl[0], f_cl[1:], ops.relative_projection(pm.to(DEV)), hypo.to(DEV), Gk, gc, fuse, temp)
+    got2 = out2.permute(0, 4, 1, 2, 3).cpu()
+    loose = (got2 - want).abs().max().item()
+    note("warp_agg_" + name, tight_max_abs=tight, own_rt_max_abs=loose, ref_absmax=want.abs().max().item(),
+         own_rt_mean_abs=(got2 - want).abs().mean().item())
+    scale = want.abs().max().item()
+    assert tight <= 5e-6 * max(scale, 1.0)
+    assert loose <= 2e-3 * max(scale, 1.0)
+    assert (got2 - want).abs().mean().item() <= 2e-5 * max(scale, 1.0)
+
+
+def test_warp_agg_source_size_differs_and_oob(golden):
+    """Source map smaller than the reference map + far-away camera (mostly zero padding)."""
+    g = golden("g1_warp")
+    for case, src_k in (("b", "a_src"), ("c", "c_src")):
+        fea = g.t(case + "_fea")                                   # [1,8,Hs,Ws]
+        depth = g.t("a_depth")                                     # [1,4,32,40]
+        ref_p, src_p = g.t("a_ref"), g.t(src_k)
+        torch.manual_seed(3)
+        ref_fea = torch.randn(1, 8, 32, 40)
+        warped = g.t(case + "_out")                                # reference homo_warping output
+        cor = (warped.reshape(1, 4, 2, 4, 32, 40) * ref_fea.unsqueeze(2).repeat(1, 1, 4, 1, 1).reshape(1, 4, 2, 4, 32, 40)).mean(2)
+        wgt = torch.softmax(cor.sum(1) / 2.0, 1) / np.sqrt(8)
+        want = (wgt.unsqueeze(1) * cor) / (1e-8 + wgt).unsqueeze(1)
+        P = torch.matmul(src_p, torch.inverse(ref_p))
+        rt = torch.cat([P[:, :3, :3].reshape(-1, 9), P[:, :3, 3]], 1).unsqueeze(1).contiguous()
+        out = ops.warp_agg_fwd_cl(ops.to_channels_last(ref_fea.to(DEV)), ops.to_channels_last(fea.to(DEV)).unsqueeze(0),
+                                  rt.to(DEV), depth.to(DEV), 4, True, True, 2.0)
+        err = (out.permute(0, 4, 1, 2, 3).cpu() - want).abs().max().item()
+        note("warp_agg_g1_" + case, max_abs=err)
+        assert err <= 5e-6 * max(want.abs().max().item(), 1.0)
+
+
+CONV_CASES = [
+    ("c3d_133_8_8", dict(cin=8, cout=8, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1)), (2, 8, 4, 20, 28)),
+    ("c3d_133_4_8", dict(cin=4, cout=8, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1)), (1, 4, 4, 18, 22)),
+    ("c3d_133s2_8_16", dict(cin=8, cout=16, k=(1, 3, 3), s=(1, 2, 2), p=(0, 1, 1)), (2, 8, 4, 20, 28)),
+    ("c3d_333_16_16", dict(cin=16, cout=16, k=3, s=1, p=1), (1, 16, 4, 14, 18)),
+    ("c3d_333_32_32", dict(cin=32, cout=32, k=3, s=1, p=1), (1, 32, 4, 10, 12)),
+    ("c3d_333_64_64", dict(cin=64, cout=64, k=3, s=1, p=1), (1, 64, 8, 8, 10)),
+    ("c3d_133s2_32_64", dict(cin=32, cout=64, k=(1, 3, 3), s=(1, 2, 2), p=(0, 1, 1)), (1, 32, 4, 12, 16)),
+    ("c3d_333s2_16_32", dict(cin=16, cout=32, k=3, s=2, p=1), (1, 16, 8, 12, 16)),
+]
+
+
+@pytest.mark.parametrize("name,cfg,shape", CONV_CASES)
+def test_conv_bn_relu(name, cfg, shape):
+    torch.manual_seed(hash(name) % 1000)
+    m = M.ConvBnReLU3D(cfg["cin"], cfg["cout"], kernel_size=cfg["k"], stride=cfg["s"], pad=cfg["p"])
+    m.load_state_dict(randomize_state(m.state_dict(), seed=3))
+    m.eval()
+    x = torch.randn(*shape)
+    with torch.no_grad():
+        want = cl5(m(x))
+    layer = cp._cbr3d(m.to(DEV))
+    worst = 0.0
+    for mt in (1, 2, 4):
+        for nt in (1, 2, 4):
+            if layer.ntile_total % nt:
+                continue
+            got = layer(cl5(x).to(DEV), tiles=(mt, nt)).cpu()
+            err = (got - want).abs().max().item()
+            worst = max(worst, err)
+            assert err <= 2e-5 * want.abs().max().item(), (name, mt, nt, err)
+    note("conv_" + name, max_abs=worst, ref_absmax=want.abs().max().item())
+
+
+@pytest.mark.parametrize("cin,cout,k,pad,op,s", [(64, 32, (1, 3, 3), (0, 1, 1), (0, 1, 1), (1, 2, 2)),
+                                                 (16, 8, (1, 3, 3), (0, 1, 1), (0, 1, 1), (1, 2, 2)),
+                                                 (32, 16, 3, 1, 1, 2)])
+def test_conv_transposed_skip(cin, cout, k, pad, op, s):
+    torch.manual_seed(cin + cout)
+    seq = M._deconv_bn_relu(cin, cout, k, pad, op, s)
+    seq.load_state_dict(randomize_state(seq.state_dict(), seed=4))
+    seq.eval()
+    x = torch.randn(2, cin, 4, 9, 11)
+    with torch.no_grad():
+        y = seq(x)
+        skip = torch.randn_like(y)
+        want = cl5(skip + y)
+    layer = cp._up3d(seq.to(DEV))
+    for tiles in ((1, 1), (2, 1), (4, layer.ntile_total)):
+        got = layer(cl5(x).to(DEV), skip=cl5(skip).to(DEV), skip_mode=cp.SKIP_ADD, tiles=tiles).cpu()
+        err = (got - want).abs().max().item()
+        assert err <= 2e-5 * want.abs().max().item(), (tiles, err)
+    note("deconv_%d_%d" % (cin, cout), max_abs=err)
+
+
+@pytest.mark.parametrize("name", ["reg2d_g8", "reg2d_g4", "reg3d_ds3", "reg3d_ds2"])
+def test_reg_networks_vs_golden(golden, name):
+    g = golden("g3_reg")
+    sd = {k.split("/", 1)[1]: g.t(k) for k in g.keys() if k.startswith(name + "/")}
+    x, want = g.t(name + "_x"), g.t(name + "_y")
+    if name.startswith("reg2d"):
+        m = M.reg2d(input_channel=x.shape[1], base_channel=8)
+    else:
+        m = M.reg3d(in_channels=x.shape[1], base_channels=8, down_size=int(name[-1]))
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV).eval()
+    xc = cl5(x).to(DEV)
+    if name.startswith("reg2d"):
+        plan = cp.Reg2dPlan(m)
+        logits = (plan(xc) @ plan.prob_w + plan.prob_b).cpu()
+    else:
+        logits = cp.Reg3dPlan(m)(xc).cpu()
+    err = (logits - want).abs().max().item()
+    note("reg_" + name, max_abs=err, ref_absmax=want.abs().max().item())
+    assert err <= 5e-5 * want.abs().max().item()
+
+
+def test_fpn_plan_vs_oracle():
+    torch.manual_seed(0)
+    m = M.FPN4(base_channels=8)
+    m.load_state_dict(randomize_state(m.state_dict(), seed=7))
+    m.eval()
+    img = torch.rand(3, 3, 64, 128)
+    o = O.FPN4(base_channels=8)
+    o.load_state_dict(m.state_dict(), strict=True)
+    o.eval()
+    with torch.no_grad():
+        want = o(img)
+    x = torch.zeros(3, 1, 64, 128, 4)
+    x[:, 0, :, :, :3] = img.permute(0, 2, 3, 1)
+    got = cp.FpnPlan(m.to(DEV))(x.to(DEV))
+    for s in range(4):
+        w = want["stage%d" % (s + 1)].permute(0, 2, 3, 1)
+        err = (got[s][:, 0].cpu() - w).abs().max().item()
+        note("fpn_stage%d" % (s + 1), max_abs=err, ref_absmax=w.abs().max().item())
+        assert err <= 5e-5 * w.abs().max().item(), s
+
+
+def test_warp_agg_backward_vs_autograd():
+    """HIP backward vs PyTorch autograd through the CPU oracle's aggregate_views."""
+    torch.manual_seed(5)
+    B, N, C, G, D, h, w = 1, 3, 8, 4, 4, 12, 16
+    _, proj, dv = make_inputs(N, h * 8, w * 8, seed=9, batch=B)
+    pm = proj["stage1"]
+    feats = [torch.randn(B, C, h, w, requires_grad=True) for _ in range(N)]
+    hypo = O.init_inverse_range(dv, D, h, w) * (1 + 0.02 * torch.rand(B, D, h, w))
+    cor = O.aggregate_views(feats, pm, hypo, True, G, attn_temp=2.0, attn_fuse_d=True)
+    gout = torch.randn_like(cor)
+    cor.backward(gout)
+    f_cl = torch.stack([f.detach() for f in feats]).permute(0, 1, 3, 4, 2).contiguous().to(DEV)
+    rt = _oracle_rt(pm).to(DEV)
+    out, wsum = ops.warp_agg_fwd_cl(f_cl[0], f_cl[1:], rt, hypo.to(DEV), G, True, True, 2.0, want_wsum=True)
+    g_ref, g_src = ops.warp_agg_bwd_cl(f_cl[0], f_cl[1:], rt, hypo.to(DEV), out, wsum,
+                                       gout.permute(0, 2, 3, 4, 1).contiguous().to(DEV), G, True, True, 2.0)
+    e_ref = (g_ref.permute(0, 3, 1, 2).cpu() - feats[0].grad).abs().max().item()
+    e_src = max((g_src[v].permute(0, 3, 1, 2).cpu() - feats[v + 1].grad).abs().max().item() for v in range(N - 1))
+    scale = max(f.grad.abs().max().item() for f in feats)
+    note("warp_agg_bwd", ref_max_abs=e_ref, src_max_abs=e_src, grad_absmax=scale)
+    assert e_ref <= 1e-4 * scale and e_src <= 1e-4 * scale      # atomics: summation order is not fixed
+
+
+def test_cpu_tensor_is_rejected():
+    with pytest.raises(RuntimeError):
+        ops.relative_projection(torch.zeros(1, 2, 2, 4, 4))

@@ -1,0 +1,194 @@
+"""MVS4net on the GPU (all-HIP eval path, autograd train path) against the golden vectors
+captured from the reference, the CPU oracle, and size-independent properties at full size."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mvster_amd import MVS4net, MVS4net_loss
+from mvster_amd.graph import GraphedForward
+from mvster_amd.synthetic import make_inputs
+from oracle import mvs4_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+REPORT = {}
+
+
+def note(name, **kv):
+    REPORT[name] = {k: float(v) for k, v in kv.items()}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_model.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def to_dev(imgs, proj, dv):
+    return [i.to(DEV) for i in imgs], {k: v.to(DEV) for k, v in proj.items()}, dv.to(DEV)
+
+
+@pytest.fixture(scope="module")
+def model(shipped_cfg, checkpoint):
+    m = MVS4net(**shipped_cfg)
+    m.load_state_dict(checkpoint, strict=True)
+    return m.to(DEV).eval()
+
+
+def test_eval_golden_teacher_forced(model, golden):
+    """Every stage fed the reference's own hypotheses: continuous tensors tight, depth tie-aware."""
+    g = golden("g6_eval")
+    H, W, N = int(g.np("H")), int(g.np("W")), int(g.np("N"))
+    imgs, proj, dv = to_dev(*make_inputs(nviews=N, H=H, W=W, seed=1))
+    teacher = {"stage%d" % s: g.t("stage%d_hypo_depth" % s, DEV) for s in range(1, 5)}
+    cap = {}
+    out = model._forward_eval(imgs, proj, dv, teacher=teacher, capture=cap)
+    for s in range(1, 5):
+        name = "stage%d" % s
+        st = out[name]
+        cor = cap[name]["cor_feats"].cpu()
+        want_cor = g.t("stage%d_cor_feats" % s)
+        logits, want_logits = cap[name]["logits"].cpu(), g.t("stage%d_logits" % s)
+        attn, want_attn = st["attn_weight"].cpu(), g.t("stage%d_attn_weight" % s)
+        margin = g.t("stage%d_margin" % s)
+        clear = margin > 1e-3
+        depth, want_depth = st["depth"].cpu(), g.t("stage%d_depth" % s)
+        flips = (depth != want_depth)
+        note("teacher_" + name, cor_max=(cor - want_cor).abs().max(), cor_mean=(cor - want_cor).abs().mean(),
+             cor_ref_absmax=want_cor.abs().max(), logits_max=(logits - want_logits).abs().max(),
+             attn_max=(attn - want_attn).abs().max(), depth_l1_clear=(depth - want_depth)[clear].abs().mean(),
+             depth_max_clear=(depth - want_depth)[clear].abs().max(), flip_rate=flips.float().mean(),
+             flip_rate_clear=flips[clear].float().mean(), clear_frac=clear.float().mean())
+        assert (cor - want_cor).abs().max() <= 2e-3 * want_cor.abs().max()
+        assert (cor - want_cor).abs().mean() <= 2e-5 * want_cor.abs().max()
+        assert (attn - want_attn).abs().max() <= 1e-3
+        assert (depth - want_depth)[clear].abs().mean() < 1e-4          # north-star tolerance: depth L1 < 1e-4
+        conf, want_conf = st["photometric_confidence"].cpu(), g.t("stage%d_photometric_confidence" % s)
+        assert conf.shape == want_conf.shape and (conf - want_conf).abs().max() <= 1e-3
+        mono = st["mono_feat"].cpu()
+        assert mono.shape == g.t("stage%d_mono_feat" % s).shape
+        assert (mono - g.t("stage%d_mono_feat" % s)).abs().max() <= 5e-5 * g.t("stage%d_mono_feat" % s).abs().max()
+
+
+def test_eval_golden_free_running(model, golden):
+    """The cascade on its own hypotheses (API call, as test_mvs4.py:205 does): stage 1 is still
+    teacher-free-identical; later stages are reported with the flip rate."""
+    g = golden("g6_eval")
+    H, W, N = int(g.np("H")), int(g.np("W")), int(g.np("N"))
+    imgs, proj, dv = to_dev(*make_inputs(nviews=N, H=H, W=W, seed=1))
+    out = model(imgs, proj, dv)
+    assert set(out.keys()) >= {"stage1", "stage2", "stage3", "stage4", "depth", "photometric_confidence", "hypo_depth",
+                               "attn_weight", "inverse_min_depth", "inverse_max_depth", "mono_feat"}
+    assert torch.equal(out["depth"], out["stage4"]["depth"])
+    for s in range(1, 5):
+        st = out["stage%d" % s]
+        want_depth = g.t("stage%d_depth" % s)
+        depth = st["depth"].cpu()
+        assert depth.shape == want_depth.shape
+        close = (depth - want_depth).abs() <= 1e-3
+        note("free_stage%d" % s, depth_l1=(depth - want_depth).abs().mean(), agree_frac=close.float().mean(),
+             hypo_max=(st["hypo_depth"].cpu() - g.t("stage%d_hypo_depth" % s)).abs().max())
+        assert st["photometric_confidence"].shape[-2:] == (H, W)
+    # stage 1 hypotheses are input-independent of earlier stages: exact
+    assert torch.equal(out["stage1"]["hypo_depth"].cpu(), g.t("stage1_hypo_depth"))
+    s1 = out["stage1"]["depth"].cpu()
+    clear = g.t("stage1_margin") > 1e-3
+    assert (s1 - g.t("stage1_depth"))[clear].abs().mean() < 1e-4
+
+
+def test_graph_replay_is_bit_identical(model):
+    imgs, proj, dv = to_dev(*make_inputs(nviews=5, H=128, W=192, seed=4))
+    eager = model(imgs, proj, dv)
+    eager = {k: v.clone() for k, v in eager.items() if torch.is_tensor(v)}
+    gf = GraphedForward(model, imgs, proj, dv)
+    out = gf()
+    torch.cuda.synchronize()
+    for k in ("depth", "attn_weight", "photometric_confidence", "hypo_depth"):
+        assert torch.equal(out[k], eager[k]), k
+    # new inputs through the static buffers
+    imgs2, proj2, dv2 = to_dev(*make_inputs(nviews=5, H=128, W=192, seed=5))
+    want = {k: v.clone() for k, v in model(imgs2, proj2, dv2).items() if torch.is_tensor(v)}
+    out = gf(imgs2, proj2, dv2)
+    torch.cuda.synchronize()
+    assert torch.equal(out["depth"], want["depth"])
+
+
+@pytest.mark.parametrize("H,W,N", [(512, 640, 5)])
+def test_full_size_properties(model, H, W, N):
+    """BASELINE config 2 at full size: properties that do not need the (slow) CPU oracle."""
+    imgs, proj, dv = to_dev(*make_inputs(nviews=N, H=H, W=W, seed=0))
+    out = model(imgs, proj, dv)
+    out2 = model(imgs, proj, dv)
+    for s in range(1, 5):
+        st = out["stage%d" % s]
+        D = st["hypo_depth"].shape[1]
+        attn = st["attn_weight"]
+        assert torch.isfinite(attn).all() and torch.isfinite(st["depth"]).all()
+        assert (attn.sum(1) - 1).abs().max() <= 1e-5                       # softmax
+        conf = st["photometric_confidence"]
+        assert conf.shape == (1, H, W) and conf.min() >= 1.0 / D - 1e-6 and conf.max() <= 1 + 1e-6
+        # winner-take-all: the depth is one of the hypotheses, the one with the largest weight
+        idx = attn.max(1, keepdim=True)[1]
+        assert torch.equal(torch.gather(st["hypo_depth"], 1, idx).squeeze(1), st["depth"])
+        # idempotence / determinism of the whole eval path (no atomics in it)
+        assert torch.equal(st["depth"], out2["stage%d" % s]["depth"])
+        assert torch.equal(attn, out2["stage%d" % s]["attn_weight"])
+        # inverse-depth bounds bracket the selected depth
+        assert (st["inverse_min_depth"] >= 1 / st["depth"]).all() and (st["inverse_max_depth"] <= 1 / st["depth"]).all()
+    # stage-1 hypotheses: index 0 is the farthest plane, exact endpoints
+    h1 = out["stage1"]["hypo_depth"]
+    assert (h1[:, 0] > h1[:, -1]).all()
+    assert (h1[:, 0] - dv[0, 1]).abs().max() <= 1e-3 and (h1[:, -1] - dv[0, 0]).abs().max() <= 1e-3
+
+
+def test_identical_views_have_uniform_attention_over_views(model):
+    """If every source view equals the reference view (same image, same camera) the warp is the
+    identity at every depth, so cor_feats = mean_c(f*f) for every depth and view."""
+    imgs, proj, dv = make_inputs(nviews=3, H=64, W=128, seed=2)
+    imgs = [imgs[0].clone() for _ in imgs]
+    for k in proj:
+        proj[k] = proj[k][:, :1].repeat(1, 3, 1, 1, 1).contiguous()
+    imgs, proj, dv = to_dev(imgs, proj, dv)
+    cap = {}
+    out = model._forward_eval(imgs, proj, dv, capture=cap)
+    f = out["stage4"]["mono_feat"]                                        # [1,8,H,W]
+    want = (f * f).reshape(1, 4, 2, 64, 128).mean(2)                      # G=4
+    got = cap["stage4"]["cor_feats"]                                      # [1,4,D,H,W]
+    inner = (slice(None), slice(None), slice(2, -2), slice(2, -2))
+    for d in range(got.shape[2]):
+        assert (got[:, :, d][inner] - want[inner]).abs().max() <= 2e-4 * want.abs().max()
+
+
+def test_train_step_vs_golden(shipped_cfg, checkpoint, golden):
+    """Train-mode forward + OT loss + backward (PyTorch-ROCm convs, HIP warp fwd/bwd) vs the reference."""
+    g = golden("g6_train")
+    H, W, N = int(g.np("H")), int(g.np("W")), int(g.np("N"))
+    imgs, proj, dv = to_dev(*make_inputs(nviews=N, H=H, W=W, seed=2, batch=2))
+    m = MVS4net(**shipped_cfg)
+    m.load_state_dict(checkpoint, strict=True)
+    m.to(DEV).train()
+    out = m(imgs, proj, dv)
+    gt = {"stage%d" % s: g.t("depth_gt_stage%d" % s, DEV) for s in range(1, 5)}
+    mask = {"stage%d" % s: g.t("mask_stage%d" % s, DEV) for s in range(1, 5)}
+    loss, l1s, ots, _ = MVS4net_loss(out, gt, mask, stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True,
+                                     ot_iter=10, ot_eps=1, ot_continous=False, mono=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    want_loss = float(g.np("loss"))
+    a1 = (out["stage1"]["attn_weight"].detach().cpu() - g.t("stage1_attn_weight")).abs().max().item()
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for k in [k for k in g.keys() if k.startswith("grad/")]:
+        ref = g.t(k)
+        rel = ((named[k[5:]].grad.cpu() - ref).abs().max() / (ref.abs().max() + 1e-12)).item()
+        worst = max(worst, rel)
+    note("train_step", loss=loss.item(), want_loss=want_loss, stage1_attn_max=a1, worst_grad_rel=worst)
+    assert out["photometric_confidence"].dim() == 0
+    assert a1 <= 1e-3
+    # later stages can pick other hypotheses on near-ties, so the total loss is compared loosely
+    assert abs(ots[0].item() - float(g.np("ot")[0])) <= 2e-3 * abs(float(g.np("ot")[0]))
+    assert abs(loss.item() - want_loss) <= 5e-2 * abs(want_loss)
+    for k in named:
+        if named[k].grad is not None:
+            assert torch.isfinite(named[k].grad).all(), k
