@@ -55,13 +55,15 @@ class KernelTimer:
 
         def conv_call(layer, x, skip=None, skip_mode=0, tiles=None):
             B, Di, Hi, Wi, _ = x.shape
-            _, mt, nt, _ = layer._geom(B, Di, Hi, Wi, skip_mode if skip is not None else 0)
+            _, mt, nt, _, variant = layer._geom(B, Di, Hi, Wi, skip_mode if skip is not None else 0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = timer._orig_conv(layer, x, skip, skip_mode, tiles)
             e1.record()
             bytes_ = 4 * (x.numel() + out.numel() + layer.wpk.numel() + (skip.numel() if skip is not None else 0))
-            timer.records.append(("conv_mfma_kernel<%d,%d,%d>" % (layer.cin, mt, nt), e0, e1,
+            kname = ("conv_lds_kernel<%d,%d,%d>|cin%d" % (mt, nt, layer.kernel[2], layer.cin)) if variant == 1 else \
+                ("conv_mfma_kernel<%d,%d,%d>" % (layer.cin, mt, nt))
+            timer.records.append((kname, e0, e1,
                                   layer.flops(B, Di, Hi, Wi), bytes_))
             return out
 

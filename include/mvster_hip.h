@@ -79,11 +79,13 @@ int mvster_upsample_bilinear(const float* in, float* out, int B, int hi, int wi,
  * scale/shift (+ReLU, +skip) epilogue.  in [B,Di,Hi,Wi,cin]; wpk = weights packed by
  * mvster_amd/conv_plan.py; scale/shift [16*ntiles]; skip optional; zeros = >=16 B of zeros;
  * geom = HOST int32 array (layout: conv_plan.GEOM), woff = HOST int64 per-class weight offsets.
+ * variant 0 = direct (operands from L1), 1 = LDS-staged input patch (ordinary convs, cin % 16 == 0,
+ * mt in {2,4}: the workgroup tile is 2*mt rows x 32 columns).
  * Conv3d/ConvTranspose3d/BatchNorm3d/ReLU of reg2d/reg3d (models/mvs4net_utils.py:870-965) and
  * Conv2d/BatchNorm2d/ReLU/upsample-add of FPN4 (:419-502). */
 int mvster_conv_mfma(const float* in, const float* wpk, const float* scale, const float* shift, const float* skip,
                      const float* zeros, float* out, const int* geom, int ngeom, const long* woff, int cin, int mt,
-                     int nt, void* stream);
+                     int nt, int variant, void* stream);
 
 /* One v_mfma_f32_16x16x4_f32: A [16,4], B [4,16] -> D [16,16] (row major).  Test hook that pins the
  * fragment layout the convolution kernels assume. */

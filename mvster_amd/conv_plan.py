@@ -41,6 +41,28 @@ def fold_bn(bn, cout, device):
     return scale.float(), shift.float()
 
 
+LDS_BUDGET = 12 * 256 * 16      # bytes of staged patch the LDS variant accepts (conv_mfma.hip kMaxStage)
+FORCE_VARIANT = None            # None = choose per layer; 0 / 1 pin the kernel variant (experiments, tests)
+
+
+def _lds_plan(B, Do, Ho, Wo, kernel, stride, ntile_total):
+    """(mt, nt) for the LDS-staged kernel, or None if the layer does not fit it."""
+    kd, kh, kw = kernel
+    if kw not in (3, 5) or Wo < 24:
+        return None
+    for mt in (4, 2):
+        ty = 2 * mt
+        patch = kd * ((ty - 1) * stride[1] + kh) * (31 * stride[2] + kw) * 64
+        if patch > LDS_BUDGET or (mt == 4 and Ho < 6):
+            continue
+        blocks = -(-Wo // 32) * -(-Ho // ty) * Do * B
+        nt = max(n for n in (4, 2, 1) if n <= ntile_total and ntile_total % n == 0)
+        while nt > 1 and blocks * (ntile_total // nt) < 512:
+            nt //= 2
+        return mt, nt
+    return None
+
+
 def _tiles(M, ntile_total, nclass):
     """(MT, NT): biggest register tile that still fills the chip (>= 2048 waves), else the most waves."""
     best = None
@@ -158,20 +180,31 @@ class ConvLayer:
             for c in self.classes:
                 arr += [c[k] for k in GEOM_CLASS]
             mt, nt = _tiles(B * Do * Ho * Wo, self.ntile_total, len(self.classes))
-            g = (np.asarray(arr, dtype=np.int32), mt, nt, (B, DoF, HoF, WoF))
+            variant = 0
+            lds = None
+            if not self.transposed and self.cin % 16 == 0 and skip_mode in (SKIP_NONE, SKIP_ADD):
+                lds = _lds_plan(B, Do, Ho, Wo, self.kernel, self.stride, self.ntile_total)
+            if lds is not None and FORCE_VARIANT != 0:
+                variant, (mt, nt) = 1, lds
+            elif FORCE_VARIANT == 1 and lds is None:
+                variant = 0
+            g = (np.asarray(arr, dtype=np.int32), mt, nt, (B, DoF, HoF, WoF), variant)
             self._geom_cache[key] = g
         return g
 
     def __call__(self, x, skip=None, skip_mode=SKIP_NONE, tiles=None):
-        """x [B,Di,Hi,Wi,cin] channels-last -> [B,Do,Ho,Wo,cout]."""
+        """x [B,Di,Hi,Wi,cin] channels-last -> [B,Do,Ho,Wo,cout].  ``tiles`` = (mt, nt[, variant]) overrides
+        the per-layer choice (tests, tuning)."""
         B, Di, Hi, Wi, C = x.shape
         if C != self.cin or not x.is_contiguous() or x.dtype != torch.float32 or not x.is_cuda:
             raise RuntimeError("conv_mfma: bad input (shape %s, cin %d)" % (tuple(x.shape), self.cin))
         if skip is None:
             skip_mode = SKIP_NONE
-        geom, mt, nt, oshape = self._geom(B, Di, Hi, Wi, skip_mode)
+        geom, mt, nt, oshape, variant = self._geom(B, Di, Hi, Wi, skip_mode)
         if tiles is not None:
-            mt, nt = tiles
+            mt, nt = tiles[0], tiles[1]
+            if len(tiles) > 2:
+                variant = tiles[2]
         out = torch.empty(oshape + (self.cout,), device=x.device, dtype=torch.float32)
         if skip is not None:
             if not skip.is_contiguous():
@@ -183,7 +216,7 @@ class ConvLayer:
             x.data_ptr(), self.wpk.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
             None if skip is None else skip.data_ptr(), self.zeros.data_ptr(), out.data_ptr(),
             geom.ctypes.data_as(ctypes.c_void_p), int(geom.size), self.woff.ctypes.data_as(ctypes.c_void_p), self.cin,
-            mt, nt, torch.cuda.current_stream().cuda_stream)
+            mt, nt, variant, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "conv_mfma")
         return out
 

@@ -45,6 +45,7 @@ struct ConvArgs {
     int Do, Ho, Wo;       // output lattice walked by M (per class)
     int DoF, HoF, WoF;    // full output dims
     int sd, sh, sw;       // input step per lattice step
+    int cin;              // input channels (LDS-staged variant; the direct kernel has it as a template argument)
     int cout;             // real output channels
     int ntile_total;      // Np / 16
     int relu;
@@ -230,6 +231,170 @@ int dispatch_tiles(const ConvArgs& a, int MT, int NT, hipStream_t s) {
     return MVSTER_ERR_UNSUPPORTED;
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-staged variant for ordinary (non-transposed) convolutions with CIN % 16 == 0.
+//
+// In the direct kernel above every A operand is a global load; a 3x3(x3) layer re-reads each
+// input texel 9 (27) times and the per-CU L1 (64 B/clk, one tag lookup per touched line) becomes
+// the limiter at ~35 % of the MFMA peak.  Here a workgroup (4 waves) owns a TY x 32 output tile of
+// one (b, z) slice, TY = 2*MT.  Per 16-channel chunk of the input it stages the
+// (KD) x (TY-1)*s+KH x 31*s+KW input patch once into LDS (zero padding materialised there, so
+// the K loop has no bounds logic at all), then every tap is MT ds_read_b128 + NT coalesced weight
+// loads feeding 4*MT*NT MFMAs.  Same packed weights, same K order (tap-major, channel-minor) and the
+// same fused epilogue as the direct kernel.  Several workgroups per CU overlap staging and math.
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxStage = 12;   // float4 loads per thread per chunk (patch <= 48 KB)
+
+template <int MT, int NT, int KW>
+__global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) float patch_raw[];
+    f32x4v* patch = reinterpret_cast<f32x4v*>(patch_raw);
+    constexpr int TY = 2 * MT;
+    const int KD = a.kd[0], KH = a.kh[0];
+    const int PW = 31 * a.sw + KW, PH = (TY - 1) * a.sh + KH;
+    const int CIN = a.cin, nchunks = CIN >> 4;
+    const int nstage = KD * PH * PW * 4;     // float4 per chunk
+
+    unsigned bid = blockIdx.x;
+    const int tile_x = bid % tiles_x; bid /= tiles_x;
+    const int tile_y = bid % tiles_y; bid /= tiles_y;
+    const int zo = bid % a.Do;
+    const int b = bid / a.Do;
+    const int ty0 = tile_y * TY, tx0 = tile_x * 32;
+    const int nt0 = blockIdx.y * NT;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lm = lane & 15, lq = lane >> 4;
+
+    // chunk-independent global element offsets of the float4s this thread stages (-1 = zero padding)
+    int goff[kMaxStage];
+#pragma unroll
+    for (int i = 0; i < kMaxStage; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        int off = -1;
+        if (idx < nstage) {
+            const int quad = idx & 3;
+            int pix = idx >> 2;
+            const int px = pix % PW; pix /= PW;
+            const int py = pix % PH;
+            const int pz = pix / PH;
+            const int iz = zo * a.sd - a.pd[0] + pz, iy = ty0 * a.sh - a.ph[0] + py, ix = tx0 * a.sw - a.pw[0] + px;
+            if ((unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
+                off = ((((b * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * CIN) + quad * 4;
+        }
+        goff[i] = off;
+    }
+    const long zero_off = a.zeros - a.in;
+
+    // LDS float4 index of this lane's A operand for tap (0,0,0) of each of its M tiles
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int t = wave * MT + mt;
+        const int row = t >> 1, xs = t & 1;
+        abase[mt] = ((row * a.sh) * PW + (xs * 16 + lm) * a.sw) * 4 + lq;
+    }
+
+    f32x4v acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    const float* wp = a.wpk + ((long)nt0 * 64 + lane) * 4;
+    const long wstep = (long)a.ntile_total * 256;
+
+    const int ngroups = (nstage + 1023) >> 10;   // staging runs in uniform groups of 4 float4 per thread
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch > 0) __syncthreads();          // everyone is done reading the previous chunk
+#pragma unroll
+        for (int g = 0; g < kMaxStage / 4; ++g) {
+            if (g < ngroups) {                // wave-uniform: 4 loads in flight, then 4 LDS writes
+                f32x4v tmp[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = goff[g * 4 + i];
+                    const long off = o >= 0 ? (long)o + ch * 16 : zero_off;
+                    tmp[i] = *reinterpret_cast<const f32x4v*>(a.in + off);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) patch[threadIdx.x + (g * 4 + i) * 256] = tmp[i];   // LDS is padded to ngroups*1024
+            }
+        }
+        __syncthreads();
+        for (int kz = 0; kz < KD; ++kz) {
+            for (int ky = 0; ky < KH; ++ky) {
+                const int rowoff = (kz * PH + ky) * PW * 4;
+                const int tap0 = (kz * KH + ky) * KW;
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx) {
+                    f32x4v af[MT], bf[NT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) af[mt] = patch[abase[mt] + rowoff + kx * 4];
+                    const float* w = wp + (long)((tap0 + kx) * nchunks + ch) * wstep;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const f32x4v*>(w + nt * 256);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // epilogue: scale/shift (+ReLU) (+ same-resolution skip)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int t = wave * MT + mt;
+        const int y = ty0 + (t >> 1);
+        if (y >= a.Ho) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int x = tx0 + (t & 1) * 16 + lq * 4 + r;
+            if (x >= a.Wo) continue;
+            const long opix = (((long)b * a.Do + zo) * a.Ho + y) * a.Wo + x;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = (nt0 + nt) * 16 + lm;
+                if (n >= a.cout) continue;
+                float v = fmaf(acc[mt][nt][r], a.scale[n], a.shift[n]);
+                if (a.relu) v = fmaxf(v, 0.0f);
+                if (a.skip_mode == 1) v += a.skip[opix * a.cout + n];
+                a.out[opix * a.cout + n] = v;
+            }
+        }
+    }
+}
+
+template <int MT, int NT, int KW>
+int launch_lds(const ConvArgs& a, hipStream_t s) {
+    constexpr int TY = 2 * MT;
+    const int PW = 31 * a.sw + KW, PH = (TY - 1) * a.sh + a.kh[0];
+    const size_t nstage = (size_t)a.kd[0] * PH * PW * 4;
+    if (nstage > (size_t)kMaxStage * 256) return MVSTER_ERR_SHAPE;
+    const size_t lds = ((nstage + 1023) / 1024) * 1024 * 16;   // padded: every thread stages 4 float4 per group
+    const int tiles_x = (a.Wo + 31) / 32, tiles_y = (a.Ho + TY - 1) / TY;
+    const long blocks = (long)tiles_x * tiles_y * a.Do * a.B;
+    if (blocks >= (1L << 31) || (long)a.B * a.Di * a.Hi * a.Wi * a.cin >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    dim3 grid((unsigned)blocks, a.ntile_total / NT, 1);
+    hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW>), grid, dim3(256), lds, s, a, tiles_x, tiles_y);
+    return mv_check_launch();
+}
+
+int dispatch_lds(const ConvArgs& a, int MT, int NT, hipStream_t s) {
+    if (a.nclass != 1 || a.cin % 16 != 0 || a.skip_mode > 1 || a.osd != 1 || a.osh != 1 || a.osw != 1)
+        return MVSTER_ERR_UNSUPPORTED;
+#define MV_L(M_, N_, K_) if (MT == M_ && NT == N_ && a.kw[0] == K_) return launch_lds<M_, N_, K_>(a, s);
+    MV_L(2, 1, 3) MV_L(2, 2, 3) MV_L(2, 4, 3) MV_L(4, 1, 3) MV_L(4, 2, 3) MV_L(4, 4, 3)
+    MV_L(2, 1, 5) MV_L(2, 2, 5) MV_L(2, 4, 5) MV_L(4, 1, 5) MV_L(4, 2, 5) MV_L(4, 4, 5)
+#undef MV_L
+    return MVSTER_ERR_UNSUPPORTED;
+}
+
 // one raw MFMA, to pin the fragment layout this file assumes (tests/test_gpu_conv.py)
 __global__ void mfma_probe_kernel(const float* A, const float* Bm, float* Dm) {
     const int lane = threadIdx.x;
@@ -245,7 +410,7 @@ __global__ void mfma_probe_kernel(const float* A, const float* Bm, float* Dm) {
 // geom: int32 array, see mvster_amd/conv_plan.py (GEOM_* layout); woff: per-class offsets (floats)
 extern "C" int mvster_conv_mfma(const float* in, const float* wpk, const float* scale, const float* shift,
                                 const float* skip, const float* zeros, float* out, const int* geom, int ngeom, const long* woff,
-                                int cin, int mt, int nt, void* stream) {
+                                int cin, int mt, int nt, int variant, void* stream) {
     if (!in || !wpk || !scale || !shift || !zeros || !out || !geom || !woff) return MVSTER_ERR_NULL;
     if (ngeom < 22) return MVSTER_ERR_SHAPE;
     ConvArgs a;
@@ -271,6 +436,9 @@ extern "C" int mvster_conv_mfma(const float* in, const float* wpk, const float* 
     if (a.skip_mode != 0 && !skip) return MVSTER_ERR_NULL;
     if (a.ntile_total % nt != 0) return MVSTER_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
+    a.cin = cin;
+    if (variant == 1) return dispatch_lds(a, mt, nt, s);
+    if (variant != 0) return MVSTER_ERR_UNSUPPORTED;
     switch (cin) {
         case 4: return dispatch_tiles<4>(a, mt, nt, s);
         case 8: return dispatch_tiles<8>(a, mt, nt, s);

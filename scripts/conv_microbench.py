@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the convolution kernels on the shapes of one 512x640x5 forward.
+For every ConvLayer call of the eval forward: time the direct kernel (variant 0) and, where it
+applies, the LDS-staged kernel (variant 1) over a few tile shapes.  GPU only."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import mvster_amd.conv_plan as cp  # noqa: E402
+from bench import SHIPPED, load_weights  # noqa: E402
+from mvster_amd import MVS4net  # noqa: E402
+from mvster_amd.synthetic import make_inputs  # noqa: E402
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3   # us
+
+
+def main():
+    dev = torch.device("cuda:0")
+    model = MVS4net(**SHIPPED)
+    model.load_state_dict(load_weights(), strict=True)
+    model.to(dev).eval()
+    imgs, proj, dv = make_inputs(5, 512, 640, seed=0, device=dev)
+    calls = []
+    orig = cp.ConvLayer.__call__
+
+    def rec(layer, x, skip=None, skip_mode=0, tiles=None):
+        calls.append((layer, tuple(x.shape), None if skip is None else tuple(skip.shape), skip_mode))
+        return orig(layer, x, skip, skip_mode, tiles)
+    cp.ConvLayer.__call__ = rec
+    model(imgs, proj, dv)
+    cp.ConvLayer.__call__ = orig
+    torch.cuda.synchronize()
+    print("%-3s %-28s %-22s %9s | %-30s" % ("#", "layer", "input", "GFLOP", "us (TFLOP/s) per variant/tile"))
+    tot = {}
+    for i, (layer, xs, ss, sm) in enumerate(calls):
+        x = torch.randn(*xs, device=dev)
+        skip = torch.randn(*ss, device=dev) if ss else None
+        B, Di, Hi, Wi, _ = xs
+        fl = layer.flops(B, Di, Hi, Wi)
+        _, mt, nt, _, var = layer._geom(B, Di, Hi, Wi, sm if skip is not None else 0)
+        desc = "%s%dx%dx%d s%s %d->%d" % ("T" if layer.transposed else "", *layer.kernel, layer.stride[1], layer.cin, layer.cout)
+        res = []
+        cands = [("auto", None)]
+        d_mt, d_nt = cp._tiles(B * Di * Hi * Wi // (layer.stride[1] * layer.stride[2]) if not layer.transposed else B * Di * Hi * Wi, layer.ntile_total, len(layer.classes))
+        cands.append(("d%d,%d" % (d_mt, d_nt), (d_mt, d_nt, 0)))
+        if not layer.transposed and layer.cin % 16 == 0 and layer.kernel[2] in (3, 5) and sm in (0, 1):
+            for m in (2, 4):
+                patch = layer.kernel[0] * ((2 * m - 1) * layer.stride[1] + layer.kernel[1]) * (31 * layer.stride[2] + layer.kernel[2]) * 64
+                if patch > cp.LDS_BUDGET:
+                    continue
+                for n in (1, 2, 4):
+                    if n <= layer.ntile_total and layer.ntile_total % n == 0:
+                        cands.append(("L%d,%d" % (m, n), (m, n, 1)))
+        best = None
+        for name, tiles in cands:
+            try:
+                us = timeit(lambda: layer(x, skip=skip, skip_mode=sm, tiles=tiles))
+            except RuntimeError as e:
+                res.append("%s:ERR" % name)
+                continue
+            res.append("%s:%.0f(%.0f)" % (name, us, fl / us / 1e6))
+            if name != "auto" and (best is None or us < best[1]):
+                best = (name, us)
+            if name == "auto":
+                tot["auto"] = tot.get("auto", 0) + us
+        tot["best"] = tot.get("best", 0) + (best[1] if best else 0)
+        print("%-3d %-28s %-22s %9.2f | auto=v%d(%d,%d) %s" % (i, desc, "x".join(map(str, xs)), fl / 1e9, var, mt, nt, " ".join(res)))
+    print("sum auto %.0f us, sum best-of-candidates %.0f us" % (tot["auto"], tot["best"]))
+
+
+if __name__ == "__main__":
+    main()

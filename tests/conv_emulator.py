@@ -29,7 +29,7 @@ def run_layer(layer, x, skip=None, skip_mode=SKIP_NONE):
     assert C == layer.cin
     if skip is None:
         skip_mode = SKIP_NONE
-    geom, mt, nt, oshape = layer._geom(B, Di, Hi, Wi, skip_mode)
+    geom, mt, nt, oshape, _variant = layer._geom(B, Di, Hi, Wi, skip_mode)
     g = dict(zip(GEOM, geom[:len(GEOM)].tolist()))
     ncls = g["nclass"]
     cls = [dict(zip(GEOM_CLASS, geom[len(GEOM) + i * len(GEOM_CLASS):len(GEOM) + (i + 1) * len(GEOM_CLASS)].tolist()))

@@ -177,6 +177,8 @@ CONV_CASES = [
     ("c3d_333_64_64", dict(cin=64, cout=64, k=3, s=1, p=1), (1, 64, 8, 8, 10)),
     ("c3d_133s2_32_64", dict(cin=32, cout=64, k=(1, 3, 3), s=(1, 2, 2), p=(0, 1, 1)), (1, 32, 4, 12, 16)),
     ("c3d_333s2_16_32", dict(cin=16, cout=32, k=3, s=2, p=1), (1, 16, 8, 12, 16)),
+    ("c2d_55s2_16_32", dict(cin=16, cout=32, k=(1, 5, 5), s=(1, 2, 2), p=(0, 2, 2)), (3, 16, 1, 44, 70)),
+    ("c2d_33_64_8", dict(cin=64, cout=8, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1)), (2, 64, 1, 21, 45)),
 ]
 
 
@@ -199,7 +201,22 @@ def test_conv_bn_relu(name, cfg, shape):
             err = (got - want).abs().max().item()
             worst = max(worst, err)
             assert err <= 2e-5 * want.abs().max().item(), (name, mt, nt, err)
-    note("conv_" + name, max_abs=worst, ref_absmax=want.abs().max().item())
+    # LDS-staged variant (ordinary convs, cin % 16 == 0, kernel width 3 or 5)
+    lds_ok = cfg["cin"] % 16 == 0 and layer.kernel[2] in (3, 5)
+    if lds_ok:
+        from mvster_amd.conv_plan import LDS_BUDGET
+        for mt in (2, 4):
+            patch = layer.kernel[0] * ((2 * mt - 1) * layer.stride[1] + layer.kernel[1]) * (31 * layer.stride[2] + layer.kernel[2]) * 64
+            if patch > LDS_BUDGET:
+                continue
+            for nt in (1, 2, 4):
+                if layer.ntile_total % nt:
+                    continue
+                got = layer(cl5(x).to(DEV), tiles=(mt, nt, 1)).cpu()
+                err = (got - want).abs().max().item()
+                worst = max(worst, err)
+                assert err <= 2e-5 * want.abs().max().item(), (name, "lds", mt, nt, err)
+    note("conv_" + name, max_abs=worst, ref_absmax=want.abs().max().item(), lds_tested=float(lds_ok))
 
 
 @pytest.mark.parametrize("cin,cout,k,pad,op,s", [(64, 32, (1, 3, 3), (0, 1, 1), (0, 1, 1), (1, 2, 2)),
