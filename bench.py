@@ -190,21 +190,32 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import mvs4_oracle as O
         cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
         oracle = O.OracleMVS4net(**SHIPPED)
         oracle.load_state_dict(load_weights(), strict=True)
         oracle.eval()
         cimgs, cproj, cdv = make_inputs(nviews=args.views, H=args.height, W=args.width, seed=units[0])
+        # PyTorch's intra-op pool does not scale to 256 hardware threads on these small convolutions
+        # (1 forward took 154 s with 256 threads): sweep a few pool sizes once, keep the fastest
+        sweep = {}
         with torch.no_grad():
-            oracle(cimgs, cproj, cdv)                       # warm-up
+            for t in sorted({min(cores, c) for c in (8, 16, 32, 64)}):
+                torch.set_num_threads(t)
+                oracle(cimgs, cproj, cdv)                   # warm-up at this pool size
+                c0 = time.perf_counter()
+                oracle(cimgs, cproj, cdv)
+                sweep[t] = time.perf_counter() - c0
+            best_t = min(sweep, key=sweep.get)
+            torch.set_num_threads(best_t)
             n, c0 = 0, time.perf_counter()
-            while n < 8 and (time.perf_counter() - c0) < 12.0:
+            while n < 12 and (time.perf_counter() - c0) < 10.0:
                 oracle(cimgs, cproj, cdv)
                 n += 1
             ct = time.perf_counter() - c0
-        cpu = {"value": round(n / ct, 4), "unit": "depth-maps/s", "cores": cores, "kind": "port",
-               "sample": "%d forwards of the same %dx%d %d-view 4-stage workload after 1 warm-up (torch %d threads)"
-                         % (n, args.height, args.width, args.views, cores)}
+        cpu = {"value": round(n / ct, 4), "unit": "depth-maps/s", "cores": best_t, "kind": "port",
+               "sample": "%d forwards of the same %dx%d %d-view 4-stage workload; torch intra-op threads swept over %s "
+                         "(s/forward: %s) on a %d-thread host, fastest kept"
+                         % (n, args.height, args.width, args.views, sorted(sweep), 
+                            ", ".join("%d:%.2f" % (k, sweep[k]) for k in sorted(sweep)), cores)}
 
     if rank == 0:
         total_maps = args.steps * world

@@ -203,8 +203,7 @@ class ConvLayer:
         geom, mt, nt, oshape, variant = self._geom(B, Di, Hi, Wi, skip_mode)
         if tiles is not None:
             mt, nt = tiles[0], tiles[1]
-            if len(tiles) > 2:
-                variant = tiles[2]
+            variant = tiles[2] if len(tiles) > 2 else 0
         out = torch.empty(oshape + (self.cout,), device=x.device, dtype=torch.float32)
         if skip is not None:
             if not skip.is_contiguous():

@@ -13,7 +13,8 @@
 //             voxel for the tap that K-slot belongs to -> feeds 4 MFMAs (the K order inside a 16-wide
 //             K step is a fixed permutation shared with the packed weights, so it cancels out)
 //   B[k][n] : weights pre-packed on the host in exactly the fragment order -> one coalesced float4 per lane
-//   D       : lane holds rows 4*(lane>>4)+r, column lane&15  (r = 0..3)
+//   D       : the two operands are passed SWAPPED (weights in the A slot), so the accumulator is D^T:
+//             lane holds output channels 4*(lane>>4)+r (r = 0..3) of voxel lane&15 -> float4 stores
 // A wave owns MT x NT tiles of 16x16; there is no LDS staging and no barrier in the K loop: the
 // activations of one stage are L2/MALL resident (<= 42 MB), every tap re-read is a cache hit, and
 // zero padding is a per-lane select.  Transposed stride-2 layers run as 2^k parity classes
@@ -59,6 +60,47 @@ struct ConvArgs {
     int nsteps[kMaxClasses];
     long woff[kMaxClasses];                                  // float offset of the class's packed weights
 };
+
+// Fused epilogue for 4 consecutive output channels n0..n0+3 of one output voxel.
+__device__ __forceinline__ void epilogue_store(const ConvArgs& a, f32x4v v, int n0, long opix, int b, int oy, int ox) {
+    const bool vec = (n0 + 3 < a.cout) && ((a.cout & 3) == 0);
+    float sc[4], sh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sc[j] = a.scale[n0 + j]; sh[j] = a.shift[n0 + j]; }   // padded to 16*ntiles
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j] = fmaf(v[j], sc[j], sh[j]);
+        if (a.relu) v[j] = fmaxf(v[j], 0.0f);
+    }
+    float* op = a.out + opix * a.cout + n0;
+    if (vec) {
+        if (a.skip_mode == 1) {
+            const f32x4v k = *reinterpret_cast<const f32x4v*>(a.skip + opix * a.cout + n0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += k[j];
+        } else if (a.skip_mode == 2) {
+            // F.interpolate(prev, x2, bilinear, align_corners) + inner(conv)   (mvs4net_utils.py:482-488)
+            const int hh = a.HoF / 2, wh = a.WoF / 2;
+            const mv::Lerp ly = mv::make_lerp(oy, hh, a.HoF), lx = mv::make_lerp(ox, wh, a.WoF);
+            const float* sk = a.skip + (long)b * hh * wh * a.cout + n0;
+            const f32x4v k00 = *reinterpret_cast<const f32x4v*>(sk + ((long)ly.i0 * wh + lx.i0) * a.cout);
+            const f32x4v k01 = *reinterpret_cast<const f32x4v*>(sk + ((long)ly.i0 * wh + lx.i1) * a.cout);
+            const f32x4v k10 = *reinterpret_cast<const f32x4v*>(sk + ((long)ly.i1 * wh + lx.i0) * a.cout);
+            const f32x4v k11 = *reinterpret_cast<const f32x4v*>(sk + ((long)ly.i1 * wh + lx.i1) * a.cout);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = mv::bilerp(ly, lx, k00[j], k01[j], k10[j], k11[j]) + v[j];
+        }
+        *reinterpret_cast<f32x4v*>(op) = v;
+    } else {
+        // channel count not a multiple of 4 (e.g. the 1-channel prob head of reg3d)
+        for (int j = 0; j < 4; ++j) {
+            if (n0 + j >= a.cout) break;
+            float r = v[j];
+            if (a.skip_mode == 1) r += a.skip[opix * a.cout + n0 + j];
+            op[j] = r;
+        }
+    }
+}
 
 template <int CIN, int MT, int NT>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
@@ -147,7 +189,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[mt][j], Bv[nt][j], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bv[nt][j], A[mt][j], acc[mt][nt], 0, 0, 0);
     };
 
     // Two register sets, ping-pong: the loads of step s+1 are in flight under the MFMAs of step s.
@@ -164,51 +206,26 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     }
     if (s < nsteps) mma_step(af, bf);
 
-    // epilogue
+    // epilogue.  The MFMA operands are swapped (weights in the A slot, activations in the B slot), so
+    // the accumulator is D^T: this lane holds 4 CONSECUTIVE output channels (4*lq .. 4*lq+3 of each
+    // N tile) of ONE voxel (its A-role voxel, lm) -> one float4 store per tile, 16 lanes x 16 B contiguous.
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        // rows 4*lq .. 4*lq+3 are consecutive lattice voxels: decompose the first, then carry
-        const unsigned m0 = (tile0 + mt) * 16u + lq * 4u;
-        int x = (int)(m0 % (unsigned)a.Wo);
-        unsigned q0 = m0 / (unsigned)a.Wo;
-        int y = (int)(q0 % (unsigned)a.Ho);
+        const unsigned m = (tile0 + mt) * 16u + lm;
+        if (m >= Mtot) continue;
+        const int x = (int)(m % (unsigned)a.Wo);
+        unsigned q0 = m / (unsigned)a.Wo;
+        const int y = (int)(q0 % (unsigned)a.Ho);
         q0 /= (unsigned)a.Ho;
-        int z = (int)(q0 % (unsigned)a.Do);
-        int b = (int)(q0 / (unsigned)a.Do);
+        const int z = (int)(q0 % (unsigned)a.Do);
+        const int b = (int)(q0 / (unsigned)a.Do);
+        const int oz = z * a.osd + a.od[cls], oy = y * a.osh + a.oh[cls], ox = x * a.osw + a.ow[cls];
+        const long opix = (((long)b * a.DoF + oz) * a.HoF + oy) * a.WoF + ox;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (r > 0) {
-                if (++x == a.Wo) { x = 0; if (++y == a.Ho) { y = 0; if (++z == a.Do) { z = 0; ++b; } } }
-            }
-            if (m0 + r >= Mtot) continue;
-            const int oz = z * a.osd + a.od[cls], oy = y * a.osh + a.oh[cls], ox = x * a.osw + a.ow[cls];
-            const long opix = (((long)b * a.DoF + oz) * a.HoF + oy) * a.WoF + ox;
-            mv::Lerp ly, lx;
-            const float* sk = a.skip;
-            if (a.skip_mode == 2) {
-                const int hh = a.HoF / 2, wh = a.WoF / 2;
-                ly = mv::make_lerp(oy, hh, a.HoF);
-                lx = mv::make_lerp(ox, wh, a.WoF);
-                sk = a.skip + (long)b * hh * wh * a.cout;
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = (nt0 + nt) * 16 + lm;
-                if (n >= a.cout) continue;
-                float v = fmaf(acc[mt][nt][r], a.scale[n], a.shift[n]);
-                if (a.relu) v = fmaxf(v, 0.0f);
-                if (a.skip_mode == 1) {
-                    v += a.skip[opix * a.cout + n];
-                } else if (a.skip_mode == 2) {
-                    const int wh = a.WoF / 2;
-                    const float up = mv::bilerp(ly, lx, sk[((long)ly.i0 * wh + lx.i0) * a.cout + n],
-                                                sk[((long)ly.i0 * wh + lx.i1) * a.cout + n],
-                                                sk[((long)ly.i1 * wh + lx.i0) * a.cout + n],
-                                                sk[((long)ly.i1 * wh + lx.i1) * a.cout + n]);
-                    v = up + v;   // F.interpolate(prev) + inner(conv)   (mvs4net_utils.py:482-488)
-                }
-                a.out[opix * a.cout + n] = v;
-            }
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n0 = (nt0 + nt) * 16 + lq * 4;
+            if (n0 >= a.cout) continue;
+            epilogue_store(a, acc[mt][nt], n0, opix, b, oy, ox);
         }
     }
 }
@@ -340,32 +357,24 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
                         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nt][j], af[mt][j], acc[mt][nt], 0, 0, 0);
                 }
             }
         }
     }
 
-    // epilogue: scale/shift (+ReLU) (+ same-resolution skip)
+    // epilogue (swapped operands: this lane holds channels 4*lq..4*lq+3 of its own voxel, see above)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int t = wave * MT + mt;
-        const int y = ty0 + (t >> 1);
-        if (y >= a.Ho) continue;
+        const int y = ty0 + (t >> 1), x = tx0 + (t & 1) * 16 + lm;
+        if (y >= a.Ho || x >= a.Wo) continue;
+        const long opix = (((long)b * a.Do + zo) * a.Ho + y) * a.Wo + x;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int x = tx0 + (t & 1) * 16 + lq * 4 + r;
-            if (x >= a.Wo) continue;
-            const long opix = (((long)b * a.Do + zo) * a.Ho + y) * a.Wo + x;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = (nt0 + nt) * 16 + lm;
-                if (n >= a.cout) continue;
-                float v = fmaf(acc[mt][nt][r], a.scale[n], a.shift[n]);
-                if (a.relu) v = fmaxf(v, 0.0f);
-                if (a.skip_mode == 1) v += a.skip[opix * a.cout + n];
-                a.out[opix * a.cout + n] = v;
-            }
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n0 = (nt0 + nt) * 16 + lq * 4;
+            if (n0 >= a.cout) continue;
+            epilogue_store(a, acc[mt][nt], n0, opix, b, y, x);
         }
     }
 }
