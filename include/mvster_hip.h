@@ -34,12 +34,13 @@ int mvster_relative_projection(const float* proj_matrices, float* rt, int B, int
  *   ref_feat [B,h,w,C] (batch stride given), src_feat view v / batch b at
  *   src_feat + v*src_view_stride + b*src_batch_stride as [Hs,Ws,C];
  *   rt [B,NV,12]; hypo [B,D,h,w]; out [B,D,h,w,G]; wsum_out optional [B,D,h,w].
- * group_cor=0 requires G == C.  Replaces models/mvs4net_utils.py:13-59 (homo_warping),
+ * group_cor=0 requires G == C.  variant: 0 = choose (lane-split kernel for C >= 32), 1 = one thread per
+ * (pixel, d), 2 = lane-split also for C == 16.  Replaces models/mvs4net_utils.py:13-59 (homo_warping),
  * :1037-1042 (correlation), :1048-1060 (attention aggregation). */
 int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat, const float* rt, const float* hypo,
                         float* out, float* wsum_out, int B, int NV, int C, int G, int D, int h, int w, int Hs,
                         int Ws, long ref_batch_stride, long src_view_stride, long src_batch_stride, int group_cor,
-                        int attn_fuse_d, float attn_temp, void* stream);
+                        int attn_fuse_d, float attn_temp, int variant, void* stream);
 
 /* Backward of mvster_warp_agg_fwd w.r.t. the features (the sampling grid carries no gradient,
  * models/mvs4net_utils.py:23).  grad_out/out [B,D,h,w,G], wsum [B,D,h,w] from the forward;
@@ -80,12 +81,21 @@ int mvster_upsample_bilinear(const float* in, float* out, int B, int hi, int wi,
  * mvster_amd/conv_plan.py; scale/shift [16*ntiles]; skip optional; zeros = >=16 B of zeros;
  * geom = HOST int32 array (layout: conv_plan.GEOM), woff = HOST int64 per-class weight offsets.
  * variant 0 = direct (operands from L1), 1 = LDS-staged input patch (ordinary convs, cin % 16 == 0,
- * mt in {2,4}: the workgroup tile is 2*mt rows x 32 columns).
+ * mt in {2,4}: the workgroup tile is 2*mt rows x 32 columns), 2 = direct with the 4 waves of a workgroup
+ * splitting K (small deep layers; cin >= 16, mt*nt <= 4).
  * Conv3d/ConvTranspose3d/BatchNorm3d/ReLU of reg2d/reg3d (models/mvs4net_utils.py:870-965) and
  * Conv2d/BatchNorm2d/ReLU/upsample-add of FPN4 (:419-502). */
 int mvster_conv_mfma(const float* in, const float* wpk, const float* scale, const float* shift, const float* skip,
                      const float* zeros, float* out, const int* geom, int ngeom, const long* woff, int cin, int mt,
                      int nt, int variant, void* stream);
+
+/* FPN4 top-down tail, re-associated: G [NB,H/2,W/2,9*CO] = 1x1 conv of the half-resolution top-down
+ * map with the 9 taps of the output conv stacked on the channel axis; vb [9,CO] = the taps applied to the
+ * lateral conv's bias; P [NB,H,W,CO] = sum over in-bounds taps of (bilinear x2 align_corners upsample of
+ * G_tap at p+tap, + vb[tap]).  Together with a 3x3 conv of the lateral input (composed weights, skip-add P)
+ * this equals out4(F.interpolate(f) + inner3(c0)) of models/mvs4net_utils.py:488-489 without the
+ * full-resolution 64-channel intermediate. */
+int mvster_fpn_tail_gather(const float* G, const float* vb, float* P, int NB, int H, int W, int CO, void* stream);
 
 /* One v_mfma_f32_16x16x4_f32: A [16,4], B [4,16] -> D [16,16] (row major).  Test hook that pins the
  * fragment layout the convolution kernels assume. */

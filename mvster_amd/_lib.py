@@ -18,7 +18,7 @@ _fl = ctypes.c_float
 
 SIGNATURES = {
     "mvster_relative_projection": [_f, _f, _i, _i, _f],
-    "mvster_warp_agg_fwd": [_f, _f, _f, _f, _f, _f] + [_i] * 9 + [_l] * 3 + [_i, _i, _fl, _f],
+    "mvster_warp_agg_fwd": [_f, _f, _f, _f, _f, _f] + [_i] * 9 + [_l] * 3 + [_i, _i, _fl, _i, _f],
     "mvster_warp_agg_bwd": [_f] * 9 + [_i] * 9 + [_l] * 3 + [_i, _i, _fl, _f],
     "mvster_init_range": [_f, _i, _f, _i, _i, _i, _i, _i, _f],
     "mvster_schedule_inverse_range": [_f, _f, _f, _i, _i, _i, _i, _f],
@@ -26,6 +26,7 @@ SIGNATURES = {
     "mvster_select_depth": [_f, _f, _f, _f, _i, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _f],
     "mvster_upsample_bilinear": [_f, _f, _i, _i, _i, _i, _i, _f],
     "mvster_conv_mfma": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _f, _i, _i, _i, _i, _f],
+    "mvster_fpn_tail_gather": [_f, _f, _f, _i, _i, _i, _i, _f],
     "mvster_mfma_probe": [_f, _f, _f, _f],
 }
 

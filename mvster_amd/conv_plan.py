@@ -12,7 +12,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, ops
 
 # geometry record shared with mvster_conv_mfma (int32, host memory)
 GEOM = ("B", "Di", "Hi", "Wi", "Do", "Ho", "Wo", "DoF", "HoF", "WoF", "sd", "sh", "sw", "cout", "ntile_total", "relu",
@@ -186,8 +186,17 @@ class ConvLayer:
                 lds = _lds_plan(B, Do, Ho, Wo, self.kernel, self.stride, self.ntile_total)
             if lds is not None and FORCE_VARIANT != 0:
                 variant, (mt, nt) = 1, lds
-            elif FORCE_VARIANT == 1 and lds is None:
-                variant = 0
+            if variant == 0 and self.cin >= 16 and FORCE_VARIANT is None:
+                # small deep layers: let the 4 waves of a workgroup split K instead of M (variant 2)
+                tiles16 = -(-(B * Do * Ho * Wo) // 16)
+                waves = -(-tiles16 // mt) * (self.ntile_total // nt) * len(self.classes)
+                if waves < 1024 and min(c["nsteps"] for c in self.classes) >= 8:
+                    variant, mt = 2, 1
+                    nt = 1
+                    for cand in (4, 2):
+                        if self.ntile_total % cand == 0 and tiles16 * (self.ntile_total // cand) * len(self.classes) >= 512:
+                            nt = cand
+                            break
             g = (np.asarray(arr, dtype=np.int32), mt, nt, (B, DoF, HoF, WoF), variant)
             self._geom_cache[key] = g
         return g
@@ -328,9 +337,24 @@ class FpnPlan:
         self.conv1 = [_cbr2d(l) for l in m.conv1]
         self.conv2 = [_cbr2d(l) for l in m.conv2]
         self.conv3 = [_cbr2d(l) for l in m.conv3]
-        self.inner1, self.inner2, self.inner3 = _plain2d(m.inner1), _plain2d(m.inner2), _plain2d(m.inner3)
-        self.out1, self.out2, self.out3, self.out4 = (_plain2d(m.out1), _plain2d(m.out2), _plain2d(m.out3),
-                                                      _plain2d(m.out4))
+        self.inner1, self.inner2 = _plain2d(m.inner1), _plain2d(m.inner2)
+        self.out1, self.out2, self.out3 = _plain2d(m.out1), _plain2d(m.out2), _plain2d(m.out3)
+        # Last level, re-associated so that the full-resolution 64-channel map
+        #   f3 = F.interpolate(f2) + inner3(c0)            (419 MB at 5 x 512 x 640)
+        # is never formed.  out4 is linear and interpolation acts per channel, hence
+        #   out4(f3)[p] = sum_tap up(W4[tap] f2)[p+tap] + sum_tap W4[tap] (W3 c0[p+tap] + b3)
+        # = gather-sum of G = (1x1 conv 64 -> 9*8 of f2 at HALF resolution)   [tail_g + fpn_tail_gather]
+        # + 3x3 conv 8 -> 8 of c0 with composed weights W4[tap] @ W3          [tail_c, skip-add]
+        # + the bias pushed through the in-bounds taps                         [tail_vb]
+        w4 = m.out4.weight.detach().double()                    # [8, 64, 3, 3]
+        w3 = m.inner3.weight.detach().double()[:, :, 0, 0]      # [64, 8]
+        b3 = m.inner3.bias.detach().double()                    # [64]
+        co = w4.shape[0]
+        wg = w4.permute(2, 3, 0, 1).reshape(9 * co, w4.shape[1], 1, 1)           # row = tap*co + co_idx
+        wc = torch.einsum("ocyx,ci->oiyx", w4, w3)                               # [8, 8, 3, 3]
+        self.tail_g = ConvLayer(wg.float(), False, (1, 1), (0, 0))
+        self.tail_c = ConvLayer(wc.float(), False, (1, 1), (1, 1))
+        self.tail_vb = torch.einsum("ocyx,c->yxo", w4, b3).reshape(9, co).float().contiguous()
 
     @staticmethod
     def _seq(layers, x):
@@ -348,6 +372,7 @@ class FpnPlan:
         o2 = self.out2(f)
         f = self.inner2(c1, skip=f, skip_mode=SKIP_UPSAMPLE_ADD)
         o3 = self.out3(f)
-        f = self.inner3(c0, skip=f, skip_mode=SKIP_UPSAMPLE_ADD)
-        o4 = self.out4(f)
+        H, W = c0.shape[2], c0.shape[3]
+        partial = ops.fpn_tail_gather(self.tail_g(f), self.tail_vb, H, W)
+        o4 = self.tail_c(c0, skip=partial, skip_mode=SKIP_ADD)
         return [o1, o2, o3, o4]

@@ -102,9 +102,14 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& a, f32x4v v, int 
     }
 }
 
-template <int CIN, int MT, int NT>
+// SPLITK: the 4 waves of a workgroup share ONE set of MT x NT tiles and each takes every 4th K step; the
+// partial accumulators are summed through LDS in a fixed order (deterministic).  For the small, deep
+// layers (e.g. 8x10x8 voxels x 64 channels, K = 1728) this turns one 108-step dependent chain per wave
+// into four 27-step chains and quadruples the number of resident waves.
+template <int CIN, int MT, int NT, bool SPLITK>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     static_assert(CIN % 4 == 0 && (CIN >= 16 ? CIN % 16 == 0 : 16 % CIN == 0), "channel packing");
+    __shared__ f32x4v red[SPLITK ? 3 * MT * NT * 64 : 1];
     __shared__ int lut_ofs[kMaxTaps];   // linear input offset (voxels) of a tap
     __shared__ int lut_zyx[kMaxTaps];   // kz | ky << 8 | kx << 16
 
@@ -124,8 +129,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     const int lq = lane >> 4;   // K slot
     // all voxel counts fit 32 bits (checked on the host side of the ABI)
     const unsigned Mtot = (unsigned)(a.B * a.Do * a.Ho * a.Wo);
-    const unsigned tile0 = (blockIdx.x * 4u + wave) * MT;   // first 16-voxel tile of this wave
-    if (tile0 * 16u >= Mtot) return;
+    const unsigned tile0 = SPLITK ? blockIdx.x * MT : (blockIdx.x * 4u + wave) * MT;   // first 16-voxel tile
+    if (!SPLITK && tile0 * 16u >= Mtot) return;
     const int nt0 = blockIdx.y * NT;
 
     // A-role voxel of this lane in each M tile
@@ -156,11 +161,15 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
 
     const float* wp = a.wpk + a.woff[cls] + ((long)nt0 * 64 + lane) * 4;
     const long wstep = (long)a.ntile_total * 256;
-    const int nsteps = a.nsteps[cls];
+    const int nsteps_all = a.nsteps[cls];
+    // K steps of this wave: first, first+stride, ... (all of them unless SPLITK)
+    const int kfirst = SPLITK ? wave : 0, kstride = SPLITK ? 4 : 1;
+    const int nsteps = SPLITK ? (nsteps_all - wave + 3) / 4 : nsteps_all;
 
     const long zero_off = a.zeros - a.in;   // element offset of the zero page relative to `in`
     f32x4v af[MT], bf[NT];
-    auto load_step = [&](int s, f32x4v (&A)[MT], f32x4v (&Bv)[NT]) {
+    auto load_step = [&](int si, f32x4v (&A)[MT], f32x4v (&Bv)[NT]) {
+        const int s = kfirst + si * kstride;
         const int kk = s * 16 + lq * 4;
         const int tap = kk / CIN;
         const int c = kk % CIN;
@@ -196,15 +205,38 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     // Every prefetch is unconditional (the last one re-reads the final step) so that hipcc can
     // count the outstanding loads exactly (a conditional prefetch makes it wait vmcnt(0)).
     f32x4v ag[MT], bg[NT];
-    load_step(0, af, bf);
-    int s = 0;
-    for (; s + 2 <= nsteps; s += 2) {
-        load_step(s + 1, ag, bg);
-        mma_step(af, bf);
-        load_step(s + 2 < nsteps ? s + 2 : nsteps - 1, af, bf);
-        mma_step(ag, bg);
+    if (nsteps > 0) {
+        load_step(0, af, bf);
+        int s = 0;
+        for (; s + 2 <= nsteps; s += 2) {
+            load_step(s + 1, ag, bg);
+            mma_step(af, bf);
+            load_step(s + 2 < nsteps ? s + 2 : nsteps - 1, af, bf);
+            mma_step(ag, bg);
+        }
+        if (s < nsteps) mma_step(af, bf);
     }
-    if (s < nsteps) mma_step(af, bf);
+
+    if (SPLITK) {
+        if (wave > 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) red[((wave - 1) * MT * NT + mt * NT + nt) * 64 + lane] = acc[mt][nt];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4v r = red[(w * MT * NT + mt * NT + nt) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mt][nt][j] += r[j];
+                }
+    }
 
     // epilogue.  The MFMA operands are swapped (weights in the A slot, activations in the B slot), so
     // the accumulator is D^T: this lane holds 4 CONSECUTIVE output channels (4*lq .. 4*lq+3 of each
@@ -230,19 +262,28 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     }
 }
 
-template <int CIN, int MT, int NT>
+template <int CIN, int MT, int NT, bool SPLITK>
 int launch(const ConvArgs& a, hipStream_t s) {
     const long Mtot = (long)a.B * a.Do * a.Ho * a.Wo;
     if (Mtot >= (1L << 31) || (long)a.B * a.Di * a.Hi * a.Wi >= (1L << 31)) return MVSTER_ERR_SHAPE;
     const long tiles = (Mtot + 15) / 16;
-    dim3 grid((unsigned)((tiles + 4 * MT - 1) / (4 * MT)), a.ntile_total / NT, a.nclass);
-    hipLaunchKernelGGL((conv_mfma_kernel<CIN, MT, NT>), grid, dim3(256), 0, s, a);
+    const long per_block = SPLITK ? MT : 4 * MT;
+    dim3 grid((unsigned)((tiles + per_block - 1) / per_block), a.ntile_total / NT, a.nclass);
+    hipLaunchKernelGGL((conv_mfma_kernel<CIN, MT, NT, SPLITK>), grid, dim3(256), 0, s, a);
     return mv_check_launch();
 }
 
 template <int CIN>
-int dispatch_tiles(const ConvArgs& a, int MT, int NT, hipStream_t s) {
-#define MV_T(M_, N_) if (MT == M_ && NT == N_) return launch<CIN, M_, N_>(a, s);
+int dispatch_tiles(const ConvArgs& a, int MT, int NT, bool splitk, hipStream_t s) {
+    if (splitk) {
+        if constexpr (CIN >= 16) {
+#define MV_S(M_, N_) if (MT == M_ && NT == N_) return launch<CIN, M_, N_, true>(a, s);
+            MV_S(1, 1) MV_S(1, 2) MV_S(1, 4) MV_S(2, 1) MV_S(2, 2)
+#undef MV_S
+        }
+        return MVSTER_ERR_UNSUPPORTED;
+    }
+#define MV_T(M_, N_) if (MT == M_ && NT == N_) return launch<CIN, M_, N_, false>(a, s);
     MV_T(1, 1) MV_T(2, 1) MV_T(4, 1) MV_T(1, 2) MV_T(2, 2) MV_T(4, 2) MV_T(1, 4) MV_T(2, 4) MV_T(4, 4)
 #undef MV_T
     return MVSTER_ERR_UNSUPPORTED;
@@ -447,13 +488,14 @@ extern "C" int mvster_conv_mfma(const float* in, const float* wpk, const float* 
     hipStream_t s = (hipStream_t)stream;
     a.cin = cin;
     if (variant == 1) return dispatch_lds(a, mt, nt, s);
-    if (variant != 0) return MVSTER_ERR_UNSUPPORTED;
+    if (variant != 0 && variant != 2) return MVSTER_ERR_UNSUPPORTED;
+    const bool splitk = variant == 2;
     switch (cin) {
-        case 4: return dispatch_tiles<4>(a, mt, nt, s);
-        case 8: return dispatch_tiles<8>(a, mt, nt, s);
-        case 16: return dispatch_tiles<16>(a, mt, nt, s);
-        case 32: return dispatch_tiles<32>(a, mt, nt, s);
-        case 64: return dispatch_tiles<64>(a, mt, nt, s);
+        case 4: return dispatch_tiles<4>(a, mt, nt, splitk, s);
+        case 8: return dispatch_tiles<8>(a, mt, nt, splitk, s);
+        case 16: return dispatch_tiles<16>(a, mt, nt, splitk, s);
+        case 32: return dispatch_tiles<32>(a, mt, nt, splitk, s);
+        case 64: return dispatch_tiles<64>(a, mt, nt, splitk, s);
         default: return MVSTER_ERR_UNSUPPORTED;
     }
 }

@@ -94,6 +94,56 @@ __global__ void upsample_bilinear_kernel(const float* __restrict__ in, float* __
     out[(long)b * ho * wo + p] = mv::upsample_pixel(in + (long)b * hi * wi, hi, wi, ho, wo, p);
 }
 
+// FPN top-down tail, re-associated (FpnPlan in mvster_amd/conv_plan.py):
+//   out4(up(f2) + inner3(c0)) = sum_tap up(W4[tap] f2)[p + tap] + conv3x3(c0; W4*W3) + bias terms
+// G = (1x1 conv 64 -> 9*CO of f2 at HALF resolution) is computed by the MFMA kernel; this kernel is
+// the bilinear "gather-sum" over the 9 taps:  P[p][co] = sum_{tap inside} ( up(G[..., tap*CO+co])[p+tap] + vb[tap][co] )
+// with the reference's x2 align_corners interpolation (mvs4net_utils.py:488) and zero padding (:459).
+template <int CO>
+__global__ void fpn_tail_gather_kernel(const float* __restrict__ G, const float* __restrict__ vb,
+                                       float* __restrict__ P, int NB, int H, int W) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (p >= H * W) return;
+    const int y = p / W, x = p - y * W;
+    const int Hh = H / 2, Wh = W / 2;
+    constexpr int CG = 9 * CO;
+    const float* g = G + (long)b * Hh * Wh * CG;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int qy = y + ky - 1;
+        if (qy < 0 || qy >= H) continue;
+        const mv::Lerp ly = mv::make_lerp(qy, Hh, H);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int qx = x + kx - 1;
+            if (qx < 0 || qx >= W) continue;
+            const mv::Lerp lx = mv::make_lerp(qx, Wh, W);
+            const int tap = ky * 3 + kx;
+            const float* g00 = g + ((long)ly.i0 * Wh + lx.i0) * CG + tap * CO;
+            const float* g01 = g + ((long)ly.i0 * Wh + lx.i1) * CG + tap * CO;
+            const float* g10 = g + ((long)ly.i1 * Wh + lx.i0) * CG + tap * CO;
+            const float* g11 = g + ((long)ly.i1 * Wh + lx.i1) * CG + tap * CO;
+#pragma unroll
+            for (int c = 0; c < CO; c += 4) {
+                const f32x4 a = ld4(g00 + c), bq = ld4(g01 + c), cq = ld4(g10 + c), dq = ld4(g11 + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[c + j] += mv::bilerp(ly, lx, a[j], bq[j], cq[j], dq[j]) + vb[tap * CO + c + j];
+            }
+        }
+    }
+    float* o = P + ((long)b * H * W + p) * CO;
+#pragma unroll
+    for (int c = 0; c < CO; c += 4) {
+        f32x4 v = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+        st4(o + c, v);
+    }
+}
+
 }  // namespace
 
 extern "C" int mvster_relative_projection(const float* proj_matrices, float* rt, int B, int N, void* stream) {
@@ -156,5 +206,16 @@ extern "C" int mvster_upsample_bilinear(const float* in, float* out, int B, int 
     if (B <= 0 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0) return MVSTER_ERR_SHAPE;
     hipLaunchKernelGGL(upsample_bilinear_kernel, dim3((ho * wo + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, in,
                        out, B, hi, wi, ho, wo);
+    return mv_check_launch();
+}
+
+extern "C" int mvster_fpn_tail_gather(const float* G, const float* vb, float* P, int NB, int H, int W, int CO,
+                                      void* stream) {
+    if (!G || !vb || !P) return MVSTER_ERR_NULL;
+    if (NB <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1)) return MVSTER_ERR_SHAPE;
+    dim3 grid((H * W + 255) / 256, NB), block(256);
+    if (CO == 8) hipLaunchKernelGGL(fpn_tail_gather_kernel<8>, grid, block, 0, (hipStream_t)stream, G, vb, P, NB, H, W);
+    else if (CO == 16) hipLaunchKernelGGL(fpn_tail_gather_kernel<16>, grid, block, 0, (hipStream_t)stream, G, vb, P, NB, H, W);
+    else return MVSTER_ERR_UNSUPPORTED;
     return mv_check_launch();
 }

@@ -160,6 +160,124 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_fwd_kernel(WarpAggArgs a) 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Lane-split variant for wide feature maps (C >= 16, group correlation).  At the coarse stages the
+// map is small (5120 pixels at stage 1) but C is 64: one thread per (pixel, d) leaves most CUs idle
+// and makes each thread walk 8 dependent gather rounds.  Here LPP = C/8 adjacent lanes share one
+// (pixel, d): lane `sub` gathers channels 8*sub..8*sub+7 (= whole correlation groups, since C/G <= 8),
+// so a tap of one pixel is LPP*32 contiguous bytes across neighbouring lanes, the chip sees LPP x more
+// waves, and there is a single gather round per view.  The G correlations are all-gathered with wave
+// shuffles and summed in group order, so scores are bit-identical to the one-thread form.
+// ------------------------------------------------------------------------------------------
+template <int C, int G, int DMAX>
+__global__ void __launch_bounds__(64 * DMAX) warp_agg_fwd_lanes_kernel(WarpAggArgs a) {
+    constexpr int LPP = C / 8;           // lanes per (pixel, d)
+    constexpr int CG = C / G;            // channels per group
+    constexpr int GPL = 8 / CG;          // whole groups per lane
+    constexpr int PPB = 64 / LPP;        // pixels per workgroup
+    static_assert(C % 8 == 0 && CG <= 8 && 8 % CG == 0 && LPP >= 1 && LPP <= 16, "lane split");
+    __shared__ float sc[2][DMAX][PPB];
+
+    const int tx = threadIdx.x;
+    const int sub = tx % LPP, pl = tx / LPP;
+    const int d = threadIdx.y;
+    const int b = blockIdx.y;
+    const int hw = a.h * a.w;
+    const int p = blockIdx.x * PPB + pl;
+    const bool valid = p < hw;
+    const int pc = valid ? p : hw - 1;
+    const int y = pc / a.w;
+    const int x = pc - y * a.w;
+    const float depth = a.hypo[((long)b * a.D + d) * hw + pc];
+    const float* rp = a.ref + (long)b * a.ref_bs + (long)pc * C + sub * 8;
+    const f32x4 R0 = ld4(rp), R1 = ld4(rp + 4);
+
+    float acc[GPL];
+#pragma unroll
+    for (int k = 0; k < GPL; ++k) acc[k] = 0.0f;
+    float wsum = 1e-8f;
+
+    for (int v = 0; v < a.NV; ++v) {
+        mv::RT m;
+        {
+            const float* r = a.rt + ((long)b * a.NV + v) * 12;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) m.r[i] = r[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) m.t[i] = r[9 + i];
+        }
+        float sx, sy;
+        mv::project(m, (float)x, (float)y, depth, a.Hs, a.Ws, sx, sy);
+        mv::Taps t = mv::make_taps(sx, sy, a.Hs, a.Ws);
+        const mv::TapsClamped tc = mv::clamp_taps(t, a.Hs, a.Ws);
+        const float* sp = a.src + (long)v * a.src_vs + (long)b * a.src_bs + sub * 8;
+        const float* p00 = sp + ((long)tc.ya * a.Ws + tc.xa) * C;
+        const float* p01 = sp + ((long)tc.ya * a.Ws + tc.xb) * C;
+        const float* p10 = sp + ((long)tc.yb * a.Ws + tc.xa) * C;
+        const float* p11 = sp + ((long)tc.yb * a.Ws + tc.xb) * C;
+        const f32x4 A0 = ld4(p00), A1 = ld4(p00 + 4), B0 = ld4(p01), B1 = ld4(p01 + 4);
+        const f32x4 C0 = ld4(p10), C1 = ld4(p10 + 4), D0 = ld4(p11), D1 = ld4(p11 + 4);
+
+        float part[GPL];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float wv = c < 4 ? mv::blend(t, A0[c & 3], B0[c & 3], C0[c & 3], D0[c & 3])
+                                   : mv::blend(t, A1[c & 3], B1[c & 3], C1[c & 3], D1[c & 3]);
+            const float pr = mv::mul_rn(wv, c < 4 ? R0[c & 3] : R1[c & 3]);
+            part[c / CG] = (c % CG == 0) ? pr : mv::add_rn(part[c / CG], pr);
+        }
+        float cg[GPL];
+#pragma unroll
+        for (int k = 0; k < GPL; ++k) cg[k] = mv::div_rn(part[k], (float)CG);
+
+        // all-gather the G correlations of this (pixel, d) and sum them in group order
+        float score = 0.0f;
+        const int lane0 = tx - sub;
+#pragma unroll
+        for (int j = 0; j < LPP; ++j)
+#pragma unroll
+            for (int k = 0; k < GPL; ++k) {
+                const float val = __shfl(cg[k], lane0 + j);
+                score = (j == 0 && k == 0) ? val : mv::add_rn(score, val);
+            }
+        if (a.fuse_d) score = mv::div_rn(score, a.attn_temp);
+
+        float (*buf)[PPB] = sc[v & 1];
+        if (sub == 0) buf[d][pl] = score;
+        __syncthreads();
+        float mx = buf[0][pl];
+        for (int j = 1; j < a.D; ++j) mx = fmaxf(mx, buf[j][pl]);
+        float den = 0.0f;
+        for (int j = 0; j < a.D; ++j) den = mv::add_rn(den, expf(mv::sub_rn(buf[j][pl], mx)));
+        float wgt;
+        if (a.fuse_d)
+            wgt = mv::div_rn(mv::div_rn(expf(mv::sub_rn(score, mx)), den), a.sqrt_c);
+        else
+            wgt = mv::div_rn(1.0f, den);
+        wsum = mv::add_rn(wsum, wgt);
+#pragma unroll
+        for (int k = 0; k < GPL; ++k) acc[k] = mv::add_rn(acc[k], mv::mul_rn(wgt, cg[k]));
+    }
+
+    if (valid) {
+        const long o = (((long)b * a.D + d) * hw + p);
+        float* op = a.out + o * G + sub * GPL;
+#pragma unroll
+        for (int k = 0; k < GPL; ++k) op[k] = mv::div_rn(acc[k], wsum);
+        if (a.wsum_out && sub == 0) a.wsum_out[o] = wsum;
+    }
+}
+
+template <int C, int G>
+int launch_fwd_lanes(const WarpAggArgs& a, hipStream_t stream) {
+    constexpr int PPB = 64 / (C / 8);
+    if (a.D > 8) return MVSTER_ERR_UNSUPPORTED;
+    dim3 block(64, a.D);
+    dim3 grid((a.h * a.w + PPB - 1) / PPB, a.B);
+    hipLaunchKernelGGL((warp_agg_fwd_lanes_kernel<C, G, 8>), grid, block, 0, stream, a);
+    return mv_check_launch();
+}
+
 template <int C, int G, bool GROUP>
 int launch_fwd(const WarpAggArgs& a, hipStream_t stream) {
     dim3 block(64, a.D);
@@ -347,7 +465,7 @@ int launch_bwd(const WarpAggBwdArgs& ba, hipStream_t stream) {
 extern "C" int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat, const float* rt, const float* hypo,
                                    float* out, float* wsum_out, int B, int NV, int C, int G, int D, int h, int w,
                                    int Hs, int Ws, long ref_batch_stride, long src_view_stride, long src_batch_stride,
-                                   int group_cor, int attn_fuse_d, float attn_temp, void* stream) {
+                                   int group_cor, int attn_fuse_d, float attn_temp, int variant, void* stream) {
     if (!ref_feat || !src_feat || !rt || !hypo || !out) return MVSTER_ERR_NULL;
     if (B <= 0 || NV <= 0 || D <= 0 || D > kMaxD || h <= 0 || w <= 0 || Hs <= 0 || Ws <= 0) return MVSTER_ERR_SHAPE;
     if (!group_cor && G != C) return MVSTER_ERR_SHAPE;
@@ -357,6 +475,13 @@ extern "C" int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat,
     a.B = B; a.NV = NV; a.D = D; a.h = h; a.w = w; a.Hs = Hs; a.Ws = Ws;
     a.attn_temp = attn_temp; a.sqrt_c = sqrtf((float)C); a.fuse_d = attn_fuse_d;
     hipStream_t s = (hipStream_t)stream;
+    // wide maps: split each (pixel, d) over C/8 lanes (variant == 1 forces the one-thread form)
+    if (group_cor && D <= 8 && variant != 1) {
+        if (C == 64 && G == 8) return launch_fwd_lanes<64, 8>(a, s);
+        if (C == 32 && G == 8) return launch_fwd_lanes<32, 8>(a, s);
+        if (C == 16 && G == 4 && variant == 2) return launch_fwd_lanes<16, 4>(a, s);
+        if (C == 16 && G == 8 && variant == 2) return launch_fwd_lanes<16, 8>(a, s);
+    }
 #define MV_CASE(CC, GG, GR) \
     if (C == CC && G == GG && (group_cor != 0) == GR) return launch_fwd<CC, GG, GR>(a, s);
     MV_CASE(64, 8, true)

@@ -44,7 +44,8 @@ def to_channels_last(feat_nchw):
     return feat_nchw.permute(0, 2, 3, 1).contiguous()
 
 
-def warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, group_cor=True, attn_fuse_d=True, attn_temp=2.0, want_wsum=False):
+def warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, group_cor=True, attn_fuse_d=True, attn_temp=2.0, want_wsum=False,
+                    variant=0):
     """ref_cl [B,h,w,C], src_cl [NV,B,Hs,Ws,C], rt [B,NV,12], hypo [B,D,h,w] ->
     cor_feats channels-last [B,D,h,w,G] (and wsum [B,D,h,w]).  mvs4net_utils.py:1025-1060."""
     for t, n in ((ref_cl, "ref"), (src_cl, "src"), (rt, "rt"), (hypo, "hypo")):
@@ -58,7 +59,7 @@ def warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, group_cor=True, attn_fuse_d=Tru
     wsum = torch.empty(B, D, h, w, device=ref_cl.device, dtype=torch.float32) if want_wsum else None
     rc = _lib.load().mvster_warp_agg_fwd(_ptr(ref_cl), _ptr(src_cl), _ptr(rt), _ptr(hypo), _ptr(out), _ptr(wsum), B, NV,
                                          C, G, D, h, w, Hs, Ws, h * w * C, B * Hs * Ws * C, Hs * Ws * C,
-                                         int(group_cor), int(attn_fuse_d), float(attn_temp), _stream())
+                                         int(group_cor), int(attn_fuse_d), float(attn_temp), int(variant), _stream())
     _lib.check(rc, "warp_agg_fwd")
     return (out, wsum) if want_wsum else out
 
@@ -165,6 +166,20 @@ def upsample_bilinear(x, scale):
     _lib.check(_lib.load().mvster_upsample_bilinear(_ptr(x), _ptr(out), B, h, w, h * scale, w * scale, _stream()),
                "upsample_bilinear")
     return out
+
+
+def fpn_tail_gather(G, vb, H, W):
+    """G [NB,1,H/2,W/2,9*CO] (or 4-D), vb [9,CO] -> P [NB,1,H,W,CO]; see include/mvster_hip.h."""
+    _chk(G, "fpn_tail_gather:G")
+    _chk(vb, "fpn_tail_gather:vb")
+    NB = G.shape[0]
+    CO = vb.shape[1]
+    if G.shape[-1] != 9 * CO or G.numel() != NB * (H // 2) * (W // 2) * 9 * CO:
+        raise RuntimeError("fpn_tail_gather: inconsistent shapes")
+    P = torch.empty(NB, 1, H, W, CO, device=G.device, dtype=torch.float32)
+    _lib.check(_lib.load().mvster_fpn_tail_gather(_ptr(G), _ptr(vb), _ptr(P), NB, H, W, CO, _stream()),
+               "fpn_tail_gather")
+    return P
 
 
 def mfma_probe(A, Bm):

@@ -64,6 +64,10 @@ def main():
                 for n in (1, 2, 4):
                     if n <= layer.ntile_total and layer.ntile_total % n == 0:
                         cands.append(("L%d,%d" % (m, n), (m, n, 1)))
+        if layer.cin >= 16 and B * Di * Hi * Wi <= 400000:
+            for n in (1, 2, 4):
+                if n <= layer.ntile_total and layer.ntile_total % n == 0:
+                    cands.append(("S1,%d" % n, (1, n, 2)))
         best = None
         for name, tiles in cands:
             try:

@@ -87,6 +87,22 @@ def run_layer(layer, x, skip=None, skip_mode=SKIP_NONE):
     return torch.from_numpy(out)
 
 
+def fpn_tail_gather_reference(G, vb, H, W):
+    """PyTorch restatement of mvster_fpn_tail_gather (CPU tests)."""
+    import torch.nn.functional as F
+    NB = G.shape[0]
+    CO = vb.shape[1]
+    g = G.reshape(NB, H // 2, W // 2, 9, CO).permute(0, 3, 4, 1, 2).reshape(NB, 9 * CO, H // 2, W // 2)
+    up = F.interpolate(g, size=(H, W), mode="bilinear", align_corners=True).reshape(NB, 9, CO, H, W)
+    up = up + vb.reshape(1, 9, CO, 1, 1)
+    up = F.pad(up, (1, 1, 1, 1))                                   # zero outside the image, bias included
+    out = 0
+    for ky in range(3):
+        for kx in range(3):
+            out = out + up[:, ky * 3 + kx, :, ky:ky + H, kx:kx + W]
+    return out.permute(0, 2, 3, 1).reshape(NB, 1, H, W, CO).contiguous()
+
+
 class Emulated:
     """Wraps a plan so that every ConvLayer call goes through run_layer()."""
 
@@ -97,7 +113,10 @@ class Emulated:
         import mvster_amd.conv_plan as cp
         orig = cp.ConvLayer.__call__
         cp.ConvLayer.__call__ = lambda self_, x_, skip=None, skip_mode=SKIP_NONE, tiles=None: run_layer(self_, x_, skip, skip_mode)
+        orig_gather = cp.ops.fpn_tail_gather
+        cp.ops.fpn_tail_gather = fpn_tail_gather_reference
         try:
             return self.plan(x)
         finally:
             cp.ConvLayer.__call__ = orig
+            cp.ops.fpn_tail_gather = orig_gather

@@ -131,9 +131,14 @@ def test_warp_agg_forward(golden, name):
     f_cl = feats.permute(0, 1, 3, 4, 2).contiguous().to(DEV)
     Gk = G if gc else C
     # (1) with the reference's own fp32 relative projection: pure per-pixel arithmetic
-    out = ops.warp_agg_fwd_cl(f_cl[0], f_cl[1:], _oracle_rt(pm).to(DEV), hypo.to(DEV), Gk, gc, fuse, temp)
+    out = ops.warp_agg_fwd_cl(f_cl[0], f_cl[1:], _oracle_rt(pm).to(DEV), hypo.to(DEV), Gk, gc, fuse, temp, variant=1)
     got = out.permute(0, 4, 1, 2, 3).cpu()
     tight = (got - want).abs().max().item()
+    # the lane-split kernel (C >= 16) is bit-identical to the one-thread-per-(pixel, d) form
+    for variant in (0, 2):
+        o2 = ops.warp_agg_fwd_cl(f_cl[0], f_cl[1:], _oracle_rt(pm).to(DEV), hypo.to(DEV), Gk, gc, fuse, temp,
+                                 variant=variant)
+        assert torch.equal(o2, out), (name, variant)
     # (2) with the kernel-computed (fp64-inverse) projection: differs by the fp32 LAPACK noise of the reference
     out2 = ops.warp_agg_fwd_cl(f_cl[0], f_cl[1:], ops.relative_projection(pm.to(DEV)), hypo.to(DEV), Gk, gc, fuse, temp)
     got2 = out2.permute(0, 4, 1, 2, 3).cpu()
@@ -201,6 +206,15 @@ def test_conv_bn_relu(name, cfg, shape):
             err = (got - want).abs().max().item()
             worst = max(worst, err)
             assert err <= 2e-5 * want.abs().max().item(), (name, mt, nt, err)
+    # split-K variant (the 4 waves of a workgroup share the tiles and split the K steps)
+    if cfg["cin"] >= 16:
+        for mt, nt in ((1, 1), (1, 2), (1, 4), (2, 1), (2, 2)):
+            if layer.ntile_total % nt:
+                continue
+            got = layer(cl5(x).to(DEV), tiles=(mt, nt, 2)).cpu()
+            err = (got - want).abs().max().item()
+            worst = max(worst, err)
+            assert err <= 2e-5 * want.abs().max().item(), (name, "splitk", mt, nt, err)
     # LDS-staged variant (ordinary convs, cin % 16 == 0, kernel width 3 or 5)
     lds_ok = cfg["cin"] % 16 == 0 and layer.kernel[2] in (3, 5)
     if lds_ok:
@@ -233,7 +247,7 @@ def test_conv_transposed_skip(cin, cout, k, pad, op, s):
         skip = torch.randn_like(y)
         want = cl5(skip + y)
     layer = cp._up3d(seq.to(DEV))
-    for tiles in ((1, 1), (2, 1), (4, layer.ntile_total)):
+    for tiles in ((1, 1), (2, 1), (4, layer.ntile_total), (1, 1, 2), (2, 1, 2)):
         got = layer(cl5(x).to(DEV), skip=cl5(skip).to(DEV), skip_mode=cp.SKIP_ADD, tiles=tiles).cpu()
         err = (got - want).abs().max().item()
         assert err <= 2e-5 * want.abs().max().item(), (tiles, err)
@@ -281,6 +295,19 @@ def test_fpn_plan_vs_oracle():
         err = (got[s][:, 0].cpu() - w).abs().max().item()
         note("fpn_stage%d" % (s + 1), max_abs=err, ref_absmax=w.abs().max().item())
         assert err <= 5e-5 * w.abs().max().item(), s
+
+
+def test_fpn_tail_gather():
+    from tests.conv_emulator import fpn_tail_gather_reference
+    g = torch.Generator().manual_seed(2)
+    for (NB, H, W, CO) in ((2, 12, 20, 8), (1, 64, 34, 8), (1, 8, 8, 16)):
+        G = torch.randn(NB, 1, H // 2, W // 2, 9 * CO, generator=g)
+        vb = torch.randn(9, CO, generator=g)
+        want = fpn_tail_gather_reference(G, vb, H, W)
+        got = ops.fpn_tail_gather(G.to(DEV), vb.to(DEV), H, W).cpu()
+        err = (got - want).abs().max().item()
+        note("fpn_tail_gather_%dx%d" % (H, W), max_abs=err, ref_absmax=want.abs().max().item())
+        assert err <= 1e-5 * want.abs().max().item()
 
 
 def test_warp_agg_backward_vs_autograd():
