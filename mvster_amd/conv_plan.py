@@ -41,6 +41,30 @@ def fold_bn(bn, cout, device):
     return scale.float(), shift.float()
 
 
+# Measured per-layer choices for gfx950 (scripts/conv_microbench.py --emit): signature -> [variant, mt, nt].
+# A missing entry falls back to the heuristics below, so the table only ever changes speed.
+_TUNING = None
+
+
+def _tuning():
+    global _TUNING
+    if _TUNING is None:
+        import json
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_gfx950.json")
+        try:
+            with open(path) as f:
+                _TUNING = json.load(f)
+        except (OSError, ValueError):
+            _TUNING = {}
+    return _TUNING
+
+
+def layer_signature(layer, B, Di, Hi, Wi, skip_mode):
+    return "%s%d-%d_k%dx%dx%d_s%dx%dx%d_%dx%dx%dx%d_sk%d" % (
+        "T" if layer.transposed else "C", layer.cin, layer.cout, *layer.kernel, *layer.stride, B, Di, Hi, Wi, skip_mode)
+
+
 LDS_BUDGET = 12 * 256 * 16      # bytes of staged patch the LDS variant accepts (conv_mfma.hip kMaxStage)
 FORCE_VARIANT = None            # None = choose per layer; 0 / 1 pin the kernel variant (experiments, tests)
 
@@ -66,7 +90,7 @@ def _lds_plan(B, Do, Ho, Wo, kernel, stride, ntile_total):
 def _tiles(M, ntile_total, nclass):
     """(MT, NT): biggest register tile that still fills the chip (>= 2048 waves), else the most waves."""
     best = None
-    for nt in (4, 2, 1):
+    for nt in (5, 4, 2, 1):
         if nt > ntile_total or ntile_total % nt:
             continue
         for mt in (4, 2, 1):
@@ -197,6 +221,9 @@ class ConvLayer:
                         if self.ntile_total % cand == 0 and tiles16 * (self.ntile_total // cand) * len(self.classes) >= 512:
                             nt = cand
                             break
+            tuned = _tuning().get(layer_signature(self, B, Di, Hi, Wi, skip_mode)) if FORCE_VARIANT is None else None
+            if tuned:
+                variant, mt, nt = tuned
             g = (np.asarray(arr, dtype=np.int32), mt, nt, (B, DoF, HoF, WoF), variant)
             self._geom_cache[key] = g
         return g

@@ -58,8 +58,27 @@ struct ConvArgs {
     int od[kMaxClasses], oh[kMaxClasses], ow[kMaxClasses];   // output phase
     int osd, osh, osw;                                       // output lattice stride
     int nsteps[kMaxClasses];
+    int all_inside[kMaxClasses];                             // no tap of any lattice voxel needs padding
     long woff[kMaxClasses];                                  // float offset of the class's packed weights
+    // filled by the C entry point: multiply-shift division by Wo, Ho, Do (valid for dividends < 2^31)
+    unsigned div_mul[3], div_shr[3];
+    unsigned in_bytes;                                       // size of `in` (< 4 GB): buffer-load range check
 };
+
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, unsigned mul, unsigned shr) {
+    return d == 1 ? n : (__umulhi(n, mul) >> shr);
+}
+
+static void find_divisor(unsigned d, unsigned& mul, unsigned& shr) {
+    if (d <= 1) { mul = 0; shr = 0; return; }
+    int lg = 31 - __builtin_clz(d);
+    if (d & (d - 1)) ++lg;                       // ceil(log2 d)
+    const int p = 31 + lg;
+    mul = (unsigned)(((1ull << p) + d - 1) / d);
+    shr = (unsigned)(p - 32);
+}
 
 // Fused epilogue for 4 consecutive output channels n0..n0+3 of one output voxel.
 __device__ __forceinline__ void epilogue_store(const ConvArgs& a, f32x4v v, int n0, long opix, int b, int oy, int ox) {
@@ -129,28 +148,38 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     const int lq = lane >> 4;   // K slot
     // all voxel counts fit 32 bits (checked on the host side of the ABI)
     const unsigned Mtot = (unsigned)(a.B * a.Do * a.Ho * a.Wo);
-    const unsigned tile0 = SPLITK ? blockIdx.x * MT : (blockIdx.x * 4u + wave) * MT;   // first 16-voxel tile
-    if (!SPLITK && tile0 * 16u >= Mtot) return;
     const int nt0 = blockIdx.y * NT;
+    const unsigned ntiles = (Mtot + 15u) >> 4;
+    // Grid-stride over tile groups (the host launches one workgroup per group; see launch()).
+    const unsigned ngroups = SPLITK ? (ntiles + MT - 1) / MT : (ntiles + 4 * MT - 1) / (4 * MT);
+    for (unsigned grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const unsigned tile0 = SPLITK ? grp * MT : (grp * 4u + wave) * MT;   // first 16-voxel tile
+    if (!SPLITK && tile0 * 16u >= Mtot) break;
 
-    // A-role voxel of this lane in each M tile
+    // A-role voxel of this lane in each M tile.  The same voxel is the one this lane stores in the
+    // epilogue (swapped MFMA operands), so its output index is computed once, here.
     int iz0[MT], iy0[MT], ix0[MT];
     int pin0[MT];
+    int opix[MT];      // output voxel index, -1 = none
+    int oyx[MT];       // oy << 16 | ox (for the upsample-add epilogue), b is opix / (DoF*HoF*WoF)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         unsigned m = (tile0 + mt) * 16u + lm;
         const bool ok = m < Mtot;
         if (!ok) m = 0;
-        const unsigned x = m % (unsigned)a.Wo;
-        unsigned r = m / (unsigned)a.Wo;
-        const unsigned y = r % (unsigned)a.Ho;
-        r /= (unsigned)a.Ho;
-        const unsigned z = r % (unsigned)a.Do;
-        const unsigned b = r / (unsigned)a.Do;
-        iz0[mt] = ok ? (int)z * a.sd - a.pd[cls] : -(1 << 20);
-        iy0[mt] = (int)y * a.sh - a.ph[cls];
-        ix0[mt] = (int)x * a.sw - a.pw[cls];
+        unsigned r = fast_div(m, a.Wo, a.div_mul[0], a.div_shr[0]);
+        const int x = (int)(m - r * (unsigned)a.Wo);
+        unsigned r2 = fast_div(r, a.Ho, a.div_mul[1], a.div_shr[1]);
+        const int y = (int)(r - r2 * (unsigned)a.Ho);
+        const unsigned b = fast_div(r2, a.Do, a.div_mul[2], a.div_shr[2]);
+        const int z = (int)(r2 - b * (unsigned)a.Do);
+        iz0[mt] = ok ? z * a.sd - a.pd[cls] : -(1 << 20);
+        iy0[mt] = y * a.sh - a.ph[cls];
+        ix0[mt] = x * a.sw - a.pw[cls];
         pin0[mt] = (((int)b * a.Di + (ok ? iz0[mt] : 0)) * a.Hi + iy0[mt]) * a.Wi + ix0[mt];
+        const int oz = z * a.osd + a.od[cls], oy = y * a.osh + a.oh[cls], ox = x * a.osw + a.ow[cls];
+        opix[mt] = ok ? (((int)b * a.DoF + oz) * a.HoF + oy) * a.WoF + ox : -1;
+        oyx[mt] = (oy << 16) | ox;
     }
 
     f32x4v acc[MT][NT];
@@ -166,7 +195,12 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     const int kfirst = SPLITK ? wave : 0, kstride = SPLITK ? 4 : 1;
     const int nsteps = SPLITK ? (nsteps_all - wave + 3) / 4 : nsteps_all;
 
-    const long zero_off = a.zeros - a.in;   // element offset of the zero page relative to `in`
+    // Activations are read through a buffer descriptor: the offset of a padded tap is pushed past the
+    // end of the tensor and the hardware range check returns zeros -- no branch, no select on the data,
+    // 32-bit address arithmetic only.
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)a.in_bytes, 0x00020000);
+    const bool no_pad = a.all_inside[cls] != 0;   // 1x1-style classes: every tap of every voxel is inside
     f32x4v af[MT], bf[NT];
     auto load_step = [&](int si, f32x4v (&A)[MT], f32x4v (&Bv)[NT]) {
         const int s = kfirst + si * kstride;
@@ -180,11 +214,12 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
         const int kz = zyx & 255, ky = (zyx >> 8) & 255, kx = zyx >> 16;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const bool ok = tap_ok && (unsigned)(iz0[mt] + kz) < (unsigned)a.Di &&
-                            (unsigned)(iy0[mt] + ky) < (unsigned)a.Hi && (unsigned)(ix0[mt] + kx) < (unsigned)a.Wi;
-            // padded taps read a zero page: one unconditional load, no exec-masked branch per tap
-            const long off = ok ? ((long)(pin0[mt] + ofs) * CIN + c) : zero_off;
-            A[mt] = *reinterpret_cast<const f32x4v*>(a.in + off);
+            bool ok = tap_ok && iz0[mt] > -(1 << 19);
+            if (!no_pad)
+                ok = ok && (unsigned)(iz0[mt] + kz) < (unsigned)a.Di && (unsigned)(iy0[mt] + ky) < (unsigned)a.Hi &&
+                     (unsigned)(ix0[mt] + kx) < (unsigned)a.Wi;
+            const unsigned off = ok ? (unsigned)((pin0[mt] + ofs) * CIN + c) * 4u : 0xFFFFFFF0u;
+            A[mt] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0));
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -225,7 +260,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
                 for (int nt = 0; nt < NT; ++nt) red[((wave - 1) * MT * NT + mt * NT + nt) * 64 + lane] = acc[mt][nt];
         }
         __syncthreads();
-        if (wave > 0) return;
+        if (wave > 0) return;    // SPLITK grids are exact (one tile group per workgroup): no second iteration
 #pragma unroll
         for (int w = 0; w < 3; ++w)
 #pragma unroll
@@ -243,23 +278,16 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     // N tile) of ONE voxel (its A-role voxel, lm) -> one float4 store per tile, 16 lanes x 16 B contiguous.
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const unsigned m = (tile0 + mt) * 16u + lm;
-        if (m >= Mtot) continue;
-        const int x = (int)(m % (unsigned)a.Wo);
-        unsigned q0 = m / (unsigned)a.Wo;
-        const int y = (int)(q0 % (unsigned)a.Ho);
-        q0 /= (unsigned)a.Ho;
-        const int z = (int)(q0 % (unsigned)a.Do);
-        const int b = (int)(q0 / (unsigned)a.Do);
-        const int oz = z * a.osd + a.od[cls], oy = y * a.osh + a.oh[cls], ox = x * a.osw + a.ow[cls];
-        const long opix = (((long)b * a.DoF + oz) * a.HoF + oy) * a.WoF + ox;
+        if (opix[mt] < 0) continue;
+        const int b = a.skip_mode == 2 ? opix[mt] / (a.DoF * a.HoF * a.WoF) : 0;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int n0 = (nt0 + nt) * 16 + lq * 4;
             if (n0 >= a.cout) continue;
-            epilogue_store(a, acc[mt][nt], n0, opix, b, oy, ox);
+            epilogue_store(a, acc[mt][nt], n0, opix[mt], b, oyx[mt] >> 16, oyx[mt] & 0xffff);
         }
     }
+    }   // grid-stride loop over tile groups
 }
 
 template <int CIN, int MT, int NT, bool SPLITK>
@@ -268,7 +296,10 @@ int launch(const ConvArgs& a, hipStream_t s) {
     if (Mtot >= (1L << 31) || (long)a.B * a.Di * a.Hi * a.Wi >= (1L << 31)) return MVSTER_ERR_SHAPE;
     const long tiles = (Mtot + 15) / 16;
     const long per_block = SPLITK ? MT : 4 * MT;
-    dim3 grid((unsigned)((tiles + per_block - 1) / per_block), a.ntile_total / NT, a.nclass);
+    long gx = (tiles + per_block - 1) / per_block;
+    // (a capped, persistent grid was measured slower on every layer: 436 vs 452 depth-maps/s; the
+    //  grid-stride loop in the kernel therefore runs exactly once)
+    dim3 grid((unsigned)gx, a.ntile_total / NT, a.nclass);
     hipLaunchKernelGGL((conv_mfma_kernel<CIN, MT, NT, SPLITK>), grid, dim3(256), 0, s, a);
     return mv_check_launch();
 }
@@ -285,6 +316,9 @@ int dispatch_tiles(const ConvArgs& a, int MT, int NT, bool splitk, hipStream_t s
     }
 #define MV_T(M_, N_) if (MT == M_ && NT == N_) return launch<CIN, M_, N_, false>(a, s);
     MV_T(1, 1) MV_T(2, 1) MV_T(4, 1) MV_T(1, 2) MV_T(2, 2) MV_T(4, 2) MV_T(1, 4) MV_T(2, 4) MV_T(4, 4)
+    if constexpr (CIN == 64) {   // 72 = 9 x 8 output channels of the re-associated FPN tail (5 N tiles)
+        MV_T(2, 5) MV_T(4, 5)
+    }
 #undef MV_T
     return MVSTER_ERR_UNSUPPORTED;
 }
@@ -483,6 +517,23 @@ extern "C" int mvster_conv_mfma(const float* in, const float* wpk, const float* 
         if (a.kd[c] * a.kh[c] * a.kw[c] > kMaxTaps || a.nsteps[c] < 1) return MVSTER_ERR_SHAPE;
     }
     if (a.B <= 0 || a.Do <= 0 || a.Ho <= 0 || a.Wo <= 0 || a.cout <= 0 || a.ntile_total <= 0) return MVSTER_ERR_SHAPE;
+    find_divisor((unsigned)a.Wo, a.div_mul[0], a.div_shr[0]);
+    find_divisor((unsigned)a.Ho, a.div_mul[1], a.div_shr[1]);
+    find_divisor((unsigned)a.Do, a.div_mul[2], a.div_shr[2]);
+    {
+        const long in_elems = (long)a.B * a.Di * a.Hi * a.Wi * cin;
+        const long out_elems = (long)a.B * a.DoF * a.HoF * a.WoF * a.cout;
+        if (in_elems >= (1L << 30) || out_elems >= (1L << 31)) return MVSTER_ERR_SHAPE;   // 32-bit offsets
+        a.in_bytes = (unsigned)(in_elems * 4);
+    }
+    for (int c = 0; c < a.nclass; ++c) {
+        // i = o*s - p + k stays inside [0, extent) for every lattice point and tap?
+        auto inside = [](int n_out, int s, int p, int k, int extent) {
+            return -p >= 0 && (n_out - 1) * s - p + (k - 1) < extent;
+        };
+        a.all_inside[c] = inside(a.Do, a.sd, a.pd[c], a.kd[c], a.Di) && inside(a.Ho, a.sh, a.ph[c], a.kh[c], a.Hi) &&
+                          inside(a.Wo, a.sw, a.pw[c], a.kw[c], a.Wi);
+    }
     if (a.skip_mode != 0 && !skip) return MVSTER_ERR_NULL;
     if (a.ntile_total % nt != 0) return MVSTER_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;

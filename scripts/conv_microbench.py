@@ -15,19 +15,104 @@ from mvster_amd.synthetic import make_inputs  # noqa: E402
 
 
 def timeit(fn, n=20):
-    for _ in range(3):
+    """GPU time per call in us: n calls captured in one hipGraph (host launch overhead, ~12 us per
+    call from Python, would otherwise hide every kernel shorter than that)."""
+    for _ in range(2):
         fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(n):
+                fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(n):
-        fn()
+    g.replay()
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3   # us
+    return e0.elapsed_time(e1) / (2 * n) * 1e3
+
+
+def candidates(layer, B, Di, Hi, Wi, sm):
+    """Every (variant, mt, nt) the kernels support for this layer."""
+    out = []
+    nts = [n for n in (1, 2, 4, 5) if n <= layer.ntile_total and layer.ntile_total % n == 0]
+    for m in (1, 2, 4):
+        for n in nts:
+            if n == 5 and (layer.cin != 64 or m == 1):
+                continue
+            out.append(("d%d,%d" % (m, n), (m, n, 0)))
+    if not layer.transposed and layer.cin % 16 == 0 and layer.kernel[2] in (3, 5) and sm in (0, 1):
+        for m in (2, 4):
+            patch = layer.kernel[0] * ((2 * m - 1) * layer.stride[1] + layer.kernel[1]) * (31 * layer.stride[2] + layer.kernel[2]) * 64
+            if patch > cp.LDS_BUDGET:
+                continue
+            for n in (1, 2, 4):
+                if n in nts:
+                    out.append(("L%d,%d" % (m, n), (m, n, 1)))
+    if layer.cin >= 16:
+        for m, n in ((1, 1), (1, 2), (1, 4), (2, 1), (2, 2)):
+            if n in nts:
+                out.append(("S%d,%d" % (m, n), (m, n, 2)))
+    return out
+
+
+def emit_table(shapes, path):
+    """Time every candidate on the layer shapes of the given workloads; write the winners as JSON."""
+    import json
+    dev = torch.device("cuda:0")
+    model = MVS4net(**SHIPPED)
+    model.load_state_dict(load_weights(), strict=True)
+    model.to(dev).eval()
+    table = {}
+    orig = cp.ConvLayer.__call__
+    cp.FORCE_VARIANT = None
+    for (H, W, N) in shapes:
+        imgs, proj, dv = make_inputs(N, H, W, seed=0, device=dev)
+        calls = []
+
+        def rec(layer, x, skip=None, skip_mode=0, tiles=None):
+            calls.append((layer, tuple(x.shape), None if skip is None else tuple(skip.shape), skip_mode if skip is not None else 0))
+            return orig(layer, x, skip, skip_mode, tiles)
+        cp.ConvLayer.__call__ = rec
+        model(imgs, proj, dv)
+        cp.ConvLayer.__call__ = orig
+        torch.cuda.synchronize()
+        for layer, xs, ss, sm in calls:
+            B, Di, Hi, Wi, _ = xs
+            sig = cp.layer_signature(layer, B, Di, Hi, Wi, sm)
+            if sig in table:
+                continue
+            x = torch.randn(*xs, device=dev)
+            skip = torch.randn(*ss, device=dev) if ss else None
+            best = None
+            for name, tiles in candidates(layer, B, Di, Hi, Wi, sm):
+                try:
+                    us = min(timeit(lambda: layer(x, skip=skip, skip_mode=sm, tiles=tiles), n=10) for _ in range(2))
+                except RuntimeError:
+                    continue
+                if best is None or us < best[0]:
+                    best = (us, tiles)
+            table[sig] = [best[1][2], best[1][0], best[1][1]]
+            print("%-48s -> v%d mt%d nt%d  %.1f us" % (sig, best[1][2], best[1][0], best[1][1], best[0]), flush=True)
+            del x, skip
+    with open(path, "w") as f:
+        json.dump(table, f, indent=0, sort_keys=True)
+    print("wrote", path, len(table), "entries")
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--emit":
+        shapes = [(512, 640, 5), (1152, 1600, 5), (1024, 1920, 7), (128, 192, 5), (128, 192, 3), (64, 128, 3)]
+        emit_table(shapes, sys.argv[2])
+        return
     dev = torch.device("cuda:0")
     model = MVS4net(**SHIPPED)
     model.load_state_dict(load_weights(), strict=True)
