@@ -61,8 +61,12 @@ class KernelTimer:
             out = timer._orig_conv(layer, x, skip, skip_mode, tiles)
             e1.record()
             bytes_ = 4 * (x.numel() + out.numel() + layer.wpk.numel() + (skip.numel() if skip is not None else 0))
-            kname = ("conv_lds_kernel<%d,%d,%d>|cin%d" % (mt, nt, layer.kernel[2], layer.cin)) if variant == 1 else \
-                ("conv_mfma_kernel<%d,%d,%d>" % (layer.cin, mt, nt))
+            if variant == 1:
+                kname = "conv_lds_kernel<%d,%d,%d>|cin%d" % (mt, nt, layer.kernel[2], layer.cin)
+            elif variant == 3:
+                kname = "conv_small_kernel<%d>" % layer.cin
+            else:
+                kname = "conv_mfma_kernel<%d,%d,%d,%s>" % (layer.cin, mt, nt, "true" if variant == 2 else "false")
             timer.records.append((kname, e0, e1,
                                   layer.flops(B, Di, Hi, Wi), bytes_))
             return out

@@ -89,6 +89,13 @@ int mvster_conv_mfma(const float* in, const float* wpk, const float* scale, cons
                      const float* zeros, float* out, const int* geom, int ngeom, const long* woff, int cin, int mt,
                      int nt, int variant, void* stream);
 
+/* 3x3 (pad 1, stride 1) convolution with 8 output channels and cin in {4, 8} on the fp32 VALU (packed FMA),
+ * for the narrow full-resolution layers where the 16-wide MFMA tile is half padding.  in [NB,H,W,cin],
+ * w [3,3,cin,8], scale/shift [8], skip optional [NB,H,W,8], out [NB,H,W,8] (depth slices folded into NB).
+ * FPN4 conv0 (models/mvs4net_utils.py:427-428), reg2d conv0 (:875), the composed out4 tail (:459). */
+int mvster_conv_small(const float* in, const float* w, const float* scale, const float* shift, const float* skip,
+                      float* out, int NB, int H, int W, int cin, int relu, void* stream);
+
 /* FPN4 top-down tail, re-associated: G [NB,H/2,W/2,9*CO] = 1x1 conv of the half-resolution top-down
  * map with the 9 taps of the output conv stacked on the channel axis; vb [9,CO] = the taps applied to the
  * lateral conv's bias; P [NB,H,W,CO] = sum over in-bounds taps of (bilinear x2 align_corners upsample of

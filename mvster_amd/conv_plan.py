@@ -175,6 +175,14 @@ class ConvLayer:
         self.shift[:cout] = shift
         self.zeros = torch.zeros(64, device=dev)
         self._geom_cache = {}
+        # narrow full-resolution layers: VALU kernel (conv_small.hip), weights as [3,3,cin,8]
+        self.w_small = None
+        if (not transposed and self.kernel == (1, 3, 3) and self.stride == (1, 1, 1) and self.padding == (0, 1, 1)
+                and cout == 8 and self.cin in (4, 8)):
+            ws = w[:, :, 0].permute(2, 3, 1, 0)                       # [3,3,cin,8]
+            if self.cin != cin:
+                ws = torch.nn.functional.pad(ws, (0, 0, 0, self.cin - cin))
+            self.w_small = ws.contiguous().to(dev)
 
     def out_shape(self, B, Di, Hi, Wi):
         kd, kh, kw = self.kernel
@@ -224,6 +232,8 @@ class ConvLayer:
             tuned = _tuning().get(layer_signature(self, B, Di, Hi, Wi, skip_mode)) if FORCE_VARIANT is None else None
             if tuned:
                 variant, mt, nt = tuned
+            if self.w_small is not None and skip_mode in (SKIP_NONE, SKIP_ADD) and FORCE_VARIANT in (None, 3):
+                variant = 3
             g = (np.asarray(arr, dtype=np.int32), mt, nt, (B, DoF, HoF, WoF), variant)
             self._geom_cache[key] = g
         return g
@@ -247,6 +257,15 @@ class ConvLayer:
             want = out.shape if skip_mode == SKIP_ADD else (B, 1, oshape[2] // 2, oshape[3] // 2, self.cout)
             if tuple(skip.shape) != tuple(want):
                 raise RuntimeError("conv_mfma: skip shape %s, expected %s" % (tuple(skip.shape), tuple(want)))
+        if variant == 3:
+            if self.w_small is None or skip_mode == SKIP_UPSAMPLE_ADD:
+                raise RuntimeError("conv_small: layer not eligible")
+            rc = _lib.load().mvster_conv_small(
+                x.data_ptr(), self.w_small.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                None if skip is None else skip.data_ptr(), out.data_ptr(), B * Di, Hi, Wi, self.cin, int(self.relu),
+                torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "conv_small")
+            return out
         rc = _lib.load().mvster_conv_mfma(
             x.data_ptr(), self.wpk.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
             None if skip is None else skip.data_ptr(), self.zeros.data_ptr(), out.data_ptr(),

@@ -1,0 +1,123 @@
+// 3x3 convolution for the narrow full-resolution layers (Cin in {4, 8}, Cout = 8) on the fp32 VALU.
+//
+// These layers (FPN conv0.*, the composed FPN tail conv, conv0 of every reg2d) have K = 36 or 72 and
+// N = 8: on the 16x16x4 MFMA half of every N tile is padding and the K loop is 3-5 steps long, so the
+// matrix path tops out near 25 TFLOP/s there.  Here one thread owns one output voxel and its 8 output
+// channels (8 packed-FMA accumulators), the 10 x 34 input patch of an 8 x 32 tile is staged once in
+// LDS (zero padding via the buffer range check), and the 9 x Cin x 8 weights are wave-uniform scalar
+// loads -- no padding waste, coalesced 32-byte stores.  fp32 FMA chain in (tap, cin) order.
+// Reference layers: models/mvs4net_utils.py:427-428 (FPN conv0), :875 (reg2d conv0), :459 (out4, composed).
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+struct SmallArgs {
+    const float* in;     // [NB, H, W, CIN]
+    const float* w;      // [9][CIN][8]
+    const float* scale;  // [8]
+    const float* shift;  // [8]
+    const float* skip;   // [NB, H, W, 8] or null
+    float* out;          // [NB, H, W, 8]
+    int NB, H, W, relu;
+    unsigned in_bytes;
+};
+
+template <int CIN>
+__global__ void __launch_bounds__(256) conv_small_kernel(SmallArgs a, int tiles_x, int tiles_y) {
+    constexpr int TY = 8, TX = 32, PH = TY + 2, PW = TX + 2, Q = CIN / 4;
+    __shared__ f32x4v patch[PH * PW * Q];
+    unsigned bid = blockIdx.x;
+    const int tile_x = bid % tiles_x; bid /= tiles_x;
+    const int tile_y = bid % tiles_y;
+    const int nb = bid / tiles_y;
+    const int y0 = tile_y * TY, x0 = tile_x * TX;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)a.in_bytes, 0x00020000);
+    constexpr int NST = (PH * PW * Q + 255) / 256;
+    f32x4v tmp[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const int q = idx % Q, pix = idx / Q;
+        const int px = pix % PW, py = pix / PW;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const bool ok = idx < PH * PW * Q && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const unsigned off = ok ? (unsigned)(((nb * a.H + iy) * a.W + ix) * CIN + q * 4) * 4u : 0xFFFFFFF0u;
+        tmp[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        if (idx < PH * PW * Q) patch[idx] = tmp[i];
+    }
+    __syncthreads();
+
+    f32x2v acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x2v){0.f, 0.f};
+    const f32x2v* w2 = reinterpret_cast<const f32x2v*>(a.w);   // wave-uniform -> scalar loads
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const f32x4v* p = patch + ((ty + ky) * PW + tx + kx) * Q;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const f32x4v xv = p[q];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int ci = q * 4 + c;
+                    const f32x2v xx = {xv[c], xv[c]};
+                    const f32x2v* wr = w2 + ((ky * 3 + kx) * CIN + ci) * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_elementwise_fma(xx, wr[j], acc[j]);
+                }
+            }
+        }
+
+    const int y = y0 + ty, x = x0 + tx;
+    if (y >= a.H || x >= a.W) return;
+    const long o = (((long)nb * a.H + y) * a.W + x) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[2 * j] = acc[j][0]; v[2 * j + 1] = acc[j][1]; }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        v[c] = fmaf(v[c], a.scale[c], a.shift[c]);
+        if (a.relu) v[c] = fmaxf(v[c], 0.0f);
+    }
+    if (a.skip) {
+        const f32x4v s0 = ld4(a.skip + o), s1 = ld4(a.skip + o + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { v[c] += s0[c]; v[4 + c] += s1[c]; }
+    }
+    st4(a.out + o, (f32x4v){v[0], v[1], v[2], v[3]});
+    st4(a.out + o + 4, (f32x4v){v[4], v[5], v[6], v[7]});
+}
+
+}  // namespace
+
+extern "C" int mvster_conv_small(const float* in, const float* w, const float* scale, const float* shift,
+                                 const float* skip, float* out, int NB, int H, int W, int cin, int relu,
+                                 void* stream) {
+    if (!in || !w || !scale || !shift || !out) return MVSTER_ERR_NULL;
+    if (NB <= 0 || H <= 0 || W <= 0) return MVSTER_ERR_SHAPE;
+    const long in_elems = (long)NB * H * W * cin;
+    if (in_elems >= (1L << 30)) return MVSTER_ERR_SHAPE;
+    SmallArgs a;
+    a.in = in; a.w = w; a.scale = scale; a.shift = shift; a.skip = skip; a.out = out;
+    a.NB = NB; a.H = H; a.W = W; a.relu = relu; a.in_bytes = (unsigned)(in_elems * 4);
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
+    const long blocks = (long)tiles_x * tiles_y * NB;
+    if (blocks >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    dim3 grid((unsigned)blocks), block(256);
+    if (cin == 8) hipLaunchKernelGGL(conv_small_kernel<8>, grid, block, 0, (hipStream_t)stream, a, tiles_x, tiles_y);
+    else if (cin == 4) hipLaunchKernelGGL(conv_small_kernel<4>, grid, block, 0, (hipStream_t)stream, a, tiles_x, tiles_y);
+    else return MVSTER_ERR_UNSUPPORTED;
+    return mv_check_launch();
+}

@@ -206,6 +206,15 @@ def test_conv_bn_relu(name, cfg, shape):
             err = (got - want).abs().max().item()
             worst = max(worst, err)
             assert err <= 2e-5 * want.abs().max().item(), (name, mt, nt, err)
+    # VALU kernel for the narrow layers (cin in {4, 8} -> 8 channels, 3x3)
+    if layer.w_small is not None:
+        got = layer(cl5(x).to(DEV), tiles=(0, 0, 3)).cpu()
+        err = (got - want).abs().max().item()
+        worst = max(worst, err)
+        assert err <= 2e-5 * want.abs().max().item(), (name, "small", err)
+        skip = torch.randn_like(want)
+        got = layer(cl5(x).to(DEV), skip=skip.to(DEV), skip_mode=cp.SKIP_ADD, tiles=(0, 0, 3)).cpu()
+        assert (got - (want + skip)).abs().max().item() <= 2e-5 * want.abs().max().item(), (name, "small+skip")
     # split-K variant (the 4 waves of a workgroup share the tiles and split the K steps)
     if cfg["cin"] >= 16:
         for mt, nt in ((1, 1), (1, 2), (1, 4), (2, 1), (2, 2)):
