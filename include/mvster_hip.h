@@ -101,8 +101,10 @@ int mvster_conv_small(const float* in, const float* w, const float* scale, const
  * lateral conv's bias; P [NB,H,W,CO] = sum over in-bounds taps of (bilinear x2 align_corners upsample of
  * G_tap at p+tap, + vb[tap]).  Together with a 3x3 conv of the lateral input (composed weights, skip-add P)
  * this equals out4(F.interpolate(f) + inner3(c0)) of models/mvs4net_utils.py:488-489 without the
- * full-resolution 64-channel intermediate. */
-int mvster_fpn_tail_gather(const float* G, const float* vb, float* P, int NB, int H, int W, int CO, void* stream);
+ * full-resolution 64-channel intermediate.  workspace: optional [NB,H,W/2,3*CO]; when given the gather runs as
+ * two separable passes (vertical into the workspace, then horizontal), otherwise as one 36-tap pass. */
+int mvster_fpn_tail_gather(const float* G, const float* vb, float* P, float* workspace, int NB, int H, int W,
+                           int CO, void* stream);
 
 /* One v_mfma_f32_16x16x4_f32: A [16,4], B [4,16] -> D [16,16] (row major).  Test hook that pins the
  * fragment layout the convolution kernels assume. */

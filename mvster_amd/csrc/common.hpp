@@ -21,3 +21,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// XCD-aware workgroup order.  MI355X dispatches workgroup b to XCD b % 8 and every XCD has its own 4 MB
+// L2, so spatially adjacent tiles (which share halo rows, source texels and weights) would land on eight
+// different L2s.  This bijection hands each XCD a contiguous 1/8 of the tile range instead; it only ever
+// changes speed (placement is not a correctness contract).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned xcd = bid & 7u, idx = bid >> 3;
+    const unsigned q = nwg >> 3, r = nwg & 7u;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

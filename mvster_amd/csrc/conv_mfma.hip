@@ -152,7 +152,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     const unsigned ntiles = (Mtot + 15u) >> 4;
     // Grid-stride over tile groups (the host launches one workgroup per group; see launch()).
     const unsigned ngroups = SPLITK ? (ntiles + MT - 1) / MT : (ntiles + 4 * MT - 1) / (4 * MT);
-    for (unsigned grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    for (unsigned grp0 = blockIdx.x; grp0 < ngroups; grp0 += gridDim.x) {
+    const unsigned grp = gridDim.x == ngroups ? xcd_remap(grp0, ngroups) : grp0;
     const unsigned tile0 = SPLITK ? grp * MT : (grp * 4u + wave) * MT;   // first 16-voxel tile
     if (!SPLITK && tile0 * 16u >= Mtot) break;
 
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     const int CIN = a.cin, nchunks = CIN >> 4;
     const int nstage = KD * PH * PW * 4;     // float4 per chunk
 
-    unsigned bid = blockIdx.x;
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_x = bid % tiles_x; bid /= tiles_x;
     const int tile_y = bid % tiles_y; bid /= tiles_y;
     const int zo = bid % a.Do;

@@ -29,7 +29,7 @@ template <int CIN>
 __global__ void __launch_bounds__(256) conv_small_kernel(SmallArgs a, int tiles_x, int tiles_y) {
     constexpr int TY = 8, TX = 32, PH = TY + 2, PW = TX + 2, Q = CIN / 4;
     __shared__ f32x4v patch[PH * PW * Q];
-    unsigned bid = blockIdx.x;
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_x = bid % tiles_x; bid /= tiles_x;
     const int tile_y = bid % tiles_y;
     const int nb = bid / tiles_y;

@@ -102,7 +102,7 @@ __global__ void upsample_bilinear_kernel(const float* __restrict__ in, float* __
 template <int CO>
 __global__ void fpn_tail_gather_kernel(const float* __restrict__ G, const float* __restrict__ vb,
                                        float* __restrict__ P, int NB, int H, int W) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (p >= H * W) return;
     const int y = p / W, x = p - y * W;
@@ -142,6 +142,80 @@ __global__ void fpn_tail_gather_kernel(const float* __restrict__ G, const float*
         f32x4 v = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
         st4(o + c, v);
     }
+}
+
+// Separable form of fpn_tail_gather (2.4x fewer loads): bilinear interpolation factorises into a
+// vertical and a horizontal 1-D lerp.
+//   pass 1  V[b][y][xh][kx*CO + co] = sum_{ky inside} lerp_y(y+ky-1)( G[b][.][xh][(ky*3+kx)*CO + co] )
+//   pass 2  P[b][y][x][co] = sum_{kx inside} ( lerp_x(x+kx-1)( V[b][y][.][kx*CO + co] ) + sum_{ky inside} vb[ky*3+kx][co] )
+template <int CO>
+__global__ void fpn_tail_vpass_kernel(const float* __restrict__ G, float* __restrict__ V, int NB, int H, int W) {
+    const int Hh = H / 2, Wh = W / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (y, xh)
+    const int b = blockIdx.y;
+    if (i >= H * Wh) return;
+    const int y = i / Wh, xh = i - y * Wh;
+    constexpr int CG = 9 * CO, CV = 3 * CO;
+    const float* g = G + ((long)b * Hh * Wh + xh) * CG;
+    float acc[CV];
+#pragma unroll
+    for (int c = 0; c < CV; ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int qy = y + ky - 1;
+        if (qy < 0 || qy >= H) continue;
+        const mv::Lerp ly = mv::make_lerp(qy, Hh, H);
+        const float* r0 = g + (long)ly.i0 * Wh * CG + ky * CV;
+        const float* r1 = g + (long)ly.i1 * Wh * CG + ky * CV;
+#pragma unroll
+        for (int c = 0; c < CV; c += 4) {
+            const f32x4 a = ld4(r0 + c), bq = ld4(r1 + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[c + j] += ly.w0 * a[j] + ly.w1 * bq[j];
+        }
+    }
+    float* o = V + ((long)b * H * Wh + i) * CV;
+#pragma unroll
+    for (int c = 0; c < CV; c += 4) st4(o + c, (f32x4){acc[c], acc[c + 1], acc[c + 2], acc[c + 3]});
+}
+
+template <int CO>
+__global__ void fpn_tail_hpass_kernel(const float* __restrict__ V, const float* __restrict__ vb,
+                                      float* __restrict__ P, int NB, int H, int W) {
+    const int Wh = W / 2;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (p >= H * W) return;
+    const int y = p / W, x = p - y * W;
+    constexpr int CV = 3 * CO;
+    const float* v = V + ((long)b * H + y) * Wh * CV;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int qx = x + kx - 1;
+        if (qx < 0 || qx >= W) continue;
+        const mv::Lerp lx = mv::make_lerp(qx, Wh, W);
+        const float* c0 = v + (long)lx.i0 * CV + kx * CO;
+        const float* c1 = v + (long)lx.i1 * CV + kx * CO;
+#pragma unroll
+        for (int c = 0; c < CO; c += 4) {
+            const f32x4 a = ld4(c0 + c), bq = ld4(c1 + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[c + j] += lx.w0 * a[j] + lx.w1 * bq[j];
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int qy = y + ky - 1;
+            if (qy < 0 || qy >= H) continue;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) acc[c] += vb[(ky * 3 + kx) * CO + c];
+        }
+    }
+    float* o = P + ((long)b * H * W + p) * CO;
+#pragma unroll
+    for (int c = 0; c < CO; c += 4) st4(o + c, (f32x4){acc[c], acc[c + 1], acc[c + 2], acc[c + 3]});
 }
 
 }  // namespace
@@ -209,13 +283,26 @@ extern "C" int mvster_upsample_bilinear(const float* in, float* out, int B, int 
     return mv_check_launch();
 }
 
-extern "C" int mvster_fpn_tail_gather(const float* G, const float* vb, float* P, int NB, int H, int W, int CO,
-                                      void* stream) {
+extern "C" int mvster_fpn_tail_gather(const float* G, const float* vb, float* P, float* workspace, int NB, int H,
+                                      int W, int CO, void* stream) {
     if (!G || !vb || !P) return MVSTER_ERR_NULL;
     if (NB <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1)) return MVSTER_ERR_SHAPE;
-    dim3 grid((H * W + 255) / 256, NB), block(256);
-    if (CO == 8) hipLaunchKernelGGL(fpn_tail_gather_kernel<8>, grid, block, 0, (hipStream_t)stream, G, vb, P, NB, H, W);
-    else if (CO == 16) hipLaunchKernelGGL(fpn_tail_gather_kernel<16>, grid, block, 0, (hipStream_t)stream, G, vb, P, NB, H, W);
-    else return MVSTER_ERR_UNSUPPORTED;
+    if (CO != 8 && CO != 16) return MVSTER_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 block(256);
+    if (workspace) {   // separable two-pass form, workspace = [NB, H, W/2, 3*CO]
+        dim3 g1((H * (W / 2) + 255) / 256, NB), g2((H * W + 255) / 256, NB);
+        if (CO == 8) {
+            hipLaunchKernelGGL(fpn_tail_vpass_kernel<8>, g1, block, 0, s, G, workspace, NB, H, W);
+            hipLaunchKernelGGL(fpn_tail_hpass_kernel<8>, g2, block, 0, s, workspace, vb, P, NB, H, W);
+        } else {
+            hipLaunchKernelGGL(fpn_tail_vpass_kernel<16>, g1, block, 0, s, G, workspace, NB, H, W);
+            hipLaunchKernelGGL(fpn_tail_hpass_kernel<16>, g2, block, 0, s, workspace, vb, P, NB, H, W);
+        }
+        return mv_check_launch();
+    }
+    dim3 grid((H * W + 255) / 256, NB);
+    if (CO == 8) hipLaunchKernelGGL(fpn_tail_gather_kernel<8>, grid, block, 0, s, G, vb, P, NB, H, W);
+    else hipLaunchKernelGGL(fpn_tail_gather_kernel<16>, grid, block, 0, s, G, vb, P, NB, H, W);
     return mv_check_launch();
 }

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_fwd_kernel(WarpAggArgs a) 
     const int tid = d * 64 + tx;
     const int b = blockIdx.y;
     const int hw = a.h * a.w;
-    const int p = blockIdx.x * 64 + tx;
+    const int p = xcd_remap(blockIdx.x, gridDim.x) * 64 + tx;
     const bool valid = p < hw;
     const int pc = valid ? p : hw - 1;  // clamped: every lane takes part in the barriers
     const int y = pc / a.w;
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_fwd_lanes_kernel(WarpAggAr
     const int d = threadIdx.y;
     const int b = blockIdx.y;
     const int hw = a.h * a.w;
-    const int p = blockIdx.x * PPB + pl;
+    const int p = xcd_remap(blockIdx.x, gridDim.x) * PPB + pl;
     const bool valid = p < hw;
     const int pc = valid ? p : hw - 1;
     const int y = pc / a.w;
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
     const int tid = d * 64 + tx;
     const int b = blockIdx.y;
     const int hw = a.h * a.w;
-    const int p = blockIdx.x * 64 + tx;
+    const int p = xcd_remap(blockIdx.x, gridDim.x) * 64 + tx;
     const bool valid = p < hw;
     const int pc = valid ? p : hw - 1;
     const int y = pc / a.w;

@@ -168,7 +168,7 @@ def upsample_bilinear(x, scale):
     return out
 
 
-def fpn_tail_gather(G, vb, H, W):
+def fpn_tail_gather(G, vb, H, W, separable=False):
     """G [NB,1,H/2,W/2,9*CO] (or 4-D), vb [9,CO] -> P [NB,1,H,W,CO]; see include/mvster_hip.h."""
     _chk(G, "fpn_tail_gather:G")
     _chk(vb, "fpn_tail_gather:vb")
@@ -177,7 +177,8 @@ def fpn_tail_gather(G, vb, H, W):
     if G.shape[-1] != 9 * CO or G.numel() != NB * (H // 2) * (W // 2) * 9 * CO:
         raise RuntimeError("fpn_tail_gather: inconsistent shapes")
     P = torch.empty(NB, 1, H, W, CO, device=G.device, dtype=torch.float32)
-    _lib.check(_lib.load().mvster_fpn_tail_gather(_ptr(G), _ptr(vb), _ptr(P), NB, H, W, CO, _stream()),
+    ws = torch.empty(NB, H, W // 2, 3 * CO, device=G.device, dtype=torch.float32) if separable else None
+    _lib.check(_lib.load().mvster_fpn_tail_gather(_ptr(G), _ptr(vb), _ptr(P), _ptr(ws), NB, H, W, CO, _stream()),
                "fpn_tail_gather")
     return P
 

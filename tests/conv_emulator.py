@@ -87,7 +87,7 @@ def run_layer(layer, x, skip=None, skip_mode=SKIP_NONE):
     return torch.from_numpy(out)
 
 
-def fpn_tail_gather_reference(G, vb, H, W):
+def fpn_tail_gather_reference(G, vb, H, W, separable=True):
     """PyTorch restatement of mvster_fpn_tail_gather (CPU tests)."""
     import torch.nn.functional as F
     NB = G.shape[0]

@@ -313,8 +313,9 @@ def test_fpn_tail_gather():
         G = torch.randn(NB, 1, H // 2, W // 2, 9 * CO, generator=g)
         vb = torch.randn(9, CO, generator=g)
         want = fpn_tail_gather_reference(G, vb, H, W)
-        got = ops.fpn_tail_gather(G.to(DEV), vb.to(DEV), H, W).cpu()
-        err = (got - want).abs().max().item()
+        got = ops.fpn_tail_gather(G.to(DEV), vb.to(DEV), H, W, separable=False).cpu()
+        got2 = ops.fpn_tail_gather(G.to(DEV), vb.to(DEV), H, W, separable=True).cpu()
+        err = max((got - want).abs().max().item(), (got2 - want).abs().max().item())
         note("fpn_tail_gather_%dx%d" % (H, W), max_abs=err, ref_absmax=want.abs().max().item())
         assert err <= 1e-5 * want.abs().max().item()
 
