@@ -29,6 +29,15 @@ extern "C" {
  * Replaces models/mvs4net_utils.py:1032-1035 (K@[R|t]) and :24-26 (inverse + matmul). */
 int mvster_relative_projection(const float* proj_matrices, float* rt, int B, int N, void* stream);
 
+/* Same for several cascade stages in one launch: proj_matrices = HOST array of nstage device pointers
+ * (each [B,N,2,4,4]); rt [nstage,B,N-1,12]. */
+int mvster_relative_projection_multi(const float* const* proj_matrices, int nstage, float* rt, int B, int N,
+                                     void* stream);
+
+/* imgs = HOST array of N device pointers, each [B,3,H,W] (the reference's `imgs` list, MVS4Net.py:60) ->
+ * out [N*B,H,W,4] channels-last RGB0, view-major: the batch FPN4 runs on. */
+int mvster_pack_images(const float* const* imgs, int N, float* out, int B, int H, int W, void* stream);
+
 /* Fused homography warp + group-wise (or squared-difference) correlation + epipolar attention
  * aggregation over all NV source views.  Channels-last features:
  *   ref_feat [B,h,w,C] (batch stride given), src_feat view v / batch b at

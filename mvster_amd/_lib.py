@@ -18,6 +18,8 @@ _fl = ctypes.c_float
 
 SIGNATURES = {
     "mvster_relative_projection": [_f, _f, _i, _i, _f],
+    "mvster_relative_projection_multi": [_f, _i, _f, _i, _i, _f],
+    "mvster_pack_images": [_f, _i, _f, _i, _i, _i, _f],
     "mvster_warp_agg_fwd": [_f, _f, _f, _f, _f, _f] + [_i] * 9 + [_l] * 3 + [_i, _i, _fl, _i, _f],
     "mvster_warp_agg_bwd": [_f] * 9 + [_i] * 9 + [_l] * 3 + [_i, _i, _fl, _f],
     "mvster_init_range": [_f, _i, _f, _i, _i, _i, _i, _i, _f],

@@ -218,6 +218,45 @@ __global__ void fpn_tail_hpass_kernel(const float* __restrict__ V, const float* 
     for (int c = 0; c < CO; c += 4) st4(o + c, (f32x4){acc[c], acc[c + 1], acc[c + 2], acc[c + 3]});
 }
 
+struct PackArgs {
+    const float* img[16];   // N views, each [B,3,H,W]
+    float* out;             // [N*B, H, W, 4]  (RGB0, channels-last)
+    int N, B, HW;
+};
+
+// list of N [B,3,H,W] images -> one channels-last RGB0 batch (feeds FPN4 conv0, mvs4net_utils.py:427)
+__global__ void pack_images_kernel(PackArgs a) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int vb = blockIdx.y;            // v * B + b
+    if (p >= a.HW) return;
+    const int v = vb / a.B, b = vb - v * a.B;
+    const float* src = a.img[v] + (long)b * 3 * a.HW + p;
+    const f32x4 px = {src[0], src[a.HW], src[2 * (long)a.HW], 0.0f};
+    st4(a.out + ((long)vb * a.HW + p) * 4, px);
+}
+
+struct MultiProjArgs {
+    const float* pm[8];     // per stage [B,N,2,4,4]
+    float* rt;              // [nstage, B, N-1, 12]
+    int nstage, B, N;
+};
+
+__global__ void relative_projection_multi_kernel(MultiProjArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int NV = a.N - 1;
+    const int per = a.B * NV;
+    if (i >= a.nstage * per) return;
+    const int s = i / per, r = i - s * per;
+    const int b = r / NV, v = r - b * NV;
+    const float* ref = a.pm[s] + ((long)b * a.N) * 32;
+    const float* src = a.pm[s] + ((long)b * a.N + v + 1) * 32;
+    mv::RT m;
+    mv::relative_projection(ref, src, m);
+    float* o = a.rt + (long)i * 12;
+    for (int k = 0; k < 9; ++k) o[k] = m.r[k];
+    for (int k = 0; k < 3; ++k) o[9 + k] = m.t[k];
+}
+
 }  // namespace
 
 extern "C" int mvster_relative_projection(const float* proj_matrices, float* rt, int B, int N, void* stream) {
@@ -304,5 +343,33 @@ extern "C" int mvster_fpn_tail_gather(const float* G, const float* vb, float* P,
     dim3 grid((H * W + 255) / 256, NB);
     if (CO == 8) hipLaunchKernelGGL(fpn_tail_gather_kernel<8>, grid, block, 0, s, G, vb, P, NB, H, W);
     else hipLaunchKernelGGL(fpn_tail_gather_kernel<16>, grid, block, 0, s, G, vb, P, NB, H, W);
+    return mv_check_launch();
+}
+
+extern "C" int mvster_pack_images(const float* const* imgs, int N, float* out, int B, int H, int W, void* stream) {
+    if (!imgs || !out) return MVSTER_ERR_NULL;
+    if (N < 1 || N > 16 || B <= 0 || H <= 0 || W <= 0) return MVSTER_ERR_SHAPE;
+    PackArgs a;
+    for (int v = 0; v < N; ++v) {
+        if (!imgs[v]) return MVSTER_ERR_NULL;
+        a.img[v] = imgs[v];
+    }
+    a.out = out; a.N = N; a.B = B; a.HW = H * W;
+    hipLaunchKernelGGL(pack_images_kernel, dim3((H * W + 255) / 256, N * B), dim3(256), 0, (hipStream_t)stream, a);
+    return mv_check_launch();
+}
+
+extern "C" int mvster_relative_projection_multi(const float* const* proj_matrices, int nstage, float* rt, int B, int N,
+                                                void* stream) {
+    if (!proj_matrices || !rt) return MVSTER_ERR_NULL;
+    if (nstage < 1 || nstage > 8 || B <= 0 || N < 2) return MVSTER_ERR_SHAPE;
+    MultiProjArgs a;
+    for (int s = 0; s < nstage; ++s) {
+        if (!proj_matrices[s]) return MVSTER_ERR_NULL;
+        a.pm[s] = proj_matrices[s];
+    }
+    a.rt = rt; a.nstage = nstage; a.B = B; a.N = N;
+    const int n = nstage * B * (N - 1);
+    hipLaunchKernelGGL(relative_projection_multi_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
     return mv_check_launch();
 }

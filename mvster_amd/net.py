@@ -141,11 +141,12 @@ class MVS4net(nn.Module):
         dev = imgs[0].device
         fpn, regs = self._get_plans()
         depth_values = depth_values.to(dev, torch.float32)
-        depth_interval = (depth_values[:, -1] - depth_values[:, 0]) / depth_values.size(1)
-
-        x = torch.zeros(N * B, 1, H, W, 4, device=dev, dtype=torch.float32)       # RGB0, channels-last
-        x[:, 0, :, :, :3] = torch.stack(imgs, 0).reshape(N * B, 3, H, W).permute(0, 2, 3, 1)
-        pyramid = fpn(x)                                                         # 4 x [N*B,1,h,w,C]
+        depth_interval = None
+        if not self.inverse_depth:
+            depth_interval = (depth_values[:, -1] - depth_values[:, 0]) / depth_values.size(1)
+        names = ["stage%d" % (s + 1) for s in range(self.num_stage)]
+        rts = ops.relative_projection_multi([proj_matrices[n].to(dev, torch.float32) for n in names])
+        pyramid = fpn(ops.pack_images(imgs))                                     # 4 x [N*B,1,h,w,C]
 
         outputs = {}
         prev = None
@@ -156,7 +157,7 @@ class MVS4net(nn.Module):
             f = f.view(N, B, h, w, C)
             ref_cl, src_cl = f[0], f[1:]
             G = self.group_cor_dim[s] if self.group_cor else C
-            rt = ops.relative_projection(proj_matrices[name].to(dev, torch.float32))
+            rt = rts[s]
             if teacher is not None and name in teacher:
                 hypo = teacher[name].contiguous()
             else:
@@ -173,7 +174,8 @@ class MVS4net(nn.Module):
                                        want_logits=want_logits)
             if capture is not None:
                 capture[name] = {"cor_feats": cor.permute(0, 4, 1, 2, 3), "logits": sel["logits"]}
-            conf = ops.upsample_bilinear(sel["conf"], 2 ** (3 - s))
+            # (x1 at the last stage is the identity, exactly: src = dst, lambda = 0)
+            conf = ops.upsample_bilinear(sel["conf"], 2 ** (3 - s)) if s < 3 else sel["conf"]
             st = {"depth": sel["depth"], "photometric_confidence": conf, "hypo_depth": hypo,
                   "attn_weight": sel["attn_weight"]}
             if self.inverse_depth:

@@ -39,6 +39,36 @@ def relative_projection(proj_matrices):
     return rt
 
 
+def relative_projection_multi(proj_list):
+    """List of per-stage [B,N,2,4,4] tensors -> rt [nstage,B,N-1,12] in one launch."""
+    import ctypes
+    pms = [p.contiguous() for p in proj_list]
+    for p in pms:
+        _chk(p, "relative_projection_multi")
+    B, N = pms[0].shape[:2]
+    rt = torch.empty(len(pms), B, N - 1, 12, device=pms[0].device, dtype=torch.float32)
+    ptrs = (ctypes.c_void_p * len(pms))(*[p.data_ptr() for p in pms])
+    _lib.check(_lib.load().mvster_relative_projection_multi(ctypes.cast(ptrs, ctypes.c_void_p), len(pms), _ptr(rt), B, N,
+                                                            _stream()), "relative_projection_multi")
+    return rt
+
+
+def pack_images(imgs):
+    """List of N [B,3,H,W] tensors -> [N*B,1,H,W,4] channels-last RGB0 batch (view-major)."""
+    import ctypes
+    imgs = [i.contiguous() for i in imgs]
+    for i in imgs:
+        _chk(i, "pack_images")
+    B, C, H, W = imgs[0].shape
+    if C != 3 or len(imgs) > 16:
+        raise RuntimeError("pack_images: expects at most 16 views of [B,3,H,W]")
+    out = torch.empty(len(imgs) * B, 1, H, W, 4, device=imgs[0].device, dtype=torch.float32)
+    ptrs = (ctypes.c_void_p * len(imgs))(*[i.data_ptr() for i in imgs])
+    _lib.check(_lib.load().mvster_pack_images(ctypes.cast(ptrs, ctypes.c_void_p), len(imgs), _ptr(out), B, H, W, _stream()),
+               "pack_images")
+    return out
+
+
 def to_channels_last(feat_nchw):
     """[B,C,H,W] -> [B,H,W,C] contiguous."""
     return feat_nchw.permute(0, 2, 3, 1).contiguous()

@@ -62,6 +62,20 @@ def test_relative_projection():
             assert torch.all((got - want).abs() <= 5e-7 * want.abs().clamp(min=1.0)), (stage, v)
 
 
+def test_pack_images_and_multi_projection():
+    g = torch.Generator().manual_seed(0)
+    imgs = [torch.rand(2, 3, 12, 20, generator=g) for _ in range(3)]
+    out = ops.pack_images([i.to(DEV) for i in imgs]).cpu()
+    want = torch.zeros(6, 1, 12, 20, 4)
+    want[:, 0, :, :, :3] = torch.stack(imgs, 0).reshape(6, 3, 12, 20).permute(0, 2, 3, 1)
+    assert torch.equal(out, want)
+    _, proj, _ = make_inputs(4, 128, 192, seed=3, batch=2)
+    names = ["stage%d" % s for s in range(1, 5)]
+    multi = ops.relative_projection_multi([proj[n].to(DEV) for n in names]).cpu()
+    for s, n in enumerate(names):
+        assert torch.equal(multi[s], ops.relative_projection(proj[n].to(DEV)).cpu())
+
+
 def test_schedulers(golden):
     g = golden("g5_sched")
     dv = g.t("dv", DEV)
