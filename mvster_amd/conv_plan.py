@@ -408,17 +408,28 @@ class FpnPlan:
             x = l(x)
         return x
 
-    def __call__(self, x):
+    def head(self, x):
+        """Bottom-up path and the two coarse levels: everything stages 1 and 2 need."""
         c0 = self._seq(self.conv0, x)
         c1 = self._seq(self.conv1, c0)
         c2 = self._seq(self.conv2, c1)
         c3 = self._seq(self.conv3, c2)
         o1 = self.out1(c3)
-        f = self.inner1(c2, skip=c3, skip_mode=SKIP_UPSAMPLE_ADD)
-        o2 = self.out2(f)
-        f = self.inner2(c1, skip=f, skip_mode=SKIP_UPSAMPLE_ADD)
-        o3 = self.out3(f)
+        f1 = self.inner1(c2, skip=c3, skip_mode=SKIP_UPSAMPLE_ADD)
+        o2 = self.out2(f1)
+        return c0, c1, f1, o1, o2
+
+    def tail(self, c0, c1, f1):
+        """The two fine levels (needed from stage 3 on); independent of stages 1-2, so the model runs it
+        on a second HIP stream underneath them."""
+        f2 = self.inner2(c1, skip=f1, skip_mode=SKIP_UPSAMPLE_ADD)
+        o3 = self.out3(f2)
         H, W = c0.shape[2], c0.shape[3]
-        partial = ops.fpn_tail_gather(self.tail_g(f), self.tail_vb, H, W)
+        partial = ops.fpn_tail_gather(self.tail_g(f2), self.tail_vb, H, W)
         o4 = self.tail_c(c0, skip=partial, skip_mode=SKIP_ADD)
+        return o3, o4
+
+    def __call__(self, x):
+        c0, c1, f1, o1, o2 = self.head(x)
+        o3, o4 = self.tail(c0, c1, f1)
         return [o1, o2, o3, o4]

@@ -87,6 +87,10 @@ class MVS4net(nn.Module):
             else:
                 raise NotImplementedError("reg_net %r" % reg_net)
         self._plans = None
+        # run the fine FPN levels on a second HIP stream underneath cascade stages 1-2 (which are small,
+        # latency-bound launches that leave most of the chip idle)
+        self.overlap_streams = True
+        self._side_streams = {}
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_plans())
 
     # ------------------------------------------------------------------ plan cache
@@ -146,12 +150,29 @@ class MVS4net(nn.Module):
             depth_interval = (depth_values[:, -1] - depth_values[:, 0]) / depth_values.size(1)
         names = ["stage%d" % (s + 1) for s in range(self.num_stage)]
         rts = ops.relative_projection_multi([proj_matrices[n].to(dev, torch.float32) for n in names])
-        pyramid = fpn(ops.pack_images(imgs))                                     # 4 x [N*B,1,h,w,C]
+        c0, c1, f1, o1, o2 = fpn.head(ops.pack_images(imgs))                     # channels-last [N*B,1,h,w,C]
+        main = torch.cuda.current_stream()
+        side = None
+        if self.overlap_streams and self.num_stage > 2:
+            side = self._side_streams.get(dev)
+            if side is None:
+                side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                o3, o4 = fpn.tail(c0, c1, f1)
+        else:
+            o3, o4 = fpn.tail(c0, c1, f1)
+        pyramid = [o1, o2, o3, o4]
 
         outputs = {}
         prev = None
         for s in range(self.num_stage):
             name = "stage%d" % (s + 1)
+            if s == 2 and side is not None:
+                main.wait_stream(side)                                           # join: stage 3 reads o3, stage 4 o4
+                if not torch.cuda.is_current_stream_capturing():
+                    for t in (o3, o4):
+                        t.record_stream(main)                                    # allocated on `side`, consumed on `main`
             f = pyramid[s]
             h, w, C = f.shape[2], f.shape[3], f.shape[4]
             f = f.view(N, B, h, w, C)
