@@ -89,14 +89,16 @@ int mvster_upsample_bilinear(const float* in, float* out, int B, int hi, int wi,
  * scale/shift (+ReLU, +skip) epilogue.  in [B,Di,Hi,Wi,cin]; wpk = weights packed by
  * mvster_amd/conv_plan.py; scale/shift [16*ntiles]; skip optional; zeros = >=16 B of zeros;
  * geom = HOST int32 array (layout: conv_plan.GEOM), woff = HOST int64 per-class weight offsets.
+ * prob_w [8] / prob_b [1] (optional, cout == 8, variants 0/2): fuse the 1x1x1 `prob` head of reg2d
+ * (models/mvs4net_utils.py:900) -- `out` is then the [B,Do,Ho,Wo] logits volume instead of the feature volume.
  * variant 0 = direct (operands from L1), 1 = LDS-staged input patch (ordinary convs, cin % 16 == 0,
  * mt in {2,4}: the workgroup tile is 2*mt rows x 32 columns), 2 = direct with the 4 waves of a workgroup
  * splitting K (small deep layers; cin >= 16, mt*nt <= 4).
  * Conv3d/ConvTranspose3d/BatchNorm3d/ReLU of reg2d/reg3d (models/mvs4net_utils.py:870-965) and
  * Conv2d/BatchNorm2d/ReLU/upsample-add of FPN4 (:419-502). */
 int mvster_conv_mfma(const float* in, const float* wpk, const float* scale, const float* shift, const float* skip,
-                     const float* zeros, float* out, const int* geom, int ngeom, const long* woff, int cin, int mt,
-                     int nt, int variant, void* stream);
+                     const float* zeros, const float* prob_w, const float* prob_b, float* out, const int* geom,
+                     int ngeom, const long* woff, int cin, int mt, int nt, int variant, void* stream);
 
 /* 3x3 (pad 1, stride 1) convolution with 8 output channels and cin in {4, 8} on the fp32 VALU (packed FMA),
  * for the narrow full-resolution layers where the 16-wide MFMA tile is half padding.  in [NB,H,W,cin],

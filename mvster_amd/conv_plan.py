@@ -105,7 +105,7 @@ def _tiles(M, ntile_total, nclass):
 class ConvLayer:
     """One fused conv (+scale/shift, +ReLU, +skip) layer on channels-last tensors."""
 
-    def __init__(self, weight, transposed, stride, padding, bn=None, bias=None, relu=False, cin_pad=None):
+    def __init__(self, weight, transposed, stride, padding, bn=None, bias=None, relu=False, cin_pad=None, prob=None):
         w = weight.detach().float()
         dev = w.device
         if w.dim() == 4:  # 2-D conv -> depth 1
@@ -175,6 +175,13 @@ class ConvLayer:
         self.shift[:cout] = shift
         self.zeros = torch.zeros(64, device=dev)
         self._geom_cache = {}
+        # optional fused 1x1x1 head: (weight [8], bias [1]) -> the layer outputs logits [B,D,H,W]
+        self.prob = None
+        if prob is not None:
+            if cout != 8:
+                raise RuntimeError("conv_mfma: the fused prob head needs 8 channels")
+            self.prob = (prob[0].detach().float().reshape(-1).contiguous().to(dev),
+                         prob[1].detach().float().reshape(-1).contiguous().to(dev))
         # narrow full-resolution layers: VALU kernel (conv_small.hip), weights as [3,3,cin,8]
         self.w_small = None
         if (not transposed and self.kernel == (1, 3, 3) and self.stride == (1, 1, 1) and self.padding == (0, 1, 1)
@@ -250,11 +257,14 @@ class ConvLayer:
         if tiles is not None:
             mt, nt = tiles[0], tiles[1]
             variant = tiles[2] if len(tiles) > 2 else 0
-        out = torch.empty(oshape + (self.cout,), device=x.device, dtype=torch.float32)
+        if self.prob is not None and variant in (1, 3):
+            variant = 0
+            mt, nt = _tiles(B * geom[4] * geom[5] * geom[6], self.ntile_total, len(self.classes))
+        out = torch.empty(oshape + ((self.cout,) if self.prob is None else ()), device=x.device, dtype=torch.float32)
         if skip is not None:
             if not skip.is_contiguous():
                 raise RuntimeError("conv_mfma: skip must be contiguous")
-            want = out.shape if skip_mode == SKIP_ADD else (B, 1, oshape[2] // 2, oshape[3] // 2, self.cout)
+            want = (oshape + (self.cout,)) if skip_mode == SKIP_ADD else (B, 1, oshape[2] // 2, oshape[3] // 2, self.cout)
             if tuple(skip.shape) != tuple(want):
                 raise RuntimeError("conv_mfma: skip shape %s, expected %s" % (tuple(skip.shape), tuple(want)))
         if variant == 3:
@@ -268,8 +278,9 @@ class ConvLayer:
             return out
         rc = _lib.load().mvster_conv_mfma(
             x.data_ptr(), self.wpk.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
-            None if skip is None else skip.data_ptr(), self.zeros.data_ptr(), out.data_ptr(),
-            geom.ctypes.data_as(ctypes.c_void_p), int(geom.size), self.woff.ctypes.data_as(ctypes.c_void_p), self.cin,
+            None if skip is None else skip.data_ptr(), self.zeros.data_ptr(),
+            None if self.prob is None else self.prob[0].data_ptr(), None if self.prob is None else self.prob[1].data_ptr(),
+            out.data_ptr(), geom.ctypes.data_as(ctypes.c_void_p), int(geom.size), self.woff.ctypes.data_as(ctypes.c_void_p), self.cin,
             mt, nt, variant, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "conv_mfma")
         return out
@@ -288,31 +299,34 @@ def _cbr3d(m, **kw):
     return ConvLayer(m.conv.weight, False, m.conv.stride, m.conv.padding, bn=m.bn, relu=True, **kw)
 
 
-def _up3d(seq):
+def _up3d(seq, prob=None):
     """Sequential(ConvTranspose3d, BatchNorm3d, ReLU) -> ConvLayer."""
     ct, bn = seq[0], seq[1]
-    return ConvLayer(ct.weight, True, ct.stride, ct.padding, bn=bn, relu=True)
+    return ConvLayer(ct.weight, True, ct.stride, ct.padding, bn=bn, relu=True, prob=prob)
 
 
 class Reg2dPlan:
     """reg2d U-Net (models/mvs4net_utils.py:870-912) on channels-last volumes; the 1x1x1 ``prob``
     head is left to the selection kernel (fused with the softmax)."""
 
-    def __init__(self, m):
+    def __init__(self, m, fuse_prob_into_conv11=True):
         self.conv0, self.conv1, self.conv2 = _cbr3d(m.conv0), _cbr3d(m.conv1), _cbr3d(m.conv2)
         self.conv3, self.conv4 = _cbr3d(m.conv3), _cbr3d(m.conv4)
         self.conv5, self.conv6 = _cbr3d(m.conv5), _cbr3d(m.conv6)
-        self.conv7, self.conv9, self.conv11 = _up3d(m.conv7), _up3d(m.conv9), _up3d(m.conv11)
+        self.conv7, self.conv9 = _up3d(m.conv7), _up3d(m.conv9)
         self.prob_w = m.prob.weight.detach().float().reshape(-1).contiguous()
         self.prob_b = m.prob.bias.detach().float().reshape(-1).contiguous()
-        self.fused_prob = True
+        # the 1x1x1 `prob` head runs in conv11's epilogue (the 8-channel volume is never written); with
+        # fuse_prob_into_conv11=False the plan returns the feature volume and the selection kernel applies it
+        self.conv11 = _up3d(m.conv11, prob=(self.prob_w, self.prob_b) if fuse_prob_into_conv11 else None)
+        self.fused_prob = not fuse_prob_into_conv11
 
     def layers(self):
         return [self.conv0, self.conv1, self.conv2, self.conv3, self.conv4, self.conv5, self.conv6, self.conv7,
                 self.conv9, self.conv11]
 
     def __call__(self, x):
-        """x [B,D,h,w,G] -> last feature volume [B,D,h,w,8] (before ``prob``)."""
+        """x [B,D,h,w,G] -> logits [B,D,h,w] (or the last feature volume [B,D,h,w,8] if ``fused_prob``)."""
         c0 = self.conv0(x)
         c2 = self.conv2(self.conv1(c0))
         c4 = self.conv4(self.conv3(c2))

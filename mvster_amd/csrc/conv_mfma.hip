@@ -41,6 +41,8 @@ struct ConvArgs {
     const float* shift;   // [Np]
     const float* skip;    // optional
     const float* zeros;   // >= 16 bytes of zeros: the "address" of every padded tap
+    const float* prob_w;  // optional fused 1x1x1 head (cout == 8): out becomes [voxels] logits
+    const float* prob_b;
     float* out;           // [B, DoF, HoF, WoF, COUT]
     int B, Di, Hi, Wi;
     int Do, Ho, Wo;       // output lattice walked by M (per class)
@@ -90,6 +92,21 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& a, f32x4v v, int 
     for (int j = 0; j < 4; ++j) {
         v[j] = fmaf(v[j], sc[j], sh[j]);
         if (a.relu) v[j] = fmaxf(v[j], 0.0f);
+    }
+    if (a.prob_w) {
+        // fused `prob` head (reference reg2d.prob, mvs4net_utils.py:900): 8-channel dot product; the two
+        // lanes holding channels 0-3 and 4-7 of this voxel are 16 apart in the wave
+        if (a.skip_mode == 1) {
+            const f32x4v k = *reinterpret_cast<const f32x4v*>(a.skip + opix * a.cout + n0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += k[j];
+        }
+        float part = v[0] * a.prob_w[n0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) part = fmaf(v[j], a.prob_w[n0 + j], part);
+        const float other = __shfl_xor(part, 16);
+        if (n0 == 0) a.out[opix] = (part + other) + a.prob_b[0];
+        return;
     }
     float* op = a.out + opix * a.cout + n0;
     if (vec) {
@@ -494,12 +511,15 @@ __global__ void mfma_probe_kernel(const float* A, const float* Bm, float* Dm) {
 
 // geom: int32 array, see mvster_amd/conv_plan.py (GEOM_* layout); woff: per-class offsets (floats)
 extern "C" int mvster_conv_mfma(const float* in, const float* wpk, const float* scale, const float* shift,
-                                const float* skip, const float* zeros, float* out, const int* geom, int ngeom, const long* woff,
-                                int cin, int mt, int nt, int variant, void* stream) {
+                                const float* skip, const float* zeros, const float* prob_w, const float* prob_b,
+                                float* out, const int* geom, int ngeom, const long* woff, int cin, int mt, int nt,
+                                int variant, void* stream) {
     if (!in || !wpk || !scale || !shift || !zeros || !out || !geom || !woff) return MVSTER_ERR_NULL;
     if (ngeom < 22) return MVSTER_ERR_SHAPE;
     ConvArgs a;
     a.in = in; a.wpk = wpk; a.scale = scale; a.shift = shift; a.skip = skip; a.zeros = zeros; a.out = out;
+    a.prob_w = prob_w; a.prob_b = prob_b;
+    if ((prob_w == nullptr) != (prob_b == nullptr)) return MVSTER_ERR_NULL;
     int i = 0;
     a.B = geom[i++]; a.Di = geom[i++]; a.Hi = geom[i++]; a.Wi = geom[i++];
     a.Do = geom[i++]; a.Ho = geom[i++]; a.Wo = geom[i++];
@@ -539,6 +559,7 @@ extern "C" int mvster_conv_mfma(const float* in, const float* wpk, const float* 
     if (a.ntile_total % nt != 0) return MVSTER_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     a.cin = cin;
+    if (prob_w && (a.cout != 8 || a.skip_mode == 2 || variant == 1)) return MVSTER_ERR_UNSUPPORTED;
     if (variant == 1) return dispatch_lds(a, mt, nt, s);
     if (variant != 0 && variant != 2) return MVSTER_ERR_UNSUPPORTED;
     const bool splitk = variant == 2;

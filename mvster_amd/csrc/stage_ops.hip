@@ -144,6 +144,70 @@ __global__ void fpn_tail_gather_kernel(const float* __restrict__ G, const float*
     }
 }
 
+// LDS-tiled form: an 8 x 32 output tile needs only a ~7 x 19 patch of the half-resolution map G (all
+// 9*CO channels, <= 46 KB).  The patch is staged once with coalesced 16-byte loads; the 36 bilinear
+// corner reads per output pixel then come from LDS instead of 72 L1/L2 gathers per thread.
+template <int CO>
+__global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* __restrict__ G,
+                                                                  const float* __restrict__ vb,
+                                                                  float* __restrict__ P, int NB, int H, int W,
+                                                                  int tiles_x, int tiles_y) {
+    constexpr int CG = 9 * CO, Q = CG / 4;     // float4 per half-resolution pixel
+    constexpr int PR = 8, PC = 20;             // patch capacity (rows, cols)
+    __shared__ f32x4 patch[PR * PC * Q];
+    const int Hh = H / 2, Wh = W / 2;
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_x = bid % tiles_x; bid /= tiles_x;
+    const int tile_y = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int y0 = tile_y * 8, x0 = tile_x * 32;
+    // half-resolution footprint of output rows y0-1 .. y0+8 and columns x0-1 .. x0+32 (clamped to the image)
+    const int ylo = max(y0 - 1, 0), yhi = min(y0 + 8, H - 1), xlo = max(x0 - 1, 0), xhi = min(x0 + 32, W - 1);
+    const int r0 = mv::make_lerp(ylo, Hh, H).i0, r1 = mv::make_lerp(yhi, Hh, H).i1;
+    const int c0 = mv::make_lerp(xlo, Wh, W).i0, c1 = mv::make_lerp(xhi, Wh, W).i1;
+    const int nr = r1 - r0 + 1, nc = c1 - c0 + 1;       // <= PR, <= PC
+    const float* g = G + (long)b * Hh * Wh * CG;
+    for (int i = threadIdx.x; i < nr * nc * Q; i += 256) {
+        const int q = i % Q, pix = i / Q;
+        const int pc = pix % nc, pr = pix / nc;
+        patch[(pr * PC + pc) * Q + q] = ld4(g + ((long)(r0 + pr) * Wh + (c0 + pc)) * CG + q * 4);
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int y = y0 + ty, x = x0 + tx;
+    if (y >= H || x >= W) return;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int qy = y + ky - 1;
+        if (qy < 0 || qy >= H) continue;
+        const mv::Lerp ly = mv::make_lerp(qy, Hh, H);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int qx = x + kx - 1;
+            if (qx < 0 || qx >= W) continue;
+            const mv::Lerp lx = mv::make_lerp(qx, Wh, W);
+            const int tap = ky * 3 + kx;
+            const f32x4* p00 = patch + ((ly.i0 - r0) * PC + (lx.i0 - c0)) * Q + tap * (CO / 4);
+            const f32x4* p01 = patch + ((ly.i0 - r0) * PC + (lx.i1 - c0)) * Q + tap * (CO / 4);
+            const f32x4* p10 = patch + ((ly.i1 - r0) * PC + (lx.i0 - c0)) * Q + tap * (CO / 4);
+            const f32x4* p11 = patch + ((ly.i1 - r0) * PC + (lx.i1 - c0)) * Q + tap * (CO / 4);
+#pragma unroll
+            for (int c = 0; c < CO; c += 4) {
+                const f32x4 a = p00[c / 4], bq = p01[c / 4], cq = p10[c / 4], dq = p11[c / 4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[c + j] += mv::bilerp(ly, lx, a[j], bq[j], cq[j], dq[j]) + vb[tap * CO + c + j];
+            }
+        }
+    }
+    float* o = P + (((long)b * H + y) * W + x) * CO;
+#pragma unroll
+    for (int c = 0; c < CO; c += 4) st4(o + c, (f32x4){acc[c], acc[c + 1], acc[c + 2], acc[c + 3]});
+}
+
 // Separable form of fpn_tail_gather (2.4x fewer loads): bilinear interpolation factorises into a
 // vertical and a horizontal 1-D lerp.
 //   pass 1  V[b][y][xh][kx*CO + co] = sum_{ky inside} lerp_y(y+ky-1)( G[b][.][xh][(ky*3+kx)*CO + co] )
@@ -338,6 +402,12 @@ extern "C" int mvster_fpn_tail_gather(const float* G, const float* vb, float* P,
             hipLaunchKernelGGL(fpn_tail_vpass_kernel<16>, g1, block, 0, s, G, workspace, NB, H, W);
             hipLaunchKernelGGL(fpn_tail_hpass_kernel<16>, g2, block, 0, s, workspace, vb, P, NB, H, W);
         }
+        return mv_check_launch();
+    }
+    if (CO == 8 && H >= 16 && W >= 64) {   // LDS-tiled gather (8 x 32 output tiles)
+        const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
+        hipLaunchKernelGGL(fpn_tail_gather_lds_kernel<8>, dim3(tiles_x * tiles_y * NB), block, 0, s, G, vb, P, NB, H, W,
+                           tiles_x, tiles_y);
         return mv_check_launch();
     }
     dim3 grid((H * W + 255) / 256, NB);

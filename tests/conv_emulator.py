@@ -84,6 +84,8 @@ def run_layer(layer, x, skip=None, skip_mode=SKIP_NONE):
             v = (wy0[:, None] * top + wy1[:, None] * bot) + v
         out[bo, oz, oy, ox] = v
     assert not np.isnan(out).any(), "some output voxel was never written"
+    if layer.prob is not None:
+        out = out @ layer.prob[0].detach().cpu().numpy() + layer.prob[1].detach().cpu().numpy()[0]
     return torch.from_numpy(out)
 
 

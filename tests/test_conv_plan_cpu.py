@@ -68,10 +68,12 @@ def test_reg2d_plan(G, D):
     x = torch.randn(1, G, D, 16, 24)
     with torch.no_grad():
         want = m(x)
-    feat = Emulated(cp.Reg2dPlan(m))(cl(x))                      # [B,D,h,w,8]
-    plan = cp.Reg2dPlan(m)
+    plan = cp.Reg2dPlan(m, fuse_prob_into_conv11=False)
+    feat = Emulated(plan)(cl(x))                                 # [B,D,h,w,8]
     logits = feat @ plan.prob_w + plan.prob_b
     assert (logits - want).abs().max() <= 5e-5 * want.abs().max()
+    fused = Emulated(cp.Reg2dPlan(m))(cl(x))                     # prob head in conv11's epilogue -> [B,D,h,w]
+    assert fused.shape == want.shape and (fused - want).abs().max() <= 5e-5 * want.abs().max()
     # same weights in the oracle's module tree give the same answer (state_dict compatibility)
     o = O.Reg2d(input_channel=G, base_channel=8)
     o.load_state_dict(m.state_dict(), strict=True)

@@ -290,8 +290,10 @@ def test_reg_networks_vs_golden(golden, name):
     m.to(DEV).eval()
     xc = cl5(x).to(DEV)
     if name.startswith("reg2d"):
-        plan = cp.Reg2dPlan(m)
+        plan = cp.Reg2dPlan(m, fuse_prob_into_conv11=False)
         logits = (plan(xc) @ plan.prob_w + plan.prob_b).cpu()
+        fused = cp.Reg2dPlan(m)(xc).cpu()                  # prob head fused into conv11's epilogue
+        assert (fused - want).abs().max().item() <= 5e-5 * want.abs().max().item()
     else:
         logits = cp.Reg3dPlan(m)(xc).cpu()
     err = (logits - want).abs().max().item()
@@ -323,7 +325,7 @@ def test_fpn_plan_vs_oracle():
 def test_fpn_tail_gather():
     from tests.conv_emulator import fpn_tail_gather_reference
     g = torch.Generator().manual_seed(2)
-    for (NB, H, W, CO) in ((2, 12, 20, 8), (1, 64, 34, 8), (1, 8, 8, 16)):
+    for (NB, H, W, CO) in ((2, 12, 20, 8), (1, 64, 34, 8), (1, 8, 8, 16), (2, 40, 96, 8), (1, 18, 70, 8)):
         G = torch.randn(NB, 1, H // 2, W // 2, 9 * CO, generator=g)
         vb = torch.randn(9, CO, generator=g)
         want = fpn_tail_gather_reference(G, vb, H, W)
