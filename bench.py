@@ -158,6 +158,8 @@ def main():
     if rank == 0:
         timer = KernelTimer()
         timer.install()
+        overlap = model.overlap_streams
+        model.overlap_streams = False      # one stream: per-kernel durations without co-running kernels
         try:
             for _ in range(3):
                 model(imgs, proj, dv)
@@ -168,6 +170,7 @@ def main():
             table = timer.summary()
         finally:
             timer.remove()
+            model.overlap_streams = overlap
         name, a = max(table.items(), key=lambda kv: kv[1]["ms"])
         avg_ms = a["ms"] / a["n"]
         if a["flops"] > 0 and name.startswith("conv"):
