@@ -62,11 +62,13 @@ class KernelTimer:
             e1.record()
             bytes_ = 4 * (x.numel() + out.numel() + layer.wpk.numel() + (skip.numel() if skip is not None else 0))
             if variant == 1:
-                kname = "conv_lds_kernel<%d,%d,%d>|cin%d" % (mt, nt, layer.kernel[2], layer.cin)
+                kname = "conv_lds_kernel<%d, %d, %d>" % (mt, nt, layer.kernel[2])
             elif variant == 3:
                 kname = "conv_small_kernel<%d>" % layer.cin
+            elif variant == 4:
+                kname = "deconv_small_kernel<%d, %d>" % (layer.cin, layer.cout)
             else:
-                kname = "conv_mfma_kernel<%d,%d,%d,%s>" % (layer.cin, mt, nt, "true" if variant == 2 else "false")
+                kname = "conv_mfma_kernel<%d, %d, %d, %s>" % (layer.cin, mt, nt, "true" if variant == 2 else "false")
             timer.records.append((kname, e0, e1,
                                   layer.flops(B, Di, Hi, Wi), bytes_))
             return out

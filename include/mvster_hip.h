@@ -107,6 +107,14 @@ int mvster_conv_mfma(const float* in, const float* wpk, const float* scale, cons
 int mvster_conv_small(const float* in, const float* w, const float* scale, const float* shift, const float* skip,
                       float* out, int NB, int H, int W, int cin, int relu, void* stream);
 
+/* ConvTranspose3d (1,3,3), stride (1,2,2), padding (0,1,1), output_padding (0,1,1) + BatchNorm scale/shift +
+ * ReLU + skip add for (cin, cout) in {(16,8), (32,16)} on the VALU (the layers are HBM-bound).  in [NB,Hi,Wi,cin],
+ * w [3,3,cin,cout], skip optional [NB,2Hi,2Wi,cout]; prob_w/prob_b optional (cout == 8): fuse the 1x1x1 head,
+ * out = logits [NB,2Hi,2Wi] instead of [NB,2Hi,2Wi,cout].  reg2d conv9 / conv11 (models/mvs4net_utils.py:890-900). */
+int mvster_deconv_small(const float* in, const float* w, const float* scale, const float* shift, const float* skip,
+                        const float* prob_w, const float* prob_b, float* out, int NB, int Hi, int Wi, int cin,
+                        int cout, int relu, void* stream);
+
 /* FPN4 top-down tail, re-associated: G [NB,H/2,W/2,9*CO] = 1x1 conv of the half-resolution top-down
  * map with the 9 taps of the output conv stacked on the channel axis; vb [9,CO] = the taps applied to the
  * lateral conv's bias; P [NB,H,W,CO] = sum over in-bounds taps of (bilinear x2 align_corners upsample of

@@ -29,6 +29,7 @@ SIGNATURES = {
     "mvster_upsample_bilinear": [_f, _f, _i, _i, _i, _i, _i, _f],
     "mvster_conv_mfma": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f, _i, _i, _i, _i, _f],
     "mvster_conv_small": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f],
+    "mvster_deconv_small": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f],
     "mvster_fpn_tail_gather": [_f, _f, _f, _f, _i, _i, _i, _i, _f],
     "mvster_mfma_probe": [_f, _f, _f, _f],
 }

@@ -175,6 +175,11 @@ class ConvLayer:
         self.shift[:cout] = shift
         self.zeros = torch.zeros(64, device=dev)
         self._geom_cache = {}
+        # HBM-bound finest up-sampling layers: VALU kernel (deconv_small), weights as [3,3,cin,cout]
+        self.w_deconv = None
+        if (transposed and self.kernel == (1, 3, 3) and self.stride == (1, 2, 2) and self.padding == (0, 1, 1)
+                and (self.cin, cout) in ((16, 8),)):      # (32, 16) measured slower than the MFMA classes
+            self.w_deconv = w[:, :, 0].permute(2, 3, 0, 1).contiguous().to(dev)     # [3,3,cin,cout]
         # optional fused 1x1x1 head: (weight [8], bias [1]) -> the layer outputs logits [B,D,H,W]
         self.prob = None
         if prob is not None:
@@ -241,6 +246,8 @@ class ConvLayer:
                 variant, mt, nt = tuned
             if self.w_small is not None and skip_mode in (SKIP_NONE, SKIP_ADD) and FORCE_VARIANT in (None, 3):
                 variant = 3
+            if self.w_deconv is not None and skip_mode in (SKIP_NONE, SKIP_ADD) and FORCE_VARIANT in (None, 4):
+                variant = 4
             g = (np.asarray(arr, dtype=np.int32), mt, nt, (B, DoF, HoF, WoF), variant)
             self._geom_cache[key] = g
         return g
@@ -257,6 +264,19 @@ class ConvLayer:
         if tiles is not None:
             mt, nt = tiles[0], tiles[1]
             variant = tiles[2] if len(tiles) > 2 else 0
+        if variant == 4:
+            if self.w_deconv is None or skip_mode == SKIP_UPSAMPLE_ADD:
+                raise RuntimeError("deconv_small: layer not eligible")
+            out = torch.empty(oshape + ((self.cout,) if self.prob is None else ()), device=x.device, dtype=torch.float32)
+            if skip is not None and tuple(skip.shape) != tuple(oshape + (self.cout,)):
+                raise RuntimeError("deconv_small: skip shape %s" % (tuple(skip.shape),))
+            rc = _lib.load().mvster_deconv_small(
+                x.data_ptr(), self.w_deconv.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                None if skip is None else skip.data_ptr(),
+                None if self.prob is None else self.prob[0].data_ptr(), None if self.prob is None else self.prob[1].data_ptr(),
+                out.data_ptr(), B * Di, Hi, Wi, self.cin, self.cout, int(self.relu), torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "deconv_small")
+            return out
         if self.prob is not None and variant in (1, 3):
             variant = 0
             mt, nt = _tiles(B * geom[4] * geom[5] * geom[6], self.ntile_total, len(self.classes))
@@ -422,20 +442,27 @@ class FpnPlan:
             x = l(x)
         return x
 
-    def head(self, x):
-        """Bottom-up path and the two coarse levels: everything stages 1 and 2 need."""
+    def trunk(self, x):
+        """Bottom-up path + the first top-down map f1: what both branches below need."""
         c0 = self._seq(self.conv0, x)
         c1 = self._seq(self.conv1, c0)
         c2 = self._seq(self.conv2, c1)
         c3 = self._seq(self.conv3, c2)
-        o1 = self.out1(c3)
         f1 = self.inner1(c2, skip=c3, skip_mode=SKIP_UPSAMPLE_ADD)
-        o2 = self.out2(f1)
+        return c0, c1, c3, f1
+
+    def coarse(self, c3, f1):
+        """Output convs of the two coarse levels: everything stages 1 and 2 need."""
+        return self.out1(c3), self.out2(f1)
+
+    def head(self, x):
+        c0, c1, c3, f1 = self.trunk(x)
+        o1, o2 = self.coarse(c3, f1)
         return c0, c1, f1, o1, o2
 
     def tail(self, c0, c1, f1):
-        """The two fine levels (needed from stage 3 on); independent of stages 1-2, so the model runs it
-        on a second HIP stream underneath them."""
+        """The two fine levels (needed from stage 3 on); independent of the coarse outputs and of cascade
+        stages 1-2, so the model runs it on a second HIP stream underneath them."""
         f2 = self.inner2(c1, skip=f1, skip_mode=SKIP_UPSAMPLE_ADD)
         o3 = self.out3(f2)
         H, W = c0.shape[2], c0.shape[3]

@@ -121,3 +121,129 @@ extern "C" int mvster_conv_small(const float* in, const float* w, const float* s
     else return MVSTER_ERR_UNSUPPORTED;
     return mv_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------
+// Transposed (1,3,3) stride-2 convolution (pad 1, output_padding 1) for the two finest up-sampling
+// layers of reg2d (conv9: 32 -> 16, conv11: 16 -> 8; models/mvs4net_utils.py:890-898) on the VALU.
+// One thread owns one INPUT lattice voxel (i, j) and produces its 2 x 2 output block:
+//   out[2i  ][2j  ] = x(i,j) W[1][1]
+//   out[2i  ][2j+1] = x(i,j) W[1][2] + x(i,j+1) W[1][0]
+//   out[2i+1][2j  ] = x(i,j) W[2][1] + x(i+1,j) W[0][1]
+//   out[2i+1][2j+1] = x(i,j) W[2][2] + x(i,j+1) W[2][0] + x(i+1,j) W[0][2] + x(i+1,j+1) W[0][0]
+// (o = 2 i - 1 + k).  The layers are HBM-bound (the skip tensor and the output are 2-4x the input);
+// weights are wave-uniform scalar loads, stores are 64 contiguous bytes per thread and row.  Epilogue:
+// BatchNorm scale/shift, ReLU, skip add, optionally the fused 1x1x1 `prob` head (COUT == 8).
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct DeconvArgs {
+    const float* in;      // [NB, Hi, Wi, CIN]
+    const float* w;       // [3][3][CIN][COUT]
+    const float* scale;
+    const float* shift;
+    const float* skip;    // [NB, 2Hi, 2Wi, COUT] or null
+    const float* prob_w;  // optional [COUT] (COUT == 8)
+    const float* prob_b;
+    float* out;           // [NB, 2Hi, 2Wi, COUT]  or logits [NB, 2Hi, 2Wi]
+    int NB, Hi, Wi, relu;
+    unsigned in_bytes;
+};
+
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256) deconv_small_kernel(DeconvArgs a) {
+    const int pix = xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    const int nb = blockIdx.y;
+    if (pix >= a.Hi * a.Wi) return;
+    const int i = pix / a.Wi, j = pix - i * a.Wi;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)a.in_bytes, 0x00020000);
+    const unsigned base = (unsigned)((nb * a.Hi + i) * a.Wi + j) * CIN * 4u;
+    const bool jn = j + 1 < a.Wi, in_ = i + 1 < a.Hi;
+    const unsigned o01 = jn ? base + CIN * 4u : 0xFFFFFFF0u;
+    const unsigned o10 = in_ ? base + (unsigned)a.Wi * CIN * 4u : 0xFFFFFFF0u;
+    const unsigned o11 = (jn && in_) ? base + (unsigned)(a.Wi + 1) * CIN * 4u : 0xFFFFFFF0u;
+
+    float acc[4][COUT];   // [dy*2+dx][co]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[q][c] = 0.0f;
+
+    auto wrow = [&](int ky, int kx, int ci) { return a.w + ((ky * 3 + kx) * CIN + ci) * COUT; };   // wave-uniform
+#pragma unroll 1
+    for (int c4 = 0; c4 < CIN; c4 += 4) {
+        const f32x4v x00 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + c4 * 4u, 0, 0));
+        const f32x4v x01 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o01 == 0xFFFFFFF0u ? o01 : o01 + c4 * 4u, 0, 0));
+        const f32x4v x10 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o10 == 0xFFFFFFF0u ? o10 : o10 + c4 * 4u, 0, 0));
+        const f32x4v x11 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o11 == 0xFFFFFFF0u ? o11 : o11 + c4 * 4u, 0, 0));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ci = c4 + k;
+            const float a00 = x00[k], a01 = x01[k], a10 = x10[k], a11 = x11[k];
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                acc[0][co] = fmaf(a00, wrow(1, 1, ci)[co], acc[0][co]);
+                acc[1][co] = fmaf(a00, wrow(1, 2, ci)[co], acc[1][co]);
+                acc[1][co] = fmaf(a01, wrow(1, 0, ci)[co], acc[1][co]);
+                acc[2][co] = fmaf(a00, wrow(2, 1, ci)[co], acc[2][co]);
+                acc[2][co] = fmaf(a10, wrow(0, 1, ci)[co], acc[2][co]);
+                acc[3][co] = fmaf(a00, wrow(2, 2, ci)[co], acc[3][co]);
+                acc[3][co] = fmaf(a01, wrow(2, 0, ci)[co], acc[3][co]);
+                acc[3][co] = fmaf(a10, wrow(0, 2, ci)[co], acc[3][co]);
+                acc[3][co] = fmaf(a11, wrow(0, 0, ci)[co], acc[3][co]);
+            }
+        }
+    }
+
+    const int Ho = 2 * a.Hi, Wo = 2 * a.Wi;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int oy = 2 * i + (q >> 1), ox = 2 * j + (q & 1);
+        const long opix = ((long)nb * Ho + oy) * Wo + ox;
+        float v[COUT];
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) {
+            v[c] = fmaf(acc[q][c], a.scale[c], a.shift[c]);
+            if (a.relu) v[c] = fmaxf(v[c], 0.0f);
+        }
+        if (a.skip) {
+#pragma unroll
+            for (int c = 0; c < COUT; c += 4) {
+                const f32x4v s4 = ld4(a.skip + opix * COUT + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[c + k] += s4[k];
+            }
+        }
+        if (a.prob_w) {
+            float lo = v[0] * a.prob_w[0], hi = v[4] * a.prob_w[4];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) { lo = fmaf(v[k], a.prob_w[k], lo); hi = fmaf(v[4 + k], a.prob_w[4 + k], hi); }
+            a.out[opix] = (lo + hi) + a.prob_b[0];
+        } else {
+#pragma unroll
+            for (int c = 0; c < COUT; c += 4) st4(a.out + opix * COUT + c, (f32x4v){v[c], v[c + 1], v[c + 2], v[c + 3]});
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mvster_deconv_small(const float* in, const float* w, const float* scale, const float* shift,
+                                   const float* skip, const float* prob_w, const float* prob_b, float* out, int NB,
+                                   int Hi, int Wi, int cin, int cout, int relu, void* stream) {
+    if (!in || !w || !scale || !shift || !out) return MVSTER_ERR_NULL;
+    if ((prob_w == nullptr) != (prob_b == nullptr)) return MVSTER_ERR_NULL;
+    if (NB <= 0 || Hi <= 0 || Wi <= 0) return MVSTER_ERR_SHAPE;
+    if (prob_w && cout != 8) return MVSTER_ERR_UNSUPPORTED;
+    const long in_elems = (long)NB * Hi * Wi * cin;
+    if (in_elems >= (1L << 30) || (long)NB * Hi * Wi * 4 * cout >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    DeconvArgs a;
+    a.in = in; a.w = w; a.scale = scale; a.shift = shift; a.skip = skip; a.prob_w = prob_w; a.prob_b = prob_b;
+    a.out = out; a.NB = NB; a.Hi = Hi; a.Wi = Wi; a.relu = relu; a.in_bytes = (unsigned)(in_elems * 4);
+    dim3 grid((Hi * Wi + 255) / 256, NB), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (cin == 16 && cout == 8) hipLaunchKernelGGL((deconv_small_kernel<16, 8>), grid, block, 0, s, a);
+    else if (cin == 32 && cout == 16) hipLaunchKernelGGL((deconv_small_kernel<32, 16>), grid, block, 0, s, a);
+    else return MVSTER_ERR_UNSUPPORTED;
+    return mv_check_launch();
+}

@@ -150,17 +150,19 @@ class MVS4net(nn.Module):
             depth_interval = (depth_values[:, -1] - depth_values[:, 0]) / depth_values.size(1)
         names = ["stage%d" % (s + 1) for s in range(self.num_stage)]
         rts = ops.relative_projection_multi([proj_matrices[n].to(dev, torch.float32) for n in names])
-        c0, c1, f1, o1, o2 = fpn.head(ops.pack_images(imgs))                     # channels-last [N*B,1,h,w,C]
+        c0, c1, c3, f1 = fpn.trunk(ops.pack_images(imgs))                        # channels-last [N*B,1,h,w,C]
         main = torch.cuda.current_stream()
         side = None
         if self.overlap_streams and self.num_stage > 2:
             side = self._side_streams.get(dev)
             if side is None:
                 side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
-            side.wait_stream(main)
+            side.wait_stream(main)                                               # fork: fine levels on `side`
             with torch.cuda.stream(side):
                 o3, o4 = fpn.tail(c0, c1, f1)
+            o1, o2 = fpn.coarse(c3, f1)
         else:
+            o1, o2 = fpn.coarse(c3, f1)
             o3, o4 = fpn.tail(c0, c1, f1)
         pyramid = [o1, o2, o3, o4]
 

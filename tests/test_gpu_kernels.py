@@ -258,6 +258,7 @@ def test_conv_bn_relu(name, cfg, shape):
 
 @pytest.mark.parametrize("cin,cout,k,pad,op,s", [(64, 32, (1, 3, 3), (0, 1, 1), (0, 1, 1), (1, 2, 2)),
                                                  (16, 8, (1, 3, 3), (0, 1, 1), (0, 1, 1), (1, 2, 2)),
+                                                 (32, 16, (1, 3, 3), (0, 1, 1), (0, 1, 1), (1, 2, 2)),
                                                  (32, 16, 3, 1, 1, 2)])
 def test_conv_transposed_skip(cin, cout, k, pad, op, s):
     torch.manual_seed(cin + cout)
@@ -270,7 +271,10 @@ def test_conv_transposed_skip(cin, cout, k, pad, op, s):
         skip = torch.randn_like(y)
         want = cl5(skip + y)
     layer = cp._up3d(seq.to(DEV))
-    for tiles in ((1, 1), (2, 1), (4, layer.ntile_total), (1, 1, 2), (2, 1, 2)):
+    tile_sets = [(1, 1), (2, 1), (4, layer.ntile_total), (1, 1, 2), (2, 1, 2)]
+    if layer.w_deconv is not None:
+        tile_sets.append((0, 0, 4))          # VALU kernel
+    for tiles in tile_sets:
         got = layer(cl5(x).to(DEV), skip=cl5(skip).to(DEV), skip_mode=cp.SKIP_ADD, tiles=tiles).cpu()
         err = (got - want).abs().max().item()
         assert err <= 2e-5 * want.abs().max().item(), (tiles, err)
