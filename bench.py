@@ -131,6 +131,8 @@ def main():
     model = MVS4net(**SHIPPED)
     model.load_state_dict(load_weights(), strict=True)
     model.to(dev).eval()
+    if os.environ.get("MVSTER_NO_OVERLAP"):
+        model.overlap_streams = False      # profiling passes: one stream, no co-running kernels
     # every rank works on its own depth maps: disjoint seeds = disjoint units of the shard
     units = shard.shard_units(world * (args.steps + args.warmup), rank, world)
     imgs, proj, dv = make_inputs(nviews=args.views, H=args.height, W=args.width, seed=units[0], device=dev)

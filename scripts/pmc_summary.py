@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Aggregate rocprofv3 --pmc counter_collection CSVs per kernel name (mean per dispatch)."""
+"""Aggregate rocprofv3 --pmc counter_collection CSVs per kernel name (mean per dispatch) and derive
+HBM traffic per launch with the gfx950 corrections of MI355X_MICROARCH.md (FETCH_SIZE is in KB and
+reports 1/2 of the bytes of wide coalesced reads -> x2; WRITE_SIZE in KB, uncalibrated)."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
@@ -11,16 +14,27 @@ agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(os.path.join(root, "*", "*counter_collection.csv")):
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            k = r.get("Kernel_Name", "?")
-            c = r.get("Counter_Name")
-            v = float(r.get("Counter_Value", 0) or 0)
-            a = agg[k][c]
-            a[0] += v
+            k = r.get("Kernel_Name", "?").replace("(anonymous namespace)::", "").replace("void ", "")
+            k = k.split("(")[0]
+            a = agg[k][r.get("Counter_Name")]
+            a[0] += float(r.get("Counter_Value", 0) or 0)
             a[1] += 1
-names = sorted({c for k in agg for c in agg[k]})
-print("kernel | " + " | ".join(names))
-def key(k):
-    return -agg[k].get("SQ_BUSY_CYCLES", [0, 1])[0]
-for k in sorted(agg, key=key)[:45]:
-    short = k.replace("(anonymous namespace)::", "").replace("void ", "")[:70]
-    print(short + " | " + " | ".join("%s=%.4g(n%d)" % (c, agg[k][c][0] / max(agg[k][c][1], 1), agg[k][c][1]) if c in agg[k] else "-" for c in names))
+out = {}
+for k in agg:
+    m = {c: agg[k][c][0] / max(agg[k][c][1], 1) for c in agg[k]}
+    m["dispatches"] = max(v[1] for v in agg[k].values())
+    if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+        m["hbm_bytes_per_launch"] = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m and m["GRBM_GUI_ACTIVE"] > 0:
+        # busy cycles summed over 1024 SIMDs vs GUI-active cycles summed over 8 XCDs
+        m["mfma_busy_frac"] = (m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (m["GRBM_GUI_ACTIVE"] / 8.0)
+    out[k] = m
+if len(sys.argv) > 2:
+    with open(sys.argv[2], "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+for k in sorted(out, key=lambda k: -out[k].get("GRBM_GUI_ACTIVE", 0) * out[k]["dispatches"])[:40]:
+    m = out[k]
+    print("%-44s n=%4d  hbm/launch %8.2f MB  mfma_busy %5.1f%%  valu/mfma %6.1f  lds_conflict %5.1f%%" % (
+        k[:44], m["dispatches"], m.get("hbm_bytes_per_launch", 0) / 1e6, 100 * m.get("mfma_busy_frac", 0),
+        m.get("SQ_INSTS_VALU", 0) / max(m.get("SQ_INSTS_MFMA", 0), 1),
+        100 * m.get("SQ_LDS_BANK_CONFLICT", 0) / max(m.get("SQ_LDS_IDX_ACTIVE", 0), 1)))
