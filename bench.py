@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="depth maps processed concurrently on one GPU: independent captured forwards replayed on "
+                         "separate HIP streams (1 = strictly one after the other)")
     args = ap.parse_args()
 
     from mvster_amd import MVS4net, shard
@@ -137,11 +140,38 @@ def main():
     units = shard.shard_units(world * (args.steps + args.warmup), rank, world)
     imgs, proj, dv = make_inputs(nviews=args.views, H=args.height, W=args.width, seed=units[0], device=dev)
 
+    sequential = None
     if args.no_graph:
         step = lambda: model(imgs, proj, dv)   # noqa: E731
-    else:
+    elif args.inflight <= 1:
         graphed = GraphedForward(model, imgs, proj, dv)
         step = lambda: graphed()               # noqa: E731
+    else:
+        # reference point: one depth map at a time (latency of a single forward)
+        g1 = GraphedForward(model, imgs, proj, dv)
+        for _ in range(args.warmup):
+            g1()
+        torch.cuda.synchronize()
+        s0 = time.perf_counter()
+        nseq = max(10, min(args.steps, 50))
+        for _ in range(nseq):
+            g1()
+        torch.cuda.synchronize()
+        sequential = (time.perf_counter() - s0) / nseq
+        del g1
+        # several independent depth maps in flight: one captured forward + one stream per slot
+        slots = []
+        for k in range(args.inflight):
+            im, pr, d = make_inputs(nviews=args.views, H=args.height, W=args.width, seed=units[0] + 1000 * k, device=dev)
+            slots.append((GraphedForward(model, im, pr, d), torch.cuda.Stream(device=dev)))
+        counter = [0]
+
+        def step():
+            g, st = slots[counter[0] % len(slots)]
+            counter[0] += 1
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                g.graph.replay()
 
     for _ in range(args.warmup):
         step()
@@ -237,9 +267,13 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DTU mid %dx%d, %d views, 4-stage cascade 8/8/4/4 hyp, B=1 eval, 1 depth map per step per GPU"
                                    % (args.height, args.width, args.views),
-                       "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "replicas x%d" % world},
+                       "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "replicas x%d" % world,
+                       "depth_maps_in_flight_per_gpu": args.inflight},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if sequential is not None:
+            line["single_forward_ms"] = round(1e3 * sequential, 4)       # one depth map at a time (latency)
+            line["value_one_in_flight"] = round(world / sequential, 3)
         if cpu:
             line["vs_cpu_baseline"] = round(line["value"] / cpu["value"], 2)
         print(json.dumps(line))

@@ -432,28 +432,44 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
             }
         }
         __syncthreads();
-        for (int kz = 0; kz < KD; ++kz) {
-            for (int ky = 0; ky < KH; ++ky) {
-                const int rowoff = (kz * PH + ky) * PW * 4;
-                const int tap0 = (kz * KH + ky) * KW;
+        // One "row" = the KW taps of one (kz, ky).  Rows are software-pipelined with two register sets:
+        // the LDS reads and weight loads of row r+1 are issued before the 4*KW*MT*NT MFMAs of row r, and
+        // every prefetch is unconditional so that hipcc emits counted waits.
+        const int nrows = KD * KH;
+        auto load_row = [&](int r, f32x4v (&A)[KW][MT], f32x4v (&Bv)[KW][NT]) {
+            const int kz = r / KH, ky = r - kz * KH;
+            const int rowoff = (kz * PH + ky) * PW * 4;
+            const float* w = wp + (long)(r * KW * nchunks + ch) * wstep;
 #pragma unroll
-                for (int kx = 0; kx < KW; ++kx) {
-                    f32x4v af[MT], bf[NT];
+            for (int kx = 0; kx < KW; ++kx) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) af[mt] = patch[abase[mt] + rowoff + kx * 4];
-                    const float* w = wp + (long)((tap0 + kx) * nchunks + ch) * wstep;
+                for (int mt = 0; mt < MT; ++mt) A[kx][mt] = patch[abase[mt] + rowoff + kx * 4];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const f32x4v*>(w + nt * 256);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nt][j], af[mt][j], acc[mt][nt], 0, 0, 0);
-                }
+                for (int nt = 0; nt < NT; ++nt)
+                    Bv[kx][nt] = *reinterpret_cast<const f32x4v*>(w + (long)kx * nchunks * wstep + nt * 256);
             }
+        };
+        auto mma_row = [&](const f32x4v (&A)[KW][MT], const f32x4v (&Bv)[KW][NT]) {
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bv[kx][nt][j], A[kx][mt][j], acc[mt][nt], 0, 0, 0);
+        };
+        f32x4v a0[KW][MT], b0[KW][NT], a1[KW][MT], b1[KW][NT];
+        load_row(0, a0, b0);
+        int r = 0;
+        for (; r + 2 <= nrows; r += 2) {
+            load_row(r + 1, a1, b1);
+            mma_row(a0, b0);
+            load_row(r + 2 < nrows ? r + 2 : nrows - 1, a0, b0);
+            mma_row(a1, b1);
         }
+        if (r < nrows) mma_row(a0, b0);
     }
 
     // epilogue (swapped operands: this lane holds channels 4*lq..4*lq+3 of its own voxel, see above)
