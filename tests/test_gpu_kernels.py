@@ -160,9 +160,10 @@ def test_warp_agg_forward(golden, name):
     note("warp_agg_" + name, tight_max_abs=tight, own_rt_max_abs=loose, ref_absmax=want.abs().max().item(),
          own_rt_mean_abs=(got2 - want).abs().mean().item())
     scale = want.abs().max().item()
-    assert tight <= 5e-6 * max(scale, 1.0)
-    assert loose <= 2e-3 * max(scale, 1.0)
-    assert (got2 - want).abs().mean().item() <= 2e-5 * max(scale, 1.0)
+    # measured: tight <= 7e-7, own projection <= 1.9e-5 max / 6e-7 mean (the reference's fp32 LAPACK noise)
+    assert tight <= 2e-6 * max(scale, 1.0)
+    assert loose <= 1e-4 * max(scale, 1.0)
+    assert (got2 - want).abs().mean().item() <= 3e-6 * max(scale, 1.0)
 
 
 def test_warp_agg_source_size_differs_and_oob(golden):

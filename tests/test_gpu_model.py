@@ -60,9 +60,10 @@ def test_eval_golden_teacher_forced(model, golden):
              attn_max=(attn - want_attn).abs().max(), depth_l1_clear=(depth - want_depth)[clear].abs().mean(),
              depth_max_clear=(depth - want_depth)[clear].abs().max(), flip_rate=flips.float().mean(),
              flip_rate_clear=flips[clear].float().mean(), clear_frac=clear.float().mean())
-        assert (cor - want_cor).abs().max() <= 2e-3 * want_cor.abs().max()
-        assert (cor - want_cor).abs().mean() <= 2e-5 * want_cor.abs().max()
-        assert (attn - want_attn).abs().max() <= 1e-3
+        # measured on MI355X (profiles/r01_k_parity_model.json): max 1.4e-5 / mean 8e-8 of the scale, attn 5e-5
+        assert (cor - want_cor).abs().max() <= 1e-4 * want_cor.abs().max()
+        assert (cor - want_cor).abs().mean() <= 2e-6 * want_cor.abs().max()
+        assert (attn - want_attn).abs().max() <= 3e-4
         assert (depth - want_depth)[clear].abs().mean() < 1e-4          # north-star tolerance: depth L1 < 1e-4
         conf, want_conf = st["photometric_confidence"].cpu(), g.t("stage%d_photometric_confidence" % s)
         assert conf.shape == want_conf.shape and (conf - want_conf).abs().max() <= 1e-3
