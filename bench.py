@@ -134,6 +134,8 @@ def main():
     model = MVS4net(**SHIPPED)
     model.load_state_dict(load_weights(), strict=True)
     model.to(dev).eval()
+    if os.environ.get("MVSTER_WARP_VARIANT"):
+        model.warp_variant = int(os.environ["MVSTER_WARP_VARIANT"])
     if os.environ.get("MVSTER_NO_OVERLAP"):
         model.overlap_streams = False      # profiling passes: one stream, no co-running kernels
     # every rank works on its own depth maps: disjoint seeds = disjoint units of the shard

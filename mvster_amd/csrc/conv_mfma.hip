@@ -355,15 +355,15 @@ int dispatch_tiles(const ConvArgs& a, int MT, int NT, bool splitk, hipStream_t s
 // ------------------------------------------------------------------------------------------
 constexpr int kMaxStage = 12;   // float4 loads per thread per chunk (patch <= 48 KB)
 
-template <int MT, int NT, int KW>
+template <int MT, int NT, int KW, int NG>
 __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) float patch_raw[];
-    f32x4v* patch = reinterpret_cast<f32x4v*>(patch_raw);
+    f32x4v* patch_base = reinterpret_cast<f32x4v*>(patch_raw);
     constexpr int TY = 2 * MT;
     const int KD = a.kd[0], KH = a.kh[0];
     const int PW = 31 * a.sw + KW, PH = (TY - 1) * a.sh + KH;
     const int CIN = a.cin, nchunks = CIN >> 4;
-    const int nstage = KD * PH * PW * 4;     // float4 per chunk
+    const int nstage = KD * PH * PW * 4;     // float4 per chunk (<= NG * 1024)
 
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_x = bid % tiles_x; bid /= tiles_x;
@@ -377,9 +377,9 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     const int lm = lane & 15, lq = lane >> 4;
 
     // chunk-independent global element offsets of the float4s this thread stages (-1 = zero padding)
-    int goff[kMaxStage];
+    int goff[NG * 4];
 #pragma unroll
-    for (int i = 0; i < kMaxStage; ++i) {
+    for (int i = 0; i < NG * 4; ++i) {
         const int idx = threadIdx.x + i * 256;
         int off = -1;
         if (idx < nstage) {
@@ -414,24 +414,28 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     const float* wp = a.wpk + ((long)nt0 * 64 + lane) * 4;
     const long wstep = (long)a.ntile_total * 256;
 
-    const int ngroups = (nstage + 1023) >> 10;   // staging runs in uniform groups of 4 float4 per thread
-    for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch > 0) __syncthreads();          // everyone is done reading the previous chunk
+    // Staging is register-double-buffered: NG groups of 4 float4 per thread.  The global loads of chunk
+    // ch+1 are issued BEFORE the MFMAs of chunk ch (their latency hides under this workgroup's own math
+    // instead of relying on other workgroups being out of phase) and written to LDS after them.
+    f32x4v stg[NG * 4];
+    auto stage_load = [&](int ch) {
 #pragma unroll
-        for (int g = 0; g < kMaxStage / 4; ++g) {
-            if (g < ngroups) {                // wave-uniform: 4 loads in flight, then 4 LDS writes
-                f32x4v tmp[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int o = goff[g * 4 + i];
-                    const long off = o >= 0 ? (long)o + ch * 16 : zero_off;
-                    tmp[i] = *reinterpret_cast<const f32x4v*>(a.in + off);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) patch[threadIdx.x + (g * 4 + i) * 256] = tmp[i];   // LDS is padded to ngroups*1024
-            }
+        for (int i = 0; i < NG * 4; ++i) {
+            const int o = goff[i];
+            const long off = o >= 0 ? (long)o + ch * 16 : zero_off;
+            stg[i] = *reinterpret_cast<const f32x4v*>(a.in + off);
         }
-        __syncthreads();
+    };
+    auto stage_store = [&](f32x4v* dst) {
+#pragma unroll
+        for (int i = 0; i < NG * 4; ++i) dst[threadIdx.x + i * 256] = stg[i];
+    };
+    stage_load(0);
+    stage_store(patch_base);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const f32x4v* patch = patch_base;
+        if (ch + 1 < nchunks) stage_load(ch + 1);
         // One "row" = the KW taps of one (kz, ky).  Rows are software-pipelined with two register sets:
         // the LDS reads and weight loads of row r+1 are issued before the 4*KW*MT*NT MFMAs of row r, and
         // every prefetch is unconditional so that hipcc emits counted waits.
@@ -470,6 +474,11 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
             mma_row(a1, b1);
         }
         if (r < nrows) mma_row(a0, b0);
+        if (ch + 1 < nchunks) {
+            __syncthreads();                  // everyone is done reading chunk ch
+            stage_store(patch_base);
+            __syncthreads();
+        }
     }
 
     // epilogue (swapped operands: this lane holds channels 4*lq..4*lq+3 of its own voxel, see above)
@@ -488,19 +497,27 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     }
 }
 
+template <int MT, int NT, int KW, int NG>
+int launch_lds_ng(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
+    const long blocks = (long)tiles_x * tiles_y * a.Do * a.B;
+    if (blocks >= (1L << 31) || (long)a.B * a.Di * a.Hi * a.Wi * a.cin >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    const size_t lds = (size_t)NG * 1024 * 16;
+    dim3 grid((unsigned)blocks, a.ntile_total / NT, 1);
+    hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW, NG>), grid, dim3(256), lds, s, a, tiles_x, tiles_y);
+    return mv_check_launch();
+}
+
 template <int MT, int NT, int KW>
 int launch_lds(const ConvArgs& a, hipStream_t s) {
     constexpr int TY = 2 * MT;
     const int PW = 31 * a.sw + KW, PH = (TY - 1) * a.sh + a.kh[0];
     const size_t nstage = (size_t)a.kd[0] * PH * PW * 4;
     if (nstage > (size_t)kMaxStage * 256) return MVSTER_ERR_SHAPE;
-    const size_t lds = ((nstage + 1023) / 1024) * 1024 * 16;   // padded: every thread stages 4 float4 per group
     const int tiles_x = (a.Wo + 31) / 32, tiles_y = (a.Ho + TY - 1) / TY;
-    const long blocks = (long)tiles_x * tiles_y * a.Do * a.B;
-    if (blocks >= (1L << 31) || (long)a.B * a.Di * a.Hi * a.Wi * a.cin >= (1L << 31)) return MVSTER_ERR_SHAPE;
-    dim3 grid((unsigned)blocks, a.ntile_total / NT, 1);
-    hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW>), grid, dim3(256), lds, s, a, tiles_x, tiles_y);
-    return mv_check_launch();
+    const int ng = (int)((nstage + 1023) / 1024);
+    if (ng == 1) return launch_lds_ng<MT, NT, KW, 1>(a, tiles_x, tiles_y, s);
+    if (ng == 2) return launch_lds_ng<MT, NT, KW, 2>(a, tiles_x, tiles_y, s);
+    return launch_lds_ng<MT, NT, KW, 3>(a, tiles_x, tiles_y, s);
 }
 
 int dispatch_lds(const ConvArgs& a, int MT, int NT, hipStream_t s) {

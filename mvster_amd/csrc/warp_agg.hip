@@ -475,12 +475,12 @@ extern "C" int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat,
     a.B = B; a.NV = NV; a.D = D; a.h = h; a.w = w; a.Hs = Hs; a.Ws = Ws;
     a.attn_temp = attn_temp; a.sqrt_c = sqrtf((float)C); a.fuse_d = attn_fuse_d;
     hipStream_t s = (hipStream_t)stream;
-    // wide maps: split each (pixel, d) over C/8 lanes (variant == 1 forces the one-thread form)
+    // C >= 16: split each (pixel, d) over C/8 lanes (variant == 1 forces the one-thread form)
     if (group_cor && D <= 8 && variant != 1) {
         if (C == 64 && G == 8) return launch_fwd_lanes<64, 8>(a, s);
         if (C == 32 && G == 8) return launch_fwd_lanes<32, 8>(a, s);
-        if (C == 16 && G == 4 && variant == 2) return launch_fwd_lanes<16, 4>(a, s);
-        if (C == 16 && G == 8 && variant == 2) return launch_fwd_lanes<16, 8>(a, s);
+        if (C == 16 && G == 4) return launch_fwd_lanes<16, 4>(a, s);    // 47 -> 33 us at 256x320 (measured)
+        if (C == 16 && G == 8) return launch_fwd_lanes<16, 8>(a, s);
     }
 #define MV_CASE(CC, GG, GR) \
     if (C == CC && G == GG && (group_cor != 0) == GR) return launch_fwd<CC, GG, GR>(a, s);

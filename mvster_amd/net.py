@@ -91,6 +91,7 @@ class MVS4net(nn.Module):
         # latency-bound launches that leave most of the chip idle)
         self.overlap_streams = True
         self._side_streams = {}
+        self.warp_variant = 0          # mvster_warp_agg_fwd variant (0 = per-shape default)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_plans())
 
     # ------------------------------------------------------------------ plan cache
@@ -186,7 +187,7 @@ class MVS4net(nn.Module):
             else:
                 hypo = self._hypotheses(s, depth_values, depth_interval, prev, h, w)
             cor = ops.warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, self.group_cor, self.attn_fuse_d,
-                                      float(self.attn_temp))
+                                      float(self.attn_temp), variant=self.warp_variant)
             plan = regs[s]
             want_logits = capture is not None
             if plan.fused_prob:
