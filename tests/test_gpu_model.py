@@ -193,3 +193,55 @@ def test_train_step_vs_golden(shipped_cfg, checkpoint, golden):
     for k in named:
         if named[k].grad is not None:
             assert torch.isfinite(named[k].grad).all(), k
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("reg3d_inverse_group", dict(reg_net="reg3d", group_cor=True, group_cor_dim=[8, 8, 4, 4], inverse_depth=True, mono=False)),
+    ("reg2d_linear_depth", dict(reg_net="reg2d", group_cor=True, group_cor_dim=[8, 8, 4, 4], inverse_depth=False, mono=True)),
+    ("reg2d_sqdiff_nofuse", dict(reg_net="reg2d", group_cor=False, inverse_depth=True, mono=False, attn_fuse_d=False,
+                                 attn_temp=1)),
+])
+def test_other_configurations_vs_oracle(name, kw):
+    """Options outside the shipped script (reg3d, linear-depth schedulers, squared-difference volume,
+    attn_fuse_d=False): the HIP eval path against the CPU oracle with the same weights, teacher-forced."""
+    from mvster_amd.synthetic import randomize_state
+    cfg = dict(arch_mode="fpn", num_stage=4, fpn_base_channel=8, reg_channel=8, stage_splits=[8, 8, 4, 4],
+               depth_interals_ratio=[0.5, 0.5, 0.5, 1], attn_temp=2, attn_fuse_d=True)
+    cfg.update(kw)
+    torch.manual_seed(3)
+    oracle = O.OracleMVS4net(**cfg)
+    sd = randomize_state(oracle.state_dict(), seed=11, prob_gain=20.0)
+    oracle.load_state_dict(sd, strict=True)
+    oracle.eval()
+    m = MVS4net(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV).eval()
+    H, W, N = 128, 192, 3
+    imgs, proj, dv = make_inputs(nviews=N, H=H, W=W, seed=6)
+    cap_o = {}
+    with torch.no_grad():
+        want = oracle(imgs, proj, dv, capture=cap_o)
+    teacher = {"stage%d" % s: want["stage%d" % s]["hypo_depth"].to(DEV) for s in range(1, 5)}
+    cap = {}
+    got = m._forward_eval(*to_dev(imgs, proj, dv), teacher=teacher, capture=cap)
+    worst_cor = worst_attn = 0.0
+    for s in range(1, 5):
+        st, wt = got["stage%d" % s], want["stage%d" % s]
+        wc = cap_o["stage%d" % s]["cor_feats"]
+        worst_cor = max(worst_cor, ((cap["stage%d" % s]["cor_feats"].cpu() - wc).abs().max() / wc.abs().max()).item())
+        worst_attn = max(worst_attn, (st["attn_weight"].cpu() - wt["attn_weight"]).abs().max().item())
+        top2 = wt["attn_weight"].topk(2, dim=1)[0]
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-3
+        assert (st["depth"].cpu() - wt["depth"])[clear].abs().mean() < 1e-4, (name, s)
+        assert set(st.keys()) == set(wt.keys()), (name, s)
+    note("cfg_" + name, cor_rel_max=worst_cor, attn_max=worst_attn)
+    assert worst_cor <= 2e-4 and worst_attn <= 1e-3
+    # the free-running cascade (own schedulers, incl. the linear-depth ones) stays finite and consistent
+    out = m(*to_dev(imgs, proj, dv))
+    for s in range(1, 5):
+        assert torch.isfinite(out["stage%d" % s]["depth"]).all()
+    if not cfg["inverse_depth"]:
+        s2 = out["stage2"]["hypo_depth"].cpu()
+        with torch.no_grad():
+            ref_h = O.schedule_range(out["stage1"]["depth"].cpu(), 8, 0.5 * (dv[:, -1] - dv[:, 0]) / dv.size(1), 32, 48)
+        assert (s2 - ref_h).abs().max() <= 5e-7 * ref_h.abs().max()
