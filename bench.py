@@ -62,7 +62,9 @@ class KernelTimer:
             e1.record()
             bytes_ = 4 * (x.numel() + out.numel() + layer.wpk.numel() + (skip.numel() if skip is not None else 0))
             if variant == 1:
-                kname = "conv_lds_kernel<%d, %d, %d>" % (mt, nt, layer.kernel[2])
+                kd, kh, kw = layer.kernel
+                nstage = kd * ((2 * mt - 1) * layer.stride[1] + kh) * (31 * layer.stride[2] + kw) * 4
+                kname = "conv_lds_kernel<%d, %d, %d, %d>" % (mt, nt, kw, -(-nstage // 1024))
             elif variant == 3:
                 kname = "conv_small_kernel<%d>" % layer.cin
             elif variant == 4:
@@ -80,7 +82,12 @@ class KernelTimer:
             e1.record()
             C = ref_cl.shape[-1]
             bytes_ = 4 * (ref_cl.numel() + src_cl.numel() + hypo.numel() + hypo.numel() * G)
-            timer.records.append(("warp_agg_fwd_kernel<%d,%d>" % (C, G), e0, e1, 0, bytes_))
+            D = hypo.shape[1]
+            if C >= 16 and C != G and D <= 8 and os.environ.get("MVSTER_WARP_VARIANT", "0") == "0":
+                kname = "warp_agg_fwd_lanes_kernel<%d, %d, 8>" % (C, G)
+            else:
+                kname = "warp_agg_fwd_kernel<%d, %d, %s, %d>" % (C, G, "true" if C != G else "false", 8 if D <= 8 else 16)
+            timer.records.append((kname, e0, e1, 0, bytes_))
             return out
 
         cp.ConvLayer.__call__ = conv_call
@@ -221,6 +228,18 @@ def main():
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                         "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": a["n"] // min(args.steps, 20),
                         "bytes_per_launch": a["bytes"] // a["n"]}
+        # HBM bytes per launch from the PMC passes (scripts/gpu_pmc.sh: separate FETCH_SIZE / WRITE_SIZE runs of
+        # this same command, FETCH_SIZE x2 on gfx950, KB -> bytes); PMC cannot be collected from inside the
+        # process, so the committed summary of the last pass is quoted and its provenance named
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if pmc.get("workload") == [args.height, args.width, args.views] and name in pmc["kernels"]:
+                roofline["traffic"] = int(pmc["kernels"][name])
+                roofline["traffic_unit"] = "bytes/launch"
+                roofline["traffic_source"] = pmc.get("source", "profiles/pmc_traffic.json")
+        except (OSError, ValueError, KeyError):
+            pass
         if args.kernel_table:
             tot = sum(v["ms"] for v in table.values())
             for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):

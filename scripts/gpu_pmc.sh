@@ -12,6 +12,6 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_
   echo "pmc $tag exit $?"
 done
 cd "$REPO"
-python scripts/pmc_summary.py gpurun_out/pmc gpurun_out/pmc/pmc_per_kernel.json > gpurun_out/pmc/summary.txt 2>&1
+python scripts/pmc_summary.py gpurun_out/pmc gpurun_out/pmc/pmc_per_kernel.json gpurun_out/pmc/pmc_traffic.json > gpurun_out/pmc/summary.txt 2>&1
 head -30 gpurun_out/pmc/summary.txt | cut -c1-250
 find gpurun_out/pmc -name "*.csv" -size +8M -delete

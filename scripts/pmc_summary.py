@@ -32,6 +32,16 @@ for k in agg:
 if len(sys.argv) > 2:
     with open(sys.argv[2], "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
+if len(sys.argv) > 3:
+    # compact per-kernel HBM traffic for bench.py's roofline.traffic (our kernels only)
+    mine = {k: round(m["hbm_bytes_per_launch"]) for k, m in out.items()
+            if "hbm_bytes_per_launch" in m and k.split("<")[0] in (
+                "conv_lds_kernel", "conv_mfma_kernel", "conv_small_kernel", "deconv_small_kernel",
+                "warp_agg_fwd_kernel", "warp_agg_fwd_lanes_kernel", "fpn_tail_gather_lds_kernel")}
+    with open(sys.argv[3], "w") as f:
+        json.dump({"workload": [512, 640, 5], "source": "scripts/gpu_pmc.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / "
+                   "WRITE_SIZE (separate passes) of bench.py --no-graph; (2*FETCH_SIZE + WRITE_SIZE) KB per launch",
+                   "kernels": mine}, f, indent=1, sort_keys=True)
 for k in sorted(out, key=lambda k: -out[k].get("GRBM_GUI_ACTIVE", 0) * out[k]["dispatches"])[:40]:
     m = out[k]
     print("%-44s n=%4d  hbm/launch %8.2f MB  mfma_busy %5.1f%%  valu/mfma %6.1f  lds_conflict %5.1f%%" % (
