@@ -83,7 +83,10 @@ class KernelTimer:
             C = ref_cl.shape[-1]
             bytes_ = 4 * (ref_cl.numel() + src_cl.numel() + hypo.numel() + hypo.numel() * G)
             D = hypo.shape[1]
-            if C >= 16 and C != G and D <= 8 and os.environ.get("MVSTER_WARP_VARIANT", "0") == "0":
+            variant = int(os.environ.get("MVSTER_WARP_VARIANT", "0"))
+            if variant in (0, 3) and C != G and D in (4, 8) and C <= 64:
+                kname = "warp_agg_fwd_wave_kernel<%d, %d, %d>" % (C, G, D)
+            elif variant != 1 and C >= 16 and C != G and D <= 8:
                 kname = "warp_agg_fwd_lanes_kernel<%d, %d, 8>" % (C, G)
             else:
                 kname = "warp_agg_fwd_kernel<%d, %d, %s, %d>" % (C, G, "true" if C != G else "false", 8 if D <= 8 else 16)

@@ -43,8 +43,9 @@ int mvster_pack_images(const float* const* imgs, int N, float* out, int B, int H
  *   ref_feat [B,h,w,C] (batch stride given), src_feat view v / batch b at
  *   src_feat + v*src_view_stride + b*src_batch_stride as [Hs,Ws,C];
  *   rt [B,NV,12]; hypo [B,D,h,w]; out [B,D,h,w,G]; wsum_out optional [B,D,h,w].
- * group_cor=0 requires G == C.  variant: 0 = choose (lane-split kernel for C >= 16), 1 = one thread per
- * (pixel, d).  Replaces models/mvs4net_utils.py:13-59 (homo_warping),
+ * group_cor=0 requires G == C.  variant: 0 = choose (the wave-local kernel whenever group_cor, D in {4, 8}
+ * and C in {8, 16, 32, 64}); 1 = one thread per (pixel, d); 2 = workgroup-level lane split (C >= 16);
+ * 3 = wave-local.  All forms return the same bits.  Replaces models/mvs4net_utils.py:13-59 (homo_warping),
  * :1037-1042 (correlation), :1048-1060 (attention aggregation). */
 int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat, const float* rt, const float* hypo,
                         float* out, float* wsum_out, int B, int NV, int C, int G, int D, int h, int w, int Hs,

@@ -42,6 +42,41 @@ MV_HD float div_rn(float a, float b) {
     return a / b;
 }
 
+// Division with a reusable reciprocal.  On the device this is the IEEE-754 fp32 division sequence
+// of the AMDGPU backend (v_rcp_f32, one Newton step on the reciprocal, quotient, two residual
+// corrections) WITHOUT its v_div_scale / v_div_fmas / v_div_fixup range handling: for normal,
+// non-zero divisors and quotients that neither overflow nor go subnormal it returns the same bits
+// as `a / b` (tests/test_gpu_kernels.py compares kernels built on both), costs 5 instructions per
+// quotient instead of 11, and the 3-instruction reciprocal is shared by every quotient with the
+// same divisor.  Callers guarantee the domain (depths, image sizes, softmax masses).  The host build
+// used by the tests is plain division.
+struct Recip {
+    float d;   // divisor
+    float r;   // refined reciprocal (device only)
+};
+
+MV_HD Recip make_recip(float d) {
+    Recip k;
+    k.d = d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    k.r = __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+#else
+    k.r = 0.0f;
+#endif
+    return k;
+}
+
+MV_HD float div_rn(float a, const Recip& k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float q = mul_rn(a, k.r);
+    q = __builtin_fmaf(__builtin_fmaf(-k.d, q, a), k.r, q);
+    return __builtin_fmaf(__builtin_fmaf(-k.d, q, a), k.r, q);
+#else
+    return div_rn(a, k.d);
+#endif
+}
+
 // 3x4 homography of one (batch, source view): p_src ~ R * (x, y, 1) * depth + t.
 struct RT {
     float r[9];
@@ -71,6 +106,40 @@ MV_HD void project(const RT& m, float x, float y, float depth, int Hs, int Ws, f
     if (pz == 0.0f) pz = 1e-9f;
     sx = grid_roundtrip(div_rn(px, pz), Ws);
     sy = grid_roundtrip(div_rn(py, pz), Hs);
+}
+
+// The same position with the per-launch constants of the round trip hoisted and shared reciprocals
+// (kernels; bit-identical to project() in the domain described at Recip).
+struct GridNorm {
+    Recip halfw, halfh;   // (Ws-1)/2, (Hs-1)/2
+    float wm1, hm1;       // Ws-1, Hs-1
+};
+
+MV_HD GridNorm make_grid_norm(int Hs, int Ws) {
+    GridNorm g;
+    g.halfw = make_recip((float)(Ws - 1) / 2.0f);
+    g.halfh = make_recip((float)(Hs - 1) / 2.0f);
+    g.wm1 = (float)(Ws - 1);
+    g.hm1 = (float)(Hs - 1);
+    return g;
+}
+
+MV_HD float grid_roundtrip(float pix, const Recip& half, float sizem1) {
+    float g = sub_rn(div_rn(pix, half), 1.0f);
+    return mul_rn(mul_rn(add_rn(g, 1.0f), 0.5f), sizem1);   // x / 2 == x * 0.5 exactly
+}
+
+MV_HD void project(const RT& m, float x, float y, float depth, const GridNorm& gn, float& sx, float& sy) {
+    float rx = add_rn(fmaf(m.r[1], y, mul_rn(m.r[0], x)), m.r[2]);
+    float ry = add_rn(fmaf(m.r[4], y, mul_rn(m.r[3], x)), m.r[5]);
+    float rz = add_rn(fmaf(m.r[7], y, mul_rn(m.r[6], x)), m.r[8]);
+    float px = add_rn(mul_rn(rx, depth), m.t[0]);
+    float py = add_rn(mul_rn(ry, depth), m.t[1]);
+    float pz = add_rn(mul_rn(rz, depth), m.t[2]);
+    if (pz == 0.0f) pz = 1e-9f;
+    const Recip z = make_recip(pz);
+    sx = grid_roundtrip(div_rn(px, z), gn.halfw, gn.wm1);
+    sy = grid_roundtrip(div_rn(py, z), gn.halfh, gn.hm1);
 }
 
 // Bilinear footprint: integer corner, the four weights, and which taps are in bounds
@@ -127,6 +196,24 @@ MV_HD TapsClamped clamp_taps(Taps& t, int Hs, int Ws) {
 MV_HD float blend(const Taps& t, float a, float b, float c, float d) {
     return add_rn(add_rn(add_rn(mul_rn(a, t.nw), mul_rn(b, t.ne)), mul_rn(c, t.sw)), mul_rn(d, t.se));
 }
+
+#if defined(__HIPCC__)
+// Two adjacent channels at a time (v_pk_mul_f32 / v_pk_add_f32 on gfx950): the same per-element
+// expression tree as blend(), on the register pairs a 16-byte load delivers.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 mul_rn2(f32x2 a, f32x2 b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ f32x2 add_rn2(f32x2 a, f32x2 b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ f32x2 blend2(float wnw, float wne, float wsw, float wse, f32x2 a, f32x2 b, f32x2 c, f32x2 d) {
+    const f32x2 nw = {wnw, wnw}, ne = {wne, wne}, sw = {wsw, wsw}, se = {wse, wse};
+    return add_rn2(add_rn2(add_rn2(mul_rn2(a, nw), mul_rn2(b, ne)), mul_rn2(c, sw)), mul_rn2(d, se));
+}
+#endif
 
 // 1-D linear upsampling coefficient, align_corners=True (ATen area_pixel_compute_source_index
 // + guard_index_and_lambda): src = dst * (in-1)/(out-1).

@@ -268,6 +268,153 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_fwd_lanes_kernel(WarpAggAr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Wave-local variant (the default whenever D and C/8 are powers of two with D*C/8 <= 64, i.e. all
+// four stages of the shipped cascade).  One wavefront owns PPW = 64/(D*C/8) pixels and ALL their
+// depth hypotheses: lane = (d*PPW + pixel)*LPP + sub.  The softmax over depth is an in-wave
+// all-gather (ds_bpermute), so there is no LDS, no barrier and no workgroup-level coupling: waves
+// run free and the only thing a wave ever waits for is its own gather (8 independent 16-byte loads
+// per lane and view; gathering two views per iteration was measured slower, it costs occupancy).
+// The kernel is VALU-bound, not HBM-bound (~200 instructions per (pixel, d, view) against 256 bytes
+// gathered), hence the shared-reciprocal divisions, the single expf per lane and the packed blend.
+// Arithmetic and summation order are those of the one-thread form: results are bit-identical to it.
+// ------------------------------------------------------------------------------------------
+template <int C, int G, int D>
+__global__ void __launch_bounds__(256) warp_agg_fwd_wave_kernel(WarpAggArgs a) {
+    constexpr int LPP = C / 8;           // lanes per (pixel, d)
+    constexpr int CG = C / G;            // channels per group
+    constexpr int GPL = 8 / CG;          // whole groups per lane
+    constexpr int PPW = 64 / (LPP * D);  // pixels per wave
+    static_assert(C % 8 == 0 && CG <= 8 && 8 % CG == 0 && PPW >= 1 && PPW * LPP * D == 64, "wave split");
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPP, pl = (lane / LPP) % PPW, d = lane / (LPP * PPW);
+    const int b = blockIdx.y;
+    const int hw = a.h * a.w;
+    const int p = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * PPW + pl;
+    const bool valid = p < hw;
+    const int pc = valid ? p : hw - 1;   // clamped: every lane takes part in the shuffles
+    const int y = pc / a.w;
+    const int x = pc - y * a.w;
+    const float depth = a.hypo[((long)b * D + d) * hw + pc];
+    const float* rp = a.ref + (long)b * a.ref_bs + (long)pc * C + sub * 8;
+    const f32x4 R0 = ld4(rp), R1 = ld4(rp + 4);
+    // per-launch divisors with their reciprocals (mvster_math.h: same bits as '/', 5 instead of 11 VALU ops)
+    const mv::GridNorm gn = mv::make_grid_norm(a.Hs, a.Ws);
+    const mv::Recip temp = mv::make_recip(a.attn_temp), sqrt_c = mv::make_recip(a.sqrt_c);
+
+    float acc[GPL];
+#pragma unroll
+    for (int k = 0; k < GPL; ++k) acc[k] = 0.0f;
+    float wsum = 1e-8f;
+
+    for (int v = 0; v < a.NV; ++v) {
+        mv::RT m;
+        const float* r = a.rt + ((long)b * a.NV + v) * 12;  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 9; ++i) m.r[i] = r[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) m.t[i] = r[9 + i];
+        float sx, sy;
+        mv::project(m, (float)x, (float)y, depth, gn, sx, sy);
+        mv::Taps t = mv::make_taps(sx, sy, a.Hs, a.Ws);
+        const mv::TapsClamped tc = mv::clamp_taps(t, a.Hs, a.Ws);
+        // wave-uniform base + 32-bit element offsets (the launcher checks Hs*Ws*C < 2^31)
+        const float* sp = a.src + (long)v * a.src_vs + (long)b * a.src_bs;
+        const unsigned ra = (unsigned)(tc.ya * a.Ws), rb = (unsigned)(tc.yb * a.Ws);
+        const float* p00 = sp + ((ra + (unsigned)tc.xa) * (unsigned)C + (unsigned)(sub * 8));
+        const float* p01 = sp + ((ra + (unsigned)tc.xb) * (unsigned)C + (unsigned)(sub * 8));
+        const float* p10 = sp + ((rb + (unsigned)tc.xa) * (unsigned)C + (unsigned)(sub * 8));
+        const float* p11 = sp + ((rb + (unsigned)tc.xb) * (unsigned)C + (unsigned)(sub * 8));
+        const f32x4 q0 = ld4(p00), q1 = ld4(p00 + 4), q2 = ld4(p01), q3 = ld4(p01 + 4);
+        const f32x4 q4 = ld4(p10), q5 = ld4(p10 + 4), q6 = ld4(p11), q7 = ld4(p11 + 4);
+        // keep the eight loads together and ahead of their uses: left alone, the scheduler sinks each
+        // load to its first use to save registers and the wave then eats eight memory latencies in a row
+        __builtin_amdgcn_sched_barrier(0);
+
+        // blend and correlate channel pairs (packed fp32 on the pairs the 16-byte loads deliver), then sum
+        // each group in channel order
+        float part[GPL];
+#define MV_PAIR(c, A, B, Cq, Dq, R, j)                                                                         \
+        {                                                                                                      \
+            const mv::f32x2 wv = mv::blend2(t.nw, t.ne, t.sw, t.se, (mv::f32x2){A[j], A[j + 1]},               \
+                                            (mv::f32x2){B[j], B[j + 1]}, (mv::f32x2){Cq[j], Cq[j + 1]},        \
+                                            (mv::f32x2){Dq[j], Dq[j + 1]});                                    \
+            const mv::f32x2 p2 = mv::mul_rn2(wv, (mv::f32x2){R[j], R[j + 1]});                                 \
+            part[(c) / CG] = ((c) % CG == 0) ? p2[0] : mv::add_rn(part[(c) / CG], p2[0]);                      \
+            part[((c) + 1) / CG] = (((c) + 1) % CG == 0) ? p2[1] : mv::add_rn(part[((c) + 1) / CG], p2[1]);    \
+        }
+        MV_PAIR(0, q0, q2, q4, q6, R0, 0)
+        MV_PAIR(2, q0, q2, q4, q6, R0, 2)
+        MV_PAIR(4, q1, q3, q5, q7, R1, 0)
+        MV_PAIR(6, q1, q3, q5, q7, R1, 2)
+#undef MV_PAIR
+        float cg[GPL];
+#pragma unroll
+        for (int k = 0; k < GPL; ++k) cg[k] = mv::div_rn(part[k], (float)CG);   // .mean(2)
+        // all-gather the G correlations of this (pixel, d) and sum them in group order: .sum(1)
+        float score = 0.0f;
+        const int lane0 = lane - sub;
+#pragma unroll
+        for (int j = 0; j < LPP; ++j)
+#pragma unroll
+            for (int k = 0; k < GPL; ++k) {
+                const float val = LPP == 1 ? cg[k] : __shfl(cg[k], lane0 + j);
+                score = (j == 0 && k == 0) ? val : mv::add_rn(score, val);
+            }
+        if (a.fuse_d) score = mv::div_rn(score, temp);
+        // softmax over depth: the D scores of this pixel live in lanes (j*PPW + pl)*LPP + sub.  Each lane
+        // exponentiates its own score once and the D terms are all-gathered and summed in depth order
+        // (the other launch forms evaluate the same D expf calls in every thread).
+        float mx = score;
+#pragma unroll
+        for (int j = 0; j < D; ++j) mx = fmaxf(mx, __shfl(score, (j * PPW + pl) * LPP + sub));
+        const float e = expf(mv::sub_rn(score, mx));
+        float den = 0.0f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) den = mv::add_rn(den, __shfl(e, (j * PPW + pl) * LPP + sub));
+        const mv::Recip rden = mv::make_recip(den);
+        float wgt;
+        if (a.fuse_d)
+            wgt = mv::div_rn(mv::div_rn(e, rden), sqrt_c);
+        else
+            wgt = mv::div_rn(1.0f, rden);  // max_d softmax = exp(0) / sum
+        wsum = mv::add_rn(wsum, wgt);
+#pragma unroll
+        for (int k = 0; k < GPL; ++k) acc[k] = mv::add_rn(acc[k], mv::mul_rn(wgt, cg[k]));
+    }
+
+    if (valid) {
+        const long o = (((long)b * D + d) * hw + p);
+        float* op = a.out + o * G + sub * GPL;
+        const mv::Recip rw = mv::make_recip(wsum);
+        if (GPL == 4) {
+            st4(op, (f32x4){mv::div_rn(acc[0], rw), mv::div_rn(acc[GPL > 1 ? 1 : 0], rw),
+                            mv::div_rn(acc[GPL > 2 ? 2 : 0], rw), mv::div_rn(acc[GPL > 3 ? 3 : 0], rw)});
+        } else {
+#pragma unroll
+            for (int k = 0; k < GPL; ++k) op[k] = mv::div_rn(acc[k], rw);
+        }
+        if (a.wsum_out && sub == 0) a.wsum_out[o] = wsum;
+    }
+}
+
+template <int C, int G, int D>
+int launch_fwd_wave(const WarpAggArgs& a, hipStream_t stream) {
+    constexpr int PPB = 4 * (64 / ((C / 8) * D));
+    if ((long)a.Hs * a.Ws * C >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    dim3 grid((a.h * a.w + PPB - 1) / PPB, a.B);
+    hipLaunchKernelGGL((warp_agg_fwd_wave_kernel<C, G, D>), grid, dim3(256), 0, stream, a);
+    return mv_check_launch();
+}
+
+template <int C, int G>
+int dispatch_fwd_wave(const WarpAggArgs& a, hipStream_t stream) {
+    if (a.D == 4) return launch_fwd_wave<C, G, 4>(a, stream);
+    if (a.D == 8) return launch_fwd_wave<C, G, 8>(a, stream);
+    return MVSTER_ERR_UNSUPPORTED;
+}
+
 template <int C, int G>
 int launch_fwd_lanes(const WarpAggArgs& a, hipStream_t stream) {
     constexpr int PPB = 64 / (C / 8);
@@ -475,7 +622,17 @@ extern "C" int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat,
     a.B = B; a.NV = NV; a.D = D; a.h = h; a.w = w; a.Hs = Hs; a.Ws = Ws;
     a.attn_temp = attn_temp; a.sqrt_c = sqrtf((float)C); a.fuse_d = attn_fuse_d;
     hipStream_t s = (hipStream_t)stream;
-    // C >= 16: split each (pixel, d) over C/8 lanes (variant == 1 forces the one-thread form)
+    // variant: 0 = choose; 1 = one thread per (pixel, d); 2 = workgroup-level lane split (C >= 16);
+    // 3 = wave-local kernel (what 0 picks whenever it applies)
+    if (group_cor && (D == 4 || D == 8) && (variant == 0 || variant == 3)) {
+        if (C == 8 && G == 4) return dispatch_fwd_wave<8, 4>(a, s);
+        if (C == 8 && G == 8) return dispatch_fwd_wave<8, 8>(a, s);
+        if (C == 16 && G == 4) return dispatch_fwd_wave<16, 4>(a, s);
+        if (C == 16 && G == 8) return dispatch_fwd_wave<16, 8>(a, s);
+        if (C == 32 && G == 8) return dispatch_fwd_wave<32, 8>(a, s);
+        if (C == 32 && G == 4) return dispatch_fwd_wave<32, 4>(a, s);
+        if (C == 64 && G == 8) return dispatch_fwd_wave<64, 8>(a, s);
+    }
     if (group_cor && D <= 8 && variant != 1) {
         if (C == 64 && G == 8) return launch_fwd_lanes<64, 8>(a, s);
         if (C == 32 && G == 8) return launch_fwd_lanes<32, 8>(a, s);

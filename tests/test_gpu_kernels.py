@@ -148,8 +148,8 @@ def test_warp_agg_forward(golden, name):
     out = ops.warp_agg_fwd_cl(f_cl[0], f_cl[1:], _oracle_rt(pm).to(DEV), hypo.to(DEV), Gk, gc, fuse, temp, variant=1)
     got = out.permute(0, 4, 1, 2, 3).cpu()
     tight = (got - want).abs().max().item()
-    # the lane-split kernel (C >= 16) is bit-identical to the one-thread-per-(pixel, d) form
-    for variant in (0, 2):
+    # the lane-split and wave-local kernels are bit-identical to the one-thread-per-(pixel, d) form
+    for variant in (0, 2, 3):
         o2 = ops.warp_agg_fwd_cl(f_cl[0], f_cl[1:], _oracle_rt(pm).to(DEV), hypo.to(DEV), Gk, gc, fuse, temp,
                                  variant=variant)
         assert torch.equal(o2, out), (name, variant)
@@ -164,6 +164,31 @@ def test_warp_agg_forward(golden, name):
     assert tight <= 2e-6 * max(scale, 1.0)
     assert loose <= 1e-4 * max(scale, 1.0)
     assert (got2 - want).abs().mean().item() <= 3e-6 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("C,G,D", [(64, 8, 8), (32, 8, 8), (16, 4, 4), (8, 4, 4), (8, 8, 8), (16, 8, 4), (32, 4, 8),
+                                   (64, 8, 4), (8, 4, 8)])
+@pytest.mark.parametrize("fuse", [True, False])
+def test_warp_agg_kernel_variants_bit_identical(C, G, D, fuse):
+    """Every launch form of the fused kernel (one thread per (pixel, d); workgroup-level lane split; wave-local
+    ; the default choice) returns the same bits, incl. ragged pixel counts,
+    out-of-image taps, odd view counts and the saved softmax mass."""
+    from mvster_amd.synthetic import make_inputs as mk
+    for (h, w, nv, B) in ((37, 53, 3, 2), (16, 24, 4, 1), (5, 7, 2, 1)):
+        g = torch.Generator().manual_seed(C * 131 + D * 7 + h)
+        _, proj, dv = mk(nviews=nv + 1, H=h * 8, W=w * 8, batch=B, seed=h, rotate=True)
+        pm = proj["stage1"]
+        ref = torch.randn(B, h, w, C, generator=g)
+        src = torch.randn(nv, B, h, w, C, generator=g)
+        hypo = dv[:, :1, None, None] + (dv[:, -1:, None, None] - dv[:, :1, None, None]) * torch.rand(B, D, h, w, generator=g)
+        rt = ops.relative_projection(pm.to(DEV))
+        args = (ref.to(DEV), src.to(DEV), rt, hypo.to(DEV), G, True, fuse, 2.0)
+        base, wbase = ops.warp_agg_fwd_cl(*args, want_wsum=True, variant=1)
+        assert torch.isfinite(base).all() and base.abs().max() > 0
+        for variant in (0, 2, 3):
+            o, ws = ops.warp_agg_fwd_cl(*args, want_wsum=True, variant=variant)
+            assert torch.equal(o, base), (C, G, D, h, w, variant)
+            assert torch.equal(ws, wbase), (C, G, D, h, w, variant)
 
 
 def test_warp_agg_source_size_differs_and_oob(golden):
