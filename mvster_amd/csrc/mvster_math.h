@@ -152,10 +152,10 @@ struct Taps {
 
 MV_HD Taps make_taps(float sx, float sy, int Hs, int Ws) {
     Taps t;
-    // clamp far-away / non-finite positions so that the int conversion is defined;
-    // anything beyond one pixel outside samples only zeros anyway
-    float cx = (sx > -4.0f) ? ((sx < (float)(Ws + 4)) ? sx : (float)(Ws + 4)) : -4.0f;   // NaN -> -4
-    float cy = (sy > -4.0f) ? ((sy < (float)(Hs + 4)) ? sy : (float)(Hs + 4)) : -4.0f;
+    // clamp far-away / non-finite positions so that the int conversion is defined; anything beyond
+    // one pixel outside samples only zeros anyway (fminf/fmaxf drop a NaN operand: NaN -> size + 4)
+    float cx = fmaxf(fminf(sx, (float)(Ws + 4)), -4.0f);
+    float cy = fmaxf(fminf(sy, (float)(Hs + 4)), -4.0f);
     float fx = floorf(cx), fy = floorf(cy);
     t.x0 = (int)fx;
     t.y0 = (int)fy;
@@ -165,10 +165,10 @@ MV_HD Taps make_taps(float sx, float sy, int Hs, int Ws) {
     t.ne = mul_rn(wy0, wx1);
     t.sw = mul_rn(wy1, wx0);
     t.se = mul_rn(wy1, wx1);
-    t.vx0 = (t.x0 >= 0) && (t.x0 < Ws);
-    t.vx1 = (t.x0 + 1 >= 0) && (t.x0 + 1 < Ws);
-    t.vy0 = (t.y0 >= 0) && (t.y0 < Hs);
-    t.vy1 = (t.y0 + 1 >= 0) && (t.y0 + 1 < Hs);
+    t.vx0 = (unsigned)t.x0 < (unsigned)Ws;
+    t.vx1 = (unsigned)(t.x0 + 1) < (unsigned)Ws;
+    t.vy0 = (unsigned)t.y0 < (unsigned)Hs;
+    t.vy1 = (unsigned)(t.y0 + 1) < (unsigned)Hs;
     return t;
 }
 
@@ -179,16 +179,21 @@ struct TapsClamped {
     int xa, xb, ya, yb;  // clamped west/east column, north/south row
 };
 
+MV_HD int clampi(int v, int hi) {   // clamp to [0, hi] (v_med3_i32)
+    v = v < hi ? v : hi;
+    return v > 0 ? v : 0;
+}
+
 MV_HD TapsClamped clamp_taps(Taps& t, int Hs, int Ws) {
     TapsClamped c;
     if (!(t.vy0 && t.vx0)) t.nw = 0.0f;
     if (!(t.vy0 && t.vx1)) t.ne = 0.0f;
     if (!(t.vy1 && t.vx0)) t.sw = 0.0f;
     if (!(t.vy1 && t.vx1)) t.se = 0.0f;
-    c.xa = t.x0 < 0 ? 0 : (t.x0 > Ws - 1 ? Ws - 1 : t.x0);
-    c.xb = t.x0 + 1 < 0 ? 0 : (t.x0 + 1 > Ws - 1 ? Ws - 1 : t.x0 + 1);
-    c.ya = t.y0 < 0 ? 0 : (t.y0 > Hs - 1 ? Hs - 1 : t.y0);
-    c.yb = t.y0 + 1 < 0 ? 0 : (t.y0 + 1 > Hs - 1 ? Hs - 1 : t.y0 + 1);
+    c.xa = clampi(t.x0, Ws - 1);
+    c.xb = clampi(t.x0 + 1, Ws - 1);
+    c.ya = clampi(t.y0, Hs - 1);
+    c.yb = clampi(t.y0 + 1, Hs - 1);
     return c;
 }
 
