@@ -126,6 +126,17 @@ int mvster_deconv_small(const float* in, const float* w, const float* scale, con
 int mvster_fpn_tail_gather(const float* G, const float* vb, float* P, float* workspace, int NB, int H, int W,
                            int CO, void* stream);
 
+/* Weight gradient of a channels-last convolution (training): for every kernel tap
+ *   dW[tap][co][ci] = sum_o gy[o][co] * x[o*s - p + tap][ci]      (zero padding)
+ * x [B,Di,Hi,Wi,CI], gy [B,Do,Ho,Wo,CO] with (Do,Ho,Wo) the conv output size for (k,s,p); CI, CO <= 64.
+ * Workgroup slot n of `partial` [nblk][kd*kh*kw][COP][CIP] (COP/CIP = CO/CI rounded up to 16, 48 -> 64)
+ * receives the sum over the output rows that workgroup visited; the caller adds the nblk slots.  With x and gy
+ * swapped it is the weight gradient of the transposed convolution.  Replaces autograd's conv weight gradients
+ * of nn.Conv3d / nn.Conv2d / nn.ConvTranspose3d (models/mvs4net_utils.py:116-123, :224-251, :870-965, :419-502). */
+int mvster_conv_wgrad(const float* x, const float* gy, float* partial, int nblk, int B, int Di, int Hi, int Wi, int CI,
+                      int Do, int Ho, int Wo, int CO, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph,
+                      int pw, void* stream);
+
 /* One v_mfma_f32_16x16x4_f32: A [16,4], B [4,16] -> D [16,16] (row major).  Test hook that pins the
  * fragment layout the convolution kernels assume. */
 int mvster_mfma_probe(const float* A, const float* B, float* D, void* stream);

@@ -31,6 +31,7 @@ SIGNATURES = {
     "mvster_conv_small": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f],
     "mvster_deconv_small": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f],
     "mvster_fpn_tail_gather": [_f, _f, _f, _f, _i, _i, _i, _i, _f],
+    "mvster_conv_wgrad": [_f, _f, _f] + [_i] * 19 + [_f],
     "mvster_mfma_probe": [_f, _f, _f, _f],
 }
 

@@ -126,44 +126,11 @@ class ConvLayer:
         self.relu = relu
         kd, kh, kw = w.shape[2:]
         self.kernel = (kd, kh, kw)
-        classes = []
-        packed = []
-        woff = []
-        off = 0
-        if not transposed:
-            wk = w.permute(2, 3, 4, 1, 0)  # [kd,kh,kw,cin,cout]
-            if self.cin != cin:
-                wk = torch.nn.functional.pad(wk, (0, 0, 0, self.cin - cin))
-            flat, nsteps = _pack_gemm(wk.reshape(kd * kh * kw * self.cin, cout))
-            classes.append(dict(kd=kd, kh=kh, kw=kw, pd=padding[0], ph=padding[1], pw=padding[2], od=0, oh=0, ow=0,
-                                nsteps=nsteps))
-            packed.append(flat)
-            woff.append(0)
-        else:
-            # stride-2 transposed conv (k=3, pad=1, output_padding=1) or stride 1 along a size-1 kernel axis:
-            # output parity p gets taps {(k=1, d=0)} (p=0) or {(k=2, d=0), (k=0, d=1)} (p=1); in = lattice + d
-            def axis_classes(k, s, p):
-                if s == 1:
-                    if k != 1 or p != 0:
-                        raise RuntimeError("conv_mfma: transposed stride-1 axis must have kernel 1")
-                    return [(0, [0])]
-                if (k, s, p) != (3, 2, 1):
-                    raise RuntimeError("conv_mfma: transposed conv must be k=3, s=2, p=1")
-                return [(0, [1]), (1, [2, 0])]
-            for pz, kzs in axis_classes(kd, stride[0], padding[0]):
-                for py, kys in axis_classes(kh, stride[1], padding[1]):
-                    for px, kxs in axis_classes(kw, stride[2], padding[2]):
-                        sub = w[:, :, kzs][:, :, :, kys][:, :, :, :, kxs]  # [cin,cout,|kz|,|ky|,|kx|]
-                        wk = sub.permute(2, 3, 4, 0, 1).reshape(-1, cout)
-                        flat, nsteps = _pack_gemm(wk)
-                        classes.append(dict(kd=len(kzs), kh=len(kys), kw=len(kxs), pd=0, ph=0, pw=0, od=pz, oh=py,
-                                            ow=px, nsteps=nsteps))
-                        packed.append(flat)
-                        woff.append(off)
-                        off += flat.numel()
-        self.classes = classes
-        self.wpk = torch.cat(packed).to(dev).contiguous()
-        self.woff = np.asarray(woff, dtype=np.int64)
+        self._cin_raw = cin
+        self.classes, self.woff = self._class_table()
+        self.wpk = None
+        self.w_small = self.w_deconv = None
+        self._pack(w)
         self.ntile_total = (cout + 15) // 16
         npad = self.ntile_total * 16
         scale, shift = fold_bn(bn, cout, dev)
@@ -175,11 +142,6 @@ class ConvLayer:
         self.shift[:cout] = shift
         self.zeros = torch.zeros(64, device=dev)
         self._geom_cache = {}
-        # HBM-bound finest up-sampling layers: VALU kernel (deconv_small), weights as [3,3,cin,cout]
-        self.w_deconv = None
-        if (transposed and self.kernel == (1, 3, 3) and self.stride == (1, 2, 2) and self.padding == (0, 1, 1)
-                and (self.cin, cout) in ((16, 8),)):      # (32, 16) measured slower than the MFMA classes
-            self.w_deconv = w[:, :, 0].permute(2, 3, 0, 1).contiguous().to(dev)     # [3,3,cin,cout]
         # optional fused 1x1x1 head: (weight [8], bias [1]) -> the layer outputs logits [B,D,H,W]
         self.prob = None
         if prob is not None:
@@ -187,14 +149,87 @@ class ConvLayer:
                 raise RuntimeError("conv_mfma: the fused prob head needs 8 channels")
             self.prob = (prob[0].detach().float().reshape(-1).contiguous().to(dev),
                          prob[1].detach().float().reshape(-1).contiguous().to(dev))
+    @staticmethod
+    def _axis_classes(k, s, p):
+        """Output-phase classes of one axis of a transposed conv: [(phase, [kernel taps in input-offset
+        order], padding)].  Output o = s*i + phase gets input i + d through tap k with o = s*i' - p + k,
+        i.e. d = (phase + p - k) / s; the class is an ordinary stride-1 conv over the input lattice with
+        those taps and padding -min(d).  (3, 2, 1) and (5, 2, 2) double the size (output_padding 1): the
+        reference's up-convolutions and the input gradients of its stride-2 3x3 / 5x5 convolutions."""
+        if s == 1:
+            if k != 1 or p != 0:
+                raise RuntimeError("conv_mfma: transposed stride-1 axis must have kernel 1")
+            return [(0, [0], 0)]
+        if (k, s, p) not in ((3, 2, 1), (5, 2, 2)):
+            raise RuntimeError("conv_mfma: transposed conv must be k=3, s=2, p=1 or k=5, s=2, p=2")
+        out = []
+        for phase in range(s):
+            taps = sorted(((phase + p - kk) // s, kk) for kk in range(k) if (phase + p - kk) % s == 0)
+            out.append((phase, [kk for _, kk in taps], -taps[0][0]))
+        return out
+
+    def _class_table(self):
+        """Weight-independent part of the plan: the GEOM_CLASS records and the packed-weight offsets."""
+        kd, kh, kw = self.kernel
+        if not self.transposed:
+            nsteps = (kd * kh * kw * self.cin + 15) // 16
+            return [dict(kd=kd, kh=kh, kw=kw, pd=self.padding[0], ph=self.padding[1], pw=self.padding[2], od=0, oh=0,
+                         ow=0, nsteps=nsteps, taps=None)], np.zeros(1, dtype=np.int64)
+        classes, woff, off = [], [], 0
+        npad = (self.cout + 15) // 16 * 16
+        for pz, kzs, qz in self._axis_classes(kd, self.stride[0], self.padding[0]):
+            for py, kys, qy in self._axis_classes(kh, self.stride[1], self.padding[1]):
+                for px, kxs, qx in self._axis_classes(kw, self.stride[2], self.padding[2]):
+                    nsteps = (len(kzs) * len(kys) * len(kxs) * self.cin + 15) // 16
+                    classes.append(dict(kd=len(kzs), kh=len(kys), kw=len(kxs), pd=qz, ph=qy, pw=qx, od=pz, oh=py,
+                                        ow=px, nsteps=nsteps, taps=(kzs, kys, kxs)))
+                    woff.append(off)
+                    off += nsteps * 16 * npad
+        return classes, np.asarray(woff, dtype=np.int64)
+
+    def _pack(self, w):
+        """(Re)build every device-side weight form from ``w`` (torch ops only, so it also runs on the device
+        once per optimizer step in training)."""
+        dev = w.device
+        kd, kh, kw = self.kernel
+        cin, cout = self._cin_raw, self.cout
+        packed = []
+        if not self.transposed:
+            wk = w.permute(2, 3, 4, 1, 0)  # [kd,kh,kw,cin,cout]
+            if self.cin != cin:
+                wk = torch.nn.functional.pad(wk, (0, 0, 0, self.cin - cin))
+            packed.append(_pack_gemm(wk.reshape(kd * kh * kw * self.cin, cout))[0])
+        else:
+            if self.cin != cin:
+                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, 0, 0, self.cin - cin))
+            for c in self.classes:
+                kzs, kys, kxs = c["taps"]
+                sub = w[:, :, kzs][:, :, :, kys][:, :, :, :, kxs]  # [cin,cout,|kz|,|ky|,|kx|]
+                packed.append(_pack_gemm(sub.permute(2, 3, 4, 0, 1).reshape(-1, cout))[0])
+        self.wpk = torch.cat(packed).contiguous()
+        # HBM-bound finest up-sampling layers: VALU kernel (deconv_small), weights as [3,3,cin,cout]
+        self.w_deconv = None
+        if (self.transposed and self.kernel == (1, 3, 3) and self.stride == (1, 2, 2) and self.padding == (0, 1, 1)
+                and (self.cin, cout) in ((16, 8),)):      # (32, 16) measured slower than the MFMA classes
+            self.w_deconv = w[:, :, 0].permute(2, 3, 0, 1).contiguous().to(dev)     # [3,3,cin,cout]
         # narrow full-resolution layers: VALU kernel (conv_small.hip), weights as [3,3,cin,8]
         self.w_small = None
-        if (not transposed and self.kernel == (1, 3, 3) and self.stride == (1, 1, 1) and self.padding == (0, 1, 1)
+        if (not self.transposed and self.kernel == (1, 3, 3) and self.stride == (1, 1, 1) and self.padding == (0, 1, 1)
                 and cout == 8 and self.cin in (4, 8)):
             ws = w[:, :, 0].permute(2, 3, 1, 0)                       # [3,3,cin,8]
             if self.cin != cin:
                 ws = torch.nn.functional.pad(ws, (0, 0, 0, self.cin - cin))
             self.w_small = ws.contiguous().to(dev)
+
+    def repack(self, weight, bias=None):
+        """Refresh the packed weights (and the bias folded into ``shift``) after a parameter update; geometry,
+        tile choices and launch records are kept."""
+        w = weight.detach().float()
+        if w.dim() == 4:
+            w = w.unsqueeze(2)
+        self._pack(w)
+        if bias is not None:
+            self.shift[:self.cout] = bias.detach().float() * self.scale[:self.cout]
 
     def out_shape(self, B, Di, Hi, Wi):
         kd, kh, kw = self.kernel

@@ -1,0 +1,153 @@
+// Weight gradient of the channels-last convolutions (training; autograd of the reference's
+// nn.Conv3d / nn.Conv2d / nn.ConvTranspose3d layers, models/mvs4net_utils.py:116-123, :224-251,
+// :870-965, :419-502).
+//
+//   dW[tap][co][ci] = sum over output voxels o of  gy[o][co] * x[o*s - p + tap][ci]
+//
+// is, per kernel tap, a [CO x P] x [P x CI] GEMM whose reduction dimension is the voxel count P
+// (up to 2.6 M here) while CO and CI are 4..64.  MIOpen's solvers for these shapes take 30-50 ms
+// per layer on gfx950; this kernel makes the voxels the K dimension of v_mfma_f32_16x16x4_f32:
+//   lane (r = lane & 15, k = lane >> 4) of a K-step of four consecutive output columns loads
+//   A = gy[x0 + k][co0 + r] and B = x[(x0 + k)*sw - pw + kx][ci0 + r], zero outside the image,
+// one workgroup = one tap x a set of output rows (one row per wave at a time, so the row/tap
+// bounds logic is wave-uniform and the inner loop only moves along x).  The four waves' partial
+// tiles are summed through LDS and written to a per-workgroup slot of `partial`
+// [nblk][taps][COT*16][CIT*16]; the host sums the slots (deterministic, no atomics).
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct WgradArgs {
+    const float* x;     // [B, Di, Hi, Wi, CI]
+    const float* gy;    // [B, Do, Ho, Wo, CO]
+    float* partial;     // [nblk, taps, COT*16, CIT*16]
+    int B, Di, Hi, Wi, CI;
+    int Do, Ho, Wo, CO;
+    int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+};
+
+template <int COT, int CIT>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [3 waves][COT*CIT][64 lanes][4]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, k = lane >> 4;
+    const int tap = blockIdx.y, ntaps = gridDim.y;
+    const int kx = tap % a.kw, ky = (tap / a.kw) % a.kh, kz = tap / (a.kw * a.kh);
+
+    f32x4v acc[COT][CIT];
+#pragma unroll
+    for (int i = 0; i < COT; ++i)
+#pragma unroll
+        for (int j = 0; j < CIT; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    // channel columns of this lane, clamped (lanes beyond the channel count contribute zeros)
+    int co[COT], ci[CIT];
+    bool vco[COT], vci[CIT];
+#pragma unroll
+    for (int i = 0; i < COT; ++i) { co[i] = min(i * 16 + r, a.CO - 1); vco[i] = i * 16 + r < a.CO; }
+#pragma unroll
+    for (int j = 0; j < CIT; ++j) { ci[j] = min(j * 16 + r, a.CI - 1); vci[j] = j * 16 + r < a.CI; }
+
+    const int nrows = a.B * a.Do * a.Ho;
+    for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {    // wave-uniform
+        const int yo = row % a.Ho, t = row / a.Ho;
+        const int zo = t % a.Do, b = t / a.Do;
+        const int iz = zo * a.sd - a.pd + kz, iy = yo * a.sh - a.ph + ky;
+        if ((unsigned)iz >= (unsigned)a.Di || (unsigned)iy >= (unsigned)a.Hi) continue;   // this tap sees padding
+        const float* grow = a.gy + (long)row * a.Wo * a.CO;
+        const float* xrow = a.x + ((((long)b * a.Di + iz) * a.Hi + iy) * a.Wi) * a.CI;
+        for (int x1 = 0; x1 < a.Wo; x1 += 16) {
+            // four K-steps per trip: all their loads are issued before the first MFMA needs one
+            float av[4][COT], bv[4][CIT];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int xo = x1 + u * 4 + k;
+                const int ix = xo * a.sw - a.pw + kx;
+                const bool vo = xo < a.Wo;
+                const bool vi = vo && (unsigned)ix < (unsigned)a.Wi;
+                const int xoc = min(xo, a.Wo - 1);
+                const int ixc = min(max(ix, 0), a.Wi - 1);
+#pragma unroll
+                for (int i = 0; i < COT; ++i) {
+                    const float v = grow[xoc * a.CO + co[i]];
+                    av[u][i] = (vo && vco[i]) ? v : 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < CIT; ++j) {
+                    const float v = xrow[ixc * a.CI + ci[j]];
+                    bv[u][j] = (vi && vci[j]) ? v : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < COT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CIT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // D fragment: lane holds rows 4*(lane>>4)+q (co), column lane&15 (ci).  Waves 1..3 hand their tiles to
+    // wave 0 through LDS; wave 0 adds them in wave order and writes the workgroup's slot.
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < COT; ++i)
+#pragma unroll
+            for (int j = 0; j < CIT; ++j)
+                *reinterpret_cast<f32x4v*>(&red[(((wave - 1) * COT * CIT + i * CIT + j) * 64 + lane) * 4]) = acc[i][j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* out = a.partial + ((long)blockIdx.x * ntaps + tap) * (COT * 16) * (CIT * 16);
+#pragma unroll
+        for (int i = 0; i < COT; ++i)
+#pragma unroll
+            for (int j = 0; j < CIT; ++j) {
+                f32x4v s = acc[i][j];
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+                    s += *reinterpret_cast<const f32x4v*>(&red[((w * COT * CIT + i * CIT + j) * 64 + lane) * 4]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    out[(i * 16 + 4 * k + q) * (CIT * 16) + j * 16 + r] = s[q];
+            }
+    }
+}
+
+template <int COT, int CIT>
+int launch_wgrad(const WgradArgs& a, int nblk, int ntaps, hipStream_t s) {
+    const size_t lds = (size_t)3 * COT * CIT * 256 * sizeof(float);
+    hipLaunchKernelGGL((conv_wgrad_kernel<COT, CIT>), dim3(nblk, ntaps), dim3(256), lds, s, a);
+    return mv_check_launch();
+}
+
+}  // namespace
+
+// x [B,Di,Hi,Wi,CI], gy [B,Do,Ho,Wo,CO] (channels-last, contiguous); partial [nblk][kd*kh*kw][COP][CIP] with
+// COP / CIP = CO / CI rounded up to 16 (<= 64).  Do/Ho/Wo must be the conv's output size for (k, s, p).
+extern "C" int mvster_conv_wgrad(const float* x, const float* gy, float* partial, int nblk, int B, int Di, int Hi, int Wi,
+                                 int CI, int Do, int Ho, int Wo, int CO, int kd, int kh, int kw, int sd, int sh, int sw,
+                                 int pd, int ph, int pw, void* stream) {
+    if (!x || !gy || !partial) return MVSTER_ERR_NULL;
+    if (B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || nblk <= 0 || kd <= 0 || kh <= 0 ||
+        kw <= 0 || sd <= 0 || sh <= 0 || sw <= 0 || pd < 0 || ph < 0 || pw < 0)
+        return MVSTER_ERR_SHAPE;
+    if (CI <= 0 || CI > 64 || CO <= 0 || CO > 64) return MVSTER_ERR_UNSUPPORTED;
+    if (Do != (Di + 2 * pd - kd) / sd + 1 || Ho != (Hi + 2 * ph - kh) / sh + 1 || Wo != (Wi + 2 * pw - kw) / sw + 1)
+        return MVSTER_ERR_SHAPE;
+    if ((long)Wo * CO >= (1L << 31) || (long)Wi * CI >= (1L << 31) || (long)kd * kh * kw > 65535) return MVSTER_ERR_SHAPE;
+    WgradArgs a;
+    a.x = x; a.gy = gy; a.partial = partial;
+    a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.CI = CI; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.CO = CO;
+    a.kd = kd; a.kh = kh; a.kw = kw; a.sd = sd; a.sh = sh; a.sw = sw; a.pd = pd; a.ph = ph; a.pw = pw;
+    const int cot = (CO + 15) / 16 == 3 ? 4 : (CO + 15) / 16, cit = (CI + 15) / 16 == 3 ? 4 : (CI + 15) / 16;
+    const int ntaps = kd * kh * kw;
+    hipStream_t s = (hipStream_t)stream;
+#define MV_W(A_, B_) if (cot == A_ && cit == B_) return launch_wgrad<A_, B_>(a, nblk, ntaps, s);
+    MV_W(1, 1) MV_W(1, 2) MV_W(1, 4) MV_W(2, 1) MV_W(2, 2) MV_W(2, 4) MV_W(4, 1) MV_W(4, 2) MV_W(4, 4)
+#undef MV_W
+    return MVSTER_ERR_UNSUPPORTED;
+}

@@ -15,6 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import train_ops as T
+
 
 class ConvBnReLU3D(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1):
@@ -25,11 +27,21 @@ class ConvBnReLU3D(nn.Module):
     def forward(self, x):
         return F.relu(self.bn(self.conv(x)), inplace=True)
 
+    def forward_cl(self, x):
+        """Channels-last [B,D,H,W,C] form on the gfx950 kernels (mvster_amd/train_ops.py)."""
+        c = self.conv
+        return torch.relu(T.batch_norm_cl(T.conv_cl(x, c.weight, None, c.stride, c.padding), self.bn))
+
 
 def _deconv_bn_relu(cin, cout, kernel, pad, out_pad, stride):
     return nn.Sequential(
         nn.ConvTranspose3d(cin, cout, kernel_size=kernel, padding=pad, output_padding=out_pad, stride=stride, bias=False),
         nn.BatchNorm3d(cout), nn.ReLU(inplace=True))
+
+
+def _deconv_bn_relu_cl(seq, x):
+    ct, bn = seq[0], seq[1]
+    return torch.relu(T.batch_norm_cl(T.conv_cl(x, ct.weight, None, ct.stride, ct.padding, transposed=True), bn))
 
 
 class reg2d(nn.Module):
@@ -62,6 +74,17 @@ class reg2d(nn.Module):
         x = c2 + self.conv9(x)
         x = c0 + self.conv11(x)
         return self.prob(x).squeeze(1)
+
+    def forward_cl(self, x):
+        """[B,D,h,w,G] -> logits [B,D,h,w]."""
+        c0 = self.conv0.forward_cl(x)
+        c2 = self.conv2.forward_cl(self.conv1.forward_cl(c0))
+        c4 = self.conv4.forward_cl(self.conv3.forward_cl(c2))
+        x = self.conv6.forward_cl(self.conv5.forward_cl(c4))
+        x = c4 + _deconv_bn_relu_cl(self.conv7, x)
+        x = c2 + _deconv_bn_relu_cl(self.conv9, x)
+        x = c0 + _deconv_bn_relu_cl(self.conv11, x)
+        return torch.matmul(x, self.prob.weight.reshape(-1)) + self.prob.bias      # 1x1x1 conv 8 -> 1
 
 
 class reg3d(nn.Module):
@@ -100,6 +123,23 @@ class reg3d(nn.Module):
         x = c0 + self.conv11(x)
         return self.prob(x).squeeze(1)
 
+    def forward_cl(self, x):
+        c0 = self.conv0.forward_cl(x)
+        c2 = self.conv2.forward_cl(self.conv1.forward_cl(c0))
+        if self.down_size == 3:
+            c4 = self.conv4.forward_cl(self.conv3.forward_cl(c2))
+            x = self.conv6.forward_cl(self.conv5.forward_cl(c4))
+            x = c4 + _deconv_bn_relu_cl(self.conv7, x)
+            x = c2 + _deconv_bn_relu_cl(self.conv9, x)
+        elif self.down_size == 2:
+            x = self.conv4.forward_cl(self.conv3.forward_cl(c2))
+            x = c2 + _deconv_bn_relu_cl(self.conv9, x)
+        else:
+            x = c2
+        x = c0 + _deconv_bn_relu_cl(self.conv11, x)
+        p = self.prob
+        return T.conv_cl(x, p.weight, None, p.stride, p.padding).squeeze(-1)
+
 
 class Conv2d(nn.Module):
     """conv (no bias) + BatchNorm2d + optional ReLU (reference Conv2d with gn=False)."""
@@ -113,6 +153,12 @@ class Conv2d(nn.Module):
     def forward(self, x):
         x = self.bn(self.conv(x))
         return F.relu(x, inplace=True) if self.relu else x
+
+    def forward_cl(self, x):
+        """[B,1,H,W,C] channels-last."""
+        c = self.conv
+        x = T.batch_norm_cl(T.conv_cl(x, c.weight, None, c.stride, c.padding), self.bn)
+        return torch.relu(x) if self.relu else x
 
 
 class FPN4(nn.Module):
@@ -153,6 +199,28 @@ class FPN4(nn.Module):
         out["stage4"] = self.out4(f)
         return out
 
+    def forward_cl(self, x):
+        """x [B,1,H,W,3] channels-last -> four channels-last maps [B,1,h,w,C]."""
+        def seq(layers, t):
+            for l in layers:
+                t = l.forward_cl(t)
+            return t
+
+        def plain(m, t):
+            return T.conv_cl(t, m.weight, m.bias, m.stride, m.padding)
+        c0 = seq(self.conv0, x)
+        c1 = seq(self.conv1, c0)
+        c2 = seq(self.conv2, c1)
+        c3 = seq(self.conv3, c2)
+        out = {"stage1": plain(self.out1, c3)}
+        f = T.upsample2x_cl(c3, "bilinear") + plain(self.inner1, c2)
+        out["stage2"] = plain(self.out2, f)
+        f = T.upsample2x_cl(f, "bilinear") + plain(self.inner2, c1)
+        out["stage3"] = plain(self.out3, f)
+        f = T.upsample2x_cl(f, "bilinear") + plain(self.inner3, c0)
+        out["stage4"] = plain(self.out4, f)
+        return out
+
 
 class mono_depth_decoder(nn.Module):
     """Training-only auxiliary monocular head."""
@@ -172,4 +240,15 @@ class mono_depth_decoder(nn.Module):
             lo = (1 / d_max)[:, None, None, None]
             hi = (1 / d_min)[:, None, None, None]
             outputs["stage%d" % (i + 1)]["mono_depth"] = (1 / (lo + (hi - lo) * disp)).squeeze(1)
+        return outputs
+
+    def forward_cl(self, outputs, feats_cl, d_min, d_max):
+        """Same head on the channels-last reference features ``feats_cl`` [stage] -> [B,1,h,w,C]."""
+        for i in range(1, 4):
+            coarse = T.upsample2x_cl(self.convblocks[i - 1].forward_cl(feats_cl[i - 1]), "nearest")
+            c = self.conv3x3[i - 1]
+            disp = torch.sigmoid(T.conv_cl(torch.cat([coarse, feats_cl[i]], -1), c.weight, c.bias, c.stride, c.padding))
+            lo = (1 / d_max)[:, None, None]
+            hi = (1 / d_min)[:, None, None]
+            outputs["stage%d" % (i + 1)]["mono_depth"] = 1 / (lo + (hi - lo) * disp[:, 0, :, :, 0])
         return outputs

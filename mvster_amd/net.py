@@ -12,9 +12,12 @@ Execution:
   upsampling.  No host synchronisation inside ``forward`` (the reference's ``.cpu().numpy()``
   at MVS4Net.py:61-62 is gone), so the whole forward can be captured in a HIP graph
   (``mvster_amd.graph.GraphedForward``).
-* train -- BatchNorm needs batch statistics, so the convolutions run through PyTorch-ROCm
-  autograd; the fused warp/aggregation kernel is wrapped in an ``autograd.Function`` with a
-  hand-written HIP backward.
+* train -- BatchNorm needs batch statistics and cannot be folded: the layers run conv -> BatchNorm
+  -> ReLU on channels-last tensors with all three convolution passes (forward, input gradient,
+  weight gradient) on the gfx950 kernels (``mvster_amd.train_ops``), and the fused
+  warp/aggregation kernel is an ``autograd.Function`` with a hand-written HIP backward.
+  ``native_train = False`` routes the convolutions through PyTorch-ROCm / MIOpen instead (the
+  on-GPU cross-check of the native path).
 There is no CPU path: CPU tensors raise.
 """
 import torch
@@ -46,6 +49,26 @@ class _WarpAgg(torch.autograd.Function):
         g_ref, g_src = ops.warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, g_cl, G, group_cor, attn_fuse_d,
                                            attn_temp)
         return g_ref.permute(0, 3, 1, 2), g_src.permute(0, 1, 4, 2, 3), None, None, None, None, None, None
+
+
+class _WarpAggCL(torch.autograd.Function):
+    """cor_feats [B,D,h,w,G] from channels-last features (ref [B,h,w,C], src [NV,B,Hs,Ws,C]); HIP forward + backward."""
+
+    @staticmethod
+    def forward(ctx, ref_cl, src_cl, rt, hypo, G, group_cor, attn_fuse_d, attn_temp):
+        ref_cl, src_cl = ref_cl.contiguous(), src_cl.contiguous()
+        out, wsum = ops.warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, group_cor, attn_fuse_d, attn_temp, want_wsum=True)
+        ctx.save_for_backward(ref_cl, src_cl, rt, hypo, out, wsum)
+        ctx.cfg = (G, group_cor, attn_fuse_d, attn_temp)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        ref_cl, src_cl, rt, hypo, out, wsum = ctx.saved_tensors
+        G, group_cor, attn_fuse_d, attn_temp = ctx.cfg
+        g_ref, g_src = ops.warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad.contiguous(), G, group_cor,
+                                           attn_fuse_d, attn_temp)
+        return g_ref, g_src, None, None, None, None, None, None
 
 
 class MVS4net(nn.Module):
@@ -92,6 +115,7 @@ class MVS4net(nn.Module):
         self.overlap_streams = True
         self._side_streams = {}
         self.warp_variant = 0          # mvster_warp_agg_fwd variant (0 = per-shape default)
+        self.native_train = True       # training convolutions on the gfx950 kernels (False: PyTorch-ROCm / MIOpen)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_plans())
 
     # ------------------------------------------------------------------ plan cache
@@ -213,7 +237,60 @@ class MVS4net(nn.Module):
         return outputs
 
     # ------------------------------------------------------------------ train: autograd
+    def _stage_outputs(self, s, logits, hypo, dev):
+        """Depth selection of one stage in training / differentiable form (models/mvs4net_utils.py:1068-1092)."""
+        attn = F.softmax(logits, dim=1)
+        idx = attn.max(1, keepdim=True)[1]
+        depth = torch.gather(hypo, 1, idx).squeeze(1)
+        if self.training:
+            conf = torch.tensor(0.0, dtype=torch.float32, device=dev, requires_grad=False)
+        else:
+            with torch.no_grad():
+                conf = ops.upsample_bilinear(attn.max(1)[0].contiguous(), 2 ** (3 - s))
+        st = {"depth": depth, "photometric_confidence": conf, "hypo_depth": hypo, "attn_weight": attn}
+        if self.inverse_depth:
+            itv = 1.0 / hypo[:, 2] - 1.0 / hypo[:, 1]
+            st["inverse_min_depth"] = 1 / depth + self.depth_interals_ratio[s] * itv
+            st["inverse_max_depth"] = 1 / depth - self.depth_interals_ratio[s] * itv
+        return st
+
     def _forward_train(self, imgs, proj_matrices, depth_values):
+        """Differentiable forward with every convolution pass (forward, input and weight gradients) and the
+        fused warp/correlation/aggregation on the gfx950 kernels; BatchNorm on batch statistics per view, like the
+        reference's per-view ``self.feature(img)`` calls (MVS4Net.py:65-68)."""
+        if not self.native_train:
+            return self._forward_train_miopen(imgs, proj_matrices, depth_values)
+        dev = imgs[0].device
+        depth_values = depth_values.to(dev, torch.float32)
+        depth_interval = (depth_values[:, -1] - depth_values[:, 0]) / depth_values.size(1)
+        pyramids = [self.feature.forward_cl(img.permute(0, 2, 3, 1).unsqueeze(1)) for img in imgs]
+        outputs = {}
+        prev = None
+        ref_feats = []
+        for s in range(self.num_stage):
+            name = "stage%d" % (s + 1)
+            feats = [p[name] for p in pyramids]                      # [B,1,h,w,C] each
+            B, _, h, w, C = feats[0].shape
+            G = self.group_cor_dim[s] if self.group_cor else C
+            with torch.no_grad():
+                rt = ops.relative_projection(proj_matrices[name].to(dev, torch.float32))
+                hypo = self._hypotheses(s, depth_values, depth_interval, prev, h, w)
+            cor = _WarpAggCL.apply(feats[0].reshape(B, h, w, C), torch.stack([f.reshape(B, h, w, C) for f in feats[1:]], 0),
+                                   rt, hypo, G, self.group_cor, self.attn_fuse_d, float(self.attn_temp))
+            st = self._stage_outputs(s, self.reg[s].forward_cl(cor), hypo, dev)
+            if self.mono:
+                st["mono_feat"] = feats[0].reshape(B, h, w, C).permute(0, 3, 1, 2)     # [B,C,h,w] view
+                ref_feats.append(feats[0])
+            prev = st
+            outputs[name] = st
+            outputs.update(st)
+        if self.mono and self.training:
+            outputs = self.mono_depth_decoder.forward_cl(outputs, ref_feats, depth_values[:, 0], depth_values[:, 1])
+        return outputs
+
+    def _forward_train_miopen(self, imgs, proj_matrices, depth_values):
+        """The same forward with the convolutions left to PyTorch-ROCm / MIOpen (``native_train = False``): kept
+        as the on-GPU cross-check of the native training path (tests/test_gpu_train.py) and for timing it."""
         dev = imgs[0].device
         depth_values = depth_values.to(dev, torch.float32)
         depth_interval = (depth_values[:, -1] - depth_values[:, 0]) / depth_values.size(1)
@@ -231,19 +308,7 @@ class MVS4net(nn.Module):
                 hypo = self._hypotheses(s, depth_values, depth_interval, prev, h, w)
             cor = _WarpAgg.apply(ref_fea, torch.stack(feats[1:], 0), rt, hypo, G, self.group_cor, self.attn_fuse_d,
                                  float(self.attn_temp))
-            attn = F.softmax(self.reg[s](cor.contiguous()), dim=1)
-            idx = attn.max(1, keepdim=True)[1]
-            depth = torch.gather(hypo, 1, idx).squeeze(1)
-            if self.training:
-                conf = torch.tensor(0.0, dtype=torch.float32, device=dev, requires_grad=False)
-            else:
-                with torch.no_grad():
-                    conf = ops.upsample_bilinear(attn.max(1)[0].contiguous(), 2 ** (3 - s))
-            st = {"depth": depth, "photometric_confidence": conf, "hypo_depth": hypo, "attn_weight": attn}
-            if self.inverse_depth:
-                itv = 1.0 / hypo[:, 2] - 1.0 / hypo[:, 1]
-                st["inverse_min_depth"] = 1 / depth + self.depth_interals_ratio[s] * itv
-                st["inverse_max_depth"] = 1 / depth - self.depth_interals_ratio[s] * itv
+            st = self._stage_outputs(s, self.reg[s](cor.contiguous()), hypo, dev)
             if self.mono:
                 st["mono_feat"] = ref_fea
             prev = st

@@ -219,3 +219,33 @@ def mfma_probe(A, Bm):
     D = torch.empty(16, 16, device=A.device, dtype=torch.float32)
     _lib.check(_lib.load().mvster_mfma_probe(_ptr(A), _ptr(Bm), _ptr(D), _stream()), "mfma_probe")
     return D
+
+
+def _wgrad_tiles(c):
+    t = (c + 15) // 16
+    return 4 if t == 3 else t
+
+
+def conv_wgrad(x_cl, gy_cl, kernel, stride, padding):
+    """Weight gradient of the channels-last convolution y = conv(x; W[CO,CI,kd,kh,kw], stride, padding):
+    x_cl [B,Di,Hi,Wi,CI], gy_cl [B,Do,Ho,Wo,CO] -> dW [CO,CI,kd,kh,kw].  With the roles of x and gy swapped it is
+    the gradient of a ConvTranspose weight [cin,cout,...].  Autograd of models/mvs4net_utils.py:116-123 etc."""
+    _chk(x_cl, "conv_wgrad:x")
+    _chk(gy_cl, "conv_wgrad:gy")
+    B, Di, Hi, Wi, CI = x_cl.shape
+    B2, Do, Ho, Wo, CO = gy_cl.shape
+    kd, kh, kw = kernel
+    if B2 != B:
+        raise RuntimeError("conv_wgrad: batch mismatch")
+    ntaps = kd * kh * kw
+    cop, cip = _wgrad_tiles(CO) * 16, _wgrad_tiles(CI) * 16
+    rows = B * Do * Ho
+    slot_bytes = ntaps * cop * cip * 4
+    nblk = max(1, min((rows + 3) // 4, (32 << 20) // slot_bytes, 1024))
+    partial = torch.empty(nblk, ntaps, cop, cip, device=x_cl.device, dtype=torch.float32)
+    rc = _lib.load().mvster_conv_wgrad(_ptr(x_cl), _ptr(gy_cl), _ptr(partial), nblk, B, Di, Hi, Wi, CI, Do, Ho, Wo, CO,
+                                       kd, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
+                                       _stream())
+    _lib.check(rc, "conv_wgrad")
+    dw = partial.sum(0)[:, :CO, :CI]                                     # [taps, CO, CI]
+    return dw.reshape(kd, kh, kw, CO, CI).permute(3, 4, 0, 1, 2).contiguous()

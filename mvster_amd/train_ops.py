@@ -1,0 +1,170 @@
+"""Differentiable channels-last building blocks of the training path, on the gfx950 kernels.
+
+Training mode cannot fold BatchNorm (it runs on batch statistics), so the training forward is
+conv -> BatchNorm(batch stats) -> ReLU layer by layer.  ``conv_cl`` is the convolution with all three
+passes native:
+  forward           mvster_conv_mfma / conv_small / deconv_small   (the inference kernels, scale 1, shift = bias)
+  input gradient    the same kernels run as the adjoint convolution: flipped + transposed weights for a
+                    stride-1 layer, the transposed (parity-class) form for a stride-2 layer, an ordinary
+                    strided conv for a ConvTranspose layer
+  weight gradient   mvster_conv_wgrad (voxels as the MFMA K dimension)
+This replaces autograd through MIOpen, whose solvers take 30-50 ms per layer for these narrow,
+spatially huge convolutions (profiles/r01_n_train_*).  BatchNorm statistics, ReLU and the skip
+additions are elementwise torch ops on the channels-last tensors.
+
+Reference: the layers of models/mvs4net_utils.py:116-123 (ConvBnReLU3D), :224-251 (Conv2d), :419-502 (FPN4),
+:833-868 (mono_depth_decoder), :870-965 (reg2d / reg3d) under torch.autograd.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .conv_plan import ConvLayer
+
+_ALLOWED_CIN = (4, 8, 16, 32, 64)
+
+
+def _cin_for(c):
+    for a in _ALLOWED_CIN:
+        if c <= a:
+            return a
+    raise RuntimeError("conv_cl: more than 64 input channels (%d)" % c)
+
+
+def _pad_last(x, c):
+    return x if x.shape[-1] == c else F.pad(x, (0, c - x.shape[-1]))
+
+
+def _triple(v, lead):
+    v = tuple(v) if isinstance(v, (tuple, list)) else (v,) * 3
+    return v if len(v) == 3 else (lead,) + v
+
+
+class _LayerCache:
+    """ConvLayer objects per (parameter, role): built once, re-packed when the parameter's version changes
+    (an optimizer step), so a training step costs a few small device ops per layer instead of a plan build."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, weight, role, build, pack_source):
+        key = (id(weight), role)
+        hit = self._d.get(key)
+        ver = weight._version
+        if hit is not None and hit[0] is weight and hit[2].wpk.device == weight.device:
+            if hit[1] != ver:
+                hit[2].repack(pack_source())
+                self._d[key] = (weight, ver, hit[2])
+            return hit[2]
+        layer = build()
+        self._d[key] = (weight, ver, layer)
+        return layer
+
+    def clear(self):
+        self._d.clear()
+
+
+CACHE = _LayerCache()
+
+
+class _ConvCL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, transposed):
+        w5 = weight if weight.dim() == 5 else weight.unsqueeze(2)
+        cin = w5.shape[0] if transposed else w5.shape[1]
+        if x.shape[-1] != cin:
+            raise RuntimeError("conv_cl: input has %d channels, weight expects %d" % (x.shape[-1], cin))
+        cin_p = _cin_for(cin)
+        xp = _pad_last(x, cin_p).contiguous()
+        layer = CACHE.get(weight, "fwd", lambda: ConvLayer(w5, transposed, stride, padding, cin_pad=cin_p),
+                          lambda: weight)
+        if bias is not None:
+            layer.shift[:layer.cout] = bias.detach()
+        y = layer(xp)
+        ctx.save_for_backward(xp, weight, bias)
+        ctx.cfg = (stride, padding, transposed, cin)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xp, weight, bias = ctx.saved_tensors
+        stride, padding, transposed, cin = ctx.cfg
+        w5 = weight if weight.dim() == 5 else weight.unsqueeze(2)
+        kernel = tuple(w5.shape[2:])
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            co = gy.shape[-1]
+            co_p = _cin_for(co)
+            gyp = _pad_last(gy, co_p).contiguous()
+            if transposed:
+                # y = convT(x; W[cin,cout]) : dx = conv(gy; W read as [out=cin, in=cout], same stride / padding)
+                layer = CACHE.get(weight, "dgrad", lambda: ConvLayer(w5, False, stride, padding, cin_pad=co_p),
+                                  lambda: weight)
+            elif stride == (1, 1, 1):
+                def flipped():
+                    return w5.detach().flip(2, 3, 4).transpose(0, 1).contiguous()
+                pad = tuple(k - 1 - p for k, p in zip(kernel, padding))
+                layer = CACHE.get(weight, "dgrad", lambda: ConvLayer(flipped(), False, stride, pad, cin_pad=co_p), flipped)
+            else:
+                # stride 2: the adjoint is the transposed conv with the same weights (parity classes)
+                layer = CACHE.get(weight, "dgrad", lambda: ConvLayer(w5, True, stride, padding, cin_pad=co_p),
+                                  lambda: weight)
+            gx = layer(gyp)
+            if tuple(gx.shape[:4]) != tuple(xp.shape[:4]):
+                raise RuntimeError("conv_cl: input gradient of a strided layer needs even input sizes (%s -> %s)"
+                                   % (tuple(xp.shape), tuple(gx.shape)))
+            gx = gx[..., :cin]
+        if ctx.needs_input_grad[1]:
+            if transposed:
+                gw = ops.conv_wgrad(gy, xp, kernel, stride, padding)[:cin]          # [cin, cout, k]
+            else:
+                gw = ops.conv_wgrad(xp, gy, kernel, stride, padding)[:, :cin]       # [cout, cin, k]
+            if weight.dim() == 4:
+                gw = gw.squeeze(2)
+        if bias is not None and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 1, 2, 3))
+        return gx, gw, gb, None, None, None
+
+
+def conv_cl(x, weight, bias=None, stride=1, padding=0, transposed=False):
+    """x [B,D,H,W,Cin] channels-last -> [B,Do,Ho,Wo,Cout]; weight in nn.Conv3d / nn.Conv2d / nn.ConvTranspose3d
+    layout (a 4-D weight is a depth-1 convolution)."""
+    lead_s, lead_p = 1, 0
+    return _ConvCL.apply(x, weight, bias, _triple(stride, lead_s), _triple(padding, lead_p), transposed)
+
+
+def batch_norm_cl(x, bn):
+    """nn.BatchNorm2d / 3d on a channels-last tensor: batch statistics + running-stat update in training,
+    running statistics in eval (torch semantics: biased variance to normalise, unbiased in the running average)."""
+    C = x.shape[-1]
+    if bn.training or not bn.track_running_stats:
+        x2 = x.reshape(-1, C)
+        var, mean = torch.var_mean(x2, dim=0, unbiased=False)
+        if bn.track_running_stats:
+            with torch.no_grad():
+                n = x2.shape[0]
+                bn.num_batches_tracked += 1
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
+    else:
+        mean, var = bn.running_mean, bn.running_var
+    scale = torch.rsqrt(var + bn.eps)
+    if bn.affine:
+        scale = scale * bn.weight
+        shift = bn.bias - mean * scale
+    else:
+        shift = -mean * scale
+    return x * scale + shift
+
+
+def upsample2x_cl(x, mode):
+    """F.interpolate(scale_factor=2) of a [B,1,H,W,C] channels-last map (bilinear: align_corners=True)."""
+    B, D, H, W, C = x.shape
+    v = x.reshape(B * D, H, W, C).permute(0, 3, 1, 2)            # NCHW view with channels-last strides
+    if mode == "bilinear":
+        v = F.interpolate(v, scale_factor=2, mode="bilinear", align_corners=True)
+    else:
+        v = F.interpolate(v, scale_factor=2, mode=mode)
+    return v.permute(0, 2, 3, 1).contiguous().reshape(B, D, 2 * H, 2 * W, C)

@@ -127,3 +127,28 @@ def test_tile_heuristic_and_flops():
     assert plan.flops(1, 4, 64, 64) == 14416 * 4 * 64 * 64
     m8 = M.reg2d(input_channel=8, base_channel=8).eval()
     assert cp.Reg2dPlan(m8).flops(1, 8, 64, 64) == 14992 * 8 * 64 * 64
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p", [(16, 8, (1, 5, 5), (1, 2, 2), (0, 2, 2)), (32, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+                                            (16, 4, 3, 2, 1)])
+def test_transposed_layer_is_the_input_gradient_of_a_strided_conv(cin, cout, k, s, p):
+    """The transposed classes (3,2,1) and (5,2,2) with output_padding 1 are what the training path uses for the
+    input gradient of the stride-2 convolutions (reg2d/reg3d 3x3, FPN 5x5): check against autograd."""
+    torch.manual_seed(cin * 7 + cout)
+    conv = torch.nn.Conv3d(cout, cin, k, stride=s, padding=p, bias=False)     # forward conv: cout -> cin channels
+    x = torch.randn(2, cout, 2 if s in (1, 2) and k == 3 else 1, 8, 12, requires_grad=True)
+    if k == 3:
+        x = torch.randn(2, cout, 4, 8, 12, requires_grad=True)
+    y = conv(x)
+    gy = torch.randn_like(y)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    layer = cp.ConvLayer(conv.weight, True, conv.stride, conv.padding)      # weight [cin_T = conv.out, cout_T = conv.in]
+    got = run_layer(layer, cl(gy))
+    assert got.shape == cl(gx).shape
+    assert (got - cl(gx)).abs().max() <= 2e-5 * gx.abs().max()
+    # repack after an in-place parameter update = a freshly built layer
+    with torch.no_grad():
+        conv.weight.mul_(0.5).add_(0.1)
+    layer.repack(conv.weight)
+    fresh = cp.ConvLayer(conv.weight, True, conv.stride, conv.padding)
+    assert torch.equal(layer.wpk, fresh.wpk)

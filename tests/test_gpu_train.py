@@ -1,0 +1,272 @@
+"""Training path on the GPU: the native convolution passes (forward / input gradient / weight gradient kernels)
+against PyTorch autograd, and a whole training step against the same step with the convolutions left to
+PyTorch-ROCm.  The fp64 CPU autograd of the same layer is the reference for the per-layer checks."""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from mvster_amd import MVS4net, MVS4net_loss, ops
+    from mvster_amd import train_ops as T
+    from mvster_amd.synthetic import make_inputs
+DEV = torch.device("cuda:0") if torch.cuda.is_available() else None
+REPORT = {}
+
+
+def note(name, **kv):
+    REPORT[name] = kv
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_train.json", "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def cl(x):      # NCDHW -> NDHWC
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+CASES = [
+    # name, cin, cout, kernel, stride, padding, transposed, bias, (B, D, H, W)
+    ("c3d_16_16", 16, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, False, (2, 4, 10, 24)),
+    ("c2d_4_8", 4, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), False, False, (2, 4, 18, 20)),
+    ("c2d_s2_8_16", 8, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1), False, False, (2, 4, 12, 28)),
+    ("c3d_s2_16_32", 16, 32, (3, 3, 3), (2, 2, 2), (1, 1, 1), False, False, (1, 4, 8, 12)),
+    ("c5x5_s2_8_16", 8, 16, (1, 5, 5), (1, 2, 2), (0, 2, 2), False, False, (2, 1, 16, 36)),
+    ("rgb_3_8", 3, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), False, False, (2, 1, 14, 22)),
+    ("c1x1_bias_32_64", 32, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, True, (2, 1, 9, 13)),
+    ("c3x3_64_8", 64, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), False, False, (1, 1, 12, 20)),
+    ("head_16_1_bias", 16, 1, (1, 3, 3), (1, 1, 1), (0, 1, 1), False, True, (2, 1, 10, 14)),
+    ("prob3d_8_1", 8, 1, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, False, (1, 4, 8, 12)),
+    ("t2d_64_32", 64, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), True, False, (2, 4, 5, 7)),
+    ("t2d_16_8", 16, 8, (1, 3, 3), (1, 2, 2), (0, 1, 1), True, False, (1, 4, 9, 33)),
+    ("t3d_16_8", 16, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1), True, False, (1, 2, 5, 6)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_cl_forward_and_gradients(case):
+    name, cin, cout, k, s, p, transposed, has_bias, (B, D, H, W) = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    wshape = (cin, cout) + k if transposed else (cout, cin) + k
+    w = (torch.randn(wshape, generator=g) / (cin * k[0] * k[1] * k[2]) ** 0.5)
+    b = torch.randn(cout, generator=g) if has_bias else None
+    x = torch.randn(B, cin, D, H, W, generator=g)
+    # fp64 reference on the CPU
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    bd = b.double().requires_grad_(True) if has_bias else None
+    if transposed:
+        yd = F.conv_transpose3d(xd, wd, bd, stride=s, padding=p, output_padding=tuple(si - 1 for si in s))
+    else:
+        yd = F.conv3d(xd, wd, bd, stride=s, padding=p)
+    gy = torch.randn(yd.shape, generator=g)
+    yd.backward(gy.double())
+    # native
+    xg = cl(x).to(DEV).requires_grad_(True)
+    wg = w.to(DEV).requires_grad_(True)
+    bg = b.to(DEV).requires_grad_(True) if has_bias else None
+    y = T.conv_cl(xg, wg, bg, s, p, transposed)
+    y.backward(cl(gy).to(DEV))
+    torch.cuda.synchronize()
+
+    def rel(a, ref):
+        return ((a.cpu().double() - ref).abs().max() / (ref.abs().max() + 1e-30)).item()
+    e_y, e_x, e_w = rel(y.detach(), cl(yd.detach())), rel(xg.grad, cl(xd.grad)), rel(wg.grad, wd.grad)
+    e_b = rel(bg.grad, bd.grad) if has_bias else 0.0
+    note("conv_cl_" + name, fwd=e_y, dx=e_x, dw=e_w, db=e_b)
+    assert tuple(y.shape) == tuple(cl(yd).shape)
+    assert e_y <= 1e-5 and e_x <= 1e-5 and e_w <= 2e-5 and e_b <= 1e-5, (e_y, e_x, e_w, e_b)
+    # a parameter update is picked up by the cached layers
+    with torch.no_grad():
+        wg.mul_(0.5)
+    y2 = T.conv_cl(xg.detach(), wg, bg, s, p, transposed)
+    want2 = cl(yd.detach()) * 0.5 if not has_bias else None
+    if want2 is not None:
+        assert rel(y2.detach(), want2) <= 1e-5
+
+
+def test_conv_wgrad_many_rows_is_deterministic():
+    """More output rows than workgroups (the row loop wraps) and a slot count > 1: same bits twice, right sum."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 96, 40, 8, generator=g).to(DEV)
+    gy = torch.randn(2, 4, 96, 40, 8, generator=g).to(DEV)
+    a = ops.conv_wgrad(x, gy, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    b = ops.conv_wgrad(x, gy, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    assert torch.equal(a, b)
+    xd = x.cpu().double().permute(0, 4, 1, 2, 3).requires_grad_(False)
+    wd = torch.zeros(8, 8, 1, 3, 3, dtype=torch.float64, requires_grad=True)
+    yd = F.conv3d(xd, wd, None, padding=(0, 1, 1))
+    yd.backward(gy.cpu().double().permute(0, 4, 1, 2, 3))
+    assert ((a.cpu().double() - wd.grad).abs().max() / wd.grad.abs().max()).item() <= 2e-5
+
+
+def test_batch_norm_cl_matches_torch():
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, 6, 10, 16, generator=g)
+    bn_a, bn_b = torch.nn.BatchNorm3d(16), torch.nn.BatchNorm3d(16)
+    with torch.no_grad():
+        bn_a.weight.uniform_(0.5, 1.5, generator=g)
+        bn_a.bias.uniform_(-0.5, 0.5, generator=g)
+    bn_b.load_state_dict(bn_a.state_dict())
+    xa = x.permute(0, 4, 1, 2, 3).contiguous().requires_grad_(True)
+    ya = bn_a(xa)
+    gy = torch.randn(ya.shape, generator=g)
+    ya.backward(gy)
+    bn_b.to(DEV)
+    xb = x.to(DEV).requires_grad_(True)
+    yb = T.batch_norm_cl(xb, bn_b)
+    yb.backward(gy.permute(0, 2, 3, 4, 1).contiguous().to(DEV))
+    assert (yb.detach().cpu() - ya.detach().permute(0, 2, 3, 4, 1)).abs().max() <= 1e-5
+    assert (xb.grad.cpu() - xa.grad.permute(0, 2, 3, 4, 1)).abs().max() <= 1e-5
+    assert (bn_b.weight.grad.cpu() - bn_a.weight.grad).abs().max() <= 1e-4
+    assert (bn_b.running_mean.cpu() - bn_a.running_mean).abs().max() <= 1e-6
+    assert (bn_b.running_var.cpu() - bn_a.running_var).abs().max() <= 1e-6
+    assert int(bn_b.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("reg_net", ["reg2d", "reg3d"])
+def test_train_step_native_vs_pytorch_rocm(reg_net):
+    """One training step (forward, OT loss, backward) with the native convolution passes against the same step with
+    the convolutions run by PyTorch-ROCm: loss, every parameter gradient and the BatchNorm running statistics."""
+    from mvster_amd.synthetic import randomize_state
+    cfg = dict(arch_mode="fpn", reg_net=reg_net, num_stage=4, fpn_base_channel=8, reg_channel=8, stage_splits=[8, 8, 4, 4],
+               depth_interals_ratio=[0.5, 0.5, 0.5, 1], group_cor=True, group_cor_dim=[8, 8, 4, 4], inverse_depth=True,
+               mono=True, attn_temp=2, attn_fuse_d=True)
+    torch.manual_seed(1)
+    ref = MVS4net(**cfg)
+    sd = randomize_state(ref.state_dict(), seed=4, prob_gain=4.0)
+    ref.load_state_dict(sd)
+    nat = MVS4net(**cfg)
+    nat.load_state_dict(sd)
+    ref.to(DEV).train()
+    nat.to(DEV).train()
+    ref.native_train = False
+    H, W, N, B = 128, 192, 3, 2
+    imgs, proj, dv = make_inputs(nviews=N, H=H, W=W, seed=8, batch=B)
+    imgs = [i.to(DEV) for i in imgs]
+    proj = {k: v.to(DEV) for k, v in proj.items()}
+    dv = dv.to(DEV)
+    g = torch.Generator().manual_seed(0)
+    gt, mask = {}, {}
+    for s in range(1, 5):
+        hs, ws = H // 2 ** (4 - s), W // 2 ** (4 - s)
+        gt["stage%d" % s] = (500 + 300 * torch.rand(B, hs, ws, generator=g)).to(DEV)
+        mask["stage%d" % s] = (torch.rand(B, hs, ws, generator=g) > 0.2).float().to(DEV)
+
+    def step(m):
+        m.zero_grad(set_to_none=True)
+        out = m(imgs, proj, dv)
+        loss = MVS4net_loss(out, gt, mask, stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10,
+                            ot_eps=1, ot_continous=False, mono=True)[0]
+        loss.backward()
+        return out, loss.item(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    bufs0 = {k: v.detach().clone() for k, v in ref.named_buffers()}
+    o_ref, l_ref, g_ref = step(ref)
+    bufs_ref = {k: v.detach().clone() for k, v in ref.named_buffers()}
+    # Yardstick: the same step on the PyTorch-ROCm path with the images perturbed by 1e-6 relative.  The step is
+    # ill-conditioned (winner-take-all depths feed the next stage's hypotheses, the OT loss takes logs of small
+    # probabilities): that perturbation moves gradients by percents, while the per-module checks below agree to 1e-6.
+    for k, v in ref.named_buffers():
+        v.copy_(bufs0[k])
+    gp = torch.Generator().manual_seed(11)
+    clean = imgs
+    imgs = [i * (1 + 1e-6 * torch.randn(i.shape, generator=gp).to(DEV)) for i in clean]
+    _, _, g_ref2 = step(ref)
+    imgs = clean
+    o_nat, l_nat, g_nat = step(nat)
+    torch.cuda.synchronize()
+    a1 = (o_ref["stage1"]["attn_weight"] - o_nat["stage1"]["attn_weight"]).abs().max().item()
+    assert set(o_ref.keys()) == set(o_nat.keys())
+    for k in ("mono_feat", "mono_depth", "depth"):
+        assert tuple(o_ref["stage4"][k].shape) == tuple(o_nat["stage4"][k].shape), k
+    md = (o_ref["stage3"]["mono_depth"] - o_nat["stage3"]["mono_depth"]).abs().max().item()
+    assert md <= 1e-3 * o_ref["stage3"]["mono_depth"].abs().max().item()
+    assert set(g_ref) == set(g_nat)
+    gmax = max(v.norm().item() for v in g_ref.values())
+    worst, worst_name, noise = 0.0, "", 0.0
+    for k, r in g_ref.items():
+        if r.norm().item() < 1e-4 * gmax:
+            continue        # e.g. a bias in front of BatchNorm / softmax: the true gradient is zero, the rest is rounding
+        e = ((g_nat[k] - r).norm() / r.norm()).item()
+        noise = max(noise, ((g_ref2[k] - r).norm() / r.norm()).item())
+        if e > worst:
+            worst, worst_name = e, k
+    bnn = dict(nat.named_buffers())
+    bworst = max(((bufs_ref[k].float() - bnn[k].float()).abs().max() / (bufs_ref[k].float().abs().max() + 1e-6)).item()
+                 for k in bufs_ref)
+    note("train_step_native_" + reg_net, loss_ref=l_ref, loss_native=l_nat, stage1_attn_max=a1, worst_grad_rel_l2=worst,
+         worst_grad=worst_name, pytorch_path_1e6_perturbation_rel_l2=noise, worst_buffer_rel=bworst)
+    assert a1 <= 1e-4
+    # later stages may pick another hypothesis on a near-tie (argmax), which moves the loss a little
+    assert abs(l_ref - l_nat) <= 2e-2 * abs(l_ref)
+    assert bworst <= 1e-3
+    assert worst <= max(2e-2, 2 * noise), (worst_name, worst, noise)
+    for k, v in g_nat.items():
+        assert torch.isfinite(v).all(), k
+
+
+def _grad_report(mod_a, mod_b):
+    pa, pb = dict(mod_a.named_parameters()), dict(mod_b.named_parameters())
+    gmax = max(p.grad.norm().item() for p in pa.values() if p.grad is not None)
+    worst, name = 0.0, ""
+    for k in pa:
+        assert (pa[k].grad is None) == (pb[k].grad is None), k
+        if pa[k].grad is None or pa[k].grad.norm().item() < 1e-4 * gmax:
+            continue
+        e = ((pa[k].grad - pb[k].grad).norm() / pa[k].grad.norm()).item()
+        if e > worst:
+            worst, name = e, k
+    return worst, name
+
+
+def test_fpn_module_gradients_native_vs_pytorch_rocm():
+    """FPN4 in train mode (batch-stat BatchNorm, bilinear top-down path): outputs, input-independent parameter
+    gradients for a random output gradient -- smooth function, so the two paths must agree to rounding."""
+    from mvster_amd.modules import FPN4
+    torch.manual_seed(3)
+    a = FPN4(8).to(DEV).train()
+    b = FPN4(8).to(DEV).train()
+    b.load_state_dict(a.state_dict())
+    x = torch.rand(2, 3, 64, 96, device=DEV)
+    oa = a(x)
+    ob = b.forward_cl(x.permute(0, 2, 3, 1).unsqueeze(1))
+    g = torch.Generator().manual_seed(1)
+    la = lb = 0.0
+    for k in oa:
+        gy = torch.randn(oa[k].shape, generator=g).to(DEV)
+        fwd = ((ob[k][:, 0].permute(0, 3, 1, 2) - oa[k]).abs().max() / oa[k].abs().max()).item()
+        assert fwd <= 2e-5, (k, fwd)
+        la = la + (oa[k] * gy).sum()
+        lb = lb + (ob[k][:, 0].permute(0, 3, 1, 2) * gy).sum()
+    la.backward()
+    lb.backward()
+    worst, name = _grad_report(a, b)
+    note("fpn_module_grads", worst_rel_l2=worst, worst=name)
+    assert worst <= 2e-4, (name, worst)
+
+
+@pytest.mark.parametrize("kind", ["reg2d_g8", "reg2d_g4", "reg3d_ds3", "reg3d_ds2"])
+def test_reg_module_gradients_native_vs_pytorch_rocm(kind):
+    from mvster_amd.modules import reg2d, reg3d
+    torch.manual_seed(5)
+    G = 4 if kind == "reg2d_g4" else 8
+    mk = (lambda: reg2d(input_channel=G, base_channel=8)) if kind.startswith("reg2d") else \
+        (lambda: reg3d(in_channels=G, base_channels=8, down_size=int(kind[-1])))
+    a, b = mk().to(DEV).train(), mk().to(DEV).train()
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(2, G, 8, 32, 48, device=DEV)
+    xa = x.clone().requires_grad_(True)
+    xb = x.permute(0, 2, 3, 4, 1).contiguous().requires_grad_(True)
+    ya, yb = a(xa), b.forward_cl(xb)
+    fwd = ((ya - yb).abs().max() / ya.abs().max()).item()
+    gy = torch.randn_like(ya)
+    (ya * gy).sum().backward()
+    (yb * gy).sum().backward()
+    worst, name = _grad_report(a, b)
+    dx = ((xb.grad.permute(0, 4, 1, 2, 3) - xa.grad).norm() / xa.grad.norm()).item()
+    note("reg_module_grads_" + kind, fwd=fwd, worst_rel_l2=worst, worst=name, dx_rel_l2=dx)
+    assert fwd <= 2e-5 and worst <= 2e-4 and dx <= 2e-4, (fwd, name, worst, dx)
