@@ -456,22 +456,39 @@ struct WarpAggBwdArgs {
     float* grad_src;        // [NV][B, Hs, Ws, C]  (same strides as src)
 };
 
+// Scatter window: the source-view gradient of one workgroup (64 reference pixels of a row x all depths) and
+// one view lands on a compact patch of the source map (a few rows around an epipolar segment), so it is
+// accumulated in LDS (ds_add_f32) over a kWinX x kWinY texel window anchored at the workgroup's smallest tap
+// coordinates, 8 channels at a time, and flushed with ONE global atomic per touched (texel, channel) instead
+// of one per (pixel, depth, tap, channel): 5-8x fewer global atomics, which is what bounds this kernel.  Taps
+// that fall outside the window (strongly rotated views) go to global memory directly.  grad_ref needs no
+// atomics at all: each reference pixel belongs to exactly one workgroup, which sums over depths and views in
+// LDS and stores once.
+constexpr int kWinX = 96, kWinY = 6;
+
 template <int C, int G, bool GROUP, int DMAX>
 __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs ba) {
     const WarpAggArgs& a = ba.f;
     constexpr int CG = C / G;
     constexpr int CB = CG > 8 ? CG : 8;
     constexpr int GB = CB / CG;
+    static_assert(CB == 8 || !GROUP, "the scatter window holds 8 channels");
+    constexpr int WC = CB < 8 ? CB : 8;                  // channels per window pass
     __shared__ float sc[2][DMAX][64];
     __shared__ float sd[2][DMAX][64];
     __shared__ float corL[G][DMAX * 64];
+    __shared__ float gref[C][64];
+    __shared__ float win[WC][kWinY][kWinX];
+    __shared__ int worg[2][2];
 
     const int tx = threadIdx.x;
     const int d = threadIdx.y;
     const int tid = d * 64 + tx;
+    const int nthr = 64 * blockDim.y;
     const int b = blockIdx.y;
     const int hw = a.h * a.w;
-    const int p = xcd_remap(blockIdx.x, gridDim.x) * 64 + tx;
+    const int p0 = xcd_remap(blockIdx.x, gridDim.x) * 64;
+    const int p = p0 + tx;
     const bool valid = p < hw;
     const int pc = valid ? p : hw - 1;
     const int y = pc / a.w;
@@ -479,7 +496,6 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
     const long o = ((long)b * a.D + d) * hw + pc;
     const float depth = a.hypo[o];
     const float* rp = a.ref + (long)b * a.ref_bs + (long)pc * C;
-    float* grp = ba.grad_ref + (long)b * a.ref_bs + (long)pc * C;
     const float W = ba.wsum[o];
     const float invW = 1.0f / W;
 
@@ -490,6 +506,9 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
         go[g] = valid ? ba.grad_out[o * G + g] : 0.0f;
         common = fmaf(go[g], ba.fwd_out[o * G + g], common);
     }
+    for (int i = tid; i < C * 64; i += nthr) (&gref[0][0])[i] = 0.0f;
+    for (int i = tid; i < WC * kWinY * kWinX; i += nthr) (&win[0][0][0])[i] = 0.0f;
+    __syncthreads();
 
     for (int v = 0; v < a.NV; ++v) {
         mv::RT m;
@@ -542,7 +561,19 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
         }
         score = mv::div_rn(score, a.attn_temp);
         sc[v & 1][d][tx] = score;
+        if (tid == 0) { worg[v & 1][0] = 0x7fffffff; worg[v & 1][1] = 0x7fffffff; }
         __syncthreads();
+        // window origin = smallest tap coordinates of the taps that carry weight (one LDS atomic per wave)
+        {
+            const bool any = valid && (t.nw != 0.0f || t.ne != 0.0f || t.sw != 0.0f || t.se != 0.0f);
+            int mnx = any ? tc.xa : 0x7fffffff, mny = any ? tc.ya : 0x7fffffff;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                mnx = min(mnx, __shfl_xor(mnx, off));
+                mny = min(mny, __shfl_xor(mny, off));
+            }
+            if (tx == 0) { atomicMin(&worg[v & 1][0], mnx); atomicMin(&worg[v & 1][1], mny); }
+        }
         float mx = sc[v & 1][0][tx];
         for (int j = 1; j < a.D; ++j) mx = fmaxf(mx, sc[v & 1][j][tx]);
         float den = 0.0f;
@@ -560,11 +591,16 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
         float dot = 0.0f;
         for (int j = 0; j < a.D; ++j) dot += sd[v & 1][j][tx];
         const float dscore = sig * (dsig - dot) / a.attn_temp;   // d/d(sum_g cor[g])
+        const int wx0 = worg[v & 1][0], wy0 = worg[v & 1][1];
+        // window coordinates of the four taps (negative / too large = outside -> global atomics)
+        const int ax = tc.xa - wx0, bx = tc.xb - wx0, ay = tc.ya - wy0, by = tc.yb - wy0;
+        const bool iax = (unsigned)ax < (unsigned)kWinX, ibx = (unsigned)bx < (unsigned)kWinX;
+        const bool iay = (unsigned)ay < (unsigned)kWinY, iby = (unsigned)by < (unsigned)kWinY;
 
-        // pass 2: re-gather, scatter the feature gradients
-        if (valid) {
-            for (int cb = 0; cb < C / CB; ++cb) {
-                const int cbase = cb * CB;
+        // pass 2: re-gather, scatter the feature gradients, 8 channels per window pass
+        for (int cb = 0; cb < C / CB; ++cb) {
+            const int cbase = cb * CB;
+            if (valid) {
 #pragma unroll
                 for (int c0 = 0; c0 < CB; c0 += 4) {
                     const f32x4 R = ld4(rp + cbase + c0);
@@ -572,7 +608,8 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
                     const f32x4 Cq = ld4(sp + o10 + cbase + c0), Dq = ld4(sp + o11 + cbase + c0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int c = cbase + c0 + j;
+                        const int cl = c0 + j;               // channel within the pass
+                        const int c = cbase + cl;
                         const int g = GROUP ? c / CG : c;
                         const float dcor = fmaf(go[g] * invW, wgt, dscore);   // direct + through the softmax
                         const float wv = mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
@@ -585,16 +622,44 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
                             dref = 2.0f * df * dcor;
                             dwv = -dref;
                         }
-                        unsafeAtomicAdd(grp + c, dref);
-                        if (t.nw != 0.0f) unsafeAtomicAdd(gsp + o00 + c, t.nw * dwv);
-                        if (t.ne != 0.0f) unsafeAtomicAdd(gsp + o01 + c, t.ne * dwv);
-                        if (t.sw != 0.0f) unsafeAtomicAdd(gsp + o10 + c, t.sw * dwv);
-                        if (t.se != 0.0f) unsafeAtomicAdd(gsp + o11 + c, t.se * dwv);
+                        unsafeAtomicAdd(&gref[c][tx], dref);
+                        if (t.nw != 0.0f) {
+                            if (iax && iay) unsafeAtomicAdd(&win[cl][ay][ax], t.nw * dwv);
+                            else unsafeAtomicAdd(gsp + o00 + c, t.nw * dwv);
+                        }
+                        if (t.ne != 0.0f) {
+                            if (ibx && iay) unsafeAtomicAdd(&win[cl][ay][bx], t.ne * dwv);
+                            else unsafeAtomicAdd(gsp + o01 + c, t.ne * dwv);
+                        }
+                        if (t.sw != 0.0f) {
+                            if (iax && iby) unsafeAtomicAdd(&win[cl][by][ax], t.sw * dwv);
+                            else unsafeAtomicAdd(gsp + o10 + c, t.sw * dwv);
+                        }
+                        if (t.se != 0.0f) {
+                            if (ibx && iby) unsafeAtomicAdd(&win[cl][by][bx], t.se * dwv);
+                            else unsafeAtomicAdd(gsp + o11 + c, t.se * dwv);
+                        }
                     }
                 }
             }
+            __syncthreads();
+            // flush (and clear) the window: one global atomic per touched (texel, channel)
+            for (int i = tid; i < WC * kWinY * kWinX; i += nthr) {
+                const float val = (&win[0][0][0])[i];
+                if (val != 0.0f) {
+                    (&win[0][0][0])[i] = 0.0f;
+                    const int wxx = i % kWinX, r2 = i / kWinX;
+                    const int wyy = r2 % kWinY, cl = r2 / kWinY;
+                    unsafeAtomicAdd(gsp + ((long)(wy0 + wyy) * a.Ws + (wx0 + wxx)) * C + cbase + cl, val);
+                }
+            }
+            __syncthreads();
         }
     }
+    // every reference pixel of this workgroup is complete: plain coalesced stores
+    float* grp = ba.grad_ref + (long)b * a.ref_bs + (long)p0 * C;
+    const int npix = min(64, hw - p0);
+    for (int i = tid; i < npix * C; i += nthr) grp[i] = gref[i % C][i / C];
 }
 
 template <int C, int G, bool GROUP>
