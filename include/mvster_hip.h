@@ -137,6 +137,20 @@ int mvster_conv_wgrad(const float* x, const float* gy, float* partial, int nblk,
                       int Do, int Ho, int Wo, int CO, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph,
                       int pw, void* stream);
 
+/* Training-mode BatchNorm + ReLU on channels-last activations x [rows, C] (C a power of two, 4..64): the elementwise
+ * half of the reference's conv -> BatchNorm -> ReLU blocks (models/mvs4net_utils.py:116-123, :224-251) and its
+ * autograd.  scale = gamma * rstd, shift = beta - mean * scale (batch statistics from the caller).
+ *   fwd:         y = relu(x*scale + shift)                               (relu = 0: affine only)
+ *   bwd_reduce:  partial[n][0][c] / [n][1][c] = workgroup n's share of sum g and sum g*xh, n < mvster_bn_blocks()
+ *   bwd_apply:   dx = scale * (g - sums[0]/rows - xh * sums[1]/rows),   g = gy * (y > 0), xh = (x - mean) * rstd */
+int mvster_bn_relu_fwd(const float* x, const float* scale, const float* shift, float* y, long rows, int C, int relu,
+                       void* stream);
+int mvster_bn_blocks(long rows, int C);
+int mvster_bn_relu_bwd_reduce(const float* x, const float* gy, const float* scale, const float* shift, const float* mean,
+                              const float* rstd, float* partial, long rows, int C, int relu, void* stream);
+int mvster_bn_relu_bwd_apply(const float* x, const float* gy, const float* scale, const float* shift, const float* mean,
+                             const float* rstd, const float* sums, float* dx, long rows, int C, int relu, void* stream);
+
 /* One v_mfma_f32_16x16x4_f32: A [16,4], B [4,16] -> D [16,16] (row major).  Test hook that pins the
  * fragment layout the convolution kernels assume. */
 int mvster_mfma_probe(const float* A, const float* B, float* D, void* stream);

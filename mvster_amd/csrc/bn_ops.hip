@@ -1,0 +1,154 @@
+// Training-mode BatchNorm + ReLU on channels-last activations [rows, C] (C in {4,...,64}, multiple of 4):
+// the elementwise half of the reference's conv -> BatchNorm -> ReLU blocks (models/mvs4net_utils.py:116-123,
+// :224-251) under autograd.  HBM-bound streaming kernels; the batch statistics themselves come from the host
+// side (torch.var_mean, one pass).  Forward 1 read + 1 write; backward 4 reads + 1 write (PyTorch's autograd
+// over the unfused ops makes ~19 passes).
+//   y  = relu(x * scale + shift)                  scale = gamma * rstd, shift = beta - mean * scale
+//   g  = gy * (y > 0)            xh = (x - mean) * rstd
+//   dbeta = sum g     dgamma = sum g * xh         dx = scale * (g - dbeta/N - xh * dgamma/N)
+// Every thread owns one float4 column group (blockDim*4 is a multiple of C), so per-channel sums stay in
+// registers along the grid-stride loop and are reduced once per workgroup through LDS into a per-workgroup
+// slot of `partial` [nblk][2][C]; the host adds the slots (deterministic).
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float bn_act(float x, float sc, float sh) { return fmaf(x, sc, sh); }
+
+// 1 where the gradient passes the ReLU.  Kept as a multiplicative mask: hipcc 7.2 if-converts
+// `cond ? g : 0.0f` on a just-loaded g into "g = 0; if (cond) {}" in the apply kernel (wrong code, caught by
+// tests/test_gpu_train.py::test_batch_norm_cl_matches_torch).
+__device__ __forceinline__ float relu_mask(int relu, float act) { return (relu == 0 || act > 0.0f) ? 1.0f : 0.0f; }
+
+__global__ void __launch_bounds__(256) bn_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, float* __restrict__ y, long n4,
+                                                          int C, int relu) {
+    const int q = C >> 2;
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(i % q) * 4;
+    const f32x4 sc = ld4(scale + cg), sh = ld4(shift + cg);
+    for (; i < n4; i += stride) {
+        const f32x4 v = ld4(x + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = bn_act(v[j], sc[j], sh[j]);
+            o[j] = relu ? fmaxf(t, 0.0f) : t;
+        }
+        st4(y + i * 4, o);
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_relu_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, float* __restrict__ partial,
+                                                                 long n4, int C, int relu) {
+    __shared__ float red[256][8];
+    const int q = C >> 2;
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(i % q) * 4;
+    const f32x4 sc = ld4(scale + cg), sh = ld4(shift + cg), mu = ld4(mean + cg), rs = ld4(rstd + cg);
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sgx[4] = {0.f, 0.f, 0.f, 0.f};
+    for (; i < n4; i += stride) {
+        const f32x4 v = ld4(x + i * 4), g4 = ld4(gy + i * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float g = g4[j] * relu_mask(relu, bn_act(v[j], sc[j], sh[j]));
+            sg[j] += g;
+            sgx[j] = fmaf(g, (v[j] - mu[j]) * rs[j], sgx[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[threadIdx.x][j] = sg[j]; red[threadIdx.x][4 + j] = sgx[j]; }
+    __syncthreads();
+    // thread t < q*8 sums one (column group, value) over the 256/q threads that share the column group
+    if (threadIdx.x < q * 8) {
+        const int grp = threadIdx.x >> 3, val = threadIdx.x & 7;
+        float s = 0.0f;
+        for (int t = grp; t < 256; t += q) s += red[t][val];
+        const int c = grp * 4 + (val & 3);
+        partial[((long)blockIdx.x * 2 + (val >> 2)) * C + c] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_relu_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd,
+                                                                const float* __restrict__ sums, float* __restrict__ dx,
+                                                                long n4, int C, int relu, float inv_n) {
+    const int q = C >> 2;
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(i % q) * 4;
+    const f32x4 sc = ld4(scale + cg), sh = ld4(shift + cg), mu = ld4(mean + cg), rs = ld4(rstd + cg);
+    const f32x4 s0 = ld4(sums + cg), s1 = ld4(sums + C + cg);
+    for (; i < n4; i += stride) {
+        const f32x4 v = ld4(x + i * 4), g4 = ld4(gy + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float g = g4[j] * relu_mask(relu, bn_act(v[j], sc[j], sh[j]));
+            const float xh = (v[j] - mu[j]) * rs[j];
+            o[j] = sc[j] * (g - s0[j] * inv_n - xh * s1[j] * inv_n);
+        }
+        st4(dx + i * 4, o);
+    }
+}
+
+int check(long rows, int C) {
+    if (rows <= 0) return MVSTER_ERR_SHAPE;
+    if (C < 4 || C > 64 || (C & (C - 1)) != 0) return MVSTER_ERR_UNSUPPORTED;
+    return MVSTER_OK;
+}
+
+int blocks_for(long n4) {
+    const long want = (n4 + 255) / 256;
+    return (int)(want < 2048 ? want : 2048);
+}
+
+}  // namespace
+
+extern "C" int mvster_bn_relu_fwd(const float* x, const float* scale, const float* shift, float* y, long rows, int C, int relu,
+                                  void* stream) {
+    if (!x || !scale || !shift || !y) return MVSTER_ERR_NULL;
+    if (int rc = check(rows, C)) return rc;
+    const long n4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(blocks_for(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, n4, C,
+                       relu);
+    return mv_check_launch();
+}
+
+// partial [nblk][2][C]; nblk is returned by mvster_bn_blocks(rows, C)
+extern "C" int mvster_bn_blocks(long rows, int C) {
+    if (check(rows, C)) return 0;
+    return blocks_for(rows * (C / 4));
+}
+
+extern "C" int mvster_bn_relu_bwd_reduce(const float* x, const float* gy, const float* scale, const float* shift,
+                                         const float* mean, const float* rstd, float* partial, long rows, int C, int relu,
+                                         void* stream) {
+    if (!x || !gy || !scale || !shift || !mean || !rstd || !partial) return MVSTER_ERR_NULL;
+    if (int rc = check(rows, C)) return rc;
+    const long n4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(blocks_for(n4)), dim3(256), 0, (hipStream_t)stream, x, gy, scale, shift,
+                       mean, rstd, partial, n4, C, relu);
+    return mv_check_launch();
+}
+
+// sums [2][C] = (sum g, sum g*xh) over all rows; dx [rows, C]
+extern "C" int mvster_bn_relu_bwd_apply(const float* x, const float* gy, const float* scale, const float* shift,
+                                        const float* mean, const float* rstd, const float* sums, float* dx, long rows, int C,
+                                        int relu, void* stream) {
+    if (!x || !gy || !scale || !shift || !mean || !rstd || !sums || !dx) return MVSTER_ERR_NULL;
+    if (int rc = check(rows, C)) return rc;
+    const long n4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(blocks_for(n4)), dim3(256), 0, (hipStream_t)stream, x, gy, scale, shift,
+                       mean, rstd, sums, dx, n4, C, relu, 1.0f / (float)rows);
+    return mv_check_launch();
+}

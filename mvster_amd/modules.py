@@ -30,7 +30,7 @@ class ConvBnReLU3D(nn.Module):
     def forward_cl(self, x):
         """Channels-last [B,D,H,W,C] form on the gfx950 kernels (mvster_amd/train_ops.py)."""
         c = self.conv
-        return torch.relu(T.batch_norm_cl(T.conv_cl(x, c.weight, None, c.stride, c.padding), self.bn))
+        return T.batch_norm_cl(T.conv_cl(x, c.weight, None, c.stride, c.padding), self.bn, relu=True)
 
 
 def _deconv_bn_relu(cin, cout, kernel, pad, out_pad, stride):
@@ -41,7 +41,7 @@ def _deconv_bn_relu(cin, cout, kernel, pad, out_pad, stride):
 
 def _deconv_bn_relu_cl(seq, x):
     ct, bn = seq[0], seq[1]
-    return torch.relu(T.batch_norm_cl(T.conv_cl(x, ct.weight, None, ct.stride, ct.padding, transposed=True), bn))
+    return T.batch_norm_cl(T.conv_cl(x, ct.weight, None, ct.stride, ct.padding, transposed=True), bn, relu=True)
 
 
 class reg2d(nn.Module):
@@ -158,8 +158,7 @@ class Conv2d(nn.Module):
     def forward_cl(self, x):
         """[B,1,H,W,C] channels-last."""
         c = self.conv
-        x = T.batch_norm_cl(T.conv_cl(x, c.weight, None, c.stride, c.padding), self.bn)
-        return torch.relu(x) if self.relu else x
+        return T.batch_norm_cl(T.conv_cl(x, c.weight, None, c.stride, c.padding), self.bn, relu=self.relu)
 
 
 class FPN4(nn.Module):

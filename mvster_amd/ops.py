@@ -249,3 +249,35 @@ def conv_wgrad(x_cl, gy_cl, kernel, stride, padding):
     _lib.check(rc, "conv_wgrad")
     dw = partial.sum(0)[:, :CO, :CI]                                     # [taps, CO, CI]
     return dw.reshape(kd, kh, kw, CO, CI).permute(3, 4, 0, 1, 2).contiguous()
+
+
+def bn_relu_fwd(x, scale, shift, relu):
+    """y = relu(x*scale + shift) on a channels-last tensor [..., C] (training-mode BatchNorm apply)."""
+    _chk(x, "bn_relu_fwd:x")
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    rc = _lib.load().mvster_bn_relu_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), x.numel() // C, C, int(relu), _stream())
+    _lib.check(rc, "bn_relu_fwd")
+    return y
+
+
+def bn_relu_bwd(x, gy, scale, shift, mean, rstd, relu):
+    """-> (dx, sum g, sum g*xh) with g = gy*(y>0), xh = (x-mean)*rstd (BatchNorm + ReLU backward, batch statistics)."""
+    _chk(x, "bn_relu_bwd:x")
+    _chk(gy, "bn_relu_bwd:gy")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    lib = _lib.load()
+    nblk = lib.mvster_bn_blocks(rows, C)
+    if nblk <= 0:
+        raise RuntimeError("bn_relu_bwd: unsupported channel count %d" % C)
+    partial = torch.empty(nblk, 2, C, device=x.device, dtype=torch.float32)
+    rc = lib.mvster_bn_relu_bwd_reduce(_ptr(x), _ptr(gy), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(partial),
+                                       rows, C, int(relu), _stream())
+    _lib.check(rc, "bn_relu_bwd_reduce")
+    sums = partial.sum(0)
+    dx = torch.empty_like(x)
+    rc = lib.mvster_bn_relu_bwd_apply(_ptr(x), _ptr(gy), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(sums),
+                                      _ptr(dx), rows, C, int(relu), _stream())
+    _lib.check(rc, "bn_relu_bwd_apply")
+    return dx, sums[0], sums[1]

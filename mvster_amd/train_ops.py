@@ -134,13 +134,36 @@ def conv_cl(x, weight, bias=None, stride=1, padding=0, transposed=False):
     return _ConvCL.apply(x, weight, bias, _triple(stride, lead_s), _triple(padding, lead_p), transposed)
 
 
-def batch_norm_cl(x, bn):
-    """nn.BatchNorm2d / 3d on a channels-last tensor: batch statistics + running-stat update in training,
-    running statistics in eval (torch semantics: biased variance to normalise, unbiased in the running average)."""
+class _BnReluCL(torch.autograd.Function):
+    """relu(BatchNorm(x)) with batch statistics: fused apply kernel forward, two fused kernels backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mean, var, eps, relu):
+        rstd = torch.rsqrt(var + eps)
+        scale = (weight * rstd).contiguous()
+        shift = (bias - mean * scale).contiguous()
+        x = x.contiguous()
+        ctx.save_for_backward(x, scale, shift, mean.contiguous(), rstd.contiguous())
+        ctx.relu = relu
+        return ops.bn_relu_fwd(x, scale, shift, relu)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, scale, shift, mean, rstd = ctx.saved_tensors
+        dx, dbeta, dgamma = ops.bn_relu_bwd(x, gy.contiguous(), scale, shift, mean, rstd, ctx.relu)
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+def batch_norm_cl(x, bn, relu=False):
+    """nn.BatchNorm2d / 3d (+ optional ReLU) on a channels-last tensor: batch statistics + running-stat update in
+    training (torch semantics: biased variance to normalise, unbiased in the running average), running statistics
+    in eval.  The training form runs the fused gfx950 kernels (mvster_bn_relu_*); gradients flow to x, gamma, beta."""
     C = x.shape[-1]
+    fused = (bn.training or not bn.track_running_stats) and bn.affine and x.is_cuda and C in (4, 8, 16, 32, 64)
     if bn.training or not bn.track_running_stats:
         x2 = x.reshape(-1, C)
-        var, mean = torch.var_mean(x2, dim=0, unbiased=False)
+        with torch.set_grad_enabled(not fused):
+            var, mean = torch.var_mean(x2, dim=0, unbiased=False)
         if bn.track_running_stats:
             with torch.no_grad():
                 n = x2.shape[0]
@@ -148,6 +171,8 @@ def batch_norm_cl(x, bn):
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
                 bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
                 bn.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
+        if fused:
+            return _BnReluCL.apply(x, bn.weight, bn.bias, mean, var, bn.eps, relu)
     else:
         mean, var = bn.running_mean, bn.running_var
     scale = torch.rsqrt(var + bn.eps)
@@ -156,7 +181,8 @@ def batch_norm_cl(x, bn):
         shift = bn.bias - mean * scale
     else:
         shift = -mean * scale
-    return x * scale + shift
+    y = x * scale + shift
+    return torch.relu(y) if relu else y
 
 
 def upsample2x_cl(x, mode):

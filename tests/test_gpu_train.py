@@ -103,25 +103,27 @@ def test_conv_wgrad_many_rows_is_deterministic():
     assert ((a.cpu().double() - wd.grad).abs().max() / wd.grad.abs().max()).item() <= 2e-5
 
 
-def test_batch_norm_cl_matches_torch():
-    g = torch.Generator().manual_seed(9)
-    x = torch.randn(2, 3, 6, 10, 16, generator=g)
-    bn_a, bn_b = torch.nn.BatchNorm3d(16), torch.nn.BatchNorm3d(16)
+@pytest.mark.parametrize("C,relu", [(16, False), (8, True), (64, True), (4, True)])
+def test_batch_norm_cl_matches_torch(C, relu):
+    g = torch.Generator().manual_seed(9 + C)
+    x = torch.randn(2, 3, 6, 10, C, generator=g) * 2 + 0.5
+    bn_a, bn_b = torch.nn.BatchNorm3d(C), torch.nn.BatchNorm3d(C)
     with torch.no_grad():
         bn_a.weight.uniform_(0.5, 1.5, generator=g)
         bn_a.bias.uniform_(-0.5, 0.5, generator=g)
     bn_b.load_state_dict(bn_a.state_dict())
     xa = x.permute(0, 4, 1, 2, 3).contiguous().requires_grad_(True)
-    ya = bn_a(xa)
+    ya = torch.relu(bn_a(xa)) if relu else bn_a(xa)
     gy = torch.randn(ya.shape, generator=g)
     ya.backward(gy)
     bn_b.to(DEV)
     xb = x.to(DEV).requires_grad_(True)
-    yb = T.batch_norm_cl(xb, bn_b)
+    yb = T.batch_norm_cl(xb, bn_b, relu=relu)
     yb.backward(gy.permute(0, 2, 3, 4, 1).contiguous().to(DEV))
     assert (yb.detach().cpu() - ya.detach().permute(0, 2, 3, 4, 1)).abs().max() <= 1e-5
     assert (xb.grad.cpu() - xa.grad.permute(0, 2, 3, 4, 1)).abs().max() <= 1e-5
-    assert (bn_b.weight.grad.cpu() - bn_a.weight.grad).abs().max() <= 1e-4
+    assert (bn_b.weight.grad.cpu() - bn_a.weight.grad).abs().max() <= 1e-4 * max(1.0, bn_a.weight.grad.abs().max().item())
+    assert (bn_b.bias.grad.cpu() - bn_a.bias.grad).abs().max() <= 1e-4 * max(1.0, bn_a.bias.grad.abs().max().item())
     assert (bn_b.running_mean.cpu() - bn_a.running_mean).abs().max() <= 1e-6
     assert (bn_b.running_var.cpu() - bn_a.running_var).abs().max() <= 1e-6
     assert int(bn_b.num_batches_tracked) == 1
