@@ -151,6 +151,13 @@ int mvster_bn_relu_bwd_reduce(const float* x, const float* gy, const float* scal
 int mvster_bn_relu_bwd_apply(const float* x, const float* gy, const float* scale, const float* shift, const float* mean,
                              const float* rstd, const float* sums, float* dx, long rows, int C, int relu, void* stream);
 
+/* Sinkhorn optimal-transport loss per pixel and its gradient, fused (discrete form, ot_continous=False):
+ * attn, hypo [B,D,HW], gt [B,HW] -> loss_pix [B,HW], jac [B,D,HW] = d loss_pix / d attn.  2 <= D <= 8,
+ * iters <= 16.  Replaces the per-pixel part of `sinkhorn` (models/mvs4net_utils.py:1096-1142) and its autograd;
+ * the masked mean over pixels stays with the caller. */
+int mvster_sinkhorn(const float* attn, const float* hypo, const float* gt, float* loss_pix, float* jac, int B, int D,
+                    long HW, int iters, float eps, void* stream);
+
 /* One v_mfma_f32_16x16x4_f32: A [16,4], B [4,16] -> D [16,16] (row major).  Test hook that pins the
  * fragment layout the convolution kernels assume. */
 int mvster_mfma_probe(const float* A, const float* B, float* D, void* stream);

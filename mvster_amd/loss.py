@@ -1,4 +1,6 @@
-"""Training losses with the reference's signatures (section 8f "next": still PyTorch ops).
+"""Training losses with the reference's signatures.  On the GPU the Sinkhorn term of ``MVS4net_loss`` /
+``Blend_loss`` runs as one fused kernel (``mvster_sinkhorn``: per-pixel loss + its gradient, no [B,HW,D,D]
+intermediates); ``sinkhorn`` itself is the tensor-level form with the reference's return values.
 
 ``MVS4net_loss`` / ``Blend_loss`` follow models/MVS4Net.py:113-206, ``sinkhorn`` follows
 models/mvs4net_utils.py:1096-1142: an entropy-regularised optimal-transport distance between
@@ -43,6 +45,34 @@ def sinkhorn(gt_depth, hypo_depth, attn_weight, mask, iters, eps=1, continuous=F
     return plan, loss
 
 
+class _SinkhornLoss(torch.autograd.Function):
+    """Masked mean of the per-pixel OT loss; gradient flows to ``attn_weight`` only (like the reference, where the
+    target and the cost are constants)."""
+
+    @staticmethod
+    def forward(ctx, attn, hypo, gt, mask, iters, eps):
+        from . import ops
+        loss_pix, jac = ops.sinkhorn_pixels(attn.contiguous(), hypo.contiguous(), gt.contiguous(), iters, eps)
+        m = mask.to(loss_pix.dtype)
+        n = m.sum()
+        ctx.save_for_backward(jac, m, n)
+        return (loss_pix * m).sum() / n
+
+    @staticmethod
+    def backward(ctx, g):
+        jac, m, n = ctx.saved_tensors
+        return jac * (m * (g / n)).unsqueeze(1), None, None, None, None, None
+
+
+def sinkhorn_loss(gt_depth, hypo_depth, attn_weight, mask, iters, eps=1, continuous=False):
+    """The loss value of ``sinkhorn`` (its second return).  CUDA tensors, discrete bins, D <= 8, iters <= 16 run the
+    fused gfx950 kernel; anything else is the tensor-level form."""
+    D = attn_weight.shape[1]
+    if attn_weight.is_cuda and not continuous and 2 <= D <= 8 and iters <= 16:
+        return _SinkhornLoss.apply(attn_weight, hypo_depth, gt_depth, mask, int(iters), float(eps))
+    return sinkhorn(gt_depth, hypo_depth, attn_weight, mask, iters, eps, continuous)[1]
+
+
 def _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):
     inverse = kwargs.get("inverse_depth", False)
     ot_iter = kwargs.get("ot_iter", 3)
@@ -65,7 +95,7 @@ def _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):
         else:
             itv = (hypo[:, 2] - hypo[:, 1]).abs()
             outside = ((hypo - gt.unsqueeze(1)).abs() <= itv.unsqueeze(1)).sum(1) == 0
-        ot = sinkhorn(gt, hypo, attn, mask, iters=ot_iter, eps=ot_eps, continuous=ot_continous)[1]
+        ot = sinkhorn_loss(gt, hypo, attn, mask, iters=ot_iter, eps=ot_eps, continuous=ot_continous)
         yield stage_idx, key, l1, ot, outside[mask].float().mean(), mask
 
 

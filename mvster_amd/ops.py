@@ -281,3 +281,19 @@ def bn_relu_bwd(x, gy, scale, shift, mean, rstd, relu):
                                       _ptr(dx), rows, C, int(relu), _stream())
     _lib.check(rc, "bn_relu_bwd_apply")
     return dx, sums[0], sums[1]
+
+
+def sinkhorn_pixels(attn, hypo, gt, iters, eps):
+    """Per-pixel Sinkhorn OT loss and its gradient w.r.t. attn: attn, hypo [B,D,H,W], gt [B,H,W] ->
+    (loss_pix [B,H,W], jac [B,D,H,W]).  models/mvs4net_utils.py:1096-1142 (ot_continous=False)."""
+    for t, n in ((attn, "attn"), (hypo, "hypo"), (gt, "gt")):
+        _chk(t, "sinkhorn:" + n)
+    B, D, H, W = attn.shape
+    if tuple(hypo.shape) != (B, D, H, W) or tuple(gt.shape) != (B, H, W):
+        raise RuntimeError("sinkhorn: inconsistent shapes")
+    loss_pix = torch.empty(B, H, W, device=attn.device, dtype=torch.float32)
+    jac = torch.empty_like(attn)
+    rc = _lib.load().mvster_sinkhorn(_ptr(attn), _ptr(hypo), _ptr(gt), _ptr(loss_pix), _ptr(jac), B, D, H * W, int(iters),
+                                     float(eps), _stream())
+    _lib.check(rc, "sinkhorn")
+    return loss_pix, jac

@@ -272,3 +272,27 @@ def test_reg_module_gradients_native_vs_pytorch_rocm(kind):
     dx = ((xb.grad.permute(0, 4, 1, 2, 3) - xa.grad).norm() / xa.grad.norm()).item()
     note("reg_module_grads_" + kind, fwd=fwd, worst_rel_l2=worst, worst=name, dx_rel_l2=dx)
     assert fwd <= 2e-5 and worst <= 2e-4 and dx <= 2e-4, (fwd, name, worst, dx)
+
+
+@pytest.mark.parametrize("D,iters,eps", [(4, 10, 1.0), (8, 10, 1.0), (8, 3, 0.5), (5, 16, 2.0)])
+def test_fused_sinkhorn_vs_tensor_form(D, iters, eps):
+    """mvster_sinkhorn (one thread per pixel, loss + gradient in one launch) against the tensor-level restatement
+    of models/mvs4net_utils.py:1096-1142 under autograd, in fp64 on the CPU."""
+    from mvster_amd.loss import sinkhorn, sinkhorn_loss
+    g = torch.Generator().manual_seed(D * 10 + iters)
+    B, H, W = 2, 13, 17
+    attn = torch.softmax(3 * torch.randn(B, D, H, W, generator=g), 1)
+    hypo = 500 + 40 * torch.arange(D).view(1, D, 1, 1) + 5 * torch.rand(B, D, H, W, generator=g)
+    gt = 500 + 40 * (D - 1) * torch.rand(B, H, W, generator=g)
+    mask = torch.rand(B, H, W, generator=g) > 0.3
+    ad = attn.double().requires_grad_(True)
+    want = sinkhorn(gt.double(), hypo.double(), ad, mask, iters, eps)[1]
+    want.backward()
+    ag = attn.to(DEV).requires_grad_(True)
+    got = sinkhorn_loss(gt.to(DEV), hypo.to(DEV), ag, mask.to(DEV), iters, eps)
+    got.backward()
+    e_l = abs(got.item() - want.item()) / abs(want.item())
+    e_g = ((ag.grad.cpu().double() - ad.grad).norm() / ad.grad.norm()).item()
+    note("sinkhorn_D%d_it%d" % (D, iters), loss_rel=e_l, grad_rel_l2=e_g, loss=want.item())
+    assert e_l <= 2e-5 and e_g <= 2e-4, (e_l, e_g)
+    assert (ag.grad.cpu()[~mask.unsqueeze(1).expand_as(attn)] == 0).all()
