@@ -439,7 +439,10 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
         // One "row" = the KW taps of one (kz, ky).  Rows are software-pipelined with two register sets:
         // the LDS reads and weight loads of row r+1 are issued before the 4*KW*MT*NT MFMAs of row r, and
         // every prefetch is unconditional so that hipcc emits counted waits.
-        const int nrows = KD * KH;
+        // depth taps that fall entirely into the zero padding of this output slice are skipped (their staged
+        // rows are zeros: 2 of the 12 (slice, kz) pairs of a 3x3x3 layer on a 4-deep volume)
+        const int kz_lo = max(0, a.pd[0] - zo * a.sd), kz_hi = min(KD, a.Di + a.pd[0] - zo * a.sd);
+        const int r_first = kz_lo * KH, nrows = kz_hi * KH;
         auto load_row = [&](int r, f32x4v (&A)[KW][MT], f32x4v (&Bv)[KW][NT]) {
             const int kz = r / KH, ky = r - kz * KH;
             const int rowoff = (kz * PH + ky) * PW * 4;
@@ -465,8 +468,8 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bv[kx][nt][j], A[kx][mt][j], acc[mt][nt], 0, 0, 0);
         };
         f32x4v a0[KW][MT], b0[KW][NT], a1[KW][MT], b1[KW][NT];
-        load_row(0, a0, b0);
-        int r = 0;
+        load_row(r_first, a0, b0);
+        int r = r_first;
         for (; r + 2 <= nrows; r += 2) {
             load_row(r + 1, a1, b1);
             mma_row(a0, b0);
