@@ -82,4 +82,6 @@ if __name__ == "__main__":
     infer(512, 640, 5)
     infer(1152, 1600, 5, steps=10)
     infer(1024, 1920, 7, steps=10)
-    train(512, 640, 5, 2, steps=3)
+    train(512, 640, 5, 2, steps=5, native=True)
+    if "--with-pytorch-train" in sys.argv:
+        train(512, 640, 5, 2, steps=3, native=False)
