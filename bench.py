@@ -64,7 +64,8 @@ class KernelTimer:
             if variant == 1:
                 kd, kh, kw = layer.kernel
                 nstage = kd * ((2 * mt - 1) * layer.stride[1] + kh) * (31 * layer.stride[2] + kw) * 4
-                kname = "conv_lds_kernel<%d, %d, %d, %d>" % (mt, nt, kw, -(-nstage // 1024))
+                wl = kd * kh * kw * nt * 64 <= 768 and not os.environ.get("MVSTER_NO_WLDS")
+                kname = "conv_lds_kernel<%d, %d, %d, %d, %s>" % (mt, nt, kw, -(-nstage // 1024), "true" if wl else "false")
             elif variant == 3:
                 kname = "conv_small_kernel<%d>" % layer.cin
             elif variant == 4:

@@ -25,6 +25,8 @@
 //
 // Roofline: the 3x3x3 layers are MFMA-bound (157.3 TFLOP/s fp32 matrix peak), the full-resolution
 // (1,3,3) layers are HBM/L2-bound.  FLOPs per launch = 2 * M * Cout * taps * Cin.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -354,11 +356,15 @@ int dispatch_tiles(const ConvArgs& a, int MT, int NT, bool splitk, hipStream_t s
 // same fused epilogue as the direct kernel.  Several workgroups per CU overlap staging and math.
 // ------------------------------------------------------------------------------------------
 constexpr int kMaxStage = 12;   // float4 loads per thread per chunk (patch <= 48 KB)
+static const bool g_no_wlds = getenv("MVSTER_NO_WLDS") != nullptr;   // experiment switch: weights from L1 again
 
-template <int MT, int NT, int KW, int NG>
+constexpr int kWlds = 3;         // WL: weight float4 per thread per chunk (taps * NT * 64 <= 768, i.e. 12 KB)
+
+template <int MT, int NT, int KW, int NG, bool WL>
 __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) float patch_raw[];
     f32x4v* patch_base = reinterpret_cast<f32x4v*>(patch_raw);
+    f32x4v* wl = patch_base + NG * 1024;     // WL: this chunk's packed weights [tap][nt][lane]
     constexpr int TY = 2 * MT;
     const int KD = a.kd[0], KH = a.kh[0];
     const int PW = 31 * a.sw + KW, PH = (TY - 1) * a.sh + KH;
@@ -417,7 +423,12 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     // Staging is register-double-buffered: NG groups of 4 float4 per thread.  The global loads of chunk
     // ch+1 are issued BEFORE the MFMAs of chunk ch (their latency hides under this workgroup's own math
     // instead of relying on other workgroups being out of phase) and written to LDS after them.
+    // WL (small tap count x NT): the chunk's weights are staged the same way, so that inside the MFMA loop
+    // both operands come from LDS (~100 cycles) instead of one of them from L1/L2 (~500+ under load), which
+    // the one-row-deep software pipeline cannot cover.
     f32x4v stg[NG * 4];
+    f32x4v wst[WL ? kWlds : 1];
+    const int nW = KD * KH * KW * NT * 64;
     auto stage_load = [&](int ch) {
 #pragma unroll
         for (int i = 0; i < NG * 4; ++i) {
@@ -425,10 +436,22 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
             const long off = o >= 0 ? (long)o + ch * 16 : zero_off;
             stg[i] = *reinterpret_cast<const f32x4v*>(a.in + off);
         }
+        if (WL) {
+#pragma unroll
+            for (int i = 0; i < kWlds; ++i) {
+                const int idx = min((int)threadIdx.x + i * 256, nW - 1);
+                const int t = idx / (NT * 64), rem = idx - t * (NT * 64);
+                wst[i] = *reinterpret_cast<const f32x4v*>(a.wpk + (long)(t * nchunks + ch) * wstep + ((long)nt0 * 64 + rem) * 4);
+            }
+        }
     };
     auto stage_store = [&](f32x4v* dst) {
 #pragma unroll
         for (int i = 0; i < NG * 4; ++i) dst[threadIdx.x + i * 256] = stg[i];
+        if (WL) {
+#pragma unroll
+            for (int i = 0; i < kWlds; ++i) wl[threadIdx.x + i * 256] = wst[i];
+        }
     };
     stage_load(0);
     stage_store(patch_base);
@@ -453,7 +476,8 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
                 for (int mt = 0; mt < MT; ++mt) A[kx][mt] = patch[abase[mt] + rowoff + kx * 4];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    Bv[kx][nt] = *reinterpret_cast<const f32x4v*>(w + (long)kx * nchunks * wstep + nt * 256);
+                    Bv[kx][nt] = WL ? wl[((r * KW + kx) * NT + nt) * 64 + lane]
+                                    : *reinterpret_cast<const f32x4v*>(w + (long)kx * nchunks * wstep + nt * 256);
             }
         };
         auto mma_row = [&](const f32x4v (&A)[KW][MT], const f32x4v (&Bv)[KW][NT]) {
@@ -504,9 +528,15 @@ template <int MT, int NT, int KW, int NG>
 int launch_lds_ng(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
     const long blocks = (long)tiles_x * tiles_y * a.Do * a.B;
     if (blocks >= (1L << 31) || (long)a.B * a.Di * a.Hi * a.Wi * a.cin >= (1L << 31)) return MVSTER_ERR_SHAPE;
-    const size_t lds = (size_t)NG * 1024 * 16;
     dim3 grid((unsigned)blocks, a.ntile_total / NT, 1);
-    hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW, NG>), grid, dim3(256), lds, s, a, tiles_x, tiles_y);
+    const bool wl = a.kd[0] * a.kh[0] * KW * NT * 64 <= kWlds * 256 && !g_no_wlds;
+    if (wl) {
+        const size_t lds = (size_t)NG * 1024 * 16 + kWlds * 256 * 16;
+        hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW, NG, true>), grid, dim3(256), lds, s, a, tiles_x, tiles_y);
+    } else {
+        const size_t lds = (size_t)NG * 1024 * 16;
+        hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW, NG, false>), grid, dim3(256), lds, s, a, tiles_x, tiles_y);
+    }
     return mv_check_launch();
 }
 
