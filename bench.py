@@ -65,7 +65,7 @@ class KernelTimer:
                 kd, kh, kw = layer.kernel
                 nstage = kd * ((2 * mt - 1) * layer.stride[1] + kh) * (31 * layer.stride[2] + kw) * 4
                 wl = kd * kh * kw * nt * 64 <= 768 and not os.environ.get("MVSTER_NO_WLDS")
-                kname = "conv_lds_kernel<%d, %d, %d, %d, %s>" % (mt, nt, kw, -(-nstage // 1024), "true" if wl else "false")
+                kname = "conv_lds_kernel<%d, %d, %d, %d, %d>" % (mt, nt, kw, -(-nstage // 1024), 3 if wl else 0)
             elif variant == 3:
                 kname = "conv_small_kernel<%d>" % layer.cin
             elif variant == 4:

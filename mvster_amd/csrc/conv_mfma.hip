@@ -358,9 +358,9 @@ int dispatch_tiles(const ConvArgs& a, int MT, int NT, bool splitk, hipStream_t s
 constexpr int kMaxStage = 12;   // float4 loads per thread per chunk (patch <= 48 KB)
 static const bool g_no_wlds = getenv("MVSTER_NO_WLDS") != nullptr;   // experiment switch: weights from L1 again
 
-constexpr int kWlds = 3;         // WL: weight float4 per thread per chunk (taps * NT * 64 <= 768, i.e. 12 KB)
-
-template <int MT, int NT, int KW, int NG, bool WL>
+// WN > 0: the chunk's weights are staged in LDS too, WN float4 per thread (taps * NT * 64 <= WN * 256).
+// Used with WN = 3 (2-D 3x3, NT = 1); WN = 7 (3x3x3, 28 KB) was measured slower: it costs a workgroup of occupancy.
+template <int MT, int NT, int KW, int NG, int WN>
 __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) float patch_raw[];
     f32x4v* patch_base = reinterpret_cast<f32x4v*>(patch_raw);
@@ -427,7 +427,8 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     // both operands come from LDS (~100 cycles) instead of one of them from L1/L2 (~500+ under load), which
     // the one-row-deep software pipeline cannot cover.
     f32x4v stg[NG * 4];
-    f32x4v wst[WL ? kWlds : 1];
+    constexpr bool WL = WN > 0;
+    f32x4v wst[WL ? WN : 1];
     const int nW = KD * KH * KW * NT * 64;
     auto stage_load = [&](int ch) {
 #pragma unroll
@@ -438,7 +439,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
         }
         if (WL) {
 #pragma unroll
-            for (int i = 0; i < kWlds; ++i) {
+            for (int i = 0; i < WN; ++i) {
                 const int idx = min((int)threadIdx.x + i * 256, nW - 1);
                 const int t = idx / (NT * 64), rem = idx - t * (NT * 64);
                 wst[i] = *reinterpret_cast<const f32x4v*>(a.wpk + (long)(t * nchunks + ch) * wstep + ((long)nt0 * 64 + rem) * 4);
@@ -450,7 +451,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
         for (int i = 0; i < NG * 4; ++i) dst[threadIdx.x + i * 256] = stg[i];
         if (WL) {
 #pragma unroll
-            for (int i = 0; i < kWlds; ++i) wl[threadIdx.x + i * 256] = wst[i];
+            for (int i = 0; i < WN; ++i) wl[threadIdx.x + i * 256] = wst[i];
         }
     };
     stage_load(0);
@@ -529,13 +530,13 @@ int launch_lds_ng(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
     const long blocks = (long)tiles_x * tiles_y * a.Do * a.B;
     if (blocks >= (1L << 31) || (long)a.B * a.Di * a.Hi * a.Wi * a.cin >= (1L << 31)) return MVSTER_ERR_SHAPE;
     dim3 grid((unsigned)blocks, a.ntile_total / NT, 1);
-    const bool wl = a.kd[0] * a.kh[0] * KW * NT * 64 <= kWlds * 256 && !g_no_wlds;
-    if (wl) {
-        const size_t lds = (size_t)NG * 1024 * 16 + kWlds * 256 * 16;
-        hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW, NG, true>), grid, dim3(256), lds, s, a, tiles_x, tiles_y);
+    const int nw = a.kd[0] * a.kh[0] * KW * NT * 64;       // weight float4 per chunk
+    if (nw <= 3 * 256 && !g_no_wlds) {
+        const size_t lds = (size_t)NG * 1024 * 16 + 3 * 256 * 16;
+        hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW, NG, 3>), grid, dim3(256), lds, s, a, tiles_x, tiles_y);
     } else {
         const size_t lds = (size_t)NG * 1024 * 16;
-        hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW, NG, false>), grid, dim3(256), lds, s, a, tiles_x, tiles_y);
+        hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW, NG, 0>), grid, dim3(256), lds, s, a, tiles_x, tiles_y);
     }
     return mv_check_launch();
 }
