@@ -158,6 +158,17 @@ int mvster_bn_relu_bwd_apply(const float* x, const float* gy, const float* scale
 int mvster_sinkhorn(const float* attn, const float* hypo, const float* gt, float* loss_pix, float* jac, int B, int D,
                     long HW, int iters, float eps, void* stream);
 
+/* Geometric-consistency filter of one reference view against NS source views, fused (test_mvs4.py:273-328 per
+ * view pair + the sums of filter_depth :362-385).  depth_ref [H,W], depth_src [NS,H,W]; ref_mats = inv(K_ref)[9],
+ * K_ref[9]; view_mats [NS][42] = (E_src inv(E_ref))[3x4], K_src[3x3], inv(K_src)[3x3], (E_ref inv(E_src))[3x4], all
+ * row major, float32 values widened to double (the reference's dtype flow).  mask_sum [H,W] = number of consistent
+ * views, depth_sum [H,W] = sum of their reprojected depths; view_mask / view_depth / x_src / y_src [NS,H,W] are
+ * optional per-view outputs (the returns of check_geometric_consistency).  Source depth is sampled like
+ * cv2.remap(INTER_LINEAR): 1/32-pixel coordinates, constant-0 border. */
+int mvster_geo_filter(const float* depth_ref, const float* depth_src, const double* ref_mats, const double* view_mats,
+                      int* mask_sum, float* depth_sum, unsigned char* view_mask, float* view_depth, float* x_src,
+                      float* y_src, int NS, int H, int W, float pix_thres, float rel_thres, void* stream);
+
 /* One v_mfma_f32_16x16x4_f32: A [16,4], B [4,16] -> D [16,16] (row major).  Test hook that pins the
  * fragment layout the convolution kernels assume. */
 int mvster_mfma_probe(const float* A, const float* B, float* D, void* stream);

@@ -1,0 +1,91 @@
+"""mvster_geo_filter against the NumPy restatement of the reference's filter (oracle/geo_filter_oracle.py) on an
+analytic multi-view scene with noise and outliers.  fp64 products may differ from NumPy's BLAS in the last bit, so
+maps are compared with a tolerance and mask disagreements are only accepted within a hair of the two thresholds."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from mvster_amd import fusion
+from mvster_amd.synthetic_scene import plane_depth_maps
+from oracle import geo_filter_oracle as GO
+
+REPORT = {}
+
+
+def note(name, **kv):
+    REPORT[name] = kv
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_fusion.json", "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+@pytest.mark.parametrize("H,W,N,noise,outl", [(48, 64, 4, 0.0, 0.0), (96, 128, 5, 2e-3, 0.05), (61, 83, 3, 5e-3, 0.2)])
+def test_check_geometric_consistency_vs_oracle(H, W, N, noise, outl):
+    depths, Ks, Es = plane_depth_maps(N, H, W, seed=H, noise=noise, outlier_frac=outl)
+    depths[1][: H // 8] = 0.0                                   # holes, like a filtered source map
+    flips = 0
+    worst_d = worst_xy = 0.0
+    for v in range(1, N):
+        want = GO.check_geometric_consistency(depths[0], Ks[0], Es[0], depths[v], Ks[v], Es[v])
+        got = fusion.check_geometric_consistency(depths[0], Ks[0], Es[0], depths[v], Ks[v], Es[v])
+        wm, wd, wx, wy = want
+        gm, gd, gx, gy = got
+        assert gm.dtype == np.bool_ and gd.dtype == np.float32 and gx.shape == (H, W)
+        fin = np.isfinite(wx) & np.isfinite(wy)
+        worst_xy = max(worst_xy, float(np.abs(gx - wx)[fin].max()), float(np.abs(gy - wy)[fin].max()))
+        same = gm == wm
+        flips += int((~same).sum())
+        both = gm & wm
+        worst_d = max(worst_d, float((np.abs(gd - wd)[both] / wd[both]).max()) if both.any() else 0.0)
+        assert (gd[~gm] == 0).all()
+    note("geo_pair_%dx%d" % (H, W), mask_flips=flips, pixels=(N - 1) * H * W, depth_rel_max=worst_d, xy_abs_max=worst_xy)
+    assert worst_xy <= 1e-3 and worst_d <= 1e-6
+    assert flips <= 2e-4 * (N - 1) * H * W                      # only pixels sitting on a threshold may differ
+
+
+def test_filter_reference_view_vs_oracle_and_timing():
+    H, W, N = 512, 640, 11
+    depths, Ks, Es = plane_depth_maps(N, H, W, seed=3, noise=1e-3, outlier_frac=0.1)
+    rng = np.random.RandomState(0)
+    conf = rng.rand(H, W).astype(np.float32)
+    t0 = time.perf_counter()
+    want = GO.filter_reference_view(depths[0], Ks[0], Es[0], conf, depths[1:], Ks[1:], Es[1:], 0.3, 3)
+    t_cpu = time.perf_counter() - t0
+    got = fusion.filter_reference_view(depths[0], Ks[0], Es[0], conf, depths[1:], Ks[1:], Es[1:], 0.3, 3)
+    torch.cuda.synchronize()
+    dsrc = torch.from_numpy(depths[1:]).cuda()
+    for _ in range(3):
+        fusion.geometric_filter(depths[0], Ks[0], Es[0], dsrc, Ks[1:], Es[1:])
+    torch.cuda.synchronize()
+    dref = torch.from_numpy(depths[0]).cuda()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        fusion.geometric_filter(dref, Ks[0], Es[0], dsrc, Ks[1:], Es[1:])
+    e1.record()
+    torch.cuda.synchronize()
+    ms_gpu = e0.elapsed_time(e1) / 10
+    ms_sum = (got["geo_mask_sum"].cpu().numpy() != want["geo_mask_sum"]).mean()
+    fm = got["final_mask"].cpu().numpy()
+    agree = fm & want["final_mask"]
+    avg = got["depth_est_averaged"].cpu().numpy()
+    same_votes = got["geo_mask_sum"].cpu().numpy() == want["geo_mask_sum"]
+    d_err = np.abs(avg - want["depth_est_averaged"])[same_votes].max()
+    note("filter_reference_view_512x640x10", cpu_oracle_s=t_cpu, gpu_call_ms=ms_gpu, mask_sum_mismatch_frac=float(ms_sum),
+         final_mask_frac=float(fm.mean()), avg_depth_abs_max=float(d_err), speedup=t_cpu * 1e3 / ms_gpu)
+    assert ms_sum <= 2e-4 and d_err <= 1e-3
+    assert abs(int(fm.sum()) - int(want["final_mask"].sum())) <= 2e-4 * H * W
+    assert got["depth_est_averaged"].dtype == torch.float64 and got["points"].shape[1] == 3
+    if (fm == want["final_mask"]).all():
+        assert np.abs(got["points"].cpu().numpy() - want["points"]).max() <= 1e-3
+    n = np.array([0.15, -0.1, 1.0]); n /= np.linalg.norm(n)
+    on_plane = np.abs(got["points"].cpu().numpy() @ n - 650.0)
+    assert np.median(on_plane) < 1.0
+    assert agree.sum() > 0.2 * H * W
