@@ -3,7 +3,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-for f in tests/test_gpu_kernels.py tests/test_gpu_model.py tests/test_gpu_train.py; do
+for f in tests/test_gpu_kernels.py tests/test_gpu_model.py tests/test_gpu_train.py tests/test_gpu_fusion.py; do
   timeout 600 python -m pytest $f -m gpu -q --timeout=300 2>&1 | tail -30 > gpurun_out/$(basename $f .py).log
   echo "== $f exit ${PIPESTATUS[0]}"; tail -4 gpurun_out/$(basename $f .py).log
 done
