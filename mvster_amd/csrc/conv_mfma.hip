@@ -144,8 +144,16 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& a, f32x4v v, int 
 // partial accumulators are summed through LDS in a fixed order (deterministic).  For the small, deep
 // layers (e.g. 8x10x8 voxels x 64 channels, K = 1728) this turns one 108-step dependent chain per wave
 // into four 27-step chains and quadruples the number of resident waves.
+// Occupancy target per tile shape (waves per SIMD = workgroups of 4 waves per CU): the direct kernel hides its
+// operand latency with co-resident waves, so the register allocator is told to fit one more wave than it would
+// pick on its own for the register-heavy tiles (measured per layer by the tuner).
+constexpr int conv_min_waves(int mt, int nt) {
+    const int t = mt * nt;
+    return t <= 2 ? 5 : (t <= 4 ? 4 : (t <= 8 ? 3 : 2));     // 2x5 at 3 waves spills (77 -> 79 us), left at 2
+}
+
 template <int CIN, int MT, int NT, bool SPLITK>
-__global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
+__global__ void __launch_bounds__(256, conv_min_waves(MT, NT)) conv_mfma_kernel(ConvArgs a) {
     static_assert(CIN % 4 == 0 && (CIN >= 16 ? CIN % 16 == 0 : 16 % CIN == 0), "channel packing");
     __shared__ f32x4v red[SPLITK ? 3 * MT * NT * 64 : 1];
     __shared__ int lut_ofs[kMaxTaps];   // linear input offset (voxels) of a tap
