@@ -51,7 +51,7 @@ def _tuning():
     if _TUNING is None:
         import json
         import os
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_gfx950.json")
+        path = os.environ.get("MVSTER_TUNING") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_gfx950.json")
         try:
             with open(path) as f:
                 _TUNING = json.load(f)
