@@ -296,3 +296,61 @@ def test_fused_sinkhorn_vs_tensor_form(D, iters, eps):
     note("sinkhorn_D%d_it%d" % (D, iters), loss_rel=e_l, grad_rel_l2=e_g, loss=want.item())
     assert e_l <= 2e-5 and e_g <= 2e-4, (e_l, e_g)
     assert (ag.grad.cpu()[~mask.unsqueeze(1).expand_as(attn)] == 0).all()
+
+
+def test_native_train_step_under_ddp_single_rank():
+    """The reference wraps the model in DistributedDataParallel (train_mvs4.py:389): the native training path (custom
+    autograd Functions, cached packed weights) must produce the same gradients through DDP's reducer (RCCL backend,
+    one rank -- multi-rank rendezvous is covered with gloo on the CPU in tests/test_shard_cpu.py)."""
+    import torch.distributed as dist
+    from mvster_amd import shard
+    from mvster_amd.synthetic import randomize_state
+    cfg = dict(arch_mode="fpn", reg_net="reg2d", num_stage=4, fpn_base_channel=8, reg_channel=8, stage_splits=[8, 8, 4, 4],
+               depth_interals_ratio=[0.5, 0.5, 0.5, 1], group_cor=True, group_cor_dim=[8, 8, 4, 4], inverse_depth=True,
+               mono=True, attn_temp=2, attn_fuse_d=True)
+    torch.manual_seed(2)
+    a = MVS4net(**cfg)
+    sd = randomize_state(a.state_dict(), seed=5, prob_gain=4.0)
+    a.load_state_dict(sd)
+    b = MVS4net(**cfg)
+    b.load_state_dict(sd)
+    a.to(DEV).train()
+    b.to(DEV).train()
+    H, W, N, B = 64, 128, 3, 2
+    imgs, proj, dv = make_inputs(nviews=N, H=H, W=W, seed=4, batch=B)
+    imgs = [i.to(DEV) for i in imgs]
+    proj = {k: v.to(DEV) for k, v in proj.items()}
+    dv = dv.to(DEV)
+    g = torch.Generator().manual_seed(0)
+    gt = {"stage%d" % s: (500 + 300 * torch.rand(B, H // 2 ** (4 - s), W // 2 ** (4 - s), generator=g)).to(DEV) for s in range(1, 5)}
+    mask = {k: torch.ones_like(v) for k, v in gt.items()}
+
+    def step(m):
+        out = m(imgs, proj, dv)
+        loss = MVS4net_loss(out, gt, mask, stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10, ot_eps=1,
+                            ot_continous=False, mono=True)[0]
+        loss.backward()
+        return loss.item()
+
+    la = step(a)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)
+        created = True
+    try:
+        ddp = shard.wrap_ddp(b, local_rank=0)
+        assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+        lb = step(ddp)
+        torch.cuda.synchronize()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert abs(la - lb) <= 1e-6 * abs(la)
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    gmax = max(p.grad.norm().item() for p in pa.values() if p.grad is not None)
+    for k in pa:
+        assert (pa[k].grad is None) == (pb[k].grad is None), k
+        if pa[k].grad is not None and pa[k].grad.norm().item() > 1e-4 * gmax:
+            assert ((pa[k].grad - pb[k].grad).norm() / pa[k].grad.norm()).item() <= 1e-4, k
