@@ -245,3 +245,24 @@ def test_other_configurations_vs_oracle(name, kw):
         with torch.no_grad():
             ref_h = O.schedule_range(out["stage1"]["depth"].cpu(), 8, 0.5 * (dv[:, -1] - dv[:, 0]) / dv.size(1), 32, 48)
         assert (s2 - ref_h).abs().max() <= 5e-7 * ref_h.abs().max()
+
+
+def test_under_data_parallel(shipped_cfg, checkpoint):
+    """The reference's test driver wraps the model in nn.DataParallel (test_mvs4.py:196) and indexes the outputs
+    with tensor2numpy: same results through the wrapper, every leaf a tensor."""
+    m = MVS4net(**shipped_cfg)
+    m.load_state_dict(checkpoint, strict=True)
+    m.to(DEV).eval()
+    imgs, proj, dv = to_dev(*make_inputs(nviews=3, H=128, W=192, seed=9))
+    want = m(imgs, proj, dv)
+    dp = torch.nn.DataParallel(m)
+    dp.eval()
+    got = dp(imgs, proj, dv)
+    assert set(got.keys()) == set(want.keys())
+    for k in ("depth", "photometric_confidence", "attn_weight", "hypo_depth"):
+        assert torch.equal(got[k], want[k]), k
+    for s in range(1, 5):
+        for k, v in got["stage%d" % s].items():
+            assert isinstance(v, torch.Tensor), (s, k)
+    state = dp.state_dict()
+    assert all(k.startswith("module.") for k in state) and len(state) == len(m.state_dict())
