@@ -137,19 +137,22 @@ int mvster_conv_wgrad(const float* x, const float* gy, float* partial, int nblk,
                       int Do, int Ho, int Wo, int CO, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph,
                       int pw, void* stream);
 
-/* Training-mode BatchNorm + ReLU on channels-last activations x [rows, C] (C a power of two, 4..64): the elementwise
- * half of the reference's conv -> BatchNorm -> ReLU blocks (models/mvs4net_utils.py:116-123, :224-251) and its
- * autograd.  scale = gamma * rstd, shift = beta - mean * scale (batch statistics from the caller).
+/* Training-mode BatchNorm + ReLU on channels-last activations (C a power of two, 4..64): the elementwise half of the
+ * reference's conv -> BatchNorm -> ReLU blocks (models/mvs4net_utils.py:116-123, :224-251) and its autograd.
+ * x [groups*rows, C]: `groups` independent statistics groups of `rows` rows each (the reference normalises every
+ * view's batch on its own, MVS4Net.py:65-68); scale = gamma * rstd, shift = beta - mean * scale, mean, rstd are
+ * [groups, C] (batch statistics from the caller).
  *   fwd:         y = relu(x*scale + shift)                               (relu = 0: affine only)
- *   bwd_reduce:  partial[n][0][c] / [n][1][c] = workgroup n's share of sum g and sum g*xh, n < mvster_bn_blocks()
- *   bwd_apply:   dx = scale * (g - sums[0]/rows - xh * sums[1]/rows),   g = gy * (y > 0), xh = (x - mean) * rstd */
+ *   bwd_reduce:  partial[g][n][0][c] / [g][n][1][c] = workgroup n's share of sum g_ and sum g_*xh, n < mvster_bn_blocks()
+ *   bwd_apply:   dx = scale * (g_ - sums[g][0]/rows - xh * sums[g][1]/rows),   g_ = gy * (y > 0), xh = (x - mean) * rstd */
 int mvster_bn_relu_fwd(const float* x, const float* scale, const float* shift, float* y, long rows, int C, int relu,
-                       void* stream);
+                       int groups, void* stream);
 int mvster_bn_blocks(long rows, int C);
 int mvster_bn_relu_bwd_reduce(const float* x, const float* gy, const float* scale, const float* shift, const float* mean,
-                              const float* rstd, float* partial, long rows, int C, int relu, void* stream);
+                              const float* rstd, float* partial, long rows, int C, int relu, int groups, void* stream);
 int mvster_bn_relu_bwd_apply(const float* x, const float* gy, const float* scale, const float* shift, const float* mean,
-                             const float* rstd, const float* sums, float* dx, long rows, int C, int relu, void* stream);
+                             const float* rstd, const float* sums, float* dx, long rows, int C, int relu, int groups,
+                             void* stream);
 
 /* Sinkhorn optimal-transport loss per pixel and its gradient, fused (discrete form, ot_continous=False):
  * attn, hypo [B,D,HW], gt [B,HW] -> loss_pix [B,HW], jac [B,D,HW] = d loss_pix / d attn.  2 <= D <= 8,

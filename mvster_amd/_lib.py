@@ -32,10 +32,10 @@ SIGNATURES = {
     "mvster_deconv_small": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f],
     "mvster_fpn_tail_gather": [_f, _f, _f, _f, _i, _i, _i, _i, _f],
     "mvster_conv_wgrad": [_f, _f, _f] + [_i] * 19 + [_f],
-    "mvster_bn_relu_fwd": [_f, _f, _f, _f, _l, _i, _i, _f],
+    "mvster_bn_relu_fwd": [_f, _f, _f, _f, _l, _i, _i, _i, _f],
     "mvster_bn_blocks": [_l, _i],
-    "mvster_bn_relu_bwd_reduce": [_f] * 7 + [_l, _i, _i, _f],
-    "mvster_bn_relu_bwd_apply": [_f] * 8 + [_l, _i, _i, _f],
+    "mvster_bn_relu_bwd_reduce": [_f] * 7 + [_l, _i, _i, _i, _f],
+    "mvster_bn_relu_bwd_apply": [_f] * 8 + [_l, _i, _i, _i, _f],
     "mvster_sinkhorn": [_f, _f, _f, _f, _f, _i, _i, _l, _i, _fl, _f],
     "mvster_geo_filter": [_f] * 10 + [_i, _i, _i, _fl, _fl, _f],
     "mvster_mfma_probe": [_f, _f, _f, _f],

@@ -20,9 +20,13 @@ __device__ __forceinline__ float bn_act(float x, float sc, float sh) { return fm
 // tests/test_gpu_train.py::test_batch_norm_cl_matches_torch).
 __device__ __forceinline__ float relu_mask(int relu, float act) { return (relu == 0 || act > 0.0f) ? 1.0f : 0.0f; }
 
+// blockIdx.y = statistics group (the reference normalises every view's batch separately): group g owns rows
+// [g*rows, (g+1)*rows) of x and row g of the per-channel parameter arrays.
 __global__ void __launch_bounds__(256) bn_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, float* __restrict__ y, long n4,
                                                           int C, int relu) {
+    x += (long)blockIdx.y * n4 * 4; y += (long)blockIdx.y * n4 * 4;
+    scale += blockIdx.y * C; shift += blockIdx.y * C;
     const int q = C >> 2;
     const long stride = (long)gridDim.x * 256;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -47,6 +51,9 @@ __global__ void __launch_bounds__(256) bn_relu_bwd_reduce_kernel(const float* __
                                                                  const float* __restrict__ rstd, float* __restrict__ partial,
                                                                  long n4, int C, int relu) {
     __shared__ float red[256][8];
+    x += (long)blockIdx.y * n4 * 4; gy += (long)blockIdx.y * n4 * 4;
+    scale += blockIdx.y * C; shift += blockIdx.y * C; mean += blockIdx.y * C; rstd += blockIdx.y * C;
+    partial += (long)blockIdx.y * gridDim.x * 2 * C;
     const int q = C >> 2;
     const long stride = (long)gridDim.x * 256;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -82,6 +89,9 @@ __global__ void __launch_bounds__(256) bn_relu_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ rstd,
                                                                 const float* __restrict__ sums, float* __restrict__ dx,
                                                                 long n4, int C, int relu, float inv_n) {
+    x += (long)blockIdx.y * n4 * 4; gy += (long)blockIdx.y * n4 * 4; dx += (long)blockIdx.y * n4 * 4;
+    scale += blockIdx.y * C; shift += blockIdx.y * C; mean += blockIdx.y * C; rstd += blockIdx.y * C;
+    sums += blockIdx.y * 2 * C;
     const int q = C >> 2;
     const long stride = (long)gridDim.x * 256;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -114,13 +124,15 @@ int blocks_for(long n4) {
 
 }  // namespace
 
+// rows = rows PER GROUP; x, y [groups*rows, C]; scale, shift (mean, rstd) [groups, C]
 extern "C" int mvster_bn_relu_fwd(const float* x, const float* scale, const float* shift, float* y, long rows, int C, int relu,
-                                  void* stream) {
+                                  int groups, void* stream) {
     if (!x || !scale || !shift || !y) return MVSTER_ERR_NULL;
     if (int rc = check(rows, C)) return rc;
+    if (groups < 1 || groups > 65535) return MVSTER_ERR_SHAPE;
     const long n4 = rows * (C / 4);
-    hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(blocks_for(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, n4, C,
-                       relu);
+    hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(blocks_for(n4), groups), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y,
+                       n4, C, relu);
     return mv_check_launch();
 }
 
@@ -130,25 +142,28 @@ extern "C" int mvster_bn_blocks(long rows, int C) {
     return blocks_for(rows * (C / 4));
 }
 
+// partial [groups][nblk][2][C]
 extern "C" int mvster_bn_relu_bwd_reduce(const float* x, const float* gy, const float* scale, const float* shift,
                                          const float* mean, const float* rstd, float* partial, long rows, int C, int relu,
-                                         void* stream) {
+                                         int groups, void* stream) {
     if (!x || !gy || !scale || !shift || !mean || !rstd || !partial) return MVSTER_ERR_NULL;
     if (int rc = check(rows, C)) return rc;
+    if (groups < 1 || groups > 65535) return MVSTER_ERR_SHAPE;
     const long n4 = rows * (C / 4);
-    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(blocks_for(n4)), dim3(256), 0, (hipStream_t)stream, x, gy, scale, shift,
-                       mean, rstd, partial, n4, C, relu);
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(blocks_for(n4), groups), dim3(256), 0, (hipStream_t)stream, x, gy, scale,
+                       shift, mean, rstd, partial, n4, C, relu);
     return mv_check_launch();
 }
 
-// sums [2][C] = (sum g, sum g*xh) over all rows; dx [rows, C]
+// sums [groups][2][C] = (sum g, sum g*xh) over the group's rows; dx [groups*rows, C]
 extern "C" int mvster_bn_relu_bwd_apply(const float* x, const float* gy, const float* scale, const float* shift,
                                         const float* mean, const float* rstd, const float* sums, float* dx, long rows, int C,
-                                        int relu, void* stream) {
+                                        int relu, int groups, void* stream) {
     if (!x || !gy || !scale || !shift || !mean || !rstd || !sums || !dx) return MVSTER_ERR_NULL;
     if (int rc = check(rows, C)) return rc;
+    if (groups < 1 || groups > 65535) return MVSTER_ERR_SHAPE;
     const long n4 = rows * (C / 4);
-    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(blocks_for(n4)), dim3(256), 0, (hipStream_t)stream, x, gy, scale, shift,
-                       mean, rstd, sums, dx, n4, C, relu, 1.0f / (float)rows);
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(blocks_for(n4), groups), dim3(256), 0, (hipStream_t)stream, x, gy, scale,
+                       shift, mean, rstd, sums, dx, n4, C, relu, 1.0f / (float)rows);
     return mv_check_launch();
 }

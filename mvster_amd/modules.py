@@ -155,10 +155,10 @@ class Conv2d(nn.Module):
         x = self.bn(self.conv(x))
         return F.relu(x, inplace=True) if self.relu else x
 
-    def forward_cl(self, x):
-        """[B,1,H,W,C] channels-last."""
+    def forward_cl(self, x, groups=1):
+        """[B,1,H,W,C] channels-last; ``groups`` = number of equal batch slices normalised separately (views)."""
         c = self.conv
-        return T.batch_norm_cl(T.conv_cl(x, c.weight, None, c.stride, c.padding), self.bn, relu=self.relu)
+        return T.batch_norm_cl(T.conv_cl(x, c.weight, None, c.stride, c.padding), self.bn, relu=self.relu, groups=groups)
 
 
 class FPN4(nn.Module):
@@ -199,11 +199,14 @@ class FPN4(nn.Module):
         out["stage4"] = self.out4(f)
         return out
 
-    def forward_cl(self, x):
-        """x [B,1,H,W,3] channels-last -> four channels-last maps [B,1,h,w,C]."""
+    def forward_cl(self, x, groups=1):
+        """x [B,1,H,W,3] channels-last -> four channels-last maps [B,1,h,w,C].  With ``groups`` = N the batch holds
+        the N views of every sample, view-major ([N*B,...]): the convolutions run once over all of them, BatchNorm
+        normalises each view's slice on its own -- the same numbers as N separate calls (the reference calls the
+        FPN once per view, MVS4Net.py:65-68), in a fifth of the launches."""
         def seq(layers, t):
             for l in layers:
-                t = l.forward_cl(t)
+                t = l.forward_cl(t, groups)
             return t
 
         def plain(m, t):

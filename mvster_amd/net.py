@@ -256,31 +256,35 @@ class MVS4net(nn.Module):
 
     def _forward_train(self, imgs, proj_matrices, depth_values):
         """Differentiable forward with every convolution pass (forward, input and weight gradients) and the
-        fused warp/correlation/aggregation on the gfx950 kernels; BatchNorm on batch statistics per view, like the
-        reference's per-view ``self.feature(img)`` calls (MVS4Net.py:65-68)."""
+        fused warp/correlation/aggregation on the gfx950 kernels.  The FPN runs once over all views (view-major
+        batch) with BatchNorm on batch statistics per view, i.e. the numbers of the reference's per-view
+        ``self.feature(img)`` calls (MVS4Net.py:65-68) in one pass."""
         if not self.native_train:
             return self._forward_train_miopen(imgs, proj_matrices, depth_values)
         dev = imgs[0].device
         depth_values = depth_values.to(dev, torch.float32)
         depth_interval = (depth_values[:, -1] - depth_values[:, 0]) / depth_values.size(1)
-        pyramids = [self.feature.forward_cl(img.permute(0, 2, 3, 1).unsqueeze(1)) for img in imgs]
+        nv, B = len(imgs), imgs[0].shape[0]
+        # all views through the FPN at once, view-major; BatchNorm statistics stay per view (groups = views)
+        x = torch.cat([img.permute(0, 2, 3, 1).unsqueeze(1) for img in imgs], 0)
+        pyramid = self.feature.forward_cl(x, groups=nv)
         outputs = {}
         prev = None
         ref_feats = []
         for s in range(self.num_stage):
             name = "stage%d" % (s + 1)
-            feats = [p[name] for p in pyramids]                      # [B,1,h,w,C] each
-            B, _, h, w, C = feats[0].shape
+            pyr = pyramid[name]                                      # [N*B,1,h,w,C], view-major
+            _, _, h, w, C = pyr.shape
             G = self.group_cor_dim[s] if self.group_cor else C
             with torch.no_grad():
                 rt = ops.relative_projection(proj_matrices[name].to(dev, torch.float32))
                 hypo = self._hypotheses(s, depth_values, depth_interval, prev, h, w)
-            cor = _WarpAggCL.apply(feats[0].reshape(B, h, w, C), torch.stack([f.reshape(B, h, w, C) for f in feats[1:]], 0),
+            cor = _WarpAggCL.apply(pyr[:B].reshape(B, h, w, C), pyr[B:].reshape(nv - 1, B, h, w, C),
                                    rt, hypo, G, self.group_cor, self.attn_fuse_d, float(self.attn_temp))
             st = self._stage_outputs(s, self.reg[s].forward_cl(cor), hypo, dev)
             if self.mono:
-                st["mono_feat"] = feats[0].reshape(B, h, w, C).permute(0, 3, 1, 2)     # [B,C,h,w] view
-                ref_feats.append(feats[0])
+                st["mono_feat"] = pyr[:B].reshape(B, h, w, C).permute(0, 3, 1, 2)      # [B,C,h,w] view
+                ref_feats.append(pyr[:B])
             prev = st
             outputs[name] = st
             outputs.update(st)

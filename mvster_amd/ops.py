@@ -251,36 +251,39 @@ def conv_wgrad(x_cl, gy_cl, kernel, stride, padding):
     return dw.reshape(kd, kh, kw, CO, CI).permute(3, 4, 0, 1, 2).contiguous()
 
 
-def bn_relu_fwd(x, scale, shift, relu):
-    """y = relu(x*scale + shift) on a channels-last tensor [..., C] (training-mode BatchNorm apply)."""
+def bn_relu_fwd(x, scale, shift, relu, groups=1):
+    """y = relu(x*scale + shift) on a channels-last tensor [groups*n, ..., C] (training-mode BatchNorm apply); scale and
+    shift are [groups, C]: each of the `groups` equal slices along dim 0 has its own statistics."""
     _chk(x, "bn_relu_fwd:x")
     C = x.shape[-1]
     y = torch.empty_like(x)
-    rc = _lib.load().mvster_bn_relu_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), x.numel() // C, C, int(relu), _stream())
+    rows = x.numel() // C // groups
+    rc = _lib.load().mvster_bn_relu_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), rows, C, int(relu), int(groups), _stream())
     _lib.check(rc, "bn_relu_fwd")
     return y
 
 
-def bn_relu_bwd(x, gy, scale, shift, mean, rstd, relu):
-    """-> (dx, sum g, sum g*xh) with g = gy*(y>0), xh = (x-mean)*rstd (BatchNorm + ReLU backward, batch statistics)."""
+def bn_relu_bwd(x, gy, scale, shift, mean, rstd, relu, groups=1):
+    """-> (dx, sum g [groups,C], sum g*xh [groups,C]) with g = gy*(y>0), xh = (x-mean)*rstd (BatchNorm + ReLU backward,
+    batch statistics per group)."""
     _chk(x, "bn_relu_bwd:x")
     _chk(gy, "bn_relu_bwd:gy")
     C = x.shape[-1]
-    rows = x.numel() // C
+    rows = x.numel() // C // groups
     lib = _lib.load()
     nblk = lib.mvster_bn_blocks(rows, C)
     if nblk <= 0:
         raise RuntimeError("bn_relu_bwd: unsupported channel count %d" % C)
-    partial = torch.empty(nblk, 2, C, device=x.device, dtype=torch.float32)
+    partial = torch.empty(groups, nblk, 2, C, device=x.device, dtype=torch.float32)
     rc = lib.mvster_bn_relu_bwd_reduce(_ptr(x), _ptr(gy), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(partial),
-                                       rows, C, int(relu), _stream())
+                                       rows, C, int(relu), int(groups), _stream())
     _lib.check(rc, "bn_relu_bwd_reduce")
-    sums = partial.sum(0)
+    sums = partial.sum(1)                                   # [groups, 2, C]
     dx = torch.empty_like(x)
     rc = lib.mvster_bn_relu_bwd_apply(_ptr(x), _ptr(gy), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(sums),
-                                      _ptr(dx), rows, C, int(relu), _stream())
+                                      _ptr(dx), rows, C, int(relu), int(groups), _stream())
     _lib.check(rc, "bn_relu_bwd_apply")
-    return dx, sums[0], sums[1]
+    return dx, sums[:, 0], sums[:, 1]
 
 
 def sinkhorn_pixels(attn, hypo, gt, iters, eps):

@@ -9,8 +9,9 @@ passes native:
                     strided conv for a ConvTranspose layer
   weight gradient   mvster_conv_wgrad (voxels as the MFMA K dimension)
 This replaces autograd through MIOpen, whose solvers take 30-50 ms per layer for these narrow,
-spatially huge convolutions (profiles/r01_n_train_*).  BatchNorm statistics, ReLU and the skip
-additions are elementwise torch ops on the channels-last tensors.
+spatially huge convolutions (profiles/r01_n_train_*).  BatchNorm + ReLU run as fused streaming kernels
+(``batch_norm_cl``, statistics per view group); skip additions and upsampling are torch ops on the
+channels-last tensors.
 
 Reference: the layers of models/mvs4net_utils.py:116-123 (ConvBnReLU3D), :224-251 (Conv2d), :419-502 (FPN4),
 :833-868 (mono_depth_decoder), :870-965 (reg2d / reg3d) under torch.autograd.
@@ -135,53 +136,62 @@ def conv_cl(x, weight, bias=None, stride=1, padding=0, transposed=False):
 
 
 class _BnReluCL(torch.autograd.Function):
-    """relu(BatchNorm(x)) with batch statistics: fused apply kernel forward, two fused kernels backward."""
+    """relu(BatchNorm(x)) with batch statistics ([groups, C], one row per statistics group): fused apply kernel
+    forward, two fused kernels backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, mean, var, eps, relu):
+    def forward(ctx, x, weight, bias, mean, var, eps, relu, groups):
         rstd = torch.rsqrt(var + eps)
         scale = (weight * rstd).contiguous()
         shift = (bias - mean * scale).contiguous()
         x = x.contiguous()
         ctx.save_for_backward(x, scale, shift, mean.contiguous(), rstd.contiguous())
-        ctx.relu = relu
-        return ops.bn_relu_fwd(x, scale, shift, relu)
+        ctx.cfg = (relu, groups)
+        return ops.bn_relu_fwd(x, scale, shift, relu, groups)
 
     @staticmethod
     def backward(ctx, gy):
         x, scale, shift, mean, rstd = ctx.saved_tensors
-        dx, dbeta, dgamma = ops.bn_relu_bwd(x, gy.contiguous(), scale, shift, mean, rstd, ctx.relu)
-        return dx, dgamma, dbeta, None, None, None, None
+        relu, groups = ctx.cfg
+        dx, dbeta, dgamma = ops.bn_relu_bwd(x, gy.contiguous(), scale, shift, mean, rstd, relu, groups)
+        return dx, dgamma.sum(0), dbeta.sum(0), None, None, None, None, None
 
 
-def batch_norm_cl(x, bn, relu=False):
+def batch_norm_cl(x, bn, relu=False, groups=1):
     """nn.BatchNorm2d / 3d (+ optional ReLU) on a channels-last tensor: batch statistics + running-stat update in
     training (torch semantics: biased variance to normalise, unbiased in the running average), running statistics
-    in eval.  The training form runs the fused gfx950 kernels (mvster_bn_relu_*); gradients flow to x, gamma, beta."""
+    in eval.  ``groups`` > 1: x holds that many equal slices along dim 0 (the views of one sample batch) which are
+    normalised separately and update the running statistics one after the other, exactly as ``groups`` separate calls
+    of the module would (the reference runs its FPN once per view).  The training form runs the fused gfx950 kernels
+    (mvster_bn_relu_*); gradients flow to x, gamma, beta."""
     C = x.shape[-1]
     fused = (bn.training or not bn.track_running_stats) and bn.affine and x.is_cuda and C in (4, 8, 16, 32, 64)
     if bn.training or not bn.track_running_stats:
-        x2 = x.reshape(-1, C)
+        xg = x.reshape(groups, -1, C)
         with torch.set_grad_enabled(not fused):
-            var, mean = torch.var_mean(x2, dim=0, unbiased=False)
+            var, mean = torch.var_mean(xg, dim=1, unbiased=False)             # [groups, C]
         if bn.track_running_stats:
             with torch.no_grad():
-                n = x2.shape[0]
-                bn.num_batches_tracked += 1
-                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-                bn.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
+                n = xg.shape[1]
+                unbiased = var * (n / max(n - 1, 1))
+                for g in range(groups):
+                    bn.num_batches_tracked += 1
+                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                    bn.running_mean.mul_(1 - mom).add_(mean[g], alpha=mom)
+                    bn.running_var.mul_(1 - mom).add_(unbiased[g], alpha=mom)
         if fused:
-            return _BnReluCL.apply(x, bn.weight, bn.bias, mean, var, bn.eps, relu)
+            return _BnReluCL.apply(x, bn.weight, bn.bias, mean, var, bn.eps, relu, groups)
     else:
-        mean, var = bn.running_mean, bn.running_var
+        mean, var = bn.running_mean.expand(groups, C), bn.running_var.expand(groups, C)
+    # unfused form (eval-mode statistics inside a training graph, non-affine layers, odd channel counts)
     scale = torch.rsqrt(var + bn.eps)
     if bn.affine:
         scale = scale * bn.weight
         shift = bn.bias - mean * scale
     else:
         shift = -mean * scale
-    y = x * scale + shift
+    n = x.shape[0] // groups
+    y = torch.cat([x[g * n:(g + 1) * n] * scale[g] + shift[g] for g in range(groups)]) if groups > 1 else x * scale[0] + shift[0]
     return torch.relu(y) if relu else y
 
 

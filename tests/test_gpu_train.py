@@ -354,3 +354,33 @@ def test_native_train_step_under_ddp_single_rank():
         assert (pa[k].grad is None) == (pb[k].grad is None), k
         if pa[k].grad is not None and pa[k].grad.norm().item() > 1e-4 * gmax:
             assert ((pa[k].grad - pb[k].grad).norm() / pa[k].grad.norm()).item() <= 1e-4, k
+
+
+def test_fpn_over_all_views_equals_per_view_calls():
+    """FPN4.forward_cl on the view-major batch with groups = views (one pass, BatchNorm statistics per view) against
+    one call per view: features, parameter gradients and the running statistics after the five sequential updates."""
+    from mvster_amd.modules import FPN4
+    torch.manual_seed(7)
+    a = FPN4(8).to(DEV).train()
+    b = FPN4(8).to(DEV).train()
+    b.load_state_dict(a.state_dict())
+    nv, B, H, W = 3, 2, 64, 64
+    views = [torch.rand(B, 1, H, W, 3, device=DEV) for _ in range(nv)]
+    per_view = [a.forward_cl(v) for v in views]
+    batched = b.forward_cl(torch.cat(views, 0), groups=nv)
+    g = torch.Generator().manual_seed(2)
+    la = lb = 0.0
+    for k in batched:
+        want = torch.cat([p[k] for p in per_view], 0)
+        assert (batched[k] - want).abs().max() <= 2e-5 * want.abs().max(), k
+        gy = torch.randn(want.shape, generator=g).to(DEV)
+        la = la + (want * gy).sum()
+        lb = lb + (batched[k] * gy).sum()
+    la.backward()
+    lb.backward()
+    worst, name = _grad_report(a, b)
+    ba, bb = dict(a.named_buffers()), dict(b.named_buffers())
+    bw = max(((ba[k].float() - bb[k].float()).abs().max() / (ba[k].float().abs().max() + 1e-6)).item() for k in ba)
+    note("fpn_batched_views", worst_grad_rel_l2=worst, worst=name, buffers_rel=bw)
+    assert worst <= 2e-4 and bw <= 1e-5
+    assert int(bb["conv0.0.bn.num_batches_tracked"]) == nv
