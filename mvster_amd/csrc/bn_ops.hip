@@ -44,6 +44,39 @@ __global__ void __launch_bounds__(256) bn_relu_fwd_kernel(const float* __restric
     }
 }
 
+// Batch statistics, one pass: per (group, channel) sums of (x - p) and (x - p)^2 with the pivot p = the group's
+// first row (keeps the E[d^2] - E[d]^2 subtraction well conditioned whatever the channel's mean is).  Same thread
+// mapping and per-workgroup partial slots as the backward reduction; the host finishes in fp64.
+__global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__ x, float* __restrict__ partial, long n4, int C) {
+    __shared__ float red[256][8];
+    x += (long)blockIdx.y * n4 * 4;
+    partial += (long)blockIdx.y * gridDim.x * 2 * C;
+    const int q = C >> 2;
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(i % q) * 4;
+    const f32x4 pv = ld4(x + cg);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (; i < n4; i += stride) {
+        const f32x4 v = ld4(x + i * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = v[j] - pv[j];
+            s1[j] += d;
+            s2[j] = fmaf(d, d, s2[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[threadIdx.x][j] = s1[j]; red[threadIdx.x][4 + j] = s2[j]; }
+    __syncthreads();
+    if (threadIdx.x < q * 8) {
+        const int grp = threadIdx.x >> 3, val = threadIdx.x & 7;
+        float s = 0.0f;
+        for (int t = grp; t < 256; t += q) s += red[t][val];
+        partial[((long)blockIdx.x * 2 + (val >> 2)) * C + grp * 4 + (val & 3)] = s;
+    }
+}
+
 __global__ void __launch_bounds__(256) bn_relu_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                  const float* __restrict__ scale,
                                                                  const float* __restrict__ shift,
@@ -140,6 +173,16 @@ extern "C" int mvster_bn_relu_fwd(const float* x, const float* scale, const floa
 extern "C" int mvster_bn_blocks(long rows, int C) {
     if (check(rows, C)) return 0;
     return blocks_for(rows * (C / 4));
+}
+
+// partial [groups][nblk][2][C]: sums of (x - x[first row of the group]) and of its square
+extern "C" int mvster_bn_stats(const float* x, float* partial, long rows, int C, int groups, void* stream) {
+    if (!x || !partial) return MVSTER_ERR_NULL;
+    if (int rc = check(rows, C)) return rc;
+    if (groups < 1 || groups > 65535) return MVSTER_ERR_SHAPE;
+    const long n4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks_for(n4), groups), dim3(256), 0, (hipStream_t)stream, x, partial, n4, C);
+    return mv_check_launch();
 }
 
 // partial [groups][nblk][2][C]

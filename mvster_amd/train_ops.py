@@ -168,8 +168,11 @@ def batch_norm_cl(x, bn, relu=False, groups=1):
     fused = (bn.training or not bn.track_running_stats) and bn.affine and x.is_cuda and C in (4, 8, 16, 32, 64)
     if bn.training or not bn.track_running_stats:
         xg = x.reshape(groups, -1, C)
-        with torch.set_grad_enabled(not fused):
-            var, mean = torch.var_mean(xg, dim=1, unbiased=False)             # [groups, C]
+        if fused:
+            with torch.no_grad():
+                mean, var = ops.bn_stats(x.contiguous(), groups)              # [groups, C]
+        else:
+            var, mean = torch.var_mean(xg, dim=1, unbiased=False)
         if bn.track_running_stats:
             with torch.no_grad():
                 n = xg.shape[1]
