@@ -126,6 +126,13 @@ int mvster_deconv_small(const float* in, const float* w, const float* scale, con
 int mvster_fpn_tail_gather(const float* G, const float* vb, float* P, float* workspace, int NB, int H, int W,
                            int CO, void* stream);
 
+/* Packed-weight refresh on the device (training, once per layer and optimizer step): writes the fragment order
+ * [K/16][N/16][64][4] that mvster_conv_mfma reads, Bm[tap*cin_pad + ci][n] = w[n*s_n + ci*s_c + kz*s_z + ky*s_y + kx*s_x]
+ * (element strides of the parameter tensor; flip = 1 mirrors the taps: the input-gradient form of a stride-1 layer),
+ * zero for ci >= cin and n >= cout.  wpk holds ceil(kd*kh*kw*cin_pad/16) * ceil(cout/16) * 256 floats. */
+int mvster_pack_conv_weights(const float* w, float* wpk, int cout, int cin, int cin_pad, int kd, int kh, int kw, long s_n,
+                             long s_c, long s_z, long s_y, long s_x, int flip, void* stream);
+
 /* Weight gradient of a channels-last convolution (training): for every kernel tap
  *   dW[tap][co][ci] = sum_o gy[o][co] * x[o*s - p + tap][ci]      (zero padding)
  * x [B,Di,Hi,Wi,CI], gy [B,Do,Ho,Wo,CO] with (Do,Ho,Wo) the conv output size for (k,s,p); CI, CO <= 64.

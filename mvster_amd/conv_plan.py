@@ -202,10 +202,17 @@ class ConvLayer:
         else:
             if self.cin != cin:
                 w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, 0, 0, self.cin - cin))
+            wf = w.reshape(w.shape[0], w.shape[1], kd * kh * kw)
             for c in self.classes:
-                kzs, kys, kxs = c["taps"]
-                sub = w[:, :, kzs][:, :, :, kys][:, :, :, :, kxs]  # [cin,cout,|kz|,|ky|,|kx|]
-                packed.append(_pack_gemm(sub.permute(2, 3, 4, 0, 1).reshape(-1, cout))[0])
+                # the class's taps as one device index over the flattened (kz, ky, kx) axis; built once per layer and
+                # device: indexing with Python lists would upload an index tensor (a synchronising copy) per call
+                idx = c.get("tap_index")
+                if idx is None or idx.device != dev:
+                    kzs, kys, kxs = c["taps"]
+                    idx = c["tap_index"] = torch.tensor([(z * kh + y) * kw + x for z in kzs for y in kys for x in kxs],
+                                                        dtype=torch.long, device=dev)
+                sub = wf.index_select(2, idx)                       # [cin,cout,|kz|*|ky|*|kx|]
+                packed.append(_pack_gemm(sub.permute(2, 0, 1).reshape(-1, cout))[0])
         self.wpk = torch.cat(packed).contiguous()
         # HBM-bound finest up-sampling layers: VALU kernel (deconv_small), weights as [3,3,cin,cout]
         self.w_deconv = None
@@ -220,6 +227,33 @@ class ConvLayer:
             if self.cin != cin:
                 ws = torch.nn.functional.pad(ws, (0, 0, 0, self.cin - cin))
             self.w_small = ws.contiguous().to(dev)
+
+    def repack_on_device(self, weight, swap=False, flip=False):
+        """Refresh ``wpk`` of an ordinary (non-transposed) layer with one kernel, reading the parameter tensor in
+        place.  ``swap``: the tensor's dim 1 is this layer's output channel (a ConvTranspose weight, or the
+        input-gradient form of a conv); ``flip``: mirror the taps (input-gradient form of a stride-1 conv)."""
+        if self.transposed:
+            raise RuntimeError("repack_on_device: transposed layers are packed per parity class (repack)")
+        w = weight.detach()
+        if w.dim() == 4:
+            w = w.unsqueeze(2)
+        if w.dtype != torch.float32 or not w.is_cuda:
+            raise RuntimeError("repack_on_device: fp32 CUDA parameter expected")
+        st = w.stride()
+        s_n, s_c = (st[1], st[0]) if swap else (st[0], st[1])
+        kd, kh, kw = self.kernel
+        rc = _lib.load().mvster_pack_conv_weights(w.data_ptr(), self.wpk.data_ptr(), self.cout, self._cin_raw, self.cin, kd,
+                                                  kh, kw, s_n, s_c, st[2], st[3], st[4], int(flip),
+                                                  torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pack_conv_weights")
+        if self.w_small is not None:
+            wv = w.transpose(0, 1) if swap else w
+            if flip:
+                wv = wv.flip(2, 3, 4)
+            ws = wv[:, :, 0].permute(2, 3, 1, 0)                      # [3,3,cin,8]
+            if self.cin != self._cin_raw:
+                ws = torch.nn.functional.pad(ws, (0, 0, 0, self.cin - self._cin_raw))
+            self.w_small.copy_(ws)
 
     def repack(self, weight, bias=None):
         """Refresh the packed weights (and the bias folded into ``shift``) after a parameter update; geometry,

@@ -653,3 +653,44 @@ extern "C" int mvster_mfma_probe(const float* A, const float* B, float* D, void*
     hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, D);
     return mv_check_launch();
 }
+
+// Packed-weight refresh on the device (training: once per layer and optimizer step).  Writes the MFMA fragment
+// order [K/16][N/16][64 lanes][4] (mvster_amd/conv_plan.py:_pack_gemm) of the implicit-GEMM B matrix
+//   Bm[k = tap*cin_pad + ci][n] = w[n*s_n + ci*s_c + kz*s_z + ky*s_y + kx*s_x]     (taps optionally flipped)
+// straight from the parameter tensor: one launch instead of the permute / pad / reshape / cat chain.
+namespace {
+__global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int nsteps,
+                                                           int ntile, int cout, int cin, int cin_pad, int kd, int kh, int kw,
+                                                           long s_n, long s_c, long s_z, long s_y, long s_x, int flip) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // one float4 of the packed array
+    if (idx >= nsteps * ntile * 64) return;
+    const int lane = idx & 63, t = (idx >> 6) % ntile, st = (idx >> 6) / ntile;
+    const int n = t * 16 + (lane & 15);
+    const int ntaps = kd * kh * kw;
+    f32x4v out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = st * 16 + (lane >> 4) * 4 + j;
+        const int tap = k / cin_pad, ci = k - tap * cin_pad;
+        float v = 0.0f;
+        if (tap < ntaps && ci < cin && n < cout) {
+            int kx = tap % kw, ky = (tap / kw) % kh, kz = tap / (kw * kh);
+            if (flip) { kx = kw - 1 - kx; ky = kh - 1 - ky; kz = kd - 1 - kz; }
+            v = w[(long)n * s_n + (long)ci * s_c + (long)kz * s_z + (long)ky * s_y + (long)kx * s_x];
+        }
+        out[j] = v;
+    }
+    *reinterpret_cast<f32x4v*>(wpk + (long)idx * 4) = out;
+}
+}  // namespace
+
+extern "C" int mvster_pack_conv_weights(const float* w, float* wpk, int cout, int cin, int cin_pad, int kd, int kh, int kw,
+                                        long s_n, long s_c, long s_z, long s_y, long s_x, int flip, void* stream) {
+    if (!w || !wpk) return MVSTER_ERR_NULL;
+    if (cout <= 0 || cin <= 0 || cin_pad < cin || kd <= 0 || kh <= 0 || kw <= 0) return MVSTER_ERR_SHAPE;
+    const int nsteps = (kd * kh * kw * cin_pad + 15) / 16, ntile = (cout + 15) / 16;
+    const int total = nsteps * ntile * 64;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, wpk, nsteps, ntile,
+                       cout, cin, cin_pad, kd, kh, kw, s_n, s_c, s_z, s_y, s_x, flip);
+    return mv_check_launch();
+}

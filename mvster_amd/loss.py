@@ -73,6 +73,13 @@ def sinkhorn_loss(gt_depth, hypo_depth, attn_weight, mask, iters, eps=1, continu
     return sinkhorn(gt_depth, hypo_depth, attn_weight, mask, iters, eps, continuous)[1]
 
 
+def _masked_mean(values, mask):
+    """``values[mask].mean()`` without the boolean-index gather: that gather needs the number of selected elements
+    on the host, i.e. a device synchronisation in the middle of every training step."""
+    m = mask.to(values.dtype)
+    return (values * m).sum() / m.sum()
+
+
 def _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):
     inverse = kwargs.get("inverse_depth", False)
     ot_iter = kwargs.get("ot_iter", 3)
@@ -86,9 +93,9 @@ def _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):
         mask = mask_ms[key] > 0.5
         gt = depth_gt_ms[key]
         if mono and stage_idx != 0:
-            l1 = F.l1_loss(st["mono_depth"][mask], gt[mask], reduction="mean")
+            l1 = _masked_mean((st["mono_depth"] - gt).abs(), mask)         # F.l1_loss(mono_depth[mask], gt[mask])
         else:
-            l1 = torch.tensor(0.0, dtype=torch.float32, device=dev, requires_grad=False)
+            l1 = torch.zeros((), dtype=torch.float32, device=dev)
         if inverse:
             itv = (1 / hypo[:, 2] - 1 / hypo[:, 1]).abs()
             outside = ((1 / hypo - 1 / gt.unsqueeze(1)).abs() <= itv.unsqueeze(1)).sum(1) == 0
@@ -96,13 +103,13 @@ def _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):
             itv = (hypo[:, 2] - hypo[:, 1]).abs()
             outside = ((hypo - gt.unsqueeze(1)).abs() <= itv.unsqueeze(1)).sum(1) == 0
         ot = sinkhorn_loss(gt, hypo, attn, mask, iters=ot_iter, eps=ot_eps, continuous=ot_continous)
-        yield stage_idx, key, l1, ot, outside[mask].float().mean(), mask
+        yield stage_idx, key, l1, ot, _masked_mean(outside.float(), mask), mask
 
 
 def MVS4net_loss(inputs, depth_gt_ms, mask_ms, **kwargs):
     stage_lw = kwargs.get("stage_lw", [1, 1, 1, 1])
     l1ot_lw = kwargs.get("l1ot_lw", [0, 1])
-    total = torch.tensor(0.0, dtype=torch.float32, device=mask_ms["stage1"].device, requires_grad=False)
+    total = torch.zeros((), dtype=torch.float32, device=mask_ms["stage1"].device)
     l1s, ots, ranges = [], [], []
     for si, _, l1, ot, rng, _ in _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):
         l1s.append(l1)
@@ -117,7 +124,7 @@ def Blend_loss(inputs, depth_gt_ms, mask_ms, **kwargs):
     l1ot_lw = kwargs.get("l1ot_lw", [0, 1])
     depth_max = kwargs.get("depth_max", 100)
     depth_min = kwargs.get("depth_min", 1)
-    total = torch.tensor(0.0, dtype=torch.float32, device=mask_ms["stage1"].device, requires_grad=False)
+    total = torch.zeros((), dtype=torch.float32, device=mask_ms["stage1"].device)
     l1s, ots, ranges = [], [], []
     last = None
     for si, key, l1, ot, rng, mask in _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):

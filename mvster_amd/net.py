@@ -243,7 +243,7 @@ class MVS4net(nn.Module):
         idx = attn.max(1, keepdim=True)[1]
         depth = torch.gather(hypo, 1, idx).squeeze(1)
         if self.training:
-            conf = torch.tensor(0.0, dtype=torch.float32, device=dev, requires_grad=False)
+            conf = torch.zeros((), dtype=torch.float32, device=dev)      # (torch.tensor(0.0, device=...) would sync)
         else:
             with torch.no_grad():
                 conf = ops.upsample_bilinear(attn.max(1)[0].contiguous(), 2 ** (3 - s))

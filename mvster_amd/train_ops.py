@@ -48,13 +48,14 @@ class _LayerCache:
     def __init__(self):
         self._d = {}
 
-    def get(self, weight, role, build, pack_source):
+    def get(self, weight, role, build, refresh):
+        """``build()`` makes the layer; ``refresh(layer)`` re-packs it from the updated parameter."""
         key = (id(weight), role)
         hit = self._d.get(key)
         ver = weight._version
         if hit is not None and hit[0] is weight and hit[2].wpk.device == weight.device:
             if hit[1] != ver:
-                hit[2].repack(pack_source())
+                refresh(hit[2])
                 self._d[key] = (weight, ver, hit[2])
             return hit[2]
         layer = build()
@@ -66,6 +67,7 @@ class _LayerCache:
 
 
 CACHE = _LayerCache()
+_EMA_WEIGHTS = {}
 
 
 class _ConvCL(torch.autograd.Function):
@@ -78,7 +80,7 @@ class _ConvCL(torch.autograd.Function):
         cin_p = _cin_for(cin)
         xp = _pad_last(x, cin_p).contiguous()
         layer = CACHE.get(weight, "fwd", lambda: ConvLayer(w5, transposed, stride, padding, cin_pad=cin_p),
-                          lambda: weight)
+                          (lambda L: L.repack(weight)) if transposed else (lambda L: L.repack_on_device(weight)))
         if bias is not None:
             layer.shift[:layer.cout] = bias.detach()
         y = layer(xp)
@@ -101,16 +103,17 @@ class _ConvCL(torch.autograd.Function):
             if transposed:
                 # y = convT(x; W[cin,cout]) : dx = conv(gy; W read as [out=cin, in=cout], same stride / padding)
                 layer = CACHE.get(weight, "dgrad", lambda: ConvLayer(w5, False, stride, padding, cin_pad=co_p),
-                                  lambda: weight)
+                                  lambda L: L.repack_on_device(weight))
             elif stride == (1, 1, 1):
                 def flipped():
                     return w5.detach().flip(2, 3, 4).transpose(0, 1).contiguous()
                 pad = tuple(k - 1 - p for k, p in zip(kernel, padding))
-                layer = CACHE.get(weight, "dgrad", lambda: ConvLayer(flipped(), False, stride, pad, cin_pad=co_p), flipped)
+                layer = CACHE.get(weight, "dgrad", lambda: ConvLayer(flipped(), False, stride, pad, cin_pad=co_p),
+                                  lambda L: L.repack_on_device(weight, swap=True, flip=True))
             else:
                 # stride 2: the adjoint is the transposed conv with the same weights (parity classes)
                 layer = CACHE.get(weight, "dgrad", lambda: ConvLayer(w5, True, stride, padding, cin_pad=co_p),
-                                  lambda: weight)
+                                  lambda L: L.repack(weight))
             gx = layer(gyp)
             if tuple(gx.shape[:4]) != tuple(xp.shape[:4]):
                 raise RuntimeError("conv_cl: input gradient of a strided layer needs even input sizes (%s -> %s)"
@@ -177,11 +180,24 @@ def batch_norm_cl(x, bn, relu=False, groups=1):
             with torch.no_grad():
                 n = xg.shape[1]
                 unbiased = var * (n / max(n - 1, 1))
-                for g in range(groups):
-                    bn.num_batches_tracked += 1
-                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                    bn.running_mean.mul_(1 - mom).add_(mean[g], alpha=mom)
-                    bn.running_var.mul_(1 - mom).add_(unbiased[g], alpha=mom)
+                if bn.momentum is not None:
+                    # `groups` exponential-average updates in a row, closed form (3 launches instead of 4 per group):
+                    # r <- (1-m)^G r + sum_g m (1-m)^(G-1-g) s_g
+                    m = float(bn.momentum)
+                    wkey = (groups, m, x.device)
+                    wts = _EMA_WEIGHTS.get(wkey)
+                    if wts is None:
+                        wts = _EMA_WEIGHTS[wkey] = torch.tensor([m * (1 - m) ** (groups - 1 - g) for g in range(groups)],
+                                                                device=x.device)
+                    bn.num_batches_tracked += groups
+                    bn.running_mean.mul_((1 - m) ** groups).add_(wts @ mean)
+                    bn.running_var.mul_((1 - m) ** groups).add_(wts @ unbiased)
+                else:
+                    for g in range(groups):
+                        bn.num_batches_tracked += 1
+                        mom = 1.0 / float(bn.num_batches_tracked)
+                        bn.running_mean.mul_(1 - mom).add_(mean[g], alpha=mom)
+                        bn.running_var.mul_(1 - mom).add_(unbiased[g], alpha=mom)
         if fused:
             return _BnReluCL.apply(x, bn.weight, bn.bias, mean, var, bn.eps, relu, groups)
     else:

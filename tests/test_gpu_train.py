@@ -79,13 +79,16 @@ def test_conv_cl_forward_and_gradients(case):
     note("conv_cl_" + name, fwd=e_y, dx=e_x, dw=e_w, db=e_b)
     assert tuple(y.shape) == tuple(cl(yd).shape)
     assert e_y <= 1e-5 and e_x <= 1e-5 and e_w <= 2e-5 and e_b <= 1e-5, (e_y, e_x, e_w, e_b)
-    # a parameter update is picked up by the cached layers
+    # a parameter update is picked up by the cached layers (forward and input-gradient forms are re-packed on the device)
+    dx1 = xg.grad.clone()
     with torch.no_grad():
         wg.mul_(0.5)
-    y2 = T.conv_cl(xg.detach(), wg, bg, s, p, transposed)
-    want2 = cl(yd.detach()) * 0.5 if not has_bias else None
-    if want2 is not None:
-        assert rel(y2.detach(), want2) <= 1e-5
+    xg.grad = None
+    y2 = T.conv_cl(xg, wg, None, s, p, transposed)
+    y2.backward(cl(gy).to(DEV))
+    if not has_bias:
+        assert rel(y2.detach(), cl(yd.detach()) * 0.5) <= 1e-5
+    assert rel(xg.grad, dx1.cpu().double() * 0.5) <= 1e-5
 
 
 def test_conv_wgrad_many_rows_is_deterministic():
