@@ -644,12 +644,14 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
             }
             __syncthreads();
             // flush (and clear) the window: one global atomic per touched (texel, channel)
+            // channel-fastest order: the atomics of a wave go to 8 neighbouring texels x 8 channels = 256 contiguous
+            // bytes (2 cache lines) instead of 64 texels of one channel plane (16 lines)
             for (int i = tid; i < WC * kWinY * kWinX; i += nthr) {
-                const float val = (&win[0][0][0])[i];
+                const int cl = i % WC, tex = i / WC;
+                const int wxx = tex % kWinX, wyy = tex / kWinX;
+                const float val = win[cl][wyy][wxx];
                 if (val != 0.0f) {
-                    (&win[0][0][0])[i] = 0.0f;
-                    const int wxx = i % kWinX, r2 = i / kWinX;
-                    const int wyy = r2 % kWinY, cl = r2 / kWinY;
+                    win[cl][wyy][wxx] = 0.0f;
                     unsafeAtomicAdd(gsp + ((long)(wy0 + wyy) * a.Ws + (wx0 + wxx)) * C + cbase + cl, val);
                 }
             }
