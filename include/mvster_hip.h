@@ -158,6 +158,10 @@ int mvster_bn_relu_fwd(const float* x, const float* scale, const float* shift, f
                        int groups, void* stream);
 int mvster_bn_blocks(long rows, int C);
 int mvster_bn_stats(const float* x, float* partial, long rows, int C, int groups, void* stream);
+/* finalize: out [5][groups][C] = mean, biased var, rstd, scale, shift from the partial sums; running_mean / running_var
+ * (optional) get the groups' exponential-average updates in order (momentum, unbiased variance) */
+int mvster_bn_finalize(const float* partial, const float* x, const float* weight, const float* bias, float* running_mean,
+                       float* running_var, float* out, long rows, int C, int groups, float eps, float momentum, void* stream);
 int mvster_bn_relu_bwd_reduce(const float* x, const float* gy, const float* scale, const float* shift, const float* mean,
                               const float* rstd, float* partial, long rows, int C, int relu, int groups, void* stream);
 int mvster_bn_relu_bwd_apply(const float* x, const float* gy, const float* scale, const float* shift, const float* mean,

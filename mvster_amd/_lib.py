@@ -36,6 +36,7 @@ SIGNATURES = {
     "mvster_bn_relu_fwd": [_f, _f, _f, _f, _l, _i, _i, _i, _f],
     "mvster_bn_blocks": [_l, _i],
     "mvster_bn_stats": [_f, _f, _l, _i, _i, _f],
+    "mvster_bn_finalize": [_f] * 7 + [_l, _i, _i, _fl, _fl, _f],
     "mvster_bn_relu_bwd_reduce": [_f] * 7 + [_l, _i, _i, _i, _f],
     "mvster_bn_relu_bwd_apply": [_f] * 8 + [_l, _i, _i, _i, _f],
     "mvster_sinkhorn": [_f, _f, _f, _f, _f, _i, _i, _l, _i, _fl, _f],

@@ -251,24 +251,24 @@ def conv_wgrad(x_cl, gy_cl, kernel, stride, padding):
     return dw.reshape(kd, kh, kw, CO, CI).permute(3, 4, 0, 1, 2).contiguous()
 
 
-def bn_stats(x, groups=1):
-    """Batch statistics of a channels-last tensor [groups*n, ..., C] per group: -> (mean, biased var) [groups, C] (one
-    pass over x; pivoted sums finished in fp64)."""
-    _chk(x, "bn_stats:x")
+def bn_batch_stats(x, weight, bias, running_mean, running_var, eps, momentum, groups=1):
+    """Statistics kernel + device-side finish in two launches: -> pack [5, groups, C] = (mean, biased var, rstd, scale,
+    shift); running_mean / running_var (or None) are updated in place, one exponential-average step per group."""
+    _chk(x, "bn_batch_stats:x")
     C = x.shape[-1]
     rows = x.numel() // C // groups
     lib = _lib.load()
     nblk = lib.mvster_bn_blocks(rows, C)
     if nblk <= 0:
-        raise RuntimeError("bn_stats: unsupported channel count %d" % C)
+        raise RuntimeError("bn_batch_stats: unsupported channel count %d" % C)
     partial = torch.empty(groups, nblk, 2, C, device=x.device, dtype=torch.float32)
     rc = lib.mvster_bn_stats(_ptr(x), _ptr(partial), rows, C, int(groups), _stream())
     _lib.check(rc, "bn_stats")
-    s = partial.double().sum(1) / rows                        # [groups, 2, C]
-    pivot = x.reshape(groups, rows, C)[:, 0]
-    mean = pivot + s[:, 0].float()
-    var = (s[:, 1] - s[:, 0] * s[:, 0]).clamp_min(0).float()
-    return mean, var
+    pack = torch.empty(5, groups, C, device=x.device, dtype=torch.float32)
+    rc = lib.mvster_bn_finalize(_ptr(partial), _ptr(x), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                _ptr(pack), rows, C, int(groups), float(eps), float(momentum), _stream())
+    _lib.check(rc, "bn_finalize")
+    return pack
 
 
 def bn_relu_fwd(x, scale, shift, relu, groups=1):

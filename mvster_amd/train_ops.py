@@ -67,7 +67,6 @@ class _LayerCache:
 
 
 CACHE = _LayerCache()
-_EMA_WEIGHTS = {}
 
 
 class _ConvCL(torch.autograd.Function):
@@ -139,25 +138,21 @@ def conv_cl(x, weight, bias=None, stride=1, padding=0, transposed=False):
 
 
 class _BnReluCL(torch.autograd.Function):
-    """relu(BatchNorm(x)) with batch statistics ([groups, C], one row per statistics group): fused apply kernel
-    forward, two fused kernels backward."""
+    """relu(BatchNorm(x)) given the statistics pack [5, groups, C] = (mean, var, rstd, scale, shift) of
+    ``ops.bn_batch_stats``: fused apply kernel forward, two fused kernels backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, mean, var, eps, relu, groups):
-        rstd = torch.rsqrt(var + eps)
-        scale = (weight * rstd).contiguous()
-        shift = (bias - mean * scale).contiguous()
-        x = x.contiguous()
-        ctx.save_for_backward(x, scale, shift, mean.contiguous(), rstd.contiguous())
+    def forward(ctx, x, weight, bias, pack, relu, groups):
+        ctx.save_for_backward(x, pack)
         ctx.cfg = (relu, groups)
-        return ops.bn_relu_fwd(x, scale, shift, relu, groups)
+        return ops.bn_relu_fwd(x, pack[3], pack[4], relu, groups)
 
     @staticmethod
     def backward(ctx, gy):
-        x, scale, shift, mean, rstd = ctx.saved_tensors
+        x, pack = ctx.saved_tensors
         relu, groups = ctx.cfg
-        dx, dbeta, dgamma = ops.bn_relu_bwd(x, gy.contiguous(), scale, shift, mean, rstd, relu, groups)
-        return dx, dgamma.sum(0), dbeta.sum(0), None, None, None, None, None
+        dx, dbeta, dgamma = ops.bn_relu_bwd(x, gy.contiguous(), pack[3], pack[4], pack[0], pack[2], relu, groups)
+        return dx, dgamma.sum(0), dbeta.sum(0), None, None, None
 
 
 def batch_norm_cl(x, bn, relu=False, groups=1):
@@ -165,44 +160,36 @@ def batch_norm_cl(x, bn, relu=False, groups=1):
     training (torch semantics: biased variance to normalise, unbiased in the running average), running statistics
     in eval.  ``groups`` > 1: x holds that many equal slices along dim 0 (the views of one sample batch) which are
     normalised separately and update the running statistics one after the other, exactly as ``groups`` separate calls
-    of the module would (the reference runs its FPN once per view).  The training form runs the fused gfx950 kernels
-    (mvster_bn_relu_*); gradients flow to x, gamma, beta."""
+    of the module would (the reference runs its FPN once per view).  The training form is four launches of the fused
+    gfx950 kernels (statistics, finish + running averages, apply; mvster_bn_*); gradients flow to x, gamma, beta."""
     C = x.shape[-1]
-    fused = (bn.training or not bn.track_running_stats) and bn.affine and x.is_cuda and C in (4, 8, 16, 32, 64)
-    if bn.training or not bn.track_running_stats:
+    batch_stats = bn.training or not bn.track_running_stats
+    if (batch_stats and bn.affine and x.is_cuda and C in (4, 8, 16, 32, 64)
+            and (bn.momentum is not None or not bn.track_running_stats)):
+        x = x.contiguous()
+        track = bn.track_running_stats
+        with torch.no_grad():
+            pack = ops.bn_batch_stats(x, bn.weight, bn.bias, bn.running_mean if track else None,
+                                      bn.running_var if track else None, bn.eps, bn.momentum or 0.0, groups)
+            if track:
+                bn.num_batches_tracked += groups
+        return _BnReluCL.apply(x, bn.weight, bn.bias, pack, relu, groups)
+    # tensor-level form (eval-mode statistics inside a training graph, cumulative-average momentum, non-affine layers,
+    # odd channel counts)
+    if batch_stats:
         xg = x.reshape(groups, -1, C)
-        if fused:
-            with torch.no_grad():
-                mean, var = ops.bn_stats(x.contiguous(), groups)              # [groups, C]
-        else:
-            var, mean = torch.var_mean(xg, dim=1, unbiased=False)
+        var, mean = torch.var_mean(xg, dim=1, unbiased=False)                  # [groups, C]
         if bn.track_running_stats:
             with torch.no_grad():
                 n = xg.shape[1]
                 unbiased = var * (n / max(n - 1, 1))
-                if bn.momentum is not None:
-                    # `groups` exponential-average updates in a row, closed form (3 launches instead of 4 per group):
-                    # r <- (1-m)^G r + sum_g m (1-m)^(G-1-g) s_g
-                    m = float(bn.momentum)
-                    wkey = (groups, m, x.device)
-                    wts = _EMA_WEIGHTS.get(wkey)
-                    if wts is None:
-                        wts = _EMA_WEIGHTS[wkey] = torch.tensor([m * (1 - m) ** (groups - 1 - g) for g in range(groups)],
-                                                                device=x.device)
-                    bn.num_batches_tracked += groups
-                    bn.running_mean.mul_((1 - m) ** groups).add_(wts @ mean)
-                    bn.running_var.mul_((1 - m) ** groups).add_(wts @ unbiased)
-                else:
-                    for g in range(groups):
-                        bn.num_batches_tracked += 1
-                        mom = 1.0 / float(bn.num_batches_tracked)
-                        bn.running_mean.mul_(1 - mom).add_(mean[g], alpha=mom)
-                        bn.running_var.mul_(1 - mom).add_(unbiased[g], alpha=mom)
-        if fused:
-            return _BnReluCL.apply(x, bn.weight, bn.bias, mean, var, bn.eps, relu, groups)
+                for g in range(groups):
+                    bn.num_batches_tracked += 1
+                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                    bn.running_mean.mul_(1 - mom).add_(mean[g], alpha=mom)
+                    bn.running_var.mul_(1 - mom).add_(unbiased[g], alpha=mom)
     else:
         mean, var = bn.running_mean.expand(groups, C), bn.running_var.expand(groups, C)
-    # unfused form (eval-mode statistics inside a training graph, non-affine layers, odd channel counts)
     scale = torch.rsqrt(var + bn.eps)
     if bn.affine:
         scale = scale * bn.weight
