@@ -168,6 +168,12 @@ int mvster_bn_relu_bwd_apply(const float* x, const float* gy, const float* scale
                              const float* rstd, const float* sums, float* dx, long rows, int C, int relu, int groups,
                              void* stream);
 
+/* Bilinear x2 up-sampling (align_corners=True) of a channels-last map, in [B,h,w,C] -> out [B,2h,2w,C], and its
+ * adjoint gout [B,2h,2w,C] -> gin [B,h,w,C] as a gather (no atomics): the FPN top-down path in training
+ * (models/mvs4net_utils.py:488-496 under autograd).  C % 4 == 0. */
+int mvster_upsample2x_cl_fwd(const float* in, float* out, int B, int h, int w, int C, void* stream);
+int mvster_upsample2x_cl_bwd(const float* gout, float* gin, int B, int h, int w, int C, void* stream);
+
 /* Sinkhorn optimal-transport loss per pixel and its gradient, fused (discrete form, ot_continous=False):
  * attn, hypo [B,D,HW], gt [B,HW] -> loss_pix [B,HW], jac [B,D,HW] = d loss_pix / d attn.  2 <= D <= 8,
  * iters <= 16.  Replaces the per-pixel part of `sinkhorn` (models/mvs4net_utils.py:1096-1142) and its autograd;

@@ -320,3 +320,21 @@ def sinkhorn_pixels(attn, hypo, gt, iters, eps):
                                      float(eps), _stream())
     _lib.check(rc, "sinkhorn")
     return loss_pix, jac
+
+
+def upsample2x_cl(x, backward=False):
+    """Bilinear x2 (align_corners=True) of a channels-last map [B,h,w,C] -> [B,2h,2w,C]; ``backward=True`` is the adjoint
+    [B,2h,2w,C] -> [B,h,w,C]."""
+    _chk(x, "upsample2x_cl")
+    B, H, W, C = x.shape
+    lib = _lib.load()
+    if backward:
+        if (H | W) & 1:
+            raise RuntimeError("upsample2x_cl: the adjoint needs even sizes")
+        out = torch.empty(B, H // 2, W // 2, C, device=x.device, dtype=torch.float32)
+        rc = lib.mvster_upsample2x_cl_bwd(_ptr(x), _ptr(out), B, H // 2, W // 2, C, _stream())
+    else:
+        out = torch.empty(B, 2 * H, 2 * W, C, device=x.device, dtype=torch.float32)
+        rc = lib.mvster_upsample2x_cl_fwd(_ptr(x), _ptr(out), B, H, W, C, _stream())
+    _lib.check(rc, "upsample2x_cl")
+    return out

@@ -201,9 +201,22 @@ def batch_norm_cl(x, bn, relu=False, groups=1):
     return torch.relu(y) if relu else y
 
 
+class _Upsample2xCL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.upsample2x_cl(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.upsample2x_cl(g.contiguous(), backward=True)
+
+
 def upsample2x_cl(x, mode):
-    """F.interpolate(scale_factor=2) of a [B,1,H,W,C] channels-last map (bilinear: align_corners=True)."""
+    """F.interpolate(scale_factor=2) of a [B,1,H,W,C] channels-last map.  Bilinear (align_corners=True, the FPN's
+    top-down path) runs the gfx950 kernel pair (gather-form adjoint, no atomics); nearest is a tensor op."""
     B, D, H, W, C = x.shape
+    if mode == "bilinear" and x.is_cuda and C % 4 == 0:
+        return _Upsample2xCL.apply(x.reshape(B * D, H, W, C)).reshape(B, D, 2 * H, 2 * W, C)
     v = x.reshape(B * D, H, W, C).permute(0, 3, 1, 2)            # NCHW view with channels-last strides
     if mode == "bilinear":
         v = F.interpolate(v, scale_factor=2, mode="bilinear", align_corners=True)

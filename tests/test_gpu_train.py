@@ -387,3 +387,20 @@ def test_fpn_over_all_views_equals_per_view_calls():
     note("fpn_batched_views", worst_grad_rel_l2=worst, worst=name, buffers_rel=bw)
     assert worst <= 2e-4 and bw <= 1e-5
     assert int(bb["conv0.0.bn.num_batches_tracked"]) == nv
+
+
+@pytest.mark.parametrize("B,h,w,C", [(2, 8, 12, 64), (1, 5, 7, 8), (3, 16, 16, 16), (1, 1, 3, 4)])
+def test_upsample2x_cl_forward_and_adjoint(B, h, w, C):
+    """Channels-last bilinear x2 (align_corners=True) and its gather-form adjoint against F.interpolate + autograd."""
+    g = torch.Generator().manual_seed(B * 100 + h)
+    x = torch.randn(B, 1, h, w, C, generator=g)
+    xa = x[:, 0].permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ya = F.interpolate(xa, scale_factor=2, mode="bilinear", align_corners=True)
+    gy = torch.randn(ya.shape, generator=g)
+    ya.backward(gy)
+    xb = x.to(DEV).requires_grad_(True)
+    yb = T.upsample2x_cl(xb, "bilinear")
+    assert tuple(yb.shape) == (B, 1, 2 * h, 2 * w, C)
+    yb.backward(gy.permute(0, 2, 3, 1).unsqueeze(1).contiguous().to(DEV))
+    assert (yb.detach().cpu()[:, 0] - ya.detach().permute(0, 2, 3, 1)).abs().max() <= 1e-6
+    assert (xb.grad.cpu()[:, 0] - xa.grad.permute(0, 2, 3, 1)).abs().max() <= 1e-5
