@@ -404,3 +404,67 @@ def test_upsample2x_cl_forward_and_adjoint(B, h, w, C):
     yb.backward(gy.permute(0, 2, 3, 1).unsqueeze(1).contiguous().to(DEV))
     assert (yb.detach().cpu()[:, 0] - ya.detach().permute(0, 2, 3, 1)).abs().max() <= 1e-6
     assert (xb.grad.cpu()[:, 0] - xa.grad.permute(0, 2, 3, 1)).abs().max() <= 1e-5
+
+
+def test_graphed_train_step_follows_the_eager_trajectory():
+    """GraphedTrainStep (forward + loss + backward + Adam in one hipGraph) against the same steps issued eagerly: same
+    losses step by step and the same parameter movement (the scatter atomics of the warp backward make two eager runs
+    differ in the last bits too, Adam amplifies that: loose bounds)."""
+    from mvster_amd.graph import GraphedTrainStep
+    from mvster_amd.synthetic import randomize_state
+    cfg = dict(arch_mode="fpn", reg_net="reg2d", num_stage=4, fpn_base_channel=8, reg_channel=8, stage_splits=[8, 8, 4, 4],
+               depth_interals_ratio=[0.5, 0.5, 0.5, 1], group_cor=True, group_cor_dim=[8, 8, 4, 4], inverse_depth=True,
+               mono=True, attn_temp=2, attn_fuse_d=True)
+    torch.manual_seed(4)
+    sd = randomize_state(MVS4net(**cfg).state_dict(), seed=6, prob_gain=4.0)
+    H, W, N, B = 128, 192, 3, 2
+    imgs, proj, dv = make_inputs(nviews=N, H=H, W=W, seed=3, batch=B)
+    imgs = [i.to(DEV) for i in imgs]
+    proj = {k: v.to(DEV) for k, v in proj.items()}
+    dv = dv.to(DEV)
+    g = torch.Generator().manual_seed(0)
+    gt = {"stage%d" % s: (500 + 300 * torch.rand(B, H // 2 ** (4 - s), W // 2 ** (4 - s), generator=g)).to(DEV) for s in range(1, 5)}
+    mask = {k: (torch.rand(v.shape, generator=g) > 0.2).float().to(DEV) for k, v in gt.items()}
+
+    def loss_fn(o, g_, m_):
+        return MVS4net_loss(o, g_, m_, stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10, ot_eps=1,
+                            ot_continous=False, mono=True)
+
+    def build():
+        m = MVS4net(**cfg)
+        m.load_state_dict(sd)
+        m.to(DEV).train()
+        return m, torch.optim.Adam(m.parameters(), lr=1e-4, capturable=True)
+
+    m1, o1 = build()
+    eager = []
+    for _ in range(6):
+        o1.zero_grad(set_to_none=False)
+        loss = loss_fn(m1(imgs, proj, dv), gt, mask)[0]
+        loss.backward()
+        o1.step()
+        eager.append(loss.item())
+    m2, o2 = build()
+    step = GraphedTrainStep(m2, o2, loss_fn, imgs, proj, dv, gt, mask, warmup=3)
+    graphed = [step().item() for _ in range(3)]                 # steps 4..6 (capturing does not execute)
+    note("graphed_train_step", eager=eager, graphed=graphed)
+    for a, b in zip(eager[3:], graphed):
+        assert abs(a - b) <= 2e-2 * abs(a), (eager, graphed)
+    assert graphed[-1] < eager[0]
+    moved, worst, worst_name = 0, 0.0, ""
+    for (k, pa), (_, pb) in zip(m1.named_parameters(), m2.named_parameters()):
+        if k.endswith("prob.bias"):
+            continue        # a bias in front of the softmax has zero gradient: Adam turns its rounding noise into steps
+        da, db = pa.detach() - sd[k].to(DEV), pb.detach() - sd[k].to(DEV)
+        if da.norm() > 0:
+            e = ((da - db).norm() / da.norm()).item()
+            if e > worst:
+                worst, worst_name = e, k
+            moved += 1
+    note("graphed_train_step", eager=eager, graphed=graphed, worst_update_rel_l2=worst, worst=worst_name, tensors=moved)
+    assert worst <= 0.3, (worst_name, worst)
+    assert moved > 150        # every learnable tensor (348 state entries include the BatchNorm buffers)
+    # new inputs go through the static buffers
+    before = step().item()
+    other = step(imgs=[i.flip(-1) for i in imgs]).item()
+    assert other != before
