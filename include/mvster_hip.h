@@ -137,12 +137,13 @@ int mvster_pack_conv_weights(const float* w, float* wpk, int cout, int cin, int 
  *   dW[tap][co][ci] = sum_o gy[o][co] * x[o*s - p + tap][ci]      (zero padding)
  * x [B,Di,Hi,Wi,CI], gy [B,Do,Ho,Wo,CO] with (Do,Ho,Wo) the conv output size for (k,s,p); CI, CO <= 64.
  * Workgroup slot n of `partial` [nblk][kd*kh*kw][COP][CIP] (COP/CIP = CO/CI rounded up to 16, 48 -> 64)
- * receives the sum over the output rows that workgroup visited; the caller adds the nblk slots.  With x and gy
- * swapped it is the weight gradient of the transposed convolution.  Replaces autograd's conv weight gradients
+ * receives the sum over the output rows that workgroup visited; the caller adds the nblk slots.  packed = 1 (CI <= 8):
+ * 16/CIP taps share one N tile (CIP = 4 or 8), partial [nblk][ceil(taps/(16/CIP))][COP][16], column = (tap % TPN)*CIP + ci.
+ * With x and gy swapped it is the weight gradient of the transposed convolution.  Replaces autograd's conv weight gradients
  * of nn.Conv3d / nn.Conv2d / nn.ConvTranspose3d (models/mvs4net_utils.py:116-123, :224-251, :870-965, :419-502). */
 int mvster_conv_wgrad(const float* x, const float* gy, float* partial, int nblk, int B, int Di, int Hi, int Wi, int CI,
                       int Do, int Ho, int Wo, int CO, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph,
-                      int pw, void* stream);
+                      int pw, int packed, void* stream);
 
 /* Training-mode BatchNorm + ReLU on channels-last activations (C a power of two, 4..64): the elementwise half of the
  * reference's conv -> BatchNorm -> ReLU blocks (models/mvs4net_utils.py:116-123, :224-251) and its autograd.

@@ -117,6 +117,91 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// Narrow input side (CI <= 8): a 16-wide N tile would be at least half padding, so TPN = 16 / CIP kernel taps share
+// one tile instead: column n = (tap within the group) * CIP + ci.  Every lane then has its own tap, i.e. its own input
+// row and column shift (no longer wave-uniform, but still one address computation per row and lane), and one MFMA
+// does the work of TPN.  blockIdx.y = tap group; partial [nblk][groups][COT*16][16].
+template <int COT, int CIP>
+__global__ void __launch_bounds__(256) conv_wgrad_packed_kernel(WgradArgs a, int ntaps) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [3 waves][COT][64 lanes][4]
+    constexpr int TPN = 16 / CIP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, k = lane >> 4;
+    const int ngroups = gridDim.y;
+    const int tap = blockIdx.y * TPN + r / CIP, ci = r % CIP;
+    const bool vlane = tap < ntaps && ci < a.CI;
+    const int tapc = min(tap, ntaps - 1), cic = min(ci, a.CI - 1);
+    const int kx = tapc % a.kw, ky = (tapc / a.kw) % a.kh, kz = tapc / (a.kw * a.kh);
+
+    f32x4v acc[COT];
+#pragma unroll
+    for (int i = 0; i < COT; ++i) acc[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    int co[COT];
+    bool vco[COT];
+#pragma unroll
+    for (int i = 0; i < COT; ++i) { co[i] = min(i * 16 + r, a.CO - 1); vco[i] = i * 16 + r < a.CO; }
+
+    const int nrows = a.B * a.Do * a.Ho;
+    for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {    // wave-uniform
+        const int yo = row % a.Ho, t = row / a.Ho;
+        const int zo = t % a.Do, b = t / a.Do;
+        const int iz = zo * a.sd - a.pd + kz, iy = yo * a.sh - a.ph + ky;         // per lane
+        const bool vrow = vlane && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi;
+        const int izc = min(max(iz, 0), a.Di - 1), iyc = min(max(iy, 0), a.Hi - 1);
+        const float* grow = a.gy + (long)row * a.Wo * a.CO;
+        const float* xrow = a.x + ((((long)b * a.Di + izc) * a.Hi + iyc) * a.Wi) * a.CI + cic;
+        for (int x1 = 0; x1 < a.Wo; x1 += 16) {
+            float av[4][COT], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int xo = x1 + u * 4 + k;
+                const int ix = xo * a.sw - a.pw + kx;
+                const bool vo = xo < a.Wo;
+                const bool vi = vo && vrow && (unsigned)ix < (unsigned)a.Wi;
+                const int xoc = min(xo, a.Wo - 1);
+                const int ixc = min(max(ix, 0), a.Wi - 1);
+#pragma unroll
+                for (int i = 0; i < COT; ++i) {
+                    const float v = grow[xoc * a.CO + co[i]];
+                    av[u][i] = (vo && vco[i]) ? v : 0.0f;
+                }
+                const float v = xrow[ixc * a.CI];
+                bv[u] = vi ? v : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < COT; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u], acc[i], 0, 0, 0);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < COT; ++i)
+            *reinterpret_cast<f32x4v*>(&red[(((wave - 1) * COT + i) * 64 + lane) * 4]) = acc[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* out = a.partial + ((long)blockIdx.x * ngroups + blockIdx.y) * (COT * 16) * 16;
+#pragma unroll
+        for (int i = 0; i < COT; ++i) {
+            f32x4v s = acc[i];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) s += *reinterpret_cast<const f32x4v*>(&red[((w * COT + i) * 64 + lane) * 4]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[(i * 16 + 4 * k + q) * 16 + r] = s[q];
+        }
+    }
+}
+
+template <int COT, int CIP>
+int launch_wgrad_packed(const WgradArgs& a, int nblk, int ntaps, hipStream_t s) {
+    constexpr int TPN = 16 / CIP;
+    const size_t lds = (size_t)3 * COT * 256 * sizeof(float);
+    hipLaunchKernelGGL((conv_wgrad_packed_kernel<COT, CIP>), dim3(nblk, (ntaps + TPN - 1) / TPN), dim3(256), lds, s, a, ntaps);
+    return mv_check_launch();
+}
+
 template <int COT, int CIT>
 int launch_wgrad(const WgradArgs& a, int nblk, int ntaps, hipStream_t s) {
     const size_t lds = (size_t)3 * COT * CIT * 256 * sizeof(float);
@@ -128,9 +213,12 @@ int launch_wgrad(const WgradArgs& a, int nblk, int ntaps, hipStream_t s) {
 
 // x [B,Di,Hi,Wi,CI], gy [B,Do,Ho,Wo,CO] (channels-last, contiguous); partial [nblk][kd*kh*kw][COP][CIP] with
 // COP / CIP = CO / CI rounded up to 16 (<= 64).  Do/Ho/Wo must be the conv's output size for (k, s, p).
+// packed = 0: partial [nblk][taps][COP][CIP16] (one kernel tap per N tile).
+// packed = 1 (CI <= 8): partial [nblk][ceil(taps/TPN)][COP][16] with TPN = 16/CIP taps per tile, CIP = 4 or 8 (CI rounded
+// up); column n of a tile = (tap % TPN) * CIP + ci.
 extern "C" int mvster_conv_wgrad(const float* x, const float* gy, float* partial, int nblk, int B, int Di, int Hi, int Wi,
                                  int CI, int Do, int Ho, int Wo, int CO, int kd, int kh, int kw, int sd, int sh, int sw,
-                                 int pd, int ph, int pw, void* stream) {
+                                 int pd, int ph, int pw, int packed, void* stream) {
     if (!x || !gy || !partial) return MVSTER_ERR_NULL;
     if (B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || nblk <= 0 || kd <= 0 || kh <= 0 ||
         kw <= 0 || sd <= 0 || sh <= 0 || sw <= 0 || pd < 0 || ph < 0 || pw < 0)
@@ -146,6 +234,14 @@ extern "C" int mvster_conv_wgrad(const float* x, const float* gy, float* partial
     const int cot = (CO + 15) / 16 == 3 ? 4 : (CO + 15) / 16, cit = (CI + 15) / 16 == 3 ? 4 : (CI + 15) / 16;
     const int ntaps = kd * kh * kw;
     hipStream_t s = (hipStream_t)stream;
+    if (packed) {
+        if (CI > 8) return MVSTER_ERR_UNSUPPORTED;
+        const int cip = CI <= 4 ? 4 : 8;
+#define MV_P(A_, B_) if (cot == A_ && cip == B_) return launch_wgrad_packed<A_, B_>(a, nblk, ntaps, s);
+        MV_P(1, 4) MV_P(1, 8) MV_P(2, 4) MV_P(2, 8) MV_P(4, 4) MV_P(4, 8)
+#undef MV_P
+        return MVSTER_ERR_UNSUPPORTED;
+    }
 #define MV_W(A_, B_) if (cot == A_ && cit == B_) return launch_wgrad<A_, B_>(a, nblk, ntaps, s);
     MV_W(1, 1) MV_W(1, 2) MV_W(1, 4) MV_W(2, 1) MV_W(2, 2) MV_W(2, 4) MV_W(4, 1) MV_W(4, 2) MV_W(4, 4)
 #undef MV_W

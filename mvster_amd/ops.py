@@ -238,16 +238,27 @@ def conv_wgrad(x_cl, gy_cl, kernel, stride, padding):
     if B2 != B:
         raise RuntimeError("conv_wgrad: batch mismatch")
     ntaps = kd * kh * kw
-    cop, cip = _wgrad_tiles(CO) * 16, _wgrad_tiles(CI) * 16
+    cop = _wgrad_tiles(CO) * 16
+    packed = CI <= 8 and ntaps > 1            # narrow input side: 16/CIP kernel taps share one MFMA N tile
+    if packed:
+        cip = 4 if CI <= 4 else 8
+        tpn = 16 // cip
+        ngrp, width = -(-ntaps // tpn), 16
+    else:
+        cip = _wgrad_tiles(CI) * 16
+        ngrp, width = ntaps, cip
     rows = B * Do * Ho
-    slot_bytes = ntaps * cop * cip * 4
+    slot_bytes = ngrp * cop * width * 4
     nblk = max(1, min((rows + 3) // 4, (32 << 20) // slot_bytes, 1024))
-    partial = torch.empty(nblk, ntaps, cop, cip, device=x_cl.device, dtype=torch.float32)
+    partial = torch.empty(nblk, ngrp, cop, width, device=x_cl.device, dtype=torch.float32)
     rc = _lib.load().mvster_conv_wgrad(_ptr(x_cl), _ptr(gy_cl), _ptr(partial), nblk, B, Di, Hi, Wi, CI, Do, Ho, Wo, CO,
                                        kd, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
-                                       _stream())
+                                       int(packed), _stream())
     _lib.check(rc, "conv_wgrad")
-    dw = partial.sum(0)[:, :CO, :CI]                                     # [taps, CO, CI]
+    dw = partial.sum(0)                                                   # [groups, COP, width]
+    if packed:
+        dw = dw.reshape(ngrp, cop, tpn, cip).permute(0, 2, 1, 3).reshape(ngrp * tpn, cop, cip)[:ntaps]
+    dw = dw[:, :CO, :CI]                                                  # [taps, CO, CI]
     return dw.reshape(kd, kh, kw, CO, CI).permute(3, 4, 0, 1, 2).contiguous()
 
 
