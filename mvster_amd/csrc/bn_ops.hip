@@ -77,46 +77,53 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__
     }
 }
 
-// Finish the statistics on the device (one launch instead of ~20 tiny tensor ops per BatchNorm call): reduce the
-// per-workgroup partial sums in fp64, form mean / biased variance / rstd / scale / shift per (group, channel) and apply
-// the running-average updates of the groups one after the other (what `groups` sequential module calls would do).
-// One workgroup; thread t owns channel t % C and every (256 / C)-th partial slot.
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ x,
-                                                          const float* __restrict__ weight, const float* __restrict__ bias,
-                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                          float* __restrict__ out, long rows, int C, int groups, int nblk,
-                                                          float eps, float momentum) {
-    __shared__ double red[2][256];
-    const int c = threadIdx.x % C, sl = threadIdx.x / C, nsl = 256 / C;
-    for (int g = 0; g < groups; ++g) {
-        const float* pg = partial + (long)g * nblk * 2 * C;
-        double s1 = 0.0, s2 = 0.0;
-        for (int n = sl; n < nblk; n += nsl) {
-            s1 += (double)pg[((long)n * 2 + 0) * C + c];
-            s2 += (double)pg[((long)n * 2 + 1) * C + c];
-        }
-        red[0][threadIdx.x] = s1;
-        red[1][threadIdx.x] = s2;
-        __syncthreads();
-        if (threadIdx.x < C) {
-            for (int j = 1; j < nsl; ++j) { s1 += red[0][j * C + c]; s2 += red[1][j * C + c]; }
-            const double m1 = s1 / (double)rows, m2 = s2 / (double)rows;
-            const float mean = x[(long)g * rows * C + c] + (float)m1;
-            float var = (float)(m2 - m1 * m1);
-            var = var > 0.0f ? var : 0.0f;
-            const float rstd = 1.0f / sqrtf(var + eps);
-            const float scale = weight[c] * rstd;
-            float* o = out + (long)g * C + c;
-            const long gs = (long)groups * C;
-            o[0] = mean; o[gs] = var; o[2 * gs] = rstd; o[3 * gs] = scale; o[4 * gs] = bias[c] - mean * scale;
-            if (running_mean) {
-                const float unbiased = var * ((float)rows / (float)(rows > 1 ? rows - 1 : 1));
-                running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
-                running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
-            }
-        }
-        __syncthreads();
+// Finish the statistics on the device (two launches instead of ~20 tiny tensor ops per BatchNorm call): reduce the
+// per-workgroup partial sums in fp64 and form mean / biased variance / rstd / scale / shift per (group, channel)
+// [bn_finalize_kernel, one workgroup of 1024 threads per group: thread t owns channel t % C and every (1024 / C)-th
+// partial slot], then apply the running-average updates of the groups one after the other (what `groups` sequential
+// module calls would do) [bn_running_kernel, one thread per channel].
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ x,
+                                                           const float* __restrict__ weight, const float* __restrict__ bias,
+                                                           float* __restrict__ out, long rows, int C, int groups, int nblk,
+                                                           float eps) {
+    __shared__ double red[2][1024];
+    const int g = blockIdx.x;
+    const int c = threadIdx.x % C, sl = threadIdx.x / C, nsl = 1024 / C;
+    const float* pg = partial + (long)g * nblk * 2 * C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = sl; n < nblk; n += nsl) {
+        s1 += (double)pg[((long)n * 2 + 0) * C + c];
+        s2 += (double)pg[((long)n * 2 + 1) * C + c];
     }
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        for (int j = 1; j < nsl; ++j) { s1 += red[0][j * C + c]; s2 += red[1][j * C + c]; }
+        const double m1 = s1 / (double)rows, m2 = s2 / (double)rows;
+        const float mean = x[(long)g * rows * C + c] + (float)m1;
+        float var = (float)(m2 - m1 * m1);
+        var = var > 0.0f ? var : 0.0f;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        const float scale = weight[c] * rstd;
+        float* o = out + (long)g * C + c;
+        const long gs = (long)groups * C;
+        o[0] = mean; o[gs] = var; o[2 * gs] = rstd; o[3 * gs] = scale; o[4 * gs] = bias[c] - mean * scale;
+    }
+}
+
+__global__ void bn_running_kernel(const float* __restrict__ out, float* __restrict__ running_mean,
+                                  float* __restrict__ running_var, long rows, int C, int groups, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float unbias = (float)rows / (float)(rows > 1 ? rows - 1 : 1);
+    float rm = running_mean[c], rv = running_var[c];
+    for (int g = 0; g < groups; ++g) {
+        rm = (1.0f - momentum) * rm + momentum * out[(long)g * C + c];
+        rv = (1.0f - momentum) * rv + momentum * (out[((long)groups + g) * C + c] * unbias);
+    }
+    running_mean[c] = rm;
+    running_var[c] = rv;
 }
 
 __global__ void __launch_bounds__(256) bn_relu_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ gy,
@@ -238,8 +245,11 @@ extern "C" int mvster_bn_finalize(const float* partial, const float* x, const fl
     if (int rc = check(rows, C)) return rc;
     if (groups < 1 || groups > 65535) return MVSTER_ERR_SHAPE;
     const int nblk = blocks_for(rows * (C / 4));
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, x, weight, bias, running_mean,
-                       running_var, out, rows, C, groups, nblk, eps, momentum);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(groups), dim3(1024), 0, (hipStream_t)stream, partial, x, weight, bias, out, rows,
+                       C, groups, nblk, eps);
+    if (running_mean)
+        hipLaunchKernelGGL(bn_running_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out, running_mean, running_var, rows, C,
+                           groups, momentum);
     return mv_check_launch();
 }
 
