@@ -121,6 +121,11 @@ class _ConvCL(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if transposed:
                 gw = ops.conv_wgrad(gy, xp, kernel, stride, padding)[:cin]          # [cin, cout, k]
+            elif stride == (1, 1, 1) and gy.shape[-1] <= 8 < xp.shape[-1] and kernel != (1, 1, 1):
+                # narrow OUTPUT side: the mirrored sum  dW[co][ci][t] = sum_q x[q][ci] * gy[q + p - t][co]  has gy as the
+                # shifted tensor, so the tap-packed kernel applies with the roles swapped (taps and padding mirrored)
+                mirror = tuple(k - 1 - p for k, p in zip(kernel, padding))
+                gw = ops.conv_wgrad(gy, xp, kernel, stride, mirror).flip(2, 3, 4).transpose(0, 1)[:, :cin]
             else:
                 gw = ops.conv_wgrad(xp, gy, kernel, stride, padding)[:, :cin]       # [cout, cin, k]
             if weight.dim() == 4:
