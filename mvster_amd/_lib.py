@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmvster_hip.so")
+LIB_PATH = os.environ.get("MVSTER_LIB") or os.path.join(_HERE, "csrc", "libmvster_hip.so")   # env: A/B builds
 
 ERRORS = {-1: "NULL pointer", -2: "bad shape", -3: "unsupported channel/tile combination", -4: "kernel launch failed"}
 
