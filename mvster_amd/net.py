@@ -82,6 +82,9 @@ class MVS4net(nn.Module):
         if dcn or asff or pos_enc or vis_ETA or vis_mono:
             raise NotImplementedError("dcn / asff / pos_enc / vis_* ablation switches are out of scope "
                                       "(SURVEY.md section 2, #10): not enabled by the shipped scripts")
+        if max(stage_splits) > 16 or min(stage_splits) < 3:
+            raise NotImplementedError("stage_splits %r: the fused kernels hold 3..16 depth hypotheses per pixel (the "
+                                      "shipped cascade uses 8/8/4/4; inverse-depth ranges need at least 3)" % (stage_splits,))
         self.arch_mode = arch_mode
         self.num_stage = num_stage
         self.depth_interals_ratio = list(depth_interals_ratio)
