@@ -266,3 +266,28 @@ def test_under_data_parallel(shipped_cfg, checkpoint):
             assert isinstance(v, torch.Tensor), (s, k)
     state = dp.state_dict()
     assert all(k.startswith("module.") for k in state) and len(state) == len(m.state_dict())
+
+
+@pytest.mark.parametrize("B,N", [(2, 2), (1, 9), (3, 4)])
+def test_batch_and_view_counts_vs_oracle(shipped_cfg, checkpoint, B, N):
+    """Batch sizes and view counts other than the benchmark's (one source view; nine views; batch 3): shipped
+    configuration, teacher-forced against the CPU oracle."""
+    oracle = O.OracleMVS4net(**shipped_cfg)
+    oracle.load_state_dict(checkpoint, strict=True)
+    oracle.eval()
+    m = MVS4net(**shipped_cfg)
+    m.load_state_dict(checkpoint, strict=True)
+    m.to(DEV).eval()
+    imgs, proj, dv = make_inputs(nviews=N, H=64, W=128, seed=B * 10 + N, batch=B)
+    with torch.no_grad():
+        want = oracle(imgs, proj, dv)
+    teacher = {"stage%d" % s: want["stage%d" % s]["hypo_depth"].to(DEV) for s in range(1, 5)}
+    got = m._forward_eval(*to_dev(imgs, proj, dv), teacher=teacher)
+    for s in range(1, 5):
+        st, wt = got["stage%d" % s], want["stage%d" % s]
+        assert tuple(st["depth"].shape) == tuple(wt["depth"].shape)
+        assert (st["attn_weight"].cpu() - wt["attn_weight"]).abs().max() <= 1e-3, (B, N, s)
+        top2 = wt["attn_weight"].topk(2, dim=1)[0]
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-3
+        assert (st["depth"].cpu() - wt["depth"])[clear].abs().mean() < 1e-4, (B, N, s)
+    assert tuple(got["photometric_confidence"].shape) == (B, 64, 128)
