@@ -21,6 +21,8 @@
 // view parity, one barrier per view) and every lane reduces the D scores of its pixel.
 //
 // Roofline: HBM-bound.  Algorithmic bytes per launch = 4*[(NV+1)*C*hw + D*hw + G*D*hw]*B.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -465,6 +467,7 @@ struct WarpAggBwdArgs {
 // atomics at all: each reference pixel belongs to exactly one workgroup, which sums over depths and views in
 // LDS and stores once.
 constexpr int kWinX = 96, kWinY = 6;
+static const bool g_bwd_no_tiles = getenv("MVSTER_BWD_NO_TILES") != nullptr;   // experiment switch
 
 template <int C, int G, bool GROUP, int DMAX>
 __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs ba) {
@@ -664,10 +667,263 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
     for (int i = tid; i < npix * C; i += nthr) grp[i] = gref[i % C][i / C];
 }
 
+// 2-D tile form for the narrow feature maps (C <= 16, the two fine stages, where this kernel's time is): one
+// workgroup owns 64 columns x R consecutive reference rows and keeps ONE scatter window per view for all of them.
+// The kernel runs at the memory-side atomic rate of the part (~18 G fp32 atomics/s whatever their pattern), and a
+// bilinear footprint makes neighbouring reference rows hit the same two source rows, so R rows need R + 2 window
+// rows instead of 3 R: about half the atomics.  Same arithmetic as warp_agg_bwd_kernel.
+template <int C, int G, bool GROUP, int R>
+__global__ void __launch_bounds__(64 * 8) warp_agg_bwd_tile_kernel(WarpAggBwdArgs ba, int tiles_x) {
+    const WarpAggArgs& a = ba.f;
+    constexpr int CG = C / G;
+    static_assert(C <= 16 && (C == 8 || C == 16) && CG <= 8, "narrow maps: one or two 8-channel window passes");
+    constexpr int GB = 8 / CG;
+    constexpr int WY = R + 6;
+    __shared__ float sc[2][8][64];
+    __shared__ float sd[2][8][64];
+    __shared__ float corL[G][8 * 64];
+    __shared__ float gref[R][C][64];
+    __shared__ float win[8][WY][kWinX];
+    __shared__ int worg[2];
+
+    const int tx = threadIdx.x;
+    const int d = threadIdx.y;
+    const int tid = d * 64 + tx;
+    const int nthr = 64 * blockDim.y;
+    const int b = blockIdx.y;
+    const int hw = a.h * a.w;
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int x0 = (int)(bid % tiles_x) * 64, y0 = (int)(bid / tiles_x) * R;
+    const int x = min(x0 + tx, a.w - 1);
+    const bool vcol = x0 + tx < a.w;
+
+    for (int i = tid; i < R * C * 64; i += nthr) (&gref[0][0][0])[i] = 0.0f;
+    for (int i = tid; i < 8 * WY * kWinX; i += nthr) (&win[0][0][0])[i] = 0.0f;
+
+    for (int v = 0; v < a.NV; ++v) {
+        mv::RT m;
+        {
+            const float* rr = a.rt + ((long)b * a.NV + v) * 12;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) m.r[i] = rr[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) m.t[i] = rr[9 + i];
+        }
+        const long voff = (long)v * a.src_vs + (long)b * a.src_bs;
+        const float* sp = a.src + voff;
+        float* gsp = ba.grad_src + voff;
+        // window origin over all rows of the tile
+        if (tid == 0) { worg[0] = 0x7fffffff; worg[1] = 0x7fffffff; }
+        __syncthreads();
+        {
+            int mnx = 0x7fffffff, mny = 0x7fffffff;
+            for (int r = 0; r < R; ++r) {
+                const int y = y0 + r;
+                if (y >= a.h) break;
+                const float depth = a.hypo[((long)b * a.D + d) * hw + (long)y * a.w + x];
+                float sx, sy;
+                mv::project(m, (float)x, (float)y, depth, a.Hs, a.Ws, sx, sy);
+                mv::Taps t = mv::make_taps(sx, sy, a.Hs, a.Ws);
+                const mv::TapsClamped tc = mv::clamp_taps(t, a.Hs, a.Ws);
+                if (vcol && (t.nw != 0.0f || t.ne != 0.0f || t.sw != 0.0f || t.se != 0.0f)) {
+                    mnx = min(mnx, tc.xa);
+                    mny = min(mny, tc.ya);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                mnx = min(mnx, __shfl_xor(mnx, off));
+                mny = min(mny, __shfl_xor(mny, off));
+            }
+            if (tx == 0) { atomicMin(&worg[0], mnx); atomicMin(&worg[1], mny); }
+        }
+        __syncthreads();
+        const int wx0 = worg[0], wy0 = worg[1];
+
+        for (int r = 0; r < R; ++r) {
+            const int y = min(y0 + r, a.h - 1);
+            const bool valid = vcol && y0 + r < a.h;
+            const long o = ((long)b * a.D + d) * hw + (long)y * a.w + x;
+            const float depth = a.hypo[o];
+            const float* rp = a.ref + (long)b * a.ref_bs + ((long)y * a.w + x) * C;
+            const float invW = 1.0f / ba.wsum[o];
+            float go[G];
+            float common = 0.0f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                go[g] = valid ? ba.grad_out[o * G + g] : 0.0f;
+                common = fmaf(go[g], ba.fwd_out[o * G + g], common);
+            }
+            float sx, sy;
+            mv::project(m, (float)x, (float)y, depth, a.Hs, a.Ws, sx, sy);
+            mv::Taps t = mv::make_taps(sx, sy, a.Hs, a.Ws);
+            const mv::TapsClamped tc = mv::clamp_taps(t, a.Hs, a.Ws);
+            const long o00 = ((long)tc.ya * a.Ws + tc.xa) * C, o01 = ((long)tc.ya * a.Ws + tc.xb) * C;
+            const long o10 = ((long)tc.yb * a.Ws + tc.xa) * C, o11 = ((long)tc.yb * a.Ws + tc.xb) * C;
+
+            // pass 1: correlations and score (same arithmetic as the forward)
+            float score = 0.0f;
+#pragma unroll
+            for (int cb = 0; cb < C / 8; ++cb) {
+                float part[GB];
+#pragma unroll
+                for (int c0 = 0; c0 < 8; c0 += 4) {
+                    const f32x4 Rv = ld4(rp + cb * 8 + c0);
+                    const f32x4 A = ld4(sp + o00 + cb * 8 + c0), Bq = ld4(sp + o01 + cb * 8 + c0);
+                    const f32x4 Cq = ld4(sp + o10 + cb * 8 + c0), Dq = ld4(sp + o11 + cb * 8 + c0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = c0 + j;
+                        const float wv = mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
+                        if (GROUP) {
+                            const float pr = mv::mul_rn(wv, Rv[j]);
+                            part[c / CG] = (c % CG == 0) ? pr : mv::add_rn(part[c / CG], pr);
+                        } else {
+                            const float df = mv::sub_rn(Rv[j], wv);
+                            part[c] = mv::mul_rn(df, df);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < GB; ++k) {
+                    const float cg = GROUP ? mv::div_rn(part[k], (float)CG) : part[k];
+                    corL[cb * GB + k][tid] = cg;
+                    score = (cb == 0 && k == 0) ? cg : mv::add_rn(score, cg);
+                }
+            }
+            score = mv::div_rn(score, a.attn_temp);
+            const int par = r & 1;
+            sc[par][d][tx] = score;
+            __syncthreads();
+            float mx = sc[par][0][tx];
+            for (int j = 1; j < a.D; ++j) mx = fmaxf(mx, sc[par][j][tx]);
+            float den = 0.0f;
+            for (int j = 0; j < a.D; ++j) den += expf(sc[par][j][tx] - mx);
+            const float sig = expf(score - mx) / den;
+            const float wgt = sig / a.sqrt_c;
+            float dw = -common;
+#pragma unroll
+            for (int g = 0; g < G; ++g) dw = fmaf(go[g], corL[g][tid], dw);
+            dw *= invW;
+            const float dsig = dw / a.sqrt_c;
+            sd[par][d][tx] = sig * dsig;
+            __syncthreads();
+            float dot = 0.0f;
+            for (int j = 0; j < a.D; ++j) dot += sd[par][j][tx];
+            const float dscore = sig * (dsig - dot) / a.attn_temp;
+            const int ax = tc.xa - wx0, bx = tc.xb - wx0, ay = tc.ya - wy0, by = tc.yb - wy0;
+            const bool iax = (unsigned)ax < (unsigned)kWinX, ibx = (unsigned)bx < (unsigned)kWinX;
+            const bool iay = (unsigned)ay < (unsigned)WY, iby = (unsigned)by < (unsigned)WY;
+
+            // pass 2: scatter into the tile's window (first 8 channels; a 16-channel map takes a second window pass)
+            if (valid) {
+#pragma unroll
+                for (int c0 = 0; c0 < 8; c0 += 4) {
+                    const f32x4 Rv = ld4(rp + c0);
+                    const f32x4 A = ld4(sp + o00 + c0), Bq = ld4(sp + o01 + c0);
+                    const f32x4 Cq = ld4(sp + o10 + c0), Dq = ld4(sp + o11 + c0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = c0 + j;
+                        const int g = GROUP ? c / CG : c;
+                        const float dcor = fmaf(go[g] * invW, wgt, dscore);
+                        const float wv = mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
+                        float dwv, dref;
+                        if (GROUP) {
+                            dwv = dcor * (1.0f / CG) * Rv[j];
+                            dref = dcor * (1.0f / CG) * wv;
+                        } else {
+                            const float df = Rv[j] - wv;
+                            dref = 2.0f * df * dcor;
+                            dwv = -dref;
+                        }
+                        unsafeAtomicAdd(&gref[r][c][tx], dref);
+                        if (t.nw != 0.0f) {
+                            if (iax && iay) unsafeAtomicAdd(&win[c][ay][ax], t.nw * dwv);
+                            else unsafeAtomicAdd(gsp + o00 + c, t.nw * dwv);
+                        }
+                        if (t.ne != 0.0f) {
+                            if (ibx && iay) unsafeAtomicAdd(&win[c][ay][bx], t.ne * dwv);
+                            else unsafeAtomicAdd(gsp + o01 + c, t.ne * dwv);
+                        }
+                        if (t.sw != 0.0f) {
+                            if (iax && iby) unsafeAtomicAdd(&win[c][by][ax], t.sw * dwv);
+                            else unsafeAtomicAdd(gsp + o10 + c, t.sw * dwv);
+                        }
+                        if (t.se != 0.0f) {
+                            if (ibx && iby) unsafeAtomicAdd(&win[c][by][bx], t.se * dwv);
+                            else unsafeAtomicAdd(gsp + o11 + c, t.se * dwv);
+                        }
+                    }
+                }
+                if (C == 16) {
+                    // channels 8..15 bypass the window (one window pass per view keeps the tile loop simple); they are the
+                    // minority of this kernel's time: stage 3 has a quarter of stage 4's pixels
+#pragma unroll
+                    for (int c0 = 8; c0 < C; c0 += 4) {
+                        const f32x4 Rv = ld4(rp + c0);
+                        const f32x4 A = ld4(sp + o00 + c0), Bq = ld4(sp + o01 + c0);
+                        const f32x4 Cq = ld4(sp + o10 + c0), Dq = ld4(sp + o11 + c0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int c = c0 + j;
+                            const int g = GROUP ? c / CG : c;
+                            const float dcor = fmaf(go[g] * invW, wgt, dscore);
+                            const float wv = mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
+                            float dwv, dref;
+                            if (GROUP) {
+                                dwv = dcor * (1.0f / CG) * Rv[j];
+                                dref = dcor * (1.0f / CG) * wv;
+                            } else {
+                                const float df = Rv[j] - wv;
+                                dref = 2.0f * df * dcor;
+                                dwv = -dref;
+                            }
+                            unsafeAtomicAdd(&gref[r][c][tx], dref);
+                            if (t.nw != 0.0f) unsafeAtomicAdd(gsp + o00 + c, t.nw * dwv);
+                            if (t.ne != 0.0f) unsafeAtomicAdd(gsp + o01 + c, t.ne * dwv);
+                            if (t.sw != 0.0f) unsafeAtomicAdd(gsp + o10 + c, t.sw * dwv);
+                            if (t.se != 0.0f) unsafeAtomicAdd(gsp + o11 + c, t.se * dwv);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 8 * WY * kWinX; i += nthr) {
+            const int cl = i % 8, tex = i / 8;
+            const int wxx = tex % kWinX, wyy = tex / kWinX;
+            const float val = win[cl][wyy][wxx];
+            if (val != 0.0f) {
+                win[cl][wyy][wxx] = 0.0f;
+                unsafeAtomicAdd(gsp + ((long)(wy0 + wyy) * a.Ws + (wx0 + wxx)) * C + cl, val);
+            }
+        }
+        __syncthreads();
+    }
+    // reference gradients of the tile: plain stores
+    for (int r = 0; r < R; ++r) {
+        const int y = y0 + r;
+        if (y >= a.h) break;
+        float* grp = ba.grad_ref + (long)b * a.ref_bs + ((long)y * a.w + x0) * C;
+        const int npix = min(64, a.w - x0);
+        for (int i = tid; i < npix * C; i += nthr) grp[i] = gref[r][i % C][i / C];
+    }
+}
+
 template <int C, int G, bool GROUP>
 int launch_bwd(const WarpAggBwdArgs& ba, hipStream_t stream) {
     const WarpAggArgs& a = ba.f;
     if (a.D > 8) return MVSTER_ERR_UNSUPPORTED;
+    if constexpr (C == 8 && C / G <= 8) {
+        if (!g_bwd_no_tiles) {
+            constexpr int R = 4;
+            const int tiles_x = (a.w + 63) / 64, tiles_y = (a.h + R - 1) / R;
+            hipLaunchKernelGGL((warp_agg_bwd_tile_kernel<C, G, GROUP, R>), dim3(tiles_x * tiles_y, a.B), dim3(64, a.D), 0, stream,
+                               ba, tiles_x);
+            return mv_check_launch();
+        }
+    }
     dim3 block(64, a.D);
     dim3 grid((a.h * a.w + 63) / 64, a.B);
     hipLaunchKernelGGL((warp_agg_bwd_kernel<C, G, GROUP, 8>), grid, block, 0, stream, ba);
