@@ -37,62 +37,85 @@ def remap_linear(src, map_x, map_y):
     return (tap(iy, ix) * w00 + tap(iy, ix + 1) * w01 + tap(iy + 1, ix) * w10 + tap(iy + 1, ix + 1) * w11).astype(np.float32)
 
 
-def reproject_with_depth(depth_ref, intrinsics_ref, extrinsics_ref, depth_src, intrinsics_src, extrinsics_src):
-    """test_mvs4.py:273-310."""
-    width, height = depth_ref.shape[1], depth_ref.shape[0]
-    x_ref, y_ref = np.meshgrid(np.arange(0, width), np.arange(0, height))
-    x_ref, y_ref = x_ref.reshape([-1]), y_ref.reshape([-1])
-    xyz_ref = np.matmul(np.linalg.inv(intrinsics_ref), np.vstack((x_ref, y_ref, np.ones_like(x_ref))) * depth_ref.reshape([-1]))
-    xyz_src = np.matmul(np.matmul(extrinsics_src, np.linalg.inv(extrinsics_ref)), np.vstack((xyz_ref, np.ones_like(x_ref))))[:3]
-    K_xyz_src = np.matmul(intrinsics_src, xyz_src)
-    xy_src = K_xyz_src[:2] / K_xyz_src[2:3]
-    x_src = xy_src[0].reshape([height, width]).astype(np.float32)
-    y_src = xy_src[1].reshape([height, width]).astype(np.float32)
-    sampled_depth_src = remap_linear(depth_src, x_src, y_src)
-    xyz_src = np.matmul(np.linalg.inv(intrinsics_src), np.vstack((xy_src, np.ones_like(x_ref))) * sampled_depth_src.reshape([-1]))
-    xyz_reprojected = np.matmul(np.matmul(extrinsics_ref, np.linalg.inv(extrinsics_src)), np.vstack((xyz_src, np.ones_like(x_ref))))[:3]
-    depth_reprojected = xyz_reprojected[2].reshape([height, width]).astype(np.float32)
-    K_xyz_reprojected = np.matmul(intrinsics_ref, xyz_reprojected)
+def _pixel_grid(height, width):
+    """Homogeneous integer pixel coordinates [3, H*W] (x fastest), as np.meshgrid + vstack give them (int64)."""
+    xs, ys = np.meshgrid(np.arange(0, width), np.arange(0, height))
+    return np.vstack((xs.reshape(-1), ys.reshape(-1), np.ones(height * width, dtype=xs.dtype)))
+
+
+def _lift(K, pix_h, depth_flat):
+    """inv(K) (float32, like np.linalg.inv of a float32 matrix) times depth-scaled homogeneous pixels (float64)."""
+    return np.matmul(np.linalg.inv(K), pix_h * depth_flat)
+
+
+def _rigid(E_to, E_from, pts):
+    """Points of camera `from` in camera `to`: (E_to inv(E_from)) in float32, applied to float64 homogeneous points."""
+    rel = np.matmul(E_to, np.linalg.inv(E_from))
+    return np.matmul(rel, np.vstack((pts, np.ones((1, pts.shape[1]), dtype=np.int64))))[:3]
+
+
+def _perspective(K, pts):
+    uvw = np.matmul(K, pts)
     with np.errstate(divide="ignore", invalid="ignore"):
-        xy_reprojected = K_xyz_reprojected[:2] / K_xyz_reprojected[2:3]
-    x_reprojected = xy_reprojected[0].reshape([height, width]).astype(np.float32)
-    y_reprojected = xy_reprojected[1].reshape([height, width]).astype(np.float32)
-    return depth_reprojected, x_reprojected, y_reprojected, x_src, y_src
+        return uvw[:2] / uvw[2:3]
+
+
+def reproject_with_depth(depth_ref, intrinsics_ref, extrinsics_ref, depth_src, intrinsics_src, extrinsics_src):
+    """Round trip reference pixel -> source view -> back, with the source depth sampled in between.  Restates
+    test_mvs4.py:273-310 step by step (lift with the reference depth :280-281, source camera :283-284, source
+    pixels :286-287, remap :291-293, lift with the sampled depth :298-299, back :301-302, re-project :304-308);
+    returns (depth_reprojected, x_reprojected, y_reprojected, x_src, y_src) as float32 maps."""
+    height, width = depth_ref.shape
+    grid = _pixel_grid(height, width)
+    in_src_cam = _rigid(extrinsics_src, extrinsics_ref, _lift(intrinsics_ref, grid, depth_ref.reshape(-1)))
+    xy_src = _perspective(intrinsics_src, in_src_cam)
+    x_src = xy_src[0].reshape(height, width).astype(np.float32)
+    y_src = xy_src[1].reshape(height, width).astype(np.float32)
+    sampled = remap_linear(depth_src, x_src, y_src)
+    src_h = np.vstack((xy_src, np.ones((1, height * width), dtype=np.int64)))
+    back = _rigid(extrinsics_ref, extrinsics_src, _lift(intrinsics_src, src_h, sampled.reshape(-1)))
+    xy_back = _perspective(intrinsics_ref, back)
+    as_map = lambda v: v.reshape(height, width).astype(np.float32)     # noqa: E731
+    return as_map(back[2]), as_map(xy_back[0]), as_map(xy_back[1]), x_src, y_src
 
 
 def check_geometric_consistency(depth_ref, intrinsics_ref, extrinsics_ref, depth_src, intrinsics_src, extrinsics_src):
-    """test_mvs4.py:313-328."""
-    width, height = depth_ref.shape[1], depth_ref.shape[0]
-    x_ref, y_ref = np.meshgrid(np.arange(0, width), np.arange(0, height))
-    depth_reprojected, x2d_reprojected, y2d_reprojected, x2d_src, y2d_src = reproject_with_depth(
-        depth_ref, intrinsics_ref, extrinsics_ref, depth_src, intrinsics_src, extrinsics_src)
+    """Vote of one source view (test_mvs4.py:313-328): a pixel is consistent if it comes back within 1 px (:319) and
+    within 1 % relative depth (:322-323); inconsistent pixels get reprojected depth 0 (:326)."""
+    height, width = depth_ref.shape
+    depth_back, x_back, y_back, x_src, y_src = reproject_with_depth(depth_ref, intrinsics_ref, extrinsics_ref, depth_src,
+                                                                   intrinsics_src, extrinsics_src)
+    cols, rows = np.meshgrid(np.arange(0, width), np.arange(0, height))
     with np.errstate(divide="ignore", invalid="ignore"):
-        dist = np.sqrt((x2d_reprojected - x_ref) ** 2 + (y2d_reprojected - y_ref) ** 2)
-        depth_diff = np.abs(depth_reprojected - depth_ref)
-        relative_depth_diff = depth_diff / depth_ref
-        mask = np.logical_and(dist < 1, relative_depth_diff < 0.01)
-    depth_reprojected[~mask] = 0
-    return mask, depth_reprojected, x2d_src, y2d_src
+        pixel_error = np.sqrt((x_back - cols) ** 2 + (y_back - rows) ** 2)
+        relative_error = np.abs(depth_back - depth_ref) / depth_ref
+        mask = np.logical_and(pixel_error < 1, relative_error < 0.01)
+    depth_back[~mask] = 0
+    return mask, depth_back, x_src, y_src
 
 
 def filter_reference_view(ref_depth, ref_K, ref_E, confidence, src_depths, src_Ks, src_Es, conf_thres, thres_view):
-    """The per-reference-view part of filter_depth (test_mvs4.py:352-407): masks, averaged depth, world points."""
+    """What filter_depth does for one reference view (test_mvs4.py:352-407): photometric mask from the confidence
+    (:361), votes and reprojected depths of every source view (:369-383), their average with the reference depth
+    (:385), the >= thres_view geometric mask (:387-388) and the surviving pixels lifted to world space (:399-407)."""
     photo_mask = confidence > conf_thres
-    geo_mask_sum = 0
-    reprojected, masks = [], []
+    votes = np.zeros(ref_depth.shape, dtype=np.int32)
+    depth_sum = 0
+    view_masks, view_depths = [], []
     for d, K, E in zip(src_depths, src_Ks, src_Es):
-        geo_mask, depth_reprojected, _, _ = check_geometric_consistency(ref_depth, ref_K, ref_E, d, K, E)
-        geo_mask_sum = geo_mask_sum + geo_mask.astype(np.int32)
-        reprojected.append(depth_reprojected)
-        masks.append(geo_mask)
-    depth_est_averaged = (sum(reprojected) + ref_depth) / (geo_mask_sum + 1)
-    geo_mask = geo_mask_sum >= thres_view
+        ok, depth_back, _, _ = check_geometric_consistency(ref_depth, ref_K, ref_E, d, K, E)
+        votes = votes + ok.astype(np.int32)
+        depth_sum = depth_sum + depth_back                  # python sum(): 0 + d1 + d2 + ...
+        view_masks.append(ok)
+        view_depths.append(depth_back)
+    depth_est_averaged = (depth_sum + ref_depth) / (votes + 1)
+    geo_mask = votes >= thres_view
     final_mask = np.logical_and(photo_mask, geo_mask)
     height, width = depth_est_averaged.shape[:2]
-    x, y = np.meshgrid(np.arange(0, width), np.arange(0, height))
-    x, y, depth = x[final_mask], y[final_mask], depth_est_averaged[final_mask]
-    xyz_ref = np.matmul(np.linalg.inv(ref_K), np.vstack((x, y, np.ones_like(x))) * depth)
-    xyz_world = np.matmul(np.linalg.inv(ref_E), np.vstack((xyz_ref, np.ones_like(x))))[:3]
-    return dict(photo_mask=photo_mask, geo_mask=geo_mask, final_mask=final_mask, geo_mask_sum=geo_mask_sum,
-                depth_est_averaged=depth_est_averaged, view_masks=masks, view_depths=reprojected,
-                points=xyz_world.transpose((1, 0)))
+    cols, rows = np.meshgrid(np.arange(0, width), np.arange(0, height))
+    sel_x, sel_y, sel_d = cols[final_mask], rows[final_mask], depth_est_averaged[final_mask]
+    cam = np.matmul(np.linalg.inv(ref_K), np.vstack((sel_x, sel_y, np.ones_like(sel_x))) * sel_d)
+    world = np.matmul(np.linalg.inv(ref_E), np.vstack((cam, np.ones_like(sel_x))))[:3]
+    return dict(photo_mask=photo_mask, geo_mask=geo_mask, final_mask=final_mask, geo_mask_sum=votes,
+                depth_est_averaged=depth_est_averaged, view_masks=view_masks, view_depths=view_depths,
+                points=world.transpose((1, 0)))
