@@ -53,7 +53,8 @@ __global__ void __launch_bounds__(256) conv_small_kernel(SmallArgs a, int tiles_
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
         const int idx = threadIdx.x + i * 256;
-        if (idx < PH * PW * Q) patch[idx] = tmp[i];
+        // plane layout [q][row][col]: neighbouring pixels are 16 bytes apart for the tap reads (conflict-free b128)
+        if (idx < PH * PW * Q) patch[(idx % Q) * (PH * PW) + idx / Q] = tmp[i];
     }
     __syncthreads();
 
@@ -65,10 +66,10 @@ __global__ void __launch_bounds__(256) conv_small_kernel(SmallArgs a, int tiles_
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const f32x4v* p = patch + ((ty + ky) * PW + tx + kx) * Q;
+            const f32x4v* p = patch + (ty + ky) * PW + tx + kx;
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                const f32x4v xv = p[q];
+                const f32x4v xv = p[q * (PH * PW)];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int ci = q * 4 + c;
