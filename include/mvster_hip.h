@@ -133,6 +133,12 @@ int mvster_fpn_tail_gather(const float* G, const float* vb, float* P, float* wor
 int mvster_pack_conv_weights(const float* w, float* wpk, int cout, int cin, int cin_pad, int kd, int kh, int kw, long s_n,
                              long s_c, long s_z, long s_y, long s_x, int flip, void* stream);
 
+/* The same refresh for a transposed layer (output-parity classes): w [cin, cout, kd, kh, kw] contiguous, ktot = kd*kh*kw
+ * <= 27; class c packs the taps taps[c*27 .. c*27 + ntaps[c]) (flattened indices, input-offset order) at float offset
+ * woff[c] of wpk. */
+int mvster_pack_conv_weights_classes(const float* w, float* wpk, int cout, int cin, int cin_pad, int ktot, int nclass,
+                                     const int* ntaps, const long* woff, const int* taps, void* stream);
+
 /* Weight gradient of a channels-last convolution (training): for every kernel tap
  *   dW[tap][co][ci] = sum_o gy[o][co] * x[o*s - p + tap][ci]      (zero padding)
  * x [B,Di,Hi,Wi,CI], gy [B,Do,Ho,Wo,CO] with (Do,Ho,Wo) the conv output size for (k,s,p); CI, CO <= 64.

@@ -232,13 +232,13 @@ class ConvLayer:
         """Refresh ``wpk`` of an ordinary (non-transposed) layer with one kernel, reading the parameter tensor in
         place.  ``swap``: the tensor's dim 1 is this layer's output channel (a ConvTranspose weight, or the
         input-gradient form of a conv); ``flip``: mirror the taps (input-gradient form of a stride-1 conv)."""
-        if self.transposed:
-            raise RuntimeError("repack_on_device: transposed layers are packed per parity class (repack)")
         w = weight.detach()
         if w.dim() == 4:
             w = w.unsqueeze(2)
         if w.dtype != torch.float32 or not w.is_cuda:
             raise RuntimeError("repack_on_device: fp32 CUDA parameter expected")
+        if self.transposed:
+            return self._repack_classes_on_device(w)
         st = w.stride()
         s_n, s_c = (st[1], st[0]) if swap else (st[0], st[1])
         kd, kh, kw = self.kernel
@@ -254,6 +254,30 @@ class ConvLayer:
             if self.cin != self._cin_raw:
                 ws = torch.nn.functional.pad(ws, (0, 0, 0, self.cin - self._cin_raw))
             self.w_small.copy_(ws)
+
+    def _repack_classes_on_device(self, w):
+        """Transposed layer: every output-parity class in one launch (tap lists and block offsets from the class table)."""
+        kd, kh, kw = self.kernel
+        if not w.is_contiguous() or tuple(w.shape[:2]) != (self._cin_raw, self.cout):
+            raise RuntimeError("repack_on_device: contiguous [cin, cout, kd, kh, kw] weight expected")
+        tab = getattr(self, "_class_pack", None)
+        if tab is None:
+            ntaps = np.zeros(len(self.classes), dtype=np.int32)
+            taps = np.zeros((len(self.classes), 27), dtype=np.int32)
+            for i, c in enumerate(self.classes):
+                kzs, kys, kxs = c["taps"]
+                flat = [(z * kh + y) * kw + x for z in kzs for y in kys for x in kxs]
+                ntaps[i] = len(flat)
+                taps[i, :len(flat)] = flat
+            tab = self._class_pack = (ntaps, np.ascontiguousarray(self.woff, dtype=np.int64), taps)
+        ntaps, woff, taps = tab
+        rc = _lib.load().mvster_pack_conv_weights_classes(
+            w.data_ptr(), self.wpk.data_ptr(), self.cout, self._cin_raw, self.cin, kd * kh * kw, len(self.classes),
+            ntaps.ctypes.data_as(ctypes.c_void_p), woff.ctypes.data_as(ctypes.c_void_p), taps.ctypes.data_as(ctypes.c_void_p),
+            torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pack_conv_weights_classes")
+        if self.w_deconv is not None:
+            self.w_deconv.copy_(w[:, :, 0].permute(2, 3, 0, 1))
 
     def repack(self, weight, bias=None):
         """Refresh the packed weights (and the bias folded into ``shift``) after a parameter update; geometry,

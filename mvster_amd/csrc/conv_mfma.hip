@@ -684,6 +684,65 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
 }
 }  // namespace
 
+namespace {
+// Transposed layers: one workgroup row (blockIdx.y) per output-parity class; the class's kernel taps are a short list
+// of flattened (kz, ky, kx) indices into w [cin, cout, kd*kh*kw] (contiguous), its packed block starts at woff.
+struct PackClasses {
+    int nclass;
+    int ntaps[kMaxClasses];
+    long woff[kMaxClasses];
+    unsigned char tap[kMaxClasses][27];
+};
+
+__global__ void __launch_bounds__(256) pack_weights_classes_kernel(const float* __restrict__ w, float* __restrict__ wpk,
+                                                                   PackClasses pc, int ntile, int cout, int cin, int cin_pad,
+                                                                   int ktot) {
+    const int cls = blockIdx.y;
+    const int ntaps = pc.ntaps[cls];
+    const int nsteps = (ntaps * cin_pad + 15) / 16;
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // one float4 of the class's packed block
+    if (idx >= nsteps * ntile * 64) return;
+    const int lane = idx & 63, t = (idx >> 6) % ntile, st = (idx >> 6) / ntile;
+    const int n = t * 16 + (lane & 15);
+    f32x4v out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = st * 16 + (lane >> 4) * 4 + j;
+        const int tl = k / cin_pad, ci = k - tl * cin_pad;
+        float v = 0.0f;
+        if (tl < ntaps && ci < cin && n < cout) v = w[((long)ci * cout + n) * ktot + pc.tap[cls][tl]];
+        out[j] = v;
+    }
+    *reinterpret_cast<f32x4v*>(wpk + pc.woff[cls] + (long)idx * 4) = out;
+}
+}  // namespace
+
+// w [cin, cout, kd, kh, kw] contiguous (ConvTranspose layout, or a conv weight [cout_fwd, cin_fwd, ...] used as the
+// input-gradient operator); taps [nclass][27] (flattened tap indices, class c uses the first ntaps[c]); woff [nclass]
+// float offsets of the classes' blocks in wpk (mvster_amd/conv_plan.py:_class_table).
+extern "C" int mvster_pack_conv_weights_classes(const float* w, float* wpk, int cout, int cin, int cin_pad, int ktot, int nclass,
+                                                const int* ntaps, const long* woff, const int* taps, void* stream) {
+    if (!w || !wpk || !ntaps || !woff || !taps) return MVSTER_ERR_NULL;
+    if (cout <= 0 || cin <= 0 || cin_pad < cin || ktot <= 0 || ktot > 27 || nclass <= 0 || nclass > kMaxClasses)
+        return MVSTER_ERR_SHAPE;
+    PackClasses pc;
+    pc.nclass = nclass;
+    int maxsteps = 0;
+    for (int c = 0; c < nclass; ++c) {
+        if (ntaps[c] <= 0 || ntaps[c] > 27) return MVSTER_ERR_SHAPE;
+        pc.ntaps[c] = ntaps[c];
+        pc.woff[c] = woff[c];
+        for (int t = 0; t < 27; ++t) pc.tap[c][t] = (unsigned char)(t < ntaps[c] ? taps[c * 27 + t] : 0);
+        const int ns = (ntaps[c] * cin_pad + 15) / 16;
+        maxsteps = ns > maxsteps ? ns : maxsteps;
+    }
+    const int ntile = (cout + 15) / 16;
+    const int total = maxsteps * ntile * 64;
+    hipLaunchKernelGGL(pack_weights_classes_kernel, dim3((total + 255) / 256, nclass), dim3(256), 0, (hipStream_t)stream, w, wpk,
+                       pc, ntile, cout, cin, cin_pad, ktot);
+    return mv_check_launch();
+}
+
 extern "C" int mvster_pack_conv_weights(const float* w, float* wpk, int cout, int cin, int cin_pad, int kd, int kh, int kw,
                                         long s_n, long s_c, long s_z, long s_y, long s_x, int flip, void* stream) {
     if (!w || !wpk) return MVSTER_ERR_NULL;

@@ -79,7 +79,7 @@ class _ConvCL(torch.autograd.Function):
         cin_p = _cin_for(cin)
         xp = _pad_last(x, cin_p).contiguous()
         layer = CACHE.get(weight, "fwd", lambda: ConvLayer(w5, transposed, stride, padding, cin_pad=cin_p),
-                          (lambda L: L.repack(weight)) if transposed else (lambda L: L.repack_on_device(weight)))
+                          lambda L: L.repack_on_device(weight))
         if bias is not None:
             layer.shift[:layer.cout] = bias.detach()
         y = layer(xp)
@@ -112,7 +112,7 @@ class _ConvCL(torch.autograd.Function):
             else:
                 # stride 2: the adjoint is the transposed conv with the same weights (parity classes)
                 layer = CACHE.get(weight, "dgrad", lambda: ConvLayer(w5, True, stride, padding, cin_pad=co_p),
-                                  lambda L: L.repack(weight))
+                                  lambda L: L.repack_on_device(weight))
             gx = layer(gyp)
             if tuple(gx.shape[:4]) != tuple(xp.shape[:4]):
                 raise RuntimeError("conv_cl: input gradient of a strided layer needs even input sizes (%s -> %s)"
