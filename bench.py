@@ -285,8 +285,14 @@ def main():
 
     if rank == 0:
         total_maps = args.steps * world
+        metric = "depth-maps/sec (DTU 512x640, 5-view, 4-stage)"
+        try:        # BASELINE.json's own wording of the metric (the file ships with the repository)
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "BASELINE.json")) as f:
+                metric = json.load(f).get("metric", metric)
+        except (OSError, ValueError):
+            pass
         line = {
-            "metric": "depth-maps/sec (DTU 512x640, 5-view, 4-stage)", "value": round(total_maps / elapsed, 3),
+            "metric": metric, "value": round(total_maps / elapsed, 3),
             "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
