@@ -10,15 +10,27 @@ A step = one ``MVS4net.forward`` (B=1, eval, fp32) = one depth map of the worklo
 synthetic inputs already resident in HBM.  Multi-GPU = independent replicas on disjoint depth maps
 (weak scaling, no data-path collective).  Rank 0 prints ONE JSON line.
 
+Without a launcher, ``--gpus N`` (N > 1) starts the N ranks itself (re-executes this file under
+torch.distributed.run on 127.0.0.1 with a free port).  ``--stub`` replaces the GPU forward by a trivial CPU
+step on the gloo backend: the launch / barrier / MAX-over-ranks / one-line protocol without a GPU
+(tests/test_bench_cpu.py).
+
 Extra objects in the line:
   roofline      the dominant kernel instance of the forward, timed with HIP events on the launch
                 stream in an instrumented eager pass inside this script (same inputs, same kernels)
+  rooflines     the same for the dominant convolution kernel AND the fused warp/aggregation kernel of each of
+                the four cascade stages (the north-star kernel; algorithmic bytes of SURVEY.md section 8d)
   cpu_baseline  the CPU oracle (pure PyTorch restatement of the reference, oracle/) timed on the
-                host cores on a bounded sample of the same workload (rank 0, N=1 only)
+                host cores on a bounded sample of the same workload (rank 0, N=1 only): independent worker
+                processes in parallel (depth maps are independent), the single-process figure beside it
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -114,11 +126,153 @@ class KernelTimer:
         return agg
 
 
+def kernel_source_hash():
+    """Fingerprint of everything that decides what the kernels do and which one runs: the HIP sources, the
+    shared headers and the per-layer tuning table.  profiles/pmc_traffic.json carries the fingerprint it was
+    measured at; a PMC figure measured on other kernels is not quoted."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "mvster_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "mvster_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "mvster_amd", "csrc", "*.hpp")) +
+                   [os.path.join(ROOT, "mvster_amd", "tuning_gfx950.json")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n):
+    """``python bench.py --gpus N`` without a launcher: one process per GPU under torch.distributed.run on this
+    node (the reference starts its ranks the same way, scripts/train_dtu.sh:20 / train_mvs4.py:321-326)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it here
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _cpu_worker(idx, threads, shape, seconds, barrier, queue):
+    """One oracle process of the parallel CPU baseline: its own depth maps, ``threads`` intra-op threads."""
+    torch.set_num_threads(threads)
+    from mvster_amd.synthetic import make_inputs
+    from oracle import mvs4_oracle as O
+    H, W, N = shape
+    oracle = O.OracleMVS4net(**SHIPPED)
+    oracle.load_state_dict(load_weights(), strict=True)
+    oracle.eval()
+    imgs, proj, dv = make_inputs(nviews=N, H=H, W=W, seed=idx)
+    with torch.no_grad():
+        oracle(imgs, proj, dv)                          # warm-up
+        barrier.wait()
+        n, t0 = 0, time.perf_counter()
+        while n == 0 or time.perf_counter() - t0 < seconds:
+            oracle(imgs, proj, dv)
+            n += 1
+        queue.put((idx, n, t0, time.perf_counter()))
+
+
+def cpu_baseline(H, W, N, seed):
+    """The oracle on this host's cores: (a) one process, torch intra-op threads swept; (b) cores // threads
+    independent worker processes side by side (what a CPU deployment of the reference would do: depth maps are
+    independent).  (b) is the reported value."""
+    import torch.multiprocessing as mp
+    from mvster_amd.synthetic import make_inputs
+    from oracle import mvs4_oracle as O
+    cores = os.cpu_count() or 1
+    oracle = O.OracleMVS4net(**SHIPPED)
+    oracle.load_state_dict(load_weights(), strict=True)
+    oracle.eval()
+    cimgs, cproj, cdv = make_inputs(nviews=N, H=H, W=W, seed=seed)
+    sweep = {}
+    with torch.no_grad():
+        # PyTorch's intra-op pool does not scale to 256 hardware threads on these small convolutions
+        # (1 forward took 154 s with 256 threads): sweep a few pool sizes once, keep the fastest
+        for t in sorted({min(cores, c) for c in (8, 16, 32)}):
+            torch.set_num_threads(t)
+            oracle(cimgs, cproj, cdv)                   # warm-up at this pool size
+            c0 = time.perf_counter()
+            oracle(cimgs, cproj, cdv)
+            sweep[t] = time.perf_counter() - c0
+        best_t = min(sweep, key=sweep.get)
+        torch.set_num_threads(best_t)
+        n, c0 = 0, time.perf_counter()
+        while n < 8 and (time.perf_counter() - c0) < 6.0:
+            oracle(cimgs, cproj, cdv)
+            n += 1
+        single = n / (time.perf_counter() - c0)
+    del oracle
+    # (b) process-parallel: throughput per thread is best at the smallest pool, so use 8-thread workers
+    threads = min(8, cores)
+    nproc = max(1, cores // threads)
+    try:
+        import psutil
+        nproc = max(1, min(nproc, int(psutil.virtual_memory().available // (6 << 30))))     # ~3 GB peak per worker
+    except ImportError:
+        nproc = min(nproc, 16)
+    nproc = min(nproc, 32)
+    ctx = mp.get_context("spawn")
+    barrier, queue = ctx.Barrier(nproc), ctx.Queue()
+    procs = [ctx.Process(target=_cpu_worker, args=(i, threads, (H, W, N), 10.0, barrier, queue)) for i in range(nproc)]
+    for p in procs:
+        p.start()
+    try:
+        res = [queue.get(timeout=300) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.kill()
+    total = sum(r[1] for r in res)
+    span = max(r[3] for r in res) - min(r[2] for r in res)
+    return {"value": round(total / span, 4), "unit": "depth-maps/s", "cores": nproc * threads, "kind": "port",
+            "processes": nproc, "threads_per_process": threads,
+            "sample": "%d forwards of the same %dx%d %d-view 4-stage workload by %d independent oracle processes x %d "
+                      "intra-op threads over %.1f s on a %d-thread host" % (total, H, W, N, nproc, threads, span, cores),
+            "single_process": {"value": round(single, 4), "cores": best_t,
+                               "sweep_s_per_forward": {str(k): round(v, 3) for k, v in sorted(sweep.items())}}}
+
+
+def stub_main(args):
+    """The launch / timing / one-line protocol on CPU tensors over gloo (no GPU, no model): what the multi-process
+    CPU test drives.  A step is a small matmul."""
+    from mvster_amd import shard
+    rank, local_rank, world = shard.init_distributed(backend="gloo")
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d: launched with WORLD_SIZE=%d" % (args.gpus, world))
+    x = torch.randn(64, 64)
+    step = lambda: (x @ x).sum().item()     # noqa: E731
+    for _ in range(args.warmup):
+        step()
+    shard.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    shard.barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0)
+    ranks_seen = int(round(shard.sum_over_ranks(1.0)))
+    if rank == 0:
+        print(json.dumps({"metric": "stub steps/s", "value": round(args.steps * world / elapsed, 3), "unit": "steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+                          "scaling": "weak", "ranks_seen": ranks_seen, "stub": True}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--views", type=int, default=5)
@@ -128,7 +282,14 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="depth maps processed concurrently on one GPU: independent captured forwards replayed on "
                          "separate HIP streams (1 = strictly one after the other)")
+    ap.add_argument("--stub", action="store_true",
+                    help="CPU/gloo dry run of the launch + timing protocol (no GPU, no model); used by the CPU tests")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))       # no launcher around us: start the ranks ourselves
+    if args.stub:
+        return stub_main(args)
 
     from mvster_amd import MVS4net, shard
     from mvster_amd.graph import GraphedForward
@@ -136,9 +297,7 @@ def main():
 
     rank, local_rank, world = shard.init_distributed()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d: launched with WORLD_SIZE=%d" % (args.gpus, world))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -198,52 +357,71 @@ def main():
     shard.barrier()
     torch.cuda.synchronize()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0)
+    ranks_seen = int(round(shard.sum_over_ranks(1.0)))
 
     # ---- instrumented eager pass: per-kernel HIP-event timing (rank 0 only) -------------------
     roofline = None
+    rooflines = []
     table = None
     if rank == 0:
         timer = KernelTimer()
         timer.install()
         overlap = model.overlap_streams
         model.overlap_streams = False      # one stream: per-kernel durations without co-running kernels
+        ninstr = max(1, min(args.steps, 20))
         try:
             for _ in range(3):
                 model(imgs, proj, dv)
             timer.records.clear()
-            for _ in range(min(args.steps, 20)):
+            for _ in range(ninstr):
                 model(imgs, proj, dv)
             torch.cuda.synchronize()
             table = timer.summary()
         finally:
             timer.remove()
             model.overlap_streams = overlap
-        name, a = max(table.items(), key=lambda kv: kv[1]["ms"])
-        avg_ms = a["ms"] / a["n"]
-        if a["flops"] > 0 and name.startswith("conv"):
-            achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
-            roofline = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                        "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": a["n"] // min(args.steps, 20),
-                        "flops_per_launch": a["flops"] // a["n"]}
-        else:
-            achieved = a["bytes"] / (a["ms"] * 1e-3) / 1e9
-            roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                        "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": a["n"] // min(args.steps, 20),
-                        "bytes_per_launch": a["bytes"] // a["n"]}
         # HBM bytes per launch from the PMC passes (scripts/gpu_pmc.sh: separate FETCH_SIZE / WRITE_SIZE runs of
-        # this same command, FETCH_SIZE x2 on gfx950, KB -> bytes); PMC cannot be collected from inside the
-        # process, so the committed summary of the last pass is quoted and its provenance named
+        # this same command, FETCH_SIZE x2 on gfx950, KB -> bytes).  PMC cannot be collected from inside the
+        # process: the committed summary is quoted ONLY if it was measured on these very kernels (source hash).
+        pmc, pmc_note = {}, None
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            if pmc.get("workload") == [args.height, args.width, args.views] and name in pmc["kernels"]:
-                roofline["traffic"] = int(pmc["kernels"][name])
-                roofline["traffic_unit"] = "bytes/launch"
-                roofline["traffic_source"] = pmc.get("source", "profiles/pmc_traffic.json")
-        except (OSError, ValueError, KeyError):
-            pass
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pj = json.load(f)
+            if pj.get("workload") != [args.height, args.width, args.views]:
+                pmc_note = "profiles/pmc_traffic.json was measured on another workload"
+            elif pj.get("kernel_source_hash") != kernel_source_hash():
+                pmc_note = ("profiles/pmc_traffic.json was measured on other kernel sources (hash %s, now %s): not quoted"
+                            % (pj.get("kernel_source_hash"), kernel_source_hash()))
+            else:
+                pmc = pj
+        except (OSError, ValueError):
+            pmc_note = "no profiles/pmc_traffic.json"
+
+        def entry(name, a):
+            avg_ms = a["ms"] / a["n"]
+            if a["flops"] > 0 and name.startswith("conv") and not name.startswith("conv_small"):
+                achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
+                e = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": a["n"] // ninstr,
+                     "flops_per_launch": a["flops"] // a["n"]}
+            else:
+                achieved = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+                e = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": a["n"] // ninstr,
+                     "bytes_per_launch": a["bytes"] // a["n"]}
+            if name in pmc.get("kernels", {}):
+                e["traffic"] = int(pmc["kernels"][name])
+                e["traffic_unit"] = "bytes/launch"
+                e["traffic_source"] = pmc.get("source", "profiles/pmc_traffic.json")
+            elif pmc_note:
+                e["traffic_note"] = pmc_note
+            return e
+
+        name, a = max(table.items(), key=lambda kv: kv[1]["ms"])
+        roofline = entry(name, a)
+        rooflines = [roofline] + [entry(k, v) for k, v in sorted(table.items()) if k.startswith("warp_agg") and k != name]
         if args.kernel_table:
             tot = sum(v["ms"] for v in table.values())
             for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
@@ -254,40 +432,13 @@ def main():
     # ---- CPU baseline: the oracle on the host cores, bounded sample ----------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import mvs4_oracle as O
-        cores = os.cpu_count() or 1
-        oracle = O.OracleMVS4net(**SHIPPED)
-        oracle.load_state_dict(load_weights(), strict=True)
-        oracle.eval()
-        cimgs, cproj, cdv = make_inputs(nviews=args.views, H=args.height, W=args.width, seed=units[0])
-        # PyTorch's intra-op pool does not scale to 256 hardware threads on these small convolutions
-        # (1 forward took 154 s with 256 threads): sweep a few pool sizes once, keep the fastest
-        sweep = {}
-        with torch.no_grad():
-            for t in sorted({min(cores, c) for c in (8, 16, 32, 64)}):
-                torch.set_num_threads(t)
-                oracle(cimgs, cproj, cdv)                   # warm-up at this pool size
-                c0 = time.perf_counter()
-                oracle(cimgs, cproj, cdv)
-                sweep[t] = time.perf_counter() - c0
-            best_t = min(sweep, key=sweep.get)
-            torch.set_num_threads(best_t)
-            n, c0 = 0, time.perf_counter()
-            while n < 12 and (time.perf_counter() - c0) < 10.0:
-                oracle(cimgs, cproj, cdv)
-                n += 1
-            ct = time.perf_counter() - c0
-        cpu = {"value": round(n / ct, 4), "unit": "depth-maps/s", "cores": best_t, "kind": "port",
-               "sample": "%d forwards of the same %dx%d %d-view 4-stage workload; torch intra-op threads swept over %s "
-                         "(s/forward: %s) on a %d-thread host, fastest kept"
-                         % (n, args.height, args.width, args.views, sorted(sweep), 
-                            ", ".join("%d:%.2f" % (k, sweep[k]) for k in sorted(sweep)), cores)}
+        cpu = cpu_baseline(args.height, args.width, args.views, units[0])
 
     if rank == 0:
         total_maps = args.steps * world
         metric = "depth-maps/sec (DTU 512x640, 5-view, 4-stage)"
         try:        # BASELINE.json's own wording of the metric (the file ships with the repository)
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "BASELINE.json")) as f:
+            with open(os.path.join(ROOT, "BASELINE.json")) as f:
                 metric = json.load(f).get("metric", metric)
         except (OSError, ValueError):
             pass
@@ -300,7 +451,7 @@ def main():
                                    % (args.height, args.width, args.views),
                        "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "replicas x%d" % world,
                        "depth_maps_in_flight_per_gpu": args.inflight},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "ranks_seen": ranks_seen, "roofline": roofline, "rooflines": rooflines, "cpu_baseline": cpu,
         }
         if sequential is not None:
             line["single_forward_ms"] = round(1e3 * sequential, 4)       # one depth map at a time (latency)

@@ -37,9 +37,12 @@ if len(sys.argv) > 3:
     mine = {k: round(m["hbm_bytes_per_launch"]) for k, m in out.items()
             if "hbm_bytes_per_launch" in m and k.split("<")[0] in (
                 "conv_lds_kernel", "conv_mfma_kernel", "conv_small_kernel", "deconv_small_kernel",
-                "warp_agg_fwd_kernel", "warp_agg_fwd_lanes_kernel", "fpn_tail_gather_lds_kernel")}
+                "warp_agg_fwd_kernel", "warp_agg_fwd_lanes_kernel", "warp_agg_fwd_wave_kernel",
+                "warp_agg_fwd_pix_kernel", "fpn_tail_gather_lds_kernel")}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_hash
     with open(sys.argv[3], "w") as f:
-        json.dump({"workload": [512, 640, 5], "source": "scripts/gpu_pmc.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / "
+        json.dump({"workload": [512, 640, 5], "kernel_source_hash": kernel_source_hash(), "source": "scripts/gpu_pmc.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / "
                    "WRITE_SIZE (separate passes) of bench.py --no-graph; (2*FETCH_SIZE + WRITE_SIZE) KB per launch",
                    "kernels": mine}, f, indent=1, sort_keys=True)
 for k in sorted(out, key=lambda k: -out[k].get("GRBM_GUI_ACTIVE", 0) * out[k]["dispatches"])[:40]:

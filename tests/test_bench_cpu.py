@@ -1,0 +1,46 @@
+"""bench.py's launch protocol without a GPU: ``--gpus 2`` starts its own two ranks (no external launcher), they
+rendezvous over gloo on 127.0.0.1, time a stub step between barriers, take the MAX over ranks, and rank 0 prints
+exactly one JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--steps", "5", "--warmup", "2"] + extra,
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks():
+    line = _run(["--gpus", "2"])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["steps"] == 5 and line["warmup"] == 2
+    assert line["value"] > 0 and line["scaling"] == "weak" and line["higher_is_better"] is True
+
+
+def test_single_rank_needs_no_launcher():
+    line = _run(["--gpus", "1"])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1
+
+
+def test_world_size_mismatch_is_an_error():
+    env = {k: v for k, v in os.environ.items()}
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--gpus", "2", "--steps", "1"],
+                       capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert p.returncode != 0
+
+
+def test_kernel_source_hash_tracks_the_sources(tmp_path):
+    sys.path.insert(0, ROOT)
+    import bench
+    h = bench.kernel_source_hash()
+    assert len(h) == 16 and h == bench.kernel_source_hash()
