@@ -180,6 +180,9 @@ int mvster_bn_relu_bwd_apply(const float* x, const float* gy, const float* scale
  * (models/mvs4net_utils.py:488-496 under autograd).  C % 4 == 0. */
 int mvster_upsample2x_cl_fwd(const float* in, float* out, int B, int h, int w, int C, void* stream);
 int mvster_upsample2x_cl_bwd(const float* gout, float* gin, int B, int h, int w, int C, void* stream);
+/* Nearest x2 (F.interpolate(scale_factor=2, mode="nearest"), the mono head's up-sampling, models/mvs4net_utils.py:858):
+ * backward = 0: in [B,h,w,C] -> out [B,2h,2w,C]; backward = 1: the adjoint, in = gout [B,2h,2w,C] -> out = gin [B,h,w,C]. */
+int mvster_upsample2x_nearest_cl(const float* in, float* out, int B, int h, int w, int C, int backward, void* stream);
 
 /* Sinkhorn optimal-transport loss per pixel and its gradient, fused (discrete form, ot_continous=False):
  * attn, hypo [B,D,HW], gt [B,HW] -> loss_pix [B,HW], jac [B,D,HW] = d loss_pix / d attn.  2 <= D <= 8,

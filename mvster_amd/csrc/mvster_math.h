@@ -294,7 +294,9 @@ MV_HD void compose_camera(const float* pm, double* P) {
     for (int j = 0; j < 4; ++j) P[12 + j] = (double)E[12 + j];
 }
 
-// src_P @ inv(ref_P), top 3x4 rounded to fp32 (mvs4net_utils.py:24-26).
+// src_P @ inv(ref_P), top 3x4 rounded to fp32 (mvs4net_utils.py:24-26).  A singular reference projection
+// (torch.inverse raises there) yields an all-NaN result, which every consumer propagates into its outputs:
+// a degenerate camera is loud, never a silently wrong warp.
 MV_HD bool relative_projection(const float* ref_pm, const float* src_pm, RT& out) {
     double Pr[16], Ps[16], Pi[16];
     compose_camera(ref_pm, Pr);
@@ -304,6 +306,7 @@ MV_HD bool relative_projection(const float* ref_pm, const float* src_pm, RT& out
         for (int j = 0; j < 4; ++j) {
             double acc = 0.0;
             for (int k = 0; k < 4; ++k) acc += Ps[i * 4 + k] * Pi[k * 4 + j];
+            if (!ok) acc = (double)NAN;
             if (j < 3) out.r[i * 3 + j] = (float)acc;
             else out.t[i] = (float)acc;
         }

@@ -73,7 +73,42 @@ __global__ void __launch_bounds__(256) upsample2x_cl_bwd_kernel(const float* __r
     st4(gin + i * 4, acc);
 }
 
+// nearest x2 (F.interpolate(scale_factor=2, mode="nearest"), the mono head's up-sampling, mvs4net_utils.py:858) and its
+// adjoint (sum of the 2 x 2 block): out[y][x] = in[y/2][x/2]
+__global__ void __launch_bounds__(256) upsample2x_nearest_cl_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                                    int h, int w, int C, int backward) {
+    const int q = C >> 2, H = 2 * h, W = 2 * w;
+    const int oh = backward ? h : H, ow = backward ? w : W;
+    const long total = (long)B * oh * ow * q;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % q);
+    long p = i / q;
+    const int x = (int)(p % ow); p /= ow;
+    const int y = (int)(p % oh);
+    const int b = (int)(p / oh);
+    if (!backward) {
+        st4(out + i * 4, ld4(in + (((long)b * h + (y >> 1)) * w + (x >> 1)) * C + c4 * 4));
+    } else {
+        const float* g = in + (((long)b * H + 2 * y) * W + 2 * x) * C + c4 * 4;
+        const f32x4 a = ld4(g), bq = ld4(g + C), c = ld4(g + (long)W * C), d = ld4(g + (long)W * C + C);
+        st4(out + i * 4, (a + bq) + (c + d));
+    }
+}
+
 }  // namespace
+
+// in [B,h,w,C] -> out [B,2h,2w,C] (backward = 0), or gout [B,2h,2w,C] -> gin [B,h,w,C] (backward = 1); C % 4 == 0
+extern "C" int mvster_upsample2x_nearest_cl(const float* in, float* out, int B, int h, int w, int C, int backward,
+                                            void* stream) {
+    if (!in || !out) return MVSTER_ERR_NULL;
+    if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || (C & 3)) return MVSTER_ERR_SHAPE;
+    const long total = (long)B * (backward ? 1 : 4) * h * w * (C / 4);
+    if ((total + 255) / 256 >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    hipLaunchKernelGGL(upsample2x_nearest_cl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in,
+                       out, B, h, w, C, backward);
+    return mv_check_launch();
+}
 
 // in [B,h,w,C] -> out [B,2h,2w,C] (C % 4 == 0), F.interpolate(scale_factor=2, mode="bilinear", align_corners=True)
 extern "C" int mvster_upsample2x_cl_fwd(const float* in, float* out, int B, int h, int w, int C, void* stream) {

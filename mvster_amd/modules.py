@@ -3,19 +3,36 @@
 These modules own the learnable state with exactly the reference's ``state_dict`` keys
 (348 tensors for the shipped configuration: ``feature.*`` 76, ``reg.{0..3}.*`` 62 each,
 ``mono_depth_decoder.*`` 24 -- SURVEY.md section 5), so reference checkpoints load with
-``strict=True``.  Their ``forward`` is the differentiable PyTorch-ROCm (MIOpen) form used in
-training mode, where BatchNorm runs on batch statistics and cannot be folded; in eval mode
-``mvster_amd.net.MVS4net`` bypasses it and runs the hand-written gfx950 kernels through
-``mvster_amd.conv_plan``.
+``strict=True``.  ``forward_cl`` is the differentiable channels-last form on the gfx950 kernels
+(``mvster_amd.train_ops``: conv -> BatchNorm -> ReLU, all passes hand-written HIP) that
+``MVS4net`` runs in training mode, where BatchNorm works on batch statistics and cannot be folded;
+``forward`` is the same thing behind the reference's NCHW / NCDHW signatures (a permute on either
+side, no second backend).  In eval mode ``mvster_amd.net.MVS4net`` bypasses both and runs the
+folded-BatchNorm plans of ``mvster_amd.conv_plan``.
 
 Reference: models/mvs4net_utils.py:116-123 (ConvBnReLU3D), :224-251 (Conv2d), :419-502 (FPN4),
 :833-868 (mono_depth_decoder), :870-912 (reg2d), :914-965 (reg3d).
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import train_ops as T
+
+
+def _to_cl5(x):      # [B,C,D,H,W] -> [B,D,H,W,C]
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _from_cl5(y):    # [B,D,H,W,C] -> [B,C,D,H,W] view
+    return y.permute(0, 4, 1, 2, 3)
+
+
+def _to_cl4(x):      # [B,C,H,W] -> [B,1,H,W,C]
+    return x.permute(0, 2, 3, 1).unsqueeze(1).contiguous()
+
+
+def _from_cl4(y):    # [B,1,H,W,C] -> [B,C,H,W] view
+    return y[:, 0].permute(0, 3, 1, 2)
 
 
 class ConvBnReLU3D(nn.Module):
@@ -25,7 +42,7 @@ class ConvBnReLU3D(nn.Module):
         self.bn = nn.BatchNorm3d(out_channels)
 
     def forward(self, x):
-        return F.relu(self.bn(self.conv(x)), inplace=True)
+        return _from_cl5(self.forward_cl(_to_cl5(x)))
 
     def forward_cl(self, x):
         """Channels-last [B,D,H,W,C] form on the gfx950 kernels (mvster_amd/train_ops.py)."""
@@ -66,14 +83,8 @@ class reg2d(nn.Module):
         self.prob = nn.Conv3d(8, 1, 1, stride=1, padding=0)   # hard-coded 8 inputs, with bias (reference :900)
 
     def forward(self, x):
-        c0 = self.conv0(x)
-        c2 = self.conv2(self.conv1(c0))
-        c4 = self.conv4(self.conv3(c2))
-        x = self.conv6(self.conv5(c4))
-        x = c4 + self.conv7(x)
-        x = c2 + self.conv9(x)
-        x = c0 + self.conv11(x)
-        return self.prob(x).squeeze(1)
+        """[B,G,D,h,w] -> logits [B,D,h,w] (the reference's signature)."""
+        return self.forward_cl(_to_cl5(x))
 
     def forward_cl(self, x):
         """[B,D,h,w,G] -> logits [B,D,h,w]."""
@@ -109,20 +120,7 @@ class reg3d(nn.Module):
         self.prob = nn.Conv3d(c, 1, 3, stride=1, padding=1, bias=False)
 
     def forward(self, x):
-        c0 = self.conv0(x)
-        c2 = self.conv2(self.conv1(c0))
-        if self.down_size == 3:
-            c4 = self.conv4(self.conv3(c2))
-            x = self.conv6(self.conv5(c4))
-            x = c4 + self.conv7(x)
-            x = c2 + self.conv9(x)
-        elif self.down_size == 2:
-            x = self.conv4(self.conv3(c2))
-            x = c2 + self.conv9(x)
-        else:
-            x = c2
-        x = c0 + self.conv11(x)
-        return self.prob(x).squeeze(1)
+        return self.forward_cl(_to_cl5(x))
 
     def forward_cl(self, x):
         c0 = self.conv0.forward_cl(x)
@@ -152,8 +150,7 @@ class Conv2d(nn.Module):
         self.relu = relu
 
     def forward(self, x):
-        x = self.bn(self.conv(x))
-        return F.relu(x, inplace=True) if self.relu else x
+        return _from_cl4(self.forward_cl(_to_cl4(x)))
 
     def forward_cl(self, x, groups=1):
         """[B,1,H,W,C] channels-last; ``groups`` = number of equal batch slices normalised separately (views)."""
@@ -186,18 +183,8 @@ class FPN4(nn.Module):
         self.out_channels = [c * 8, c * 4, c * 2, c]
 
     def forward(self, x):
-        c0 = self.conv0(x)
-        c1 = self.conv1(c0)
-        c2 = self.conv2(c1)
-        c3 = self.conv3(c2)
-        out = {"stage1": self.out1(c3)}
-        f = F.interpolate(c3, scale_factor=2, mode="bilinear", align_corners=True) + self.inner1(c2)
-        out["stage2"] = self.out2(f)
-        f = F.interpolate(f, scale_factor=2, mode="bilinear", align_corners=True) + self.inner2(c1)
-        out["stage3"] = self.out3(f)
-        f = F.interpolate(f, scale_factor=2, mode="bilinear", align_corners=True) + self.inner3(c0)
-        out["stage4"] = self.out4(f)
-        return out
+        """[B,3,H,W] -> {"stage1".."stage4": [B,C,h,w]} (the reference's signature; views of channels-last maps)."""
+        return {k: _from_cl4(v) for k, v in self.forward_cl(_to_cl4(x)).items()}
 
     def forward_cl(self, x, groups=1):
         """x [B,1,H,W,3] channels-last -> four channels-last maps [B,1,h,w,C].  With ``groups`` = N the batch holds
@@ -235,15 +222,8 @@ class mono_depth_decoder(nn.Module):
         self.conv3x3 = nn.ModuleList([nn.Conv2d(64, 1, 3, 1, 1), nn.Conv2d(32, 1, 3, 1, 1), nn.Conv2d(16, 1, 3, 1, 1)])
 
     def forward(self, outputs, d_min, d_max):
-        for i in range(1, 4):
-            coarse = outputs["stage%d" % i]["mono_feat"]
-            fine = outputs["stage%d" % (i + 1)]["mono_feat"]
-            coarse = F.interpolate(self.convblocks[i - 1](coarse), scale_factor=2, mode="nearest")
-            disp = torch.sigmoid(self.conv3x3[i - 1](torch.cat([coarse, fine], 1)))
-            lo = (1 / d_max)[:, None, None, None]
-            hi = (1 / d_min)[:, None, None, None]
-            outputs["stage%d" % (i + 1)]["mono_depth"] = (1 / (lo + (hi - lo) * disp)).squeeze(1)
-        return outputs
+        """The reference's signature: reads ``outputs[stage]["mono_feat"]`` ([B,C,h,w])."""
+        return self.forward_cl(outputs, [_to_cl4(outputs["stage%d" % i]["mono_feat"]) for i in range(1, 5)], d_min, d_max)
 
     def forward_cl(self, outputs, feats_cl, d_min, d_max):
         """Same head on the channels-last reference features ``feats_cl`` [stage] -> [B,1,h,w,C]."""

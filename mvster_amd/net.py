@@ -16,9 +16,8 @@ Execution:
   -> ReLU on channels-last tensors with all three convolution passes (forward, input gradient,
   weight gradient) on the gfx950 kernels (``mvster_amd.train_ops``), and the fused
   warp/aggregation kernel is an ``autograd.Function`` with a hand-written HIP backward.
-  ``native_train = False`` routes the convolutions through PyTorch-ROCm / MIOpen instead (the
-  on-GPU cross-check of the native path).
-There is no CPU path: CPU tensors raise.
+There is no CPU path and no PyTorch-ROCm / MIOpen path: CPU tensors raise, and the on-GPU cross-check of the
+training step is the oracle module tree moved to the GPU (tests/test_gpu_train.py).
 """
 import torch
 import torch.nn as nn
@@ -27,28 +26,6 @@ import torch.nn.functional as F
 from . import ops
 from .conv_plan import FpnPlan, Reg2dPlan, Reg3dPlan
 from .modules import FPN4, mono_depth_decoder, reg2d, reg3d
-
-
-class _WarpAgg(torch.autograd.Function):
-    """cor_feats [B,G,D,h,w] from NCHW features; HIP forward + HIP backward."""
-
-    @staticmethod
-    def forward(ctx, ref_fea, src_feas, rt, hypo, G, group_cor, attn_fuse_d, attn_temp):
-        ref_cl = ops.to_channels_last(ref_fea)
-        src_cl = src_feas.permute(0, 1, 3, 4, 2).contiguous()          # [NV,B,C,Hs,Ws] -> [NV,B,Hs,Ws,C]
-        out, wsum = ops.warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, group_cor, attn_fuse_d, attn_temp, want_wsum=True)
-        ctx.save_for_backward(ref_cl, src_cl, rt, hypo, out, wsum)
-        ctx.cfg = (G, group_cor, attn_fuse_d, attn_temp)
-        return out.permute(0, 4, 1, 2, 3)                              # [B,G,D,h,w] view
-
-    @staticmethod
-    def backward(ctx, grad):
-        ref_cl, src_cl, rt, hypo, out, wsum = ctx.saved_tensors
-        G, group_cor, attn_fuse_d, attn_temp = ctx.cfg
-        g_cl = grad.permute(0, 2, 3, 4, 1).contiguous()                # [B,D,h,w,G]
-        g_ref, g_src = ops.warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, g_cl, G, group_cor, attn_fuse_d,
-                                           attn_temp)
-        return g_ref.permute(0, 3, 1, 2), g_src.permute(0, 1, 4, 2, 3), None, None, None, None, None, None
 
 
 class _WarpAggCL(torch.autograd.Function):
@@ -112,37 +89,45 @@ class MVS4net(nn.Module):
                 self.reg.append(reg3d(in_channels=in_dim, base_channels=reg_channel, down_size=down_size[idx]))
             else:
                 raise NotImplementedError("reg_net %r" % reg_net)
-        self._plans = None
+        self._plans = {}               # device -> (FpnPlan, [RegPlan]); shared by nn.DataParallel replicas
         # run the fine FPN levels on a second HIP stream underneath cascade stages 1-2 (which are small,
         # latency-bound launches that leave most of the chip idle)
         self.overlap_streams = True
         self._side_streams = {}
         self.warp_variant = 0          # mvster_warp_agg_fwd variant (0 = per-shape default)
-        self.native_train = True       # training convolutions on the gfx950 kernels (False: PyTorch-ROCm / MIOpen)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_plans())
 
     # ------------------------------------------------------------------ plan cache
     def invalidate_plans(self):
-        """Drop the packed-weight plans; they are rebuilt on the next eval forward.  Called
-        automatically by load_state_dict(), train()/eval() and .to()/.cuda(); call it by hand
-        after modifying parameters in place while in eval mode."""
-        self._plans = None
+        """Drop the packed-weight plans (eval) and the cached packed layers of the training path; they are
+        rebuilt on the next forward.  Called automatically by load_state_dict(), by train()/eval() when the
+        mode actually changes and by .to()/.cuda(); call it by hand after modifying parameters in place while
+        in eval mode, or through ``p.data`` in training mode (see ``train_ops._LayerCache``)."""
+        self._plans.clear()            # in place: nn.DataParallel replicas share the dict
+        from . import train_ops
+        train_ops.CACHE.clear()
 
     def train(self, mode=True):
-        self._plans = None
+        # the reference's validation loop calls .eval() for every sample (train_mvs4.py:258): only a real
+        # mode change (parameters were trained in between) costs a plan rebuild
+        if mode != self.training:
+            self._plans.clear()
         return super().train(mode)
 
     def _apply(self, fn, *args, **kwargs):
-        self._plans = None
+        self._plans.clear()
         return super()._apply(fn, *args, **kwargs)
 
     def _get_plans(self):
-        if self._plans is None:
+        # per device: an nn.DataParallel replica on cuda:1 must not run plans whose packed weights live on cuda:0
+        dev = next(self.parameters()).device
+        plans = self._plans.get(dev)
+        if plans is None:
             with torch.no_grad():
                 fpn = FpnPlan(self.feature)
                 regs = [Reg2dPlan(m) if isinstance(m, reg2d) else Reg3dPlan(m) for m in self.reg]
-            self._plans = (fpn, regs)
-        return self._plans
+            plans = self._plans[dev] = (fpn, regs)
+        return plans
 
     # ------------------------------------------------------------------ pieces
     def _hypotheses(self, stage_idx, depth_values, depth_interval, prev, H, W):
@@ -262,8 +247,6 @@ class MVS4net(nn.Module):
         fused warp/correlation/aggregation on the gfx950 kernels.  The FPN runs once over all views (view-major
         batch) with BatchNorm on batch statistics per view, i.e. the numbers of the reference's per-view
         ``self.feature(img)`` calls (MVS4Net.py:65-68) in one pass."""
-        if not self.native_train:
-            return self._forward_train_miopen(imgs, proj_matrices, depth_values)
         dev = imgs[0].device
         depth_values = depth_values.to(dev, torch.float32)
         depth_interval = (depth_values[:, -1] - depth_values[:, 0]) / depth_values.size(1)
@@ -293,36 +276,6 @@ class MVS4net(nn.Module):
             outputs.update(st)
         if self.mono and self.training:
             outputs = self.mono_depth_decoder.forward_cl(outputs, ref_feats, depth_values[:, 0], depth_values[:, 1])
-        return outputs
-
-    def _forward_train_miopen(self, imgs, proj_matrices, depth_values):
-        """The same forward with the convolutions left to PyTorch-ROCm / MIOpen (``native_train = False``): kept
-        as the on-GPU cross-check of the native training path (tests/test_gpu_train.py) and for timing it."""
-        dev = imgs[0].device
-        depth_values = depth_values.to(dev, torch.float32)
-        depth_interval = (depth_values[:, -1] - depth_values[:, 0]) / depth_values.size(1)
-        pyramids = [self.feature(img) for img in imgs]     # per view, like the reference (BN batch stats per view)
-        outputs = {}
-        prev = None
-        for s in range(self.num_stage):
-            name = "stage%d" % (s + 1)
-            feats = [p[name] for p in pyramids]
-            ref_fea = feats[0]
-            B, C, h, w = ref_fea.shape
-            G = self.group_cor_dim[s] if self.group_cor else C
-            with torch.no_grad():
-                rt = ops.relative_projection(proj_matrices[name].to(dev, torch.float32))
-                hypo = self._hypotheses(s, depth_values, depth_interval, prev, h, w)
-            cor = _WarpAgg.apply(ref_fea, torch.stack(feats[1:], 0), rt, hypo, G, self.group_cor, self.attn_fuse_d,
-                                 float(self.attn_temp))
-            st = self._stage_outputs(s, self.reg[s](cor.contiguous()), hypo, dev)
-            if self.mono:
-                st["mono_feat"] = ref_fea
-            prev = st
-            outputs[name] = st
-            outputs.update(st)
-        if self.mono and self.training:
-            outputs = self.mono_depth_decoder(outputs, depth_values[:, 0], depth_values[:, 1])
         return outputs
 
     def forward(self, imgs, proj_matrices, depth_values, filename=None):

@@ -294,9 +294,10 @@ def bn_relu_fwd(x, scale, shift, relu, groups=1):
     return y
 
 
-def bn_relu_bwd(x, gy, scale, shift, mean, rstd, relu, groups=1):
+def bn_relu_bwd(x, gy, scale, shift, mean, rstd, relu, groups=1, frozen=False):
     """-> (dx, sum g [groups,C], sum g*xh [groups,C]) with g = gy*(y>0), xh = (x-mean)*rstd (BatchNorm + ReLU backward,
-    batch statistics per group)."""
+    batch statistics per group).  ``frozen``: mean / rstd are constants (running statistics), so dx = g * scale: the
+    apply kernel is run with zero sums."""
     _chk(x, "bn_relu_bwd:x")
     _chk(gy, "bn_relu_bwd:gy")
     C = x.shape[-1]
@@ -311,7 +312,8 @@ def bn_relu_bwd(x, gy, scale, shift, mean, rstd, relu, groups=1):
     _lib.check(rc, "bn_relu_bwd_reduce")
     sums = partial.sum(1)                                   # [groups, 2, C]
     dx = torch.empty_like(x)
-    rc = lib.mvster_bn_relu_bwd_apply(_ptr(x), _ptr(gy), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(sums),
+    rc = lib.mvster_bn_relu_bwd_apply(_ptr(x), _ptr(gy), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
+                                      _ptr(torch.zeros_like(sums) if frozen else sums),
                                       _ptr(dx), rows, C, int(relu), int(groups), _stream())
     _lib.check(rc, "bn_relu_bwd_apply")
     return dx, sums[:, 0], sums[:, 1]
@@ -333,19 +335,29 @@ def sinkhorn_pixels(attn, hypo, gt, iters, eps):
     return loss_pix, jac
 
 
-def upsample2x_cl(x, backward=False):
-    """Bilinear x2 (align_corners=True) of a channels-last map [B,h,w,C] -> [B,2h,2w,C]; ``backward=True`` is the adjoint
-    [B,2h,2w,C] -> [B,h,w,C]."""
+def upsample2x_cl(x, backward=False, mode="bilinear"):
+    """x2 up-sampling of a channels-last map [B,h,w,C] -> [B,2h,2w,C], ``mode`` "bilinear" (align_corners=True) or
+    "nearest"; ``backward=True`` is the adjoint [B,2h,2w,C] -> [B,h,w,C]."""
     _chk(x, "upsample2x_cl")
     B, H, W, C = x.shape
+    if mode not in ("bilinear", "nearest"):
+        raise NotImplementedError("upsample2x_cl: mode %r (the path uses bilinear and nearest only)" % (mode,))
+    if C % 4:
+        raise NotImplementedError("upsample2x_cl: %d channels (the kernels move 4 channels per lane)" % C)
     lib = _lib.load()
     if backward:
         if (H | W) & 1:
             raise RuntimeError("upsample2x_cl: the adjoint needs even sizes")
         out = torch.empty(B, H // 2, W // 2, C, device=x.device, dtype=torch.float32)
-        rc = lib.mvster_upsample2x_cl_bwd(_ptr(x), _ptr(out), B, H // 2, W // 2, C, _stream())
+        if mode == "nearest":
+            rc = lib.mvster_upsample2x_nearest_cl(_ptr(x), _ptr(out), B, H // 2, W // 2, C, 1, _stream())
+        else:
+            rc = lib.mvster_upsample2x_cl_bwd(_ptr(x), _ptr(out), B, H // 2, W // 2, C, _stream())
     else:
         out = torch.empty(B, 2 * H, 2 * W, C, device=x.device, dtype=torch.float32)
-        rc = lib.mvster_upsample2x_cl_fwd(_ptr(x), _ptr(out), B, H, W, C, _stream())
+        if mode == "nearest":
+            rc = lib.mvster_upsample2x_nearest_cl(_ptr(x), _ptr(out), B, H, W, C, 0, _stream())
+        else:
+            rc = lib.mvster_upsample2x_cl_fwd(_ptr(x), _ptr(out), B, H, W, C, _stream())
     _lib.check(rc, "upsample2x_cl")
     return out

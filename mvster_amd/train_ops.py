@@ -42,24 +42,32 @@ def _triple(v, lead):
 
 
 class _LayerCache:
-    """ConvLayer objects per (parameter, role): built once, re-packed when the parameter's version changes
-    (an optimizer step), so a training step costs a few small device ops per layer instead of a plan build."""
+    """ConvLayer objects per (parameter, role): built once, re-packed when the parameter changes, so a training step
+    costs a few small device ops per layer instead of a plan build.
+
+    "Changed" = another ``_version`` (in-place updates through the tensor: torch.optim steps, ``p.mul_()``) or another
+    storage address (``p.data = t``, ``vector_to_parameters``).  In-place writes through ``p.data`` / a detached alias
+    (``p.data.add_()``, some third-party optimizers, EMA helpers) move neither: they cannot be seen from here, so either
+    call ``train_ops.CACHE.clear()`` / ``model.invalidate_plans()`` after such an update or set
+    ``train_ops.CACHE.always_repack = True`` (one small kernel per layer and pass; already what a captured
+    ``GraphedTrainStep`` replays every step)."""
 
     def __init__(self):
         self._d = {}
+        self.always_repack = False
 
     def get(self, weight, role, build, refresh):
         """``build()`` makes the layer; ``refresh(layer)`` re-packs it from the updated parameter."""
         key = (id(weight), role)
         hit = self._d.get(key)
-        ver = weight._version
+        stamp = (weight._version, weight.data_ptr())
         if hit is not None and hit[0] is weight and hit[2].wpk.device == weight.device:
-            if hit[1] != ver:
+            if hit[1] != stamp or self.always_repack or torch.cuda.is_current_stream_capturing():
                 refresh(hit[2])
-                self._d[key] = (weight, ver, hit[2])
+                self._d[key] = (weight, stamp, hit[2])
             return hit[2]
         layer = build()
-        self._d[key] = (weight, ver, layer)
+        self._d[key] = (weight, stamp, layer)
         return layer
 
     def clear(self):
@@ -143,88 +151,72 @@ def conv_cl(x, weight, bias=None, stride=1, padding=0, transposed=False):
 
 
 class _BnReluCL(torch.autograd.Function):
-    """relu(BatchNorm(x)) given the statistics pack [5, groups, C] = (mean, var, rstd, scale, shift) of
-    ``ops.bn_batch_stats``: fused apply kernel forward, two fused kernels backward."""
+    """relu(BatchNorm(x)) given the statistics pack [5, groups, C] = (mean, var, rstd, scale, shift): fused apply kernel
+    forward, two fused kernels backward.  ``frozen``: the pack holds the running statistics (a BatchNorm in eval mode
+    inside a training graph), which do not depend on x."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pack, relu, groups):
+    def forward(ctx, x, weight, bias, pack, relu, groups, frozen):
         ctx.save_for_backward(x, pack)
-        ctx.cfg = (relu, groups)
+        ctx.cfg = (relu, groups, frozen)
         return ops.bn_relu_fwd(x, pack[3], pack[4], relu, groups)
 
     @staticmethod
     def backward(ctx, gy):
         x, pack = ctx.saved_tensors
-        relu, groups = ctx.cfg
-        dx, dbeta, dgamma = ops.bn_relu_bwd(x, gy.contiguous(), pack[3], pack[4], pack[0], pack[2], relu, groups)
-        return dx, dgamma.sum(0), dbeta.sum(0), None, None, None
+        relu, groups, frozen = ctx.cfg
+        dx, dbeta, dgamma = ops.bn_relu_bwd(x, gy.contiguous(), pack[3], pack[4], pack[0], pack[2], relu, groups, frozen)
+        return dx, dgamma.sum(0), dbeta.sum(0), None, None, None, None
 
 
 def batch_norm_cl(x, bn, relu=False, groups=1):
-    """nn.BatchNorm2d / 3d (+ optional ReLU) on a channels-last tensor: batch statistics + running-stat update in
-    training (torch semantics: biased variance to normalise, unbiased in the running average), running statistics
-    in eval.  ``groups`` > 1: x holds that many equal slices along dim 0 (the views of one sample batch) which are
-    normalised separately and update the running statistics one after the other, exactly as ``groups`` separate calls
-    of the module would (the reference runs its FPN once per view).  The training form is four launches of the fused
-    gfx950 kernels (statistics, finish + running averages, apply; mvster_bn_*); gradients flow to x, gamma, beta."""
+    """nn.BatchNorm2d / 3d (+ optional ReLU) on a channels-last tensor, on the fused gfx950 kernels (mvster_bn_*):
+    batch statistics + running-stat update in training (torch semantics: biased variance to normalise, unbiased in the
+    running average), running statistics when the module is in eval mode.  ``groups`` > 1: x holds that many equal
+    slices along dim 0 (the views of one sample batch) which are normalised separately and update the running
+    statistics one after the other, exactly as ``groups`` separate calls of the module would (the reference runs its
+    FPN once per view).  Gradients flow to x, gamma, beta.  Configurations the kernels do not cover raise."""
     C = x.shape[-1]
+    if not x.is_cuda:
+        raise RuntimeError("batch_norm_cl: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if C not in (4, 8, 16, 32, 64):
+        raise NotImplementedError("batch_norm_cl: %d channels (the kernels cover 4/8/16/32/64, the path's widths)" % C)
+    if not bn.affine:
+        raise NotImplementedError("batch_norm_cl: non-affine BatchNorm (not used by the path)")
+    x = x.contiguous()
     batch_stats = bn.training or not bn.track_running_stats
-    if (batch_stats and bn.affine and x.is_cuda and C in (4, 8, 16, 32, 64)
-            and (bn.momentum is not None or not bn.track_running_stats)):
-        x = x.contiguous()
+    if batch_stats:
         track = bn.track_running_stats
+        if track and bn.momentum is None:
+            raise NotImplementedError("batch_norm_cl: cumulative-average running statistics (momentum=None)")
         with torch.no_grad():
             pack = ops.bn_batch_stats(x, bn.weight, bn.bias, bn.running_mean if track else None,
                                       bn.running_var if track else None, bn.eps, bn.momentum or 0.0, groups)
             if track:
                 bn.num_batches_tracked += groups
-        return _BnReluCL.apply(x, bn.weight, bn.bias, pack, relu, groups)
-    # tensor-level form (eval-mode statistics inside a training graph, cumulative-average momentum, non-affine layers,
-    # odd channel counts)
-    if batch_stats:
-        xg = x.reshape(groups, -1, C)
-        var, mean = torch.var_mean(xg, dim=1, unbiased=False)                  # [groups, C]
-        if bn.track_running_stats:
-            with torch.no_grad():
-                n = xg.shape[1]
-                unbiased = var * (n / max(n - 1, 1))
-                for g in range(groups):
-                    bn.num_batches_tracked += 1
-                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                    bn.running_mean.mul_(1 - mom).add_(mean[g], alpha=mom)
-                    bn.running_var.mul_(1 - mom).add_(unbiased[g], alpha=mom)
-    else:
-        mean, var = bn.running_mean.expand(groups, C), bn.running_var.expand(groups, C)
-    scale = torch.rsqrt(var + bn.eps)
-    if bn.affine:
-        scale = scale * bn.weight
-        shift = bn.bias - mean * scale
-    else:
-        shift = -mean * scale
-    n = x.shape[0] // groups
-    y = torch.cat([x[g * n:(g + 1) * n] * scale[g] + shift[g] for g in range(groups)]) if groups > 1 else x * scale[0] + shift[0]
-    return torch.relu(y) if relu else y
+        return _BnReluCL.apply(x, bn.weight, bn.bias, pack, relu, groups, False)
+    with torch.no_grad():            # [C]-sized parameter preparation, like weight packing
+        rstd = torch.rsqrt(bn.running_var + bn.eps)
+        scale = bn.weight * rstd
+        pack = torch.stack([bn.running_mean, bn.running_var, rstd, scale, bn.bias - bn.running_mean * scale])
+        pack = pack.unsqueeze(1).expand(5, groups, C).contiguous()
+    return _BnReluCL.apply(x, bn.weight, bn.bias, pack, relu, groups, True)
 
 
 class _Upsample2xCL(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
-        return ops.upsample2x_cl(x.contiguous())
+    def forward(ctx, x, mode):
+        ctx.mode = mode
+        return ops.upsample2x_cl(x.contiguous(), mode=mode)
 
     @staticmethod
     def backward(ctx, g):
-        return ops.upsample2x_cl(g.contiguous(), backward=True)
+        return ops.upsample2x_cl(g.contiguous(), backward=True, mode=ctx.mode), None
 
 
 def upsample2x_cl(x, mode):
-    """F.interpolate(scale_factor=2) of a [B,1,H,W,C] channels-last map.  Bilinear (align_corners=True, the FPN's
-    top-down path) runs the gfx950 kernel pair (gather-form adjoint, no atomics); nearest is a tensor op."""
+    """F.interpolate(scale_factor=2) of a [B,D,H,W,C] channels-last map (per depth slice): "bilinear"
+    (align_corners=True, the FPN's top-down path) or "nearest" (the mono head), each a gfx950 kernel pair with a
+    gather-form adjoint (no atomics)."""
     B, D, H, W, C = x.shape
-    if mode == "bilinear" and x.is_cuda and C % 4 == 0:
-        return _Upsample2xCL.apply(x.reshape(B * D, H, W, C)).reshape(B, D, 2 * H, 2 * W, C)
-    v = x.reshape(B * D, H, W, C).permute(0, 3, 1, 2)            # NCHW view with channels-last strides
-    if mode == "bilinear":
-        v = F.interpolate(v, scale_factor=2, mode="bilinear", align_corners=True)
-    else:
-        v = F.interpolate(v, scale_factor=2, mode=mode)
-    return v.permute(0, 2, 3, 1).contiguous().reshape(B, D, 2 * H, 2 * W, C)
+    return _Upsample2xCL.apply(x.reshape(B * D, H, W, C), mode).reshape(B, D, 2 * H, 2 * W, C)

@@ -44,11 +44,10 @@ def infer(H, W, N, steps=20):
     torch.cuda.reset_peak_memory_stats()
 
 
-def train(H, W, N, B, steps=5, native=True):
+def train(H, W, N, B, steps=5):
     model = MVS4net(**SHIPPED)
     model.load_state_dict(load_weights(), strict=True)
     model.to(dev).train()
-    model.native_train = native
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     imgs, proj, dv = make_inputs(N, H, W, seed=0, device=dev, batch=B)
     g = torch.Generator().manual_seed(0)
@@ -71,8 +70,7 @@ def train(H, W, N, B, steps=5, native=True):
         losses.append(loss.item())
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    print(json.dumps({"config": "train %dx%d N=%d B=%d (1 rank, Adam, OT loss), convolutions: %s" % (
-        H, W, N, B, "gfx950 kernels" if native else "PyTorch-ROCm/MIOpen"),
+    print(json.dumps({"config": "train %dx%d N=%d B=%d (1 rank, Adam, OT loss), gfx950 kernels" % (H, W, N, B),
                       "s_per_step": round(dt, 4), "loss_first": round(losses[0], 4), "loss_last": round(losses[-1], 4),
                       "finite": all(l == l for l in losses),
                       "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
@@ -82,6 +80,4 @@ if __name__ == "__main__":
     infer(512, 640, 5)
     infer(1152, 1600, 5, steps=10)
     infer(1024, 1920, 7, steps=10)
-    train(512, 640, 5, 2, steps=5, native=True)
-    if "--with-pytorch-train" in sys.argv:
-        train(512, 640, 5, 2, steps=3, native=False)
+    train(512, 640, 5, 2, steps=5)

@@ -30,6 +30,12 @@ def cl5(x):   # NCDHW -> NDHWC
     return x.permute(0, 2, 3, 4, 1).contiguous()
 
 
+def twin(oracle_module, m):
+    """The oracle's PyTorch module with the product module's parameters: the CPU reference."""
+    oracle_module.load_state_dict(m.state_dict(), strict=True)
+    return oracle_module.eval()
+
+
 def test_library_is_loaded_from_the_tree():
     from mvster_amd import _lib
     lib = _lib.load()
@@ -235,7 +241,7 @@ def test_conv_bn_relu(name, cfg, shape):
     m.eval()
     x = torch.randn(*shape)
     with torch.no_grad():
-        want = cl5(m(x))
+        want = cl5(twin(O._CBR3d(cfg["cin"], cfg["cout"], kernel_size=cfg["k"], stride=cfg["s"], pad=cfg["p"]), m)(x))
     layer = cp._cbr3d(m.to(DEV))
     worst = 0.0
     for mt in (1, 2, 4):
@@ -293,7 +299,7 @@ def test_conv_transposed_skip(cin, cout, k, pad, op, s):
     seq.eval()
     x = torch.randn(2, cin, 4, 9, 11)
     with torch.no_grad():
-        y = seq(x)
+        y = twin(O._up3d(cin, cout, k, pad, op, s), seq)(x)
         skip = torch.randn_like(y)
         want = cl5(skip + y)
     layer = cp._up3d(seq.to(DEV))

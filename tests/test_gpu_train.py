@@ -1,6 +1,7 @@
 """Training path on the GPU: the native convolution passes (forward / input gradient / weight gradient kernels)
-against PyTorch autograd, and a whole training step against the same step with the convolutions left to
-PyTorch-ROCm.  The fp64 CPU autograd of the same layer is the reference for the per-layer checks."""
+against PyTorch autograd, and a whole training step against the same step of the ORACLE module tree moved to the
+GPU (plain PyTorch-ROCm: MIOpen convolutions, F.grid_sample, tensor-level Sinkhorn under autograd -- nothing of the
+product in it).  The fp64 CPU autograd of the same layer is the reference for the per-layer checks."""
 import json
 import os
 
@@ -14,6 +15,7 @@ if torch.cuda.is_available():
     from mvster_amd import MVS4net, MVS4net_loss, ops
     from mvster_amd import train_ops as T
     from mvster_amd.synthetic import make_inputs
+    from oracle import mvs4_oracle as O
 DEV = torch.device("cuda:0") if torch.cuda.is_available() else None
 REPORT = {}
 
@@ -141,14 +143,13 @@ def test_train_step_native_vs_pytorch_rocm(reg_net):
                depth_interals_ratio=[0.5, 0.5, 0.5, 1], group_cor=True, group_cor_dim=[8, 8, 4, 4], inverse_depth=True,
                mono=True, attn_temp=2, attn_fuse_d=True)
     torch.manual_seed(1)
-    ref = MVS4net(**cfg)
+    ref = O.OracleMVS4net(**cfg)
     sd = randomize_state(ref.state_dict(), seed=4, prob_gain=4.0)
     ref.load_state_dict(sd)
     nat = MVS4net(**cfg)
-    nat.load_state_dict(sd)
+    nat.load_state_dict(sd, strict=True)
     ref.to(DEV).train()
     nat.to(DEV).train()
-    ref.native_train = False
     H, W, N, B = 128, 192, 3, 2
     imgs, proj, dv = make_inputs(nviews=N, H=H, W=W, seed=8, batch=B)
     imgs = [i.to(DEV) for i in imgs]
@@ -164,8 +165,9 @@ def test_train_step_native_vs_pytorch_rocm(reg_net):
     def step(m):
         m.zero_grad(set_to_none=True)
         out = m(imgs, proj, dv)
-        loss = MVS4net_loss(out, gt, mask, stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10,
-                            ot_eps=1, ot_continous=False, mono=True)[0]
+        loss_fn = O.mvs4net_loss if isinstance(m, O.OracleMVS4net) else MVS4net_loss
+        loss = loss_fn(out, gt, mask, stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10,
+                       ot_eps=1, ot_continous=False, mono=True)[0]
         loss.backward()
         return out, loss.item(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
 
@@ -233,9 +235,9 @@ def test_fpn_module_gradients_native_vs_pytorch_rocm():
     gradients for a random output gradient -- smooth function, so the two paths must agree to rounding."""
     from mvster_amd.modules import FPN4
     torch.manual_seed(3)
-    a = FPN4(8).to(DEV).train()
+    a = O.FPN4(8).to(DEV).train()
     b = FPN4(8).to(DEV).train()
-    b.load_state_dict(a.state_dict())
+    b.load_state_dict(a.state_dict(), strict=True)
     x = torch.rand(2, 3, 64, 96, device=DEV)
     oa = a(x)
     ob = b.forward_cl(x.permute(0, 2, 3, 1).unsqueeze(1))
@@ -259,10 +261,13 @@ def test_reg_module_gradients_native_vs_pytorch_rocm(kind):
     from mvster_amd.modules import reg2d, reg3d
     torch.manual_seed(5)
     G = 4 if kind == "reg2d_g4" else 8
-    mk = (lambda: reg2d(input_channel=G, base_channel=8)) if kind.startswith("reg2d") else \
-        (lambda: reg3d(in_channels=G, base_channels=8, down_size=int(kind[-1])))
-    a, b = mk().to(DEV).train(), mk().to(DEV).train()
-    b.load_state_dict(a.state_dict())
+    if kind.startswith("reg2d"):
+        a, b = O.Reg2d(input_channel=G, base_channel=8), reg2d(input_channel=G, base_channel=8)
+    else:
+        a = O.Reg3d(in_channels=G, base_channels=8, down_size=int(kind[-1]))
+        b = reg3d(in_channels=G, base_channels=8, down_size=int(kind[-1]))
+    a, b = a.to(DEV).train(), b.to(DEV).train()
+    b.load_state_dict(a.state_dict(), strict=True)
     x = torch.randn(2, G, 8, 32, 48, device=DEV)
     xa = x.clone().requires_grad_(True)
     xb = x.permute(0, 2, 3, 4, 1).contiguous().requires_grad_(True)

@@ -79,6 +79,18 @@ def test_relative_projection_close_to_fp32_lapack(hm):
             assert np.all(np.abs(rt - want) <= 5e-7 * np.maximum(np.abs(want), 1.0))
 
 
+def test_singular_reference_projection_is_loud(hm):
+    """torch.inverse raises on a singular ref_proj (mvs4net_utils.py:25); the kernel arithmetic marks the whole
+    relative projection NaN instead of returning a silently wrong warp."""
+    from mvster_amd.synthetic import make_inputs
+    _, proj, _ = make_inputs(2, 64, 64, seed=0)
+    pm = proj["stage1"][0].numpy().copy()
+    pm[0, 0, 2, :] = 0.0                       # third extrinsic row zero: K @ E has rank 2
+    rt = np.zeros(12, np.float32)
+    assert hm.hm_relative_projection(fp(c(pm[0])), fp(c(pm[1])), fp(rt)) == -1
+    assert np.isnan(rt).all()
+
+
 def test_schedulers(hm, golden):
     g = golden("g5_sched")
     dv = g.np("dv")
