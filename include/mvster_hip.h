@@ -190,6 +190,11 @@ int mvster_upsample2x_nearest_cl(const float* in, float* out, int B, int h, int 
  * the masked mean over pixels stays with the caller. */
 int mvster_sinkhorn(const float* attn, const float* hypo, const float* gt, float* loss_pix, float* jac, int B, int D,
                     long HW, int iters, float eps, void* stream);
+/* The continuous form (ot_continous=True, models/mvs4net_utils.py:1111-1123): D + 1 target columns, all the mass on
+ * the extra one, whose cost is the distance of every bin to the ground truth's fractional bin position (10 where
+ * mask <= 0.5).  mask [B,HW] float; 3 <= D <= 8, iters <= 16. */
+int mvster_sinkhorn_continuous(const float* attn, const float* hypo, const float* gt, const float* mask, float* loss_pix,
+                               float* jac, int B, int D, long HW, int iters, float eps, void* stream);
 
 /* Geometric-consistency filter of one reference view against NS source views, fused (test_mvs4.py:273-328 per
  * view pair + the sums of filter_depth :362-385).  depth_ref [H,W], depth_src [NS,H,W]; ref_mats = inv(K_ref)[9],

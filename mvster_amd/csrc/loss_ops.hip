@@ -9,23 +9,30 @@
 //   a_j = log(onehot(nearest hypothesis to gt)_j + 1e-12)        b_i = log(pred_i + 1e-12)
 //   v_j = a_j - LSE_i(K_ij + u_i),  u_i = b_i - LSE_j(K_ij + v_j),  K = |i-j| / eps     (iters times, u0 = 0)
 //   loss = sum_ij exp(K_ij + u_i + v_j) * |i-j|
+// The continuous variant (ot_continous, :1111-1123) has D + 1 target columns; see the kernel.
 #include "common.hpp"
 
 namespace {
 
 constexpr int kMaxIters = 16;
 
-template <int D>
+// CONT = false: the discrete form (D target bins, one-hot on the hypothesis nearest to the ground truth).
+// CONT = true: the continuous form (ot_continous, models/mvs4net_utils.py:1111-1123): E = D + 1 target columns, all the
+// mass on the extra one, whose cost column is |pos - i| with pos = (1/gt - 1/hypo_0) / (1/hypo_2 - 1/hypo_1) the
+// ground truth's fractional bin (10 where the pixel is masked out, like the reference; `mask` is only read then).
+template <int D, bool CONT>
 __global__ void __launch_bounds__(128) sinkhorn_kernel(const float* __restrict__ attn, const float* __restrict__ hypo,
-                                                       const float* __restrict__ gt, float* __restrict__ loss_pix,
-                                                       float* __restrict__ jac, int B, long HW, int iters, float inv_eps) {
+                                                       const float* __restrict__ gt, const float* __restrict__ mask,
+                                                       float* __restrict__ loss_pix, float* __restrict__ jac, int B, long HW,
+                                                       int iters, float inv_eps) {
+    constexpr int E = CONT ? D + 1 : D;
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (long)B * HW) return;
     const long b = p / HW, q = p - b * HW;
     const float* ap = attn + b * D * HW + q;
     const float* hp = hypo + b * D * HW + q;
     const float g = gt[p];
-    float pred[D], bl[D], a[D];
+    float pred[D], bl[D], a[E], last[D];
     int nearest = 0;
     float best = 0.0f;
 #pragma unroll
@@ -35,50 +42,64 @@ __global__ void __launch_bounds__(128) sinkhorn_kernel(const float* __restrict__
         const float dist = fabsf(hp[i * HW] - g);
         if (i == 0 || dist < best) { best = dist; nearest = i; }      // first minimum, like torch.min
     }
+    if (CONT) {
+        const float itv = 1.0f / hp[2 * HW] - 1.0f / hp[HW];
+        float pos = (1.0f / g - 1.0f / hp[0]) / itv;
+        if (!(mask[p] > 0.5f)) pos = 10.0f;
 #pragma unroll
-    for (int j = 0; j < D; ++j) a[j] = logf((j == nearest ? 1.0f : 0.0f) + 1e-12f);
+        for (int i = 0; i < D; ++i) last[i] = fabsf(pos - (float)i);
+        nearest = D;
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) a[j] = logf((j == nearest ? 1.0f : 0.0f) + 1e-12f);
+    // cost of moving bin i to target column j
+    auto cost = [&](int i, int j) -> float { return (CONT && j == D) ? last[i] : fabsf((float)(i - j)); };
 
-    float uh[kMaxIters][D], vh[kMaxIters][D];      // potentials after every iteration (reverse sweep)
-    float u[D], v[D];
+    float uh[kMaxIters][D], vh[kMaxIters][E];      // potentials after every iteration (reverse sweep)
+    float u[D], v[E];
 #pragma unroll
     for (int i = 0; i < D; ++i) u[i] = 0.0f;
     for (int t = 0; t < iters; ++t) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
+        for (int j = 0; j < E; ++j) {
             float m = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < D; ++i) m = fmaxf(m, fabsf((float)(i - j)) * inv_eps + u[i]);
+            for (int i = 0; i < D; ++i) m = fmaxf(m, cost(i, j) * inv_eps + u[i]);
             float s = 0.0f;
 #pragma unroll
-            for (int i = 0; i < D; ++i) s += expf(fabsf((float)(i - j)) * inv_eps + u[i] - m);
+            for (int i = 0; i < D; ++i) s += expf(cost(i, j) * inv_eps + u[i] - m);
             v[j] = a[j] - (m + logf(s));
         }
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             float m = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < D; ++j) m = fmaxf(m, fabsf((float)(i - j)) * inv_eps + v[j]);
+            for (int j = 0; j < E; ++j) m = fmaxf(m, cost(i, j) * inv_eps + v[j]);
             float s = 0.0f;
 #pragma unroll
-            for (int j = 0; j < D; ++j) s += expf(fabsf((float)(i - j)) * inv_eps + v[j] - m);
+            for (int j = 0; j < E; ++j) s += expf(cost(i, j) * inv_eps + v[j] - m);
             u[i] = bl[i] - (m + logf(s));
         }
 #pragma unroll
-        for (int i = 0; i < D; ++i) { uh[t][i] = u[i]; vh[t][i] = v[i]; }
+        for (int i = 0; i < D; ++i) uh[t][i] = u[i];
+#pragma unroll
+        for (int j = 0; j < E; ++j) vh[t][j] = v[j];
     }
     if (iters == 0) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) v[j] = 0.0f;
+        for (int j = 0; j < E; ++j) v[j] = 0.0f;
     }
     // loss and the gradients of the final plan
-    float loss = 0.0f, du[D], dv[D], db[D];
+    float loss = 0.0f, du[D], dv[E], db[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) { du[i] = 0.0f; dv[i] = 0.0f; db[i] = 0.0f; }
+    for (int i = 0; i < D; ++i) { du[i] = 0.0f; db[i] = 0.0f; }
+#pragma unroll
+    for (int j = 0; j < E; ++j) dv[j] = 0.0f;
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            const float c = fabsf((float)(i - j));
+        for (int j = 0; j < E; ++j) {
+            const float c = cost(i, j);
             const float pc = expf(c * inv_eps + u[i] + v[j]) * c;
             loss += pc;
             du[i] += pc;
@@ -87,21 +108,22 @@ __global__ void __launch_bounds__(128) sinkhorn_kernel(const float* __restrict__
     loss_pix[p] = loss;
     // reverse sweep
     for (int t = iters - 1; t >= 0; --t) {
-        float ut[D], vt[D], up[D];
+        float ut[D], vt[E], up[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             ut[i] = uh[t][i];
-            vt[i] = vh[t][i];
             up[i] = t > 0 ? uh[t - 1][i] : 0.0f;
         }
+#pragma unroll
+        for (int j = 0; j < E; ++j) vt[j] = vh[t][j];
         // u_i = b_i - LSE_j(K_ij + v_j):  softmax_ij = exp(K_ij + v_j + u_i - b_i)
 #pragma unroll
         for (int i = 0; i < D; ++i) db[i] += du[i];
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
+        for (int j = 0; j < E; ++j) {
             float acc = 0.0f;
 #pragma unroll
-            for (int i = 0; i < D; ++i) acc += du[i] * expf(fabsf((float)(i - j)) * inv_eps + vt[j] + ut[i] - bl[i]);
+            for (int i = 0; i < D; ++i) acc += du[i] * expf(cost(i, j) * inv_eps + vt[j] + ut[i] - bl[i]);
             dv[j] -= acc;
         }
         // v_j = a_j - LSE_i(K_ij + u'_i) with u' the previous iterate:  softmax_ij = exp(K_ij + u'_i + v_j - a_j)
@@ -109,15 +131,28 @@ __global__ void __launch_bounds__(128) sinkhorn_kernel(const float* __restrict__
         for (int i = 0; i < D; ++i) {
             float acc = 0.0f;
 #pragma unroll
-            for (int j = 0; j < D; ++j) acc += dv[j] * expf(fabsf((float)(i - j)) * inv_eps + up[i] + vt[j] - a[j]);
+            for (int j = 0; j < E; ++j) acc += dv[j] * expf(cost(i, j) * inv_eps + up[i] + vt[j] - a[j]);
             du[i] = -acc;
         }
 #pragma unroll
-        for (int j = 0; j < D; ++j) dv[j] = 0.0f;
+        for (int j = 0; j < E; ++j) dv[j] = 0.0f;
     }
     float* jp = jac + b * D * HW + q;
 #pragma unroll
     for (int i = 0; i < D; ++i) jp[i * HW] = db[i] / (pred[i] + 1e-12f);
+}
+
+template <bool CONT>
+int launch_sinkhorn(const float* attn, const float* hypo, const float* gt, const float* mask, float* loss_pix, float* jac,
+                    int B, int D, long HW, int iters, float eps, hipStream_t s) {
+    const long n = (long)B * HW;
+    dim3 grid((unsigned)((n + 127) / 128)), block(128);
+    const float inv_eps = 1.0f / eps;
+#define MV_S(D_) if (D == D_) { hipLaunchKernelGGL((sinkhorn_kernel<D_, CONT>), grid, block, 0, s, attn, hypo, gt, mask, loss_pix, jac, B, HW, iters, inv_eps); return mv_check_launch(); }
+    if (!CONT) { MV_S(2) }
+    MV_S(3) MV_S(4) MV_S(5) MV_S(6) MV_S(7) MV_S(8)
+#undef MV_S
+    return MVSTER_ERR_UNSUPPORTED;
 }
 
 }  // namespace
@@ -128,12 +163,15 @@ extern "C" int mvster_sinkhorn(const float* attn, const float* hypo, const float
     if (!attn || !hypo || !gt || !loss_pix || !jac) return MVSTER_ERR_NULL;
     if (B <= 0 || HW <= 0 || iters < 0 || !(eps > 0.0f)) return MVSTER_ERR_SHAPE;
     if (iters > kMaxIters) return MVSTER_ERR_UNSUPPORTED;
-    const long n = (long)B * HW;
-    dim3 grid((unsigned)((n + 127) / 128)), block(128);
-    hipStream_t s = (hipStream_t)stream;
-    const float inv_eps = 1.0f / eps;
-#define MV_S(D_) if (D == D_) { hipLaunchKernelGGL(sinkhorn_kernel<D_>, grid, block, 0, s, attn, hypo, gt, loss_pix, jac, B, HW, iters, inv_eps); return mv_check_launch(); }
-    MV_S(2) MV_S(3) MV_S(4) MV_S(5) MV_S(6) MV_S(7) MV_S(8)
-#undef MV_S
-    return MVSTER_ERR_UNSUPPORTED;
+    return launch_sinkhorn<false>(attn, hypo, gt, nullptr, loss_pix, jac, B, D, HW, iters, eps, (hipStream_t)stream);
+}
+
+// The continuous form (ot_continous=True): as above with mask [B,HW] (> 0.5 = valid); D in {3,...,8}.
+extern "C" int mvster_sinkhorn_continuous(const float* attn, const float* hypo, const float* gt, const float* mask,
+                                          float* loss_pix, float* jac, int B, int D, long HW, int iters, float eps,
+                                          void* stream) {
+    if (!attn || !hypo || !gt || !mask || !loss_pix || !jac) return MVSTER_ERR_NULL;
+    if (B <= 0 || HW <= 0 || iters < 0 || !(eps > 0.0f)) return MVSTER_ERR_SHAPE;
+    if (iters > kMaxIters) return MVSTER_ERR_UNSUPPORTED;
+    return launch_sinkhorn<true>(attn, hypo, gt, mask, loss_pix, jac, B, D, HW, iters, eps, (hipStream_t)stream);
 }

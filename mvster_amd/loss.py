@@ -50,27 +50,36 @@ class _SinkhornLoss(torch.autograd.Function):
     target and the cost are constants)."""
 
     @staticmethod
-    def forward(ctx, attn, hypo, gt, mask, iters, eps):
+    def forward(ctx, attn, hypo, gt, mask, iters, eps, continuous):
         from . import ops
-        loss_pix, jac = ops.sinkhorn_pixels(attn.contiguous(), hypo.contiguous(), gt.contiguous(), iters, eps)
-        m = mask.to(loss_pix.dtype)
+        m = mask.to(torch.float32).contiguous()
+        loss_pix, jac = ops.sinkhorn_pixels(attn.contiguous(), hypo.contiguous(), gt.contiguous(), iters, eps, mask=m,
+                                            continuous=continuous)
         n = m.sum()
         ctx.save_for_backward(jac, m, n)
-        return (loss_pix * m).sum() / n
+        # masked mean without a boolean-index gather (which would synchronise); where() keeps a non-finite loss of a
+        # masked-out pixel (ground-truth depth 0) out of the sum
+        return torch.where(m > 0.5, loss_pix, torch.zeros_like(loss_pix)).sum() / n
 
     @staticmethod
     def backward(ctx, g):
         jac, m, n = ctx.saved_tensors
-        return jac * (m * (g / n)).unsqueeze(1), None, None, None, None, None
+        w = (m * (g / n)).unsqueeze(1)
+        return torch.where(w != 0, jac * w, torch.zeros_like(jac)), None, None, None, None, None, None
 
 
 def sinkhorn_loss(gt_depth, hypo_depth, attn_weight, mask, iters, eps=1, continuous=False):
-    """The loss value of ``sinkhorn`` (its second return).  CUDA tensors, discrete bins, D <= 8, iters <= 16 run the
-    fused gfx950 kernel; anything else is the tensor-level form."""
+    """The loss value of ``sinkhorn`` (its second return) on the fused gfx950 kernel (``mvster_sinkhorn`` /
+    ``mvster_sinkhorn_continuous``): GPU tensors, D <= 8 hypotheses, iters <= 16 -- the range of the reference's
+    configurations.  There is no tensor-level fallback: other inputs raise (``sinkhorn`` above is the explicit
+    reference-shaped form that also returns the transport plan)."""
     D = attn_weight.shape[1]
-    if attn_weight.is_cuda and not continuous and 2 <= D <= 8 and iters <= 16:
-        return _SinkhornLoss.apply(attn_weight, hypo_depth, gt_depth, mask, int(iters), float(eps))
-    return sinkhorn(gt_depth, hypo_depth, attn_weight, mask, iters, eps, continuous)[1]
+    if not attn_weight.is_cuda:
+        raise RuntimeError("mvster_amd.loss.sinkhorn_loss runs on MI355X only (there is no CPU fallback)")
+    if not ((3 if continuous else 2) <= D <= 8 and 0 <= iters <= 16):
+        raise NotImplementedError("sinkhorn_loss: D=%d hypotheses / %d iterations (the fused kernel holds a pixel's whole "
+                                  "problem in registers: D <= 8, iters <= 16)" % (D, iters))
+    return _SinkhornLoss.apply(attn_weight, hypo_depth, gt_depth, mask, int(iters), float(eps), bool(continuous))
 
 
 def _masked_mean(values, mask):

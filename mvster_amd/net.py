@@ -176,7 +176,8 @@ class MVS4net(nn.Module):
             o1, o2 = fpn.coarse(c3, f1)
         else:
             o1, o2 = fpn.coarse(c3, f1)
-            o3, o4 = fpn.tail(c0, c1, f1)
+            # a 1- or 2-stage cascade (BASELINE config 1) never reads the two fine levels
+            o3, o4 = fpn.tail(c0, c1, f1) if self.num_stage > 2 else (None, None)
         pyramid = [o1, o2, o3, o4]
 
         outputs = {}
@@ -209,7 +210,8 @@ class MVS4net(nn.Module):
                 sel = ops.select_depth(hypo, self.depth_interals_ratio[s], self.inverse_depth, logits=plan(cor),
                                        want_logits=want_logits)
             if capture is not None:
-                capture[name] = {"cor_feats": cor.permute(0, 4, 1, 2, 3), "logits": sel["logits"]}
+                capture[name] = {"cor_feats": cor.permute(0, 4, 1, 2, 3), "logits": sel["logits"],
+                                 "feats_cl": f}                                  # [N,B,h,w,C], view 0 = reference
             # (x1 at the last stage is the identity, exactly: src = dst, lambda = 0)
             conf = ops.upsample_bilinear(sel["conf"], 2 ** (3 - s)) if s < 3 else sel["conf"]
             st = {"depth": sel["depth"], "photometric_confidence": conf, "hypo_depth": hypo,

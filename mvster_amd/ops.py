@@ -319,9 +319,10 @@ def bn_relu_bwd(x, gy, scale, shift, mean, rstd, relu, groups=1, frozen=False):
     return dx, sums[:, 0], sums[:, 1]
 
 
-def sinkhorn_pixels(attn, hypo, gt, iters, eps):
+def sinkhorn_pixels(attn, hypo, gt, iters, eps, mask=None, continuous=False):
     """Per-pixel Sinkhorn OT loss and its gradient w.r.t. attn: attn, hypo [B,D,H,W], gt [B,H,W] ->
-    (loss_pix [B,H,W], jac [B,D,H,W]).  models/mvs4net_utils.py:1096-1142 (ot_continous=False)."""
+    (loss_pix [B,H,W], jac [B,D,H,W]).  models/mvs4net_utils.py:1096-1142; ``continuous`` selects the
+    ot_continous form (:1111-1123), which also reads ``mask`` [B,H,W] (float, > 0.5 = valid)."""
     for t, n in ((attn, "attn"), (hypo, "hypo"), (gt, "gt")):
         _chk(t, "sinkhorn:" + n)
     B, D, H, W = attn.shape
@@ -329,8 +330,15 @@ def sinkhorn_pixels(attn, hypo, gt, iters, eps):
         raise RuntimeError("sinkhorn: inconsistent shapes")
     loss_pix = torch.empty(B, H, W, device=attn.device, dtype=torch.float32)
     jac = torch.empty_like(attn)
-    rc = _lib.load().mvster_sinkhorn(_ptr(attn), _ptr(hypo), _ptr(gt), _ptr(loss_pix), _ptr(jac), B, D, H * W, int(iters),
-                                     float(eps), _stream())
+    if continuous:
+        _chk(mask, "sinkhorn:mask")
+        if mask is None or tuple(mask.shape) != (B, H, W):
+            raise RuntimeError("sinkhorn: the continuous form needs mask [B,H,W]")
+        rc = _lib.load().mvster_sinkhorn_continuous(_ptr(attn), _ptr(hypo), _ptr(gt), _ptr(mask), _ptr(loss_pix), _ptr(jac), B,
+                                                    D, H * W, int(iters), float(eps), _stream())
+    else:
+        rc = _lib.load().mvster_sinkhorn(_ptr(attn), _ptr(hypo), _ptr(gt), _ptr(loss_pix), _ptr(jac), B, D, H * W, int(iters),
+                                         float(eps), _stream())
     _lib.check(rc, "sinkhorn")
     return loss_pix, jac
 

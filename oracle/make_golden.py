@@ -295,17 +295,88 @@ def g8_loss(U):
     npz("g8_sinkhorn", hypo=hypo, attn=attn, gt=gt, mask=mask, T=T, loss=loss)
 
 
+def g8b_loss_continuous(U):
+    """sinkhorn with the continuous ground-truth offset (ot_continous=True, train_mvs4.py:64): D x (D+1) cost."""
+    torch.manual_seed(19)
+    out = {}
+    for name, (B, D, h, w) in (("d4", (2, 4, 6, 10)), ("d8", (1, 8, 5, 7))):
+        inv = 1.0 / 900 + (1.0 / 450 - 1.0 / 900) * torch.rand(B, 1, h, w)
+        step = 2e-5 * (0.5 + torch.rand(B, 1, h, w))
+        hypo = 1.0 / (inv + step * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1))      # index 0 = farthest
+        attn = torch.softmax(2 * torch.randn(B, D, h, w), 1)
+        # ground truth inside, at the edge of and outside the hypothesis range; invalid (masked) pixels hold depth 0
+        pos = -1.5 + (D + 2.0) * torch.rand(B, h, w)
+        gt = 1.0 / (inv[:, 0] + step[:, 0] * pos)
+        mask = torch.rand(B, h, w) > 0.25
+        gt[~mask] = 0.0
+        for iters, eps in ((10, 1.0), (3, 0.5)):
+            T, loss = U.sinkhorn(gt, hypo, attn, mask, iters=iters, eps=eps, continuous=True)
+            out["%s_it%d_T" % (name, iters)] = T
+            out["%s_it%d_loss" % (name, iters)] = loss
+        out.update({name + "_hypo": hypo, name + "_attn": attn, name + "_gt": gt, name + "_mask": mask})
+    npz("g8b_sinkhorn_continuous", **out)
+
+
+def g9_losses(M):
+    """MVS4net_loss (range ratios, linear / inverse, continuous OT) and Blend_loss (MVS4Net.py:113-206) on the stage
+    outputs stored in g6_train."""
+    z = np.load(os.path.join(OUT, "g6_train.npz"))
+    inputs, gt, mask = {}, {}, {}
+    for s in range(1, 5):
+        st = {k: torch.from_numpy(z["stage%d_%s" % (s, k)]) for k in ("depth", "hypo_depth", "attn_weight")}
+        if s > 1:
+            st["mono_depth"] = torch.from_numpy(z["stage%d_mono_depth" % s])
+        inputs["stage%d" % s] = st
+        gt["stage%d" % s] = torch.from_numpy(z["depth_gt_stage%d" % s])
+        mask["stage%d" % s] = torch.from_numpy(z["mask_stage%d" % s])
+    out = {"depth_max": torch.tensor([935.0, 900.0]), "depth_min": torch.tensor([425.0, 430.0])}
+    cases = {
+        "inv": dict(stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10, ot_eps=1, mono=True),
+        "lin_l1": dict(stage_lw=[0.5, 1, 1.5, 2], l1ot_lw=[0.3, 0.7], inverse_depth=False, ot_iter=3, ot_eps=1, mono=True),
+        "cont": dict(stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10, ot_eps=1, ot_continous=True,
+                     mono=False),
+    }
+    for name, kw in cases.items():
+        total, l1s, ots, rng = M.MVS4net_loss(inputs, gt, mask, **kw)
+        out["mvs4_%s_total" % name] = total
+        out["mvs4_%s_l1" % name] = torch.stack(l1s)
+        out["mvs4_%s_ot" % name] = torch.stack(ots)
+        out["mvs4_%s_range" % name] = torch.stack(rng)
+        r = M.Blend_loss(inputs, gt, mask, depth_max=out["depth_max"], depth_min=out["depth_min"], **kw)
+        out["blend_%s_total" % name] = r[0]
+        out["blend_%s_l1" % name] = torch.stack(r[1])
+        out["blend_%s_ot" % name] = torch.stack(r[2])
+        out["blend_%s_range" % name] = torch.stack(r[3])
+        out["blend_%s_epe_err3_err1" % name] = torch.stack([r[4], r[5], r[6]])
+    npz("g9_losses", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     U, M = _import_reference()
-    g1_warp(U)
-    g2_aggregate(U)
-    g3_reg(U)
-    g4_select(U)
-    g5_sched(U)
-    g6_g7_end_to_end(U, M)
-    g8_loss(U)
+    only = set(sys.argv[1:])          # e.g. ``make_golden.py g8b g9`` adds fixtures without rewriting the others
+
+    def want(tag):
+        return not only or tag in only
+    if want("g1"):
+        g1_warp(U)
+    if want("g2"):
+        g2_aggregate(U)
+    if want("g3"):
+        g3_reg(U)
+    if want("g4"):
+        g4_select(U)
+    if want("g5"):
+        g5_sched(U)
+    if want("g6"):
+        g6_g7_end_to_end(U, M)
+    if want("g8"):
+        g8_loss(U)
+    if want("g8b"):
+        g8b_loss_continuous(U)
+    if want("g9"):
+        g9_losses(M)
 
 
 if __name__ == "__main__":

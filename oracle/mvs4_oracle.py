@@ -81,16 +81,18 @@ def compose_projection(pm):
     return out
 
 
-def warp_grid(src_proj, ref_proj, depth_values, Hs, Ws):
+def warp_grid(src_proj, ref_proj, depth_values, Hs, Ws, origin=(0, 0)):
     """Normalised sampling grid [B, D, Hr*Wr, 2] of a source view for every
-    reference pixel/hypothesis.  Follows models/mvs4net_utils.py:23-45."""
+    reference pixel/hypothesis.  Follows models/mvs4net_utils.py:23-45.
+    ``origin`` = (y0, x0): ``depth_values`` is the [y0:y0+Hr, x0:x0+Wr] window of a larger reference map (same
+    arithmetic per pixel as the full map; used to check full-size outputs on a window in seconds)."""
     B, D, Hr, Wr = depth_values.shape
     dev = depth_values.device
     proj = torch.matmul(src_proj, torch.inverse(ref_proj))
     rot = proj[:, :3, :3]
     trans = proj[:, :3, 3:4]
-    yy, xx = torch.meshgrid(torch.arange(0, Hr, dtype=torch.float32, device=dev),
-                            torch.arange(0, Wr, dtype=torch.float32, device=dev), indexing="ij")
+    yy, xx = torch.meshgrid(torch.arange(origin[0], origin[0] + Hr, dtype=torch.float32, device=dev),
+                            torch.arange(origin[1], origin[1] + Wr, dtype=torch.float32, device=dev), indexing="ij")
     yy = yy.reshape(Hr * Wr)
     xx = xx.reshape(Hr * Wr)
     pix = torch.stack((xx, yy, torch.ones_like(xx))).unsqueeze(0).repeat(B, 1, 1)
@@ -105,13 +107,13 @@ def warp_grid(src_proj, ref_proj, depth_values, Hs, Ws):
     return torch.stack((gx, gy), dim=3)
 
 
-def homo_warping(src_fea, src_proj, ref_proj, depth_values):
+def homo_warping(src_fea, src_proj, ref_proj, depth_values, origin=(0, 0)):
     """[B,C,Hs,Ws] source feature -> [B,C,D,Hr,Wr] warped volume (bilinear,
     zeros padding, align_corners=True).  Follows models/mvs4net_utils.py:13-59."""
     B, C, Hs, Ws = src_fea.shape
     _, D, Hr, Wr = depth_values.shape
     with torch.no_grad():
-        grid = warp_grid(src_proj, ref_proj, depth_values, Hs, Ws)
+        grid = warp_grid(src_proj, ref_proj, depth_values, Hs, Ws, origin)
     out = F.grid_sample(src_fea, grid.reshape(B, D * Hr, Wr, 2), mode="bilinear",
                         padding_mode="zeros", align_corners=True)
     return out.reshape(B, C, D, Hr, Wr)
@@ -121,11 +123,12 @@ def homo_warping(src_fea, src_proj, ref_proj, depth_values):
 # correlation + epipolar attention aggregation                                 #
 # --------------------------------------------------------------------------- #
 def aggregate_views(features, proj_matrices, depth_hypo, group_cor, group_cor_dim,
-                    attn_temp=2.0, attn_fuse_d=True):
+                    attn_temp=2.0, attn_fuse_d=True, origin=(0, 0)):
     """Per-stage parameter-free part: warp every source view, correlate with the
     reference feature, weight each view by a softmax over the depth axis, sum
     over views and normalise.  Returns cor_feats [B,G|C,D,h,w].
-    Follows models/mvs4net_utils.py:1015-1060."""
+    Follows models/mvs4net_utils.py:1015-1060.  With ``origin`` = (y0, x0) the reference feature and
+    ``depth_hypo`` are the window [y0:y0+h, x0:x0+w] of a larger reference map (source features stay whole)."""
     pms = torch.unbind(proj_matrices, 1)
     ref_fea, src_feas = features[0], features[1:]
     B, D, H, W = depth_hypo.shape
@@ -136,7 +139,7 @@ def aggregate_views(features, proj_matrices, depth_hypo, group_cor, group_cor_di
     ref_p = compose_projection(pms[0])
     for src_fea, pm in zip(src_feas, pms[1:]):
         src_p = compose_projection(pm)
-        warped = homo_warping(src_fea, src_p, ref_p, depth_hypo)
+        warped = homo_warping(src_fea, src_p, ref_p, depth_hypo, origin)
         if group_cor:
             G = group_cor_dim
             cor = (warped.reshape(B, G, C // G, D, H, W) * ref_vol.reshape(B, G, C // G, D, H, W)).mean(2)
@@ -431,17 +434,30 @@ class OracleMVS4net(nn.Module):
 # losses (section 8f "next"; restated so training parity can be pinned)        #
 # --------------------------------------------------------------------------- #
 def sinkhorn(gt_depth, hypo_depth, attn_weight, mask, iters, eps=1, continuous=False):
-    """Entropy-regularised OT between the one-hot GT bin and attn_weight.
-    Follows models/mvs4net_utils.py:1096-1142 (discrete branch)."""
-    assert not continuous
+    """Entropy-regularised OT between the ground-truth depth and attn_weight.
+    Follows models/mvs4net_utils.py:1096-1142: the discrete branch (:1105-1110) transports onto the one-hot bin of
+    the nearest hypothesis with the |i-j| cost; the continuous branch (:1111-1123) adds a (D+1)-th target column
+    that holds all the mass and whose cost is the distance of every bin to the ground truth's fractional bin
+    position (10 on masked-out pixels)."""
     B, D, H, W = attn_weight.shape
     dev = gt_depth.device
-    cost = torch.stack([torch.arange(-i, D - i, 1, dtype=torch.float32, device=dev) for i in range(D)], dim=1).abs()
-    cost = cost[None, None].repeat(B, H * W, 1, 1)
-    gt_idx = torch.abs(hypo_depth - gt_depth[:, None]).min(1)[1].reshape(B * H * W, 1)
-    gt = torch.zeros_like(hypo_depth).permute(0, 2, 3, 1).reshape(B * H * W, D)
-    gt.scatter_add_(1, gt_idx, torch.ones([gt.shape[0], 1], dtype=gt.dtype, device=dev))
-    gt = gt.reshape(B, H * W, D)
+    bins = torch.arange(D, dtype=torch.float32, device=dev)
+    absdiff = (bins[None, :] - bins[:, None]).abs()                                   # |i - j|
+    if not continuous:
+        cost = absdiff[None, None].repeat(B, H * W, 1, 1)
+        gt_idx = torch.abs(hypo_depth - gt_depth[:, None]).min(1)[1].reshape(B * H * W, 1)
+        gt = torch.zeros_like(hypo_depth).permute(0, 2, 3, 1).reshape(B * H * W, D)
+        gt.scatter_add_(1, gt_idx, torch.ones([gt.shape[0], 1], dtype=gt.dtype, device=dev))
+        gt = gt.reshape(B, H * W, D)
+    else:
+        gt = torch.zeros((B, H * W, D + 1), dtype=torch.float32, device=dev)
+        gt[:, :, -1] = 1
+        itv = 1 / hypo_depth[:, 2] - 1 / hypo_depth[:, 1]
+        pos = (1 / gt_depth - 1 / hypo_depth[:, 0]) / itv                             # fractional bin of the GT
+        pos[~mask] = 10
+        last = (pos.unsqueeze(-1) - bins.view(1, 1, 1, D)).abs()                      # [B,H,W,D]
+        cost = torch.cat([absdiff.view(1, 1, 1, D, D).expand(B, H, W, D, D), last.unsqueeze(-1)], dim=-1)
+        cost = cost.reshape(B, H * W, D, D + 1)
     pred = attn_weight.permute(0, 2, 3, 1).reshape(B, H * W, D)
     log_mu = (gt + 1e-12).log()
     log_nu = (pred + 1e-12).log()
@@ -461,6 +477,7 @@ def mvs4net_loss(inputs, depth_gt_ms, mask_ms, **kw):
     inverse = kw.get("inverse_depth", False)
     ot_iter = kw.get("ot_iter", 3)
     ot_eps = kw.get("ot_eps", 1)
+    ot_continous = kw.get("ot_continous", False)
     mono = kw.get("mono", False)
     dev = mask_ms["stage1"].device
     total = torch.tensor(0.0, dtype=torch.float32, device=dev)
@@ -482,8 +499,19 @@ def mvs4net_loss(inputs, depth_gt_ms, mask_ms, **kw):
             itv = (hypo[:, 2] - hypo[:, 1]).abs()
             oor = ((hypo - gt.unsqueeze(1)).abs() <= itv.unsqueeze(1)).sum(1) == 0
         ranges.append(oor[mask].float().mean())
-        ot = sinkhorn(gt, hypo, attn, mask, iters=ot_iter, eps=ot_eps)[1]
+        ot = sinkhorn(gt, hypo, attn, mask, iters=ot_iter, eps=ot_eps, continuous=ot_continous)[1]
         l1s.append(l1)
         ots.append(ot)
         total = total + stage_lw[si] * (l1ot_lw[0] * l1 + l1ot_lw[1] * ot)
     return total, l1s, ots, ranges
+
+
+def blend_loss(inputs, depth_gt_ms, mask_ms, **kw):
+    """Follows models/MVS4Net.py:158-206: MVS4net_loss plus the last stage's normalised end-point error and its
+    <=3 / <=1 inlier percentages (depths scaled by 128 / (depth_max - depth_min))."""
+    total, l1s, ots, ranges = mvs4net_loss(inputs, depth_gt_ms, mask_ms, **kw)
+    key = [k for k in inputs.keys() if "stage" in k][-1]
+    scale = 128 / (kw.get("depth_max", 100) - kw.get("depth_min", 1))[:, None, None]
+    m = mask_ms[key] > 0.5
+    err = ((inputs[key]["depth"] * scale)[m] - (depth_gt_ms[key] * scale)[m]).abs()
+    return total, l1s, ots, ranges, err.mean(), (err <= 3).float().mean() * 100, (err <= 1).float().mean() * 100

@@ -115,11 +115,17 @@ def test_graph_replay_is_bit_identical(model):
     assert torch.equal(out["depth"], want["depth"])
 
 
-@pytest.mark.parametrize("H,W,N", [(512, 640, 5)])
+FULL_SIZE = [(512, 640, 5),        # BASELINE config 2: DTU mid
+             (1152, 1600, 5),      # config 3: DTU raw (1200x1600 cropped to a multiple of 64)
+             (1024, 1920, 7)]      # config 5: Tanks & Temples (1920x1056 -> 1024 rows), 7 views
+
+
+@pytest.mark.parametrize("H,W,N", FULL_SIZE)
 def test_full_size_properties(model, H, W, N):
-    """BASELINE config 2 at full size: properties that do not need the (slow) CPU oracle."""
+    """BASELINE configs 2, 3 and 5 at full size: properties that do not need the (slow) CPU oracle."""
     imgs, proj, dv = to_dev(*make_inputs(nviews=N, H=H, W=W, seed=0))
     out = model(imgs, proj, dv)
+    out = {k: ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v.clone()) for k, v in out.items()}
     out2 = model(imgs, proj, dv)
     for s in range(1, 5):
         st = out["stage%d" % s]
@@ -141,6 +147,97 @@ def test_full_size_properties(model, H, W, N):
     h1 = out["stage1"]["hypo_depth"]
     assert (h1[:, 0] > h1[:, -1]).all()
     assert (h1[:, 0] - dv[0, 1]).abs().max() <= 1e-3 and (h1[:, -1] - dv[0, 0]).abs().max() <= 1e-3
+    # the captured two-stream hipGraph replays the same bits
+    gf = GraphedForward(model, imgs, proj, dv)
+    rep = gf()
+    torch.cuda.synchronize()
+    for s in range(1, 5):
+        for k in ("depth", "attn_weight", "photometric_confidence", "hypo_depth"):
+            assert torch.equal(rep["stage%d" % s][k], out["stage%d" % s][k]), (s, k)
+    del gf
+    torch.cuda.empty_cache()
+
+
+def _windows(h, w, wh=192, ww=224):
+    """(y0, x0, y1, x1) windows of a stage map: far corner (largest offsets), near corner, an interior one; origins are
+    multiples of 8 so that the U-Net's three stride-2 levels see the same sampling lattice as in the full map."""
+    wh, ww = min(wh, h), min(ww, w)
+    cands = {(h - wh, w - ww), (0, 0), (((h - wh) // 2) // 8 * 8, ((w - ww) // 3) // 8 * 8)}
+    return [(y0, x0, y0 + wh, x0 + ww) for (y0, x0) in sorted(cands)]
+
+
+def _interior(y0, x0, y1, x1, h, w, margin=48):
+    """The part of a window whose U-Net receptive field (< 48 pixels) lies inside the window or beyond a true map border
+    (where the window's zero padding is the real one)."""
+    iy0 = 0 if y0 == 0 else margin
+    ix0 = 0 if x0 == 0 else margin
+    iy1 = (y1 - y0) if y1 == h else (y1 - y0) - margin
+    ix1 = (x1 - x0) if x1 == w else (x1 - x0) - margin
+    return slice(iy0, iy1), slice(ix0, ix1)
+
+
+@pytest.mark.parametrize("H,W,N", FULL_SIZE)
+def test_full_size_windows_vs_oracle(model, checkpoint, shipped_cfg, H, W, N):
+    """Values at full size (large offsets, every tile edge class, 32-bit addressing) against the CPU oracle on windows
+    of every stage: (a) the fused warp/correlation/aggregation kernel given the reference-style fp32 projection, (b)
+    the regularisation U-Net given the kernel's own cost volume (window interior), (c) softmax / winner-take-all given
+    the logits.  The oracle runs windows in seconds where the whole 1152x1600 map would take minutes."""
+    from mvster_amd import ops
+    from tests.test_gpu_kernels import _oracle_rt
+    oracle = O.OracleMVS4net(**shipped_cfg)
+    oracle.load_state_dict(checkpoint, strict=True)
+    oracle.eval()
+    imgs, proj, dv = make_inputs(nviews=N, H=H, W=W, seed=0)
+    cap = {}
+    out = model._forward_eval(*to_dev(imgs, proj, dv), capture=cap)
+    worst = dict(cor_tight=0.0, cor_own=0.0, logits=0.0, attn=0.0, flips_clear=0.0)
+    for s in range(4):
+        name = "stage%d" % (s + 1)
+        feats_cl = cap[name]["feats_cl"]                               # [N,1,h,w,C] on the GPU
+        h, w, C = feats_cl.shape[2:]
+        G, D = shipped_cfg["group_cor_dim"][s], shipped_cfg["stage_splits"][s]
+        hypo = out[name]["hypo_depth"]
+        pm = proj[name]
+        # (a) same kernel, reference-style projection (fp32 torch.inverse on the CPU): pure per-pixel arithmetic
+        rt_ref = _oracle_rt(pm).to(DEV)
+        cor_tight = ops.warp_agg_fwd_cl(feats_cl[0].contiguous(), feats_cl[1:].contiguous(), rt_ref, hypo, G, True, True,
+                                        2.0).permute(0, 4, 1, 2, 3)    # [1,G,D,h,w]
+        cor_own = cap[name]["cor_feats"]
+        feats = [feats_cl[v].permute(0, 3, 1, 2).cpu() for v in range(N)]    # NCHW on the CPU
+        hypo_c = hypo.cpu()
+        logits_gpu, attn_gpu, depth_gpu = cap[name]["logits"].cpu(), out[name]["attn_weight"].cpu(), out[name]["depth"].cpu()
+        for (y0, x0, y1, x1) in _windows(h, w):
+            with torch.no_grad():
+                want = O.aggregate_views([feats[0][:, :, y0:y1, x0:x1]] + feats[1:], pm, hypo_c[:, :, y0:y1, x0:x1].contiguous(),
+                                         True, G, attn_temp=2.0, attn_fuse_d=True, origin=(y0, x0))
+                scale = max(want.abs().max().item(), 1.0)
+                e_t = (cor_tight[:, :, :, y0:y1, x0:x1].cpu() - want).abs().max().item() / scale
+                own_win = cor_own[:, :, :, y0:y1, x0:x1].cpu().contiguous()
+                e_o = (own_win - want).abs().max().item() / scale
+                worst["cor_tight"], worst["cor_own"] = max(worst["cor_tight"], e_t), max(worst["cor_own"], e_o)
+                assert e_t <= 2e-6, (name, (y0, x0), e_t)
+                # (b) the U-Net on the kernel's own cost volume window
+                lo = oracle.reg[s](own_win)                                # [1,D,wh,ww]
+                iy, ix = _interior(y0, x0, y1, x1, h, w)
+                lg = logits_gpu[:, :, y0:y1, x0:x1][:, :, iy, ix]
+                lscale = max(lo.abs().max().item(), 1.0)
+                e_l = (lg - lo[:, :, iy, ix]).abs().max().item() / lscale
+                worst["logits"] = max(worst["logits"], e_l)
+                assert e_l <= 5e-5, (name, (y0, x0), e_l)
+                # (c) selection given the GPU's logits
+                sel = O.select_depth(logits_gpu[:, :, y0:y1, x0:x1], hypo_c[:, :, y0:y1, x0:x1], s, True,
+                                     shipped_cfg["depth_interals_ratio"][s])
+                e_a = (attn_gpu[:, :, y0:y1, x0:x1] - sel["attn_weight"]).abs().max().item()
+                worst["attn"] = max(worst["attn"], e_a)
+                assert e_a <= 3e-7, (name, (y0, x0), e_a)
+                top2 = sel["attn_weight"].topk(2, dim=1)[0]
+                clear = (top2[:, 0] - top2[:, 1]) > 1e-6
+                flips = (depth_gpu[:, y0:y1, x0:x1] != sel["depth"])[clear].float().mean().item()
+                worst["flips_clear"] = max(worst["flips_clear"], flips)
+                assert flips == 0.0, (name, (y0, x0), flips)
+    note("full_size_windows_%dx%dx%d" % (H, W, N), **worst)
+    # the kernel's own (fp64-inverse) projection differs from the reference's fp32 LAPACK inverse by that inverse's noise
+    assert worst["cor_own"] <= 1e-3
 
 
 def test_identical_views_have_uniform_attention_over_views(model):
@@ -162,7 +259,7 @@ def test_identical_views_have_uniform_attention_over_views(model):
 
 
 def test_train_step_vs_golden(shipped_cfg, checkpoint, golden):
-    """Train-mode forward + OT loss + backward (PyTorch-ROCm convs, HIP warp fwd/bwd) vs the reference."""
+    """Train-mode forward + OT loss + backward (all HIP: convolutions, BatchNorm, warp fwd/bwd, Sinkhorn) vs the reference."""
     g = golden("g6_train")
     H, W, N = int(g.np("H")), int(g.np("W")), int(g.np("N"))
     imgs, proj, dv = to_dev(*make_inputs(nviews=N, H=H, W=W, seed=2, batch=2))
@@ -187,6 +284,8 @@ def test_train_step_vs_golden(shipped_cfg, checkpoint, golden):
     note("train_step", loss=loss.item(), want_loss=want_loss, stage1_attn_max=a1, worst_grad_rel=worst)
     assert out["photometric_confidence"].dim() == 0
     assert a1 <= 1e-3
+    # the reference's own parameter gradients (7 tensors across the FPN and the U-Nets); measured 0.86 %
+    assert worst <= 2e-2
     # later stages can pick other hypotheses on near-ties, so the total loss is compared loosely
     assert abs(ots[0].item() - float(g.np("ot")[0])) <= 2e-3 * abs(float(g.np("ot")[0]))
     assert abs(loss.item() - want_loss) <= 5e-2 * abs(want_loss)
@@ -268,7 +367,7 @@ def test_under_data_parallel(shipped_cfg, checkpoint):
     assert all(k.startswith("module.") for k in state) and len(state) == len(m.state_dict())
 
 
-@pytest.mark.parametrize("B,N", [(2, 2), (1, 9), (3, 4)])
+@pytest.mark.parametrize("B,N", [(2, 2), (1, 7), (1, 9), (3, 4)])
 def test_batch_and_view_counts_vs_oracle(shipped_cfg, checkpoint, B, N):
     """Batch sizes and view counts other than the benchmark's (one source view; nine views; batch 3): shipped
     configuration, teacher-forced against the CPU oracle."""
@@ -291,3 +390,106 @@ def test_batch_and_view_counts_vs_oracle(shipped_cfg, checkpoint, B, N):
         clear = (top2[:, 0] - top2[:, 1]) > 1e-3
         assert (st["depth"].cpu() - wt["depth"])[clear].abs().mean() < 1e-4, (B, N, s)
     assert tuple(got["photometric_confidence"].shape) == (B, 64, 128)
+
+
+def test_stage1_only_configuration_vs_oracle():
+    """BASELINE config 1: DTU mid 512x640, 5 views, stage-1 only (8 hypotheses), B=1 -- the whole forward against the
+    CPU oracle at full size (the FPN of five views plus one 64x80 stage is cheap enough for the CPU)."""
+    from mvster_amd.synthetic import randomize_state
+    cfg = dict(arch_mode="fpn", reg_net="reg2d", num_stage=1, fpn_base_channel=8, reg_channel=8, stage_splits=[8],
+               depth_interals_ratio=[0.5], group_cor=True, group_cor_dim=[8], inverse_depth=True, mono=False, attn_temp=2,
+               attn_fuse_d=True)
+    torch.manual_seed(8)
+    oracle = O.OracleMVS4net(**cfg)
+    sd = randomize_state(oracle.state_dict(), seed=13, prob_gain=20.0)
+    oracle.load_state_dict(sd, strict=True)
+    oracle.eval()
+    m = MVS4net(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV).eval()
+    imgs, proj, dv = make_inputs(nviews=5, H=512, W=640, seed=12)
+    cap_o, cap = {}, {}
+    with torch.no_grad():
+        want = oracle(imgs, proj, dv, capture=cap_o)
+    got = m._forward_eval(*to_dev(imgs, proj, dv), capture=cap)
+    assert set(got.keys()) == set(want.keys()) == {"stage1", "depth", "photometric_confidence", "hypo_depth", "attn_weight",
+                                                   "inverse_min_depth", "inverse_max_depth"}
+    assert torch.equal(got["hypo_depth"].cpu(), want["hypo_depth"])
+    wc = cap_o["stage1"]["cor_feats"]
+    e_cor = ((cap["stage1"]["cor_feats"].cpu() - wc).abs().max() / wc.abs().max()).item()
+    e_attn = (got["attn_weight"].cpu() - want["attn_weight"]).abs().max().item()
+    top2 = want["attn_weight"].topk(2, dim=1)[0]
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-3
+    l1 = (got["depth"].cpu() - want["depth"])[clear].abs().mean().item()
+    conf = (got["photometric_confidence"].cpu() - want["photometric_confidence"]).abs().max().item()
+    note("stage1_only_512x640x5", cor_rel_max=e_cor, attn_max=e_attn, depth_l1_clear=l1, conf_max=conf,
+         clear_frac=clear.float().mean().item())
+    assert tuple(got["photometric_confidence"].shape) == (1, 512, 640)
+    assert e_cor <= 2e-4 and e_attn <= 1e-3 and l1 < 1e-4 and conf <= 1e-3
+    # the public call (own hypotheses, graph capture) gives the same result
+    out = m(*to_dev(imgs, proj, dv))
+    assert torch.equal(out["depth"], got["depth"])
+
+
+def test_train_step_full_size_vs_pytorch_rocm(shipped_cfg, checkpoint):
+    """BASELINE config 4 on one rank at full size: 512x640, 5 views, B=2, one training step (forward, OT loss, backward)
+    of the native path against the same step of the oracle module tree on the GPU (plain PyTorch-ROCm)."""
+    import time
+    from mvster_amd import MVS4net_loss
+    H, W, N, B = 512, 640, 5, 2
+    ref = O.OracleMVS4net(**shipped_cfg)
+    ref.load_state_dict(checkpoint, strict=True)
+    nat = MVS4net(**shipped_cfg)
+    nat.load_state_dict(checkpoint, strict=True)
+    ref.to(DEV).train()
+    nat.to(DEV).train()
+    imgs, proj, dv = to_dev(*make_inputs(nviews=N, H=H, W=W, seed=21, batch=B))
+    g = torch.Generator().manual_seed(0)
+    gt, mask = {}, {}
+    for s in range(1, 5):
+        hs, ws = H // 2 ** (4 - s), W // 2 ** (4 - s)
+        gt["stage%d" % s] = (500 + 300 * torch.rand(B, hs, ws, generator=g)).to(DEV)
+        mask["stage%d" % s] = (torch.rand(B, hs, ws, generator=g) > 0.2).float().to(DEV)
+    kw = dict(stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10, ot_eps=1, ot_continous=False, mono=True)
+
+    def step(m, loss_fn, images):
+        m.zero_grad(set_to_none=True)
+        out = m(images, proj, dv)
+        res = loss_fn(out, gt, mask, **kw)
+        res[0].backward()
+        torch.cuda.synchronize()
+        return out, res, {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    t0 = time.perf_counter()
+    o_ref, r_ref, g_ref = step(ref, O.mvs4net_loss, imgs)
+    t_ref = time.perf_counter() - t0
+    # yardstick: the PyTorch-ROCm step with the images perturbed by 1e-6 relative (the step is ill-conditioned: argmax
+    # depths feed the next stage's hypotheses, the OT loss takes logs of small probabilities)
+    gp = torch.Generator().manual_seed(11)
+    pert = [i * (1 + 1e-6 * torch.randn(i.shape, generator=gp).to(DEV)) for i in imgs]
+    bufs = {k: v.detach().clone() for k, v in ref.named_buffers()}
+    _, _, g_ref2 = step(ref, O.mvs4net_loss, pert)
+    t0 = time.perf_counter()
+    o_nat, r_nat, g_nat = step(nat, MVS4net_loss, imgs)
+    t_nat = time.perf_counter() - t0
+    a1 = (o_ref["stage1"]["attn_weight"] - o_nat["stage1"]["attn_weight"]).abs().max().item()
+    ot1 = abs(r_ref[2][0].item() - r_nat[2][0].item()) / abs(r_ref[2][0].item())
+    l_ref, l_nat = r_ref[0].item(), r_nat[0].item()
+    gmax = max(v.norm().item() for v in g_ref.values())
+    worst, worst_name, noise = 0.0, "", 0.0
+    for k, r in g_ref.items():
+        if r.norm().item() < 1e-4 * gmax:
+            continue
+        e = ((g_nat[k] - r).norm() / r.norm()).item()
+        noise = max(noise, ((g_ref2[k] - r).norm() / r.norm()).item())
+        if e > worst:
+            worst, worst_name = e, k
+    note("train_step_full_size_512x640x5_B2", loss_ref=l_ref, loss_native=l_nat, stage1_attn_max=a1, stage1_ot_rel=ot1,
+         worst_grad_rel_l2=worst, pytorch_path_1e6_perturbation_rel_l2=noise, first_step_s_pytorch_rocm=t_ref,
+         first_step_s_native=t_nat)
+    assert set(g_ref) == set(g_nat)
+    assert a1 <= 1e-4 and ot1 <= 2e-3
+    assert abs(l_ref - l_nat) <= 2e-2 * abs(l_ref)
+    assert worst <= max(2e-2, 2 * noise), (worst_name, worst, noise)
+    for k, v in g_nat.items():
+        assert torch.isfinite(v).all(), k

@@ -282,28 +282,50 @@ def test_reg_module_gradients_native_vs_pytorch_rocm(kind):
     assert fwd <= 2e-5 and worst <= 2e-4 and dx <= 2e-4, (fwd, name, worst, dx)
 
 
-@pytest.mark.parametrize("D,iters,eps", [(4, 10, 1.0), (8, 10, 1.0), (8, 3, 0.5), (5, 16, 2.0)])
-def test_fused_sinkhorn_vs_tensor_form(D, iters, eps):
-    """mvster_sinkhorn (one thread per pixel, loss + gradient in one launch) against the tensor-level restatement
-    of models/mvs4net_utils.py:1096-1142 under autograd, in fp64 on the CPU."""
-    from mvster_amd.loss import sinkhorn, sinkhorn_loss
+@pytest.mark.parametrize("D,iters,eps,cont", [(4, 10, 1.0, False), (8, 10, 1.0, False), (8, 3, 0.5, False), (5, 16, 2.0, False),
+                                              (4, 10, 1.0, True), (8, 10, 1.0, True), (3, 3, 0.5, True), (5, 16, 2.0, True)])
+def test_fused_sinkhorn_vs_tensor_form(D, iters, eps, cont):
+    """mvster_sinkhorn / mvster_sinkhorn_continuous (one thread per pixel, loss + gradient in one launch) against the
+    oracle's tensor-level restatement of models/mvs4net_utils.py:1096-1142 under autograd, in fp64 on the CPU."""
+    from mvster_amd.loss import sinkhorn_loss
     g = torch.Generator().manual_seed(D * 10 + iters)
     B, H, W = 2, 13, 17
     attn = torch.softmax(3 * torch.randn(B, D, H, W, generator=g), 1)
-    hypo = 500 + 40 * torch.arange(D).view(1, D, 1, 1) + 5 * torch.rand(B, D, H, W, generator=g)
-    gt = 500 + 40 * (D - 1) * torch.rand(B, H, W, generator=g)
+    inv = 1.0 / 900 + 2e-5 * (torch.arange(D).view(1, D, 1, 1) + 0.1 * torch.rand(B, D, H, W, generator=g))
+    hypo = (1.0 / inv).float()                                          # index 0 = farthest, like the inverse ranges
+    gt = (1.0 / (1.0 / 900 + 2e-5 * (-1.0 + (D + 1) * torch.rand(B, H, W, generator=g)))).float()
     mask = torch.rand(B, H, W, generator=g) > 0.3
+    gt[~mask] = 0.0                                                     # invalid ground truth, as the loaders deliver it
     ad = attn.double().requires_grad_(True)
-    want = sinkhorn(gt.double(), hypo.double(), ad, mask, iters, eps)[1]
+    want = O.sinkhorn(gt.double(), hypo.double(), ad, mask, iters, eps, continuous=cont)[1]
     want.backward()
     ag = attn.to(DEV).requires_grad_(True)
-    got = sinkhorn_loss(gt.to(DEV), hypo.to(DEV), ag, mask.to(DEV), iters, eps)
+    got = sinkhorn_loss(gt.to(DEV), hypo.to(DEV), ag, mask.to(DEV), iters, eps, continuous=cont)
     got.backward()
     e_l = abs(got.item() - want.item()) / abs(want.item())
     e_g = ((ag.grad.cpu().double() - ad.grad).norm() / ad.grad.norm()).item()
-    note("sinkhorn_D%d_it%d" % (D, iters), loss_rel=e_l, grad_rel_l2=e_g, loss=want.item())
+    note("sinkhorn_D%d_it%d%s" % (D, iters, "_cont" if cont else ""), loss_rel=e_l, grad_rel_l2=e_g, loss=want.item())
     assert e_l <= 2e-5 and e_g <= 2e-4, (e_l, e_g)
+    assert torch.isfinite(ag.grad).all()
     assert (ag.grad.cpu()[~mask.unsqueeze(1).expand_as(attn)] == 0).all()
+
+
+def test_fused_sinkhorn_vs_reference_values(golden):
+    """The fused kernels against what the reference's own ``sinkhorn`` returned (fixtures G8 discrete, G8b continuous)."""
+    from mvster_amd.loss import sinkhorn_loss
+    g = golden("g8_sinkhorn")
+    got = sinkhorn_loss(g.t("gt", DEV), g.t("hypo", DEV), g.t("attn", DEV), g.t("mask", DEV), 10, 1.0)
+    assert abs(got.item() - float(g.np("loss"))) <= 1e-5 * abs(float(g.np("loss")))
+    gb = golden("g8b_sinkhorn_continuous")
+    for name, iters, eps in (("d4", 10, 1.0), ("d4", 3, 0.5), ("d8", 10, 1.0), ("d8", 3, 0.5)):
+        got = sinkhorn_loss(gb.t(name + "_gt", DEV), gb.t(name + "_hypo", DEV), gb.t(name + "_attn", DEV),
+                            gb.t(name + "_mask", DEV), iters, eps, continuous=True)
+        want = float(gb.np("%s_it%d_loss" % (name, iters)))
+        note("sinkhorn_g8b_%s_it%d" % (name, iters), got=got.item(), want=want)
+        assert abs(got.item() - want) <= 2e-5 * abs(want), (name, iters)
+    with pytest.raises(NotImplementedError):
+        sinkhorn_loss(g.t("gt", DEV), g.t("hypo", DEV)[:, :2].contiguous(), g.t("attn", DEV)[:, :2].contiguous(),
+                      g.t("mask", DEV), 10, 1.0, continuous=True)
 
 
 def test_native_train_step_under_ddp_single_rank():

@@ -150,3 +150,72 @@ def test_g8_sinkhorn(golden):
     T, loss = O.sinkhorn(g.t("gt"), g.t("hypo"), g.t("attn"), g.t("mask"), iters=10, eps=1)
     assert maxdiff(T, g.t("T")) <= 1e-6
     assert abs(loss.item() - float(g.np("loss"))) <= 1e-6
+
+
+def test_window_origin_reproduces_the_full_map():
+    """aggregate_views on a window (``origin``) returns the window of the full-map result (same sampling grid bit for
+    bit; ATen's vectorised reductions round 1 % of the elements differently by one ulp at another tensor shape): the
+    windowed form is what the full-size GPU tests use as the CPU reference."""
+    from mvster_amd.synthetic import make_inputs
+    torch.manual_seed(0)
+    _, proj, dv = make_inputs(nviews=3, H=32 * 8, W=40 * 8, seed=3)
+    feats = [torch.randn(1, 8, 32, 40) for _ in range(3)]
+    hypo = O.init_inverse_range(dv, 4, 32, 40) * (1 + 0.01 * torch.rand(1, 4, 32, 40))
+    full = O.aggregate_views(feats, proj["stage1"], hypo, True, 4)
+    y0, x0, h, w = 9, 17, 14, 20
+    win = O.aggregate_views([feats[0][:, :, y0:y0 + h, x0:x0 + w]] + feats[1:], proj["stage1"],
+                            hypo[:, :, y0:y0 + h, x0:x0 + w].contiguous(), True, 4, origin=(y0, x0))
+    pm = torch.unbind(proj["stage1"], 1)
+    rp, sp = O.compose_projection(pm[0]), O.compose_projection(pm[1])
+    g_full = O.warp_grid(sp, rp, hypo, 32, 40).reshape(1, 4, 32, 40, 2)[:, :, y0:y0 + h, x0:x0 + w]
+    g_win = O.warp_grid(sp, rp, hypo[:, :, y0:y0 + h, x0:x0 + w].contiguous(), 32, 40, origin=(y0, x0)).reshape(1, 4, h, w, 2)
+    assert torch.equal(g_full, g_win)
+    assert (win - full[:, :, :, y0:y0 + h, x0:x0 + w]).abs().max() <= 2e-7 * full.abs().max()
+
+
+@pytest.mark.parametrize("name,iters,eps", [("d4", 10, 1.0), ("d4", 3, 0.5), ("d8", 10, 1.0), ("d8", 3, 0.5)])
+def test_g8b_sinkhorn_continuous(golden, name, iters, eps):
+    g = golden("g8b_sinkhorn_continuous")
+    T, loss = O.sinkhorn(g.t(name + "_gt"), g.t(name + "_hypo"), g.t(name + "_attn"), g.t(name + "_mask"), iters=iters,
+                         eps=eps, continuous=True)
+    want_T, want = g.t("%s_it%d_T" % (name, iters)), float(g.np("%s_it%d_loss" % (name, iters)))
+    assert T.shape == want_T.shape and (T - want_T).abs().max() <= 2e-6 * want_T.abs().max()
+    assert abs(loss.item() - want) <= 1e-6 * abs(want)
+
+
+def _g6_train_stage_dicts(golden):
+    g = golden("g6_train")
+    inputs, gt, mask = {}, {}, {}
+    for s in range(1, 5):
+        st = {k: g.t("stage%d_%s" % (s, k)) for k in ("depth", "hypo_depth", "attn_weight")}
+        if s > 1:
+            st["mono_depth"] = g.t("stage%d_mono_depth" % s)
+        inputs["stage%d" % s] = st
+        gt["stage%d" % s] = g.t("depth_gt_stage%d" % s)
+        mask["stage%d" % s] = g.t("mask_stage%d" % s)
+    return inputs, gt, mask
+
+
+G9_CASES = {
+    "inv": dict(stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10, ot_eps=1, mono=True),
+    "lin_l1": dict(stage_lw=[0.5, 1, 1.5, 2], l1ot_lw=[0.3, 0.7], inverse_depth=False, ot_iter=3, ot_eps=1, mono=True),
+    "cont": dict(stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10, ot_eps=1, ot_continous=True, mono=False),
+}
+
+
+@pytest.mark.parametrize("name", sorted(G9_CASES))
+def test_g9_losses(golden, name):
+    """MVS4net_loss / Blend_loss restatements against the reference's values (MVS4Net.py:113-206)."""
+    g = golden("g9_losses")
+    inputs, gt, mask = _g6_train_stage_dicts(golden)
+    kw = G9_CASES[name]
+    total, l1s, ots, rng = O.mvs4net_loss(inputs, gt, mask, **kw)
+    assert abs(total.item() - float(g.np("mvs4_%s_total" % name))) <= 1e-5 * abs(float(g.np("mvs4_%s_total" % name)))
+    assert torch.allclose(torch.stack(l1s), g.t("mvs4_%s_l1" % name), rtol=1e-5)
+    assert torch.allclose(torch.stack(ots), g.t("mvs4_%s_ot" % name), rtol=1e-5)
+    assert torch.equal(torch.stack(rng), g.t("mvs4_%s_range" % name))
+    r = O.blend_loss(inputs, gt, mask, depth_max=g.t("depth_max"), depth_min=g.t("depth_min"), **kw)
+    assert len(r) == 7
+    assert abs(r[0].item() - float(g.np("blend_%s_total" % name))) <= 1e-5 * abs(float(g.np("blend_%s_total" % name)))
+    assert torch.equal(torch.stack(r[3]), g.t("blend_%s_range" % name))
+    assert torch.allclose(torch.stack(list(r[4:])), g.t("blend_%s_epe_err3_err1" % name), rtol=1e-6)
