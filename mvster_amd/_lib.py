@@ -61,7 +61,10 @@ def load():
                 "mvster_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no PyTorch fallback for the HIP path." % LIB_PATH)
         lib = ctypes.CDLL(LIB_PATH)
+        lax = bool(os.environ.get("MVSTER_LIB")) and bool(os.environ.get("MVSTER_LIB_LAX"))   # A/B against an older build
         for name, argtypes in SIGNATURES.items():
+            if lax and not hasattr(lib, name):
+                continue
             fn = getattr(lib, name)        # AttributeError if the library does not export it
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int

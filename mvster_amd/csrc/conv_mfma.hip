@@ -363,7 +363,15 @@ int dispatch_tiles(const ConvArgs& a, int MT, int NT, bool splitk, hipStream_t s
 // loads feeding 4*MT*NT MFMAs.  Same packed weights, same K order (tap-major, channel-minor) and the
 // same fused epilogue as the direct kernel.  Several workgroups per CU overlap staging and math.
 // ------------------------------------------------------------------------------------------
+// LDS layout of the staged patch: two planes of [pixel][2 quads] (quad = 4 consecutive channels of the 16-channel
+// chunk), plane = quad >> 1.  A ds_read_b128 is served in groups of 16 lanes that must cover 16 distinct 16-byte slots
+// modulo 256 B; with this kernel's lane = (quad, m) mapping each group holds eight lanes of quad 2k (pixels m) and eight
+// of quad 2k+1, i.e. slots 2*(P + m) and 2*(P + m) + 1 of one plane for eight m that are distinct modulo 8: conflict-free
+// for stride-1 layers at any tap offset (the previous [pixel][4 quads] layout put m and m + 4 on the same banks: 30-40 %
+// of the LDS cycles were conflicts, r01_o PMC).  patch_plane() pads a plane to 4 mod 8 slots, which keeps the two planes
+// 16 banks apart for the staging stores (a thread quartet writes quads 0..3 of one pixel).
 constexpr int kMaxStage = 12;   // float4 loads per thread per chunk (patch <= 48 KB)
+__device__ __forceinline__ int patch_plane(int npix) { return ((npix * 2 + 7) & ~7) + 4; }   // float4 units, = 4 mod 8
 static const bool g_no_wlds = getenv("MVSTER_NO_WLDS") != nullptr;   // experiment switch: weights from L1 again
 
 // WN > 0: the chunk's weights are staged in LDS too, WN float4 per thread (taps * NT * 64 <= WN * 256).
@@ -372,12 +380,13 @@ template <int MT, int NT, int KW, int NG, int WN>
 __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) float patch_raw[];
     f32x4v* patch_base = reinterpret_cast<f32x4v*>(patch_raw);
-    f32x4v* wl = patch_base + NG * 1024;     // WL: this chunk's packed weights [tap][nt][lane]
+    f32x4v* wl = patch_base + NG * 1024 + 32;     // WL: this chunk's packed weights [tap][nt][lane] (after the plane pads)
     constexpr int TY = 2 * MT;
     const int KD = a.kd[0], KH = a.kh[0];
     const int PW = 31 * a.sw + KW, PH = (TY - 1) * a.sh + KH;
     const int CIN = a.cin, nchunks = CIN >> 4;
     const int nstage = KD * PH * PW * 4;     // float4 per chunk (<= NG * 1024)
+    const int plane = patch_plane(KD * PH * PW);
 
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_x = bid % tiles_x; bid /= tiles_x;
@@ -416,7 +425,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     for (int mt = 0; mt < MT; ++mt) {
         const int t = wave * MT + mt;
         const int row = t >> 1, xs = t & 1;
-        abase[mt] = ((row * a.sh) * PW + (xs * 16 + lm) * a.sw) * 4 + lq;
+        abase[mt] = ((row * a.sh) * PW + (xs * 16 + lm) * a.sw) * 2 + (lq >> 1) * plane + (lq & 1);
     }
 
     f32x4v acc[MT][NT];
@@ -456,7 +465,10 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     };
     auto stage_store = [&](f32x4v* dst) {
 #pragma unroll
-        for (int i = 0; i < NG * 4; ++i) dst[threadIdx.x + i * 256] = stg[i];
+        for (int i = 0; i < NG * 4; ++i) {
+            const int idx = threadIdx.x + i * 256, quad = idx & 3;       // idx = pixel * 4 + quad, as loaded
+            if (idx < nstage) dst[(quad >> 1) * plane + (idx >> 2) * 2 + (quad & 1)] = stg[i];
+        }
         if (WL) {
 #pragma unroll
             for (int i = 0; i < WN; ++i) wl[threadIdx.x + i * 256] = wst[i];
@@ -477,12 +489,12 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
         const int r_first = kz_lo * KH, nrows = kz_hi * KH;
         auto load_row = [&](int r, f32x4v (&A)[KW][MT], f32x4v (&Bv)[KW][NT]) {
             const int kz = r / KH, ky = r - kz * KH;
-            const int rowoff = (kz * PH + ky) * PW * 4;
+            const int rowoff = (kz * PH + ky) * PW * 2;
             const float* w = wp + (long)(r * KW * nchunks + ch) * wstep;
 #pragma unroll
             for (int kx = 0; kx < KW; ++kx) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) A[kx][mt] = patch[abase[mt] + rowoff + kx * 4];
+                for (int mt = 0; mt < MT; ++mt) A[kx][mt] = patch[abase[mt] + rowoff + kx * 2];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     Bv[kx][nt] = WL ? wl[((r * KW + kx) * NT + nt) * 64 + lane]
@@ -540,10 +552,10 @@ int launch_lds_ng(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
     dim3 grid((unsigned)blocks, a.ntile_total / NT, 1);
     const int nw = a.kd[0] * a.kh[0] * KW * NT * 64;       // weight float4 per chunk
     if (nw <= 3 * 256 && !g_no_wlds) {
-        const size_t lds = (size_t)NG * 1024 * 16 + 3 * 256 * 16;
+        const size_t lds = (size_t)(NG * 1024 + 32) * 16 + 3 * 256 * 16;
         hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW, NG, 3>), grid, dim3(256), lds, s, a, tiles_x, tiles_y);
     } else {
-        const size_t lds = (size_t)NG * 1024 * 16;
+        const size_t lds = (size_t)(NG * 1024 + 32) * 16;
         hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW, NG, 0>), grid, dim3(256), lds, s, a, tiles_x, tiles_y);
     }
     return mv_check_launch();

@@ -401,6 +401,240 @@ __global__ void __launch_bounds__(256) warp_agg_fwd_wave_kernel(WarpAggArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Pixel-major variant for the two fine stages (C <= 16, where the time is): lane = (pixel, sub), and the lane
+// walks ALL D hypotheses of its pixel.  The wave-local kernel above is VALU-issue-bound (PMC: ~205 VALU
+// instructions per (pixel, d, view) against 256 gathered bytes; 77 % of the SIMD issue cycles busy), so this one
+// removes instructions rather than bytes:
+//   * R*(x, y, 1) once per (pixel, view) instead of once per (pixel, d, view);
+//   * the per-hypothesis scalar chain (r*depth + t, the IEEE division by z, the normalise / un-normalise round trip,
+//     the fractional weights) runs on PAIRS of hypotheses in packed fp32 (v_pk_mul/add/fma_f32): same rounding per
+//     element, half the issue slots;
+//   * taps are fetched with raw buffer loads: ONE 32-bit offset per tap row ((y0*Ws + x0) << log2(4C), 24-bit
+//     multiply-add), the other seven addresses are immediate offsets, and no index clamping at all -- a tap outside
+//     the map either falls outside the descriptor (the hardware returns 0) or reads some other texel, and in both
+//     cases its weight is already 0;
+//   * the softmax over depth is in registers: no ds_bpermute, one reciprocal per pixel.
+// Arithmetic per element and every summation order are those of warp_agg_fwd_kernel: bit-identical output.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ mv::f32x2 fma2(mv::f32x2 a, mv::f32x2 b, mv::f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ mv::f32x2 splat2(float v) { return (mv::f32x2){v, v}; }
+
+struct Recip2 {
+    mv::f32x2 d, r;
+};
+__device__ __forceinline__ Recip2 make_recip2(mv::f32x2 d) {
+    Recip2 k;
+    k.d = d;
+    const mv::f32x2 r0 = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    k.r = fma2(fma2(-d, r0, splat2(1.0f)), r0, r0);
+    return k;
+}
+// same sequence as mv::div_rn(float, Recip) on both elements
+__device__ __forceinline__ mv::f32x2 div_rn2(mv::f32x2 a, const Recip2& k) {
+    mv::f32x2 q = mv::mul_rn2(a, k.r);
+    q = fma2(fma2(-k.d, q, a), k.r, q);
+    return fma2(fma2(-k.d, q, a), k.r, q);
+}
+__device__ __forceinline__ mv::f32x2 div_rn2(mv::f32x2 a, const mv::Recip& k) {
+    const mv::f32x2 d = splat2(k.d), r = splat2(k.r);
+    mv::f32x2 q = mv::mul_rn2(a, r);
+    q = fma2(fma2(-d, q, a), r, q);
+    return fma2(fma2(-d, q, a), r, q);
+}
+__device__ __forceinline__ mv::f32x2 sub_rn2(mv::f32x2 a, mv::f32x2 b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+
+template <int C, int G, int D, int NW>
+__global__ void __launch_bounds__(64 * NW) warp_agg_fwd_pix_kernel(WarpAggArgs a) {
+    constexpr int LPP = C / 8;           // lanes per pixel (channel slices of 8)
+    constexpr int CG = C / G;            // channels per group
+    constexpr int GPL = 8 / CG;          // whole groups per lane
+    constexpr int PPB = 64 * NW / LPP;   // pixels per workgroup (NW waves; waves never talk to each other)
+    constexpr int SH = C == 8 ? 5 : (C == 16 ? 6 : (C == 32 ? 7 : 8));   // log2(bytes per texel)
+    static_assert(C % 8 == 0 && CG <= 8 && 8 % CG == 0 && LPP >= 1 && LPP <= 4 && D % 2 == 0 && D <= 8, "pixel split");
+
+    const int sub = threadIdx.x % LPP;
+    const int b = blockIdx.y;
+    const int hw = a.h * a.w;
+    const int p = xcd_remap(blockIdx.x, gridDim.x) * PPB + threadIdx.x / LPP;
+    const bool valid = p < hw;
+    const int pc = valid ? p : hw - 1;   // clamped: every lane takes part in the cross-lane sums
+    const int y = pc / a.w;
+    const int x = pc - y * a.w;
+    const float xf = (float)x, yf = (float)y;
+    const float* hp = a.hypo + (long)b * D * hw + pc;
+    mv::f32x2 depth2[D / 2];
+#pragma unroll
+    for (int q = 0; q < D / 2; ++q) depth2[q] = (mv::f32x2){hp[(long)(2 * q) * hw], hp[(long)(2 * q + 1) * hw]};
+    const float* rp = a.ref + (long)b * a.ref_bs + (long)pc * C + sub * 8;
+    const f32x4 R0 = ld4(rp), R1 = ld4(rp + 4);
+    const mv::GridNorm gn = mv::make_grid_norm(a.Hs, a.Ws);
+    const mv::Recip temp = mv::make_recip(a.attn_temp), sqrt_c = mv::make_recip(a.sqrt_c);
+    const float xhi = (float)(a.Ws + 4), yhi = (float)(a.Hs + 4);
+    const unsigned src_bytes = (unsigned)a.Hs * (unsigned)a.Ws * (unsigned)(C * 4);
+    const int row_bytes = a.Ws << SH;
+
+    float acc[D][GPL], wsum[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        wsum[d] = 1e-8f;
+#pragma unroll
+        for (int k = 0; k < GPL; ++k) acc[d][k] = 0.0f;
+    }
+
+    for (int v = 0; v < a.NV; ++v) {
+        const float* r = a.rt + ((long)b * a.NV + v) * 12;  // wave-uniform
+        // rot @ (x, y, 1): the reference's sgemm FMA chain (mv::project), once per (pixel, view)
+        const float rx = mv::add_rn(fmaf(r[1], yf, mv::mul_rn(r[0], xf)), r[2]);
+        const float ry = mv::add_rn(fmaf(r[4], yf, mv::mul_rn(r[3], xf)), r[5]);
+        const float rz = mv::add_rn(fmaf(r[7], yf, mv::mul_rn(r[6], xf)), r[8]);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.src + (long)v * a.src_vs + (long)b * a.src_bs), (short)0, (int)src_bytes, 0x00020000);
+
+        float cg[D][GPL], score[D];
+#pragma unroll
+        for (int q = 0; q < D / 2; ++q) {
+            // two hypotheses at a time through the scalar chain, packed
+            const mv::f32x2 dz = depth2[q];
+            const mv::f32x2 px = mv::add_rn2(mv::mul_rn2(splat2(rx), dz), splat2(r[9]));
+            const mv::f32x2 py = mv::add_rn2(mv::mul_rn2(splat2(ry), dz), splat2(r[10]));
+            mv::f32x2 pz = mv::add_rn2(mv::mul_rn2(splat2(rz), dz), splat2(r[11]));
+            if (pz[0] == 0.0f) pz[0] = 1e-9f;
+            if (pz[1] == 0.0f) pz[1] = 1e-9f;
+            const Recip2 z = make_recip2(pz);
+            // grid_roundtrip(): / half, - 1, + 1, * 0.5, * (size - 1)
+            mv::f32x2 sx = sub_rn2(div_rn2(div_rn2(px, z), gn.halfw), splat2(1.0f));
+            mv::f32x2 sy = sub_rn2(div_rn2(div_rn2(py, z), gn.halfh), splat2(1.0f));
+            sx = mv::mul_rn2(mv::mul_rn2(mv::add_rn2(sx, splat2(1.0f)), splat2(0.5f)), splat2(gn.wm1));
+            sy = mv::mul_rn2(mv::mul_rn2(mv::add_rn2(sy, splat2(1.0f)), splat2(0.5f)), splat2(gn.hm1));
+            // make_taps(): clamp far-away / NaN positions, corner, fractional weights
+            const mv::f32x2 cx = {__builtin_amdgcn_fmed3f(sx[0], -4.0f, xhi), __builtin_amdgcn_fmed3f(sx[1], -4.0f, xhi)};
+            const mv::f32x2 cy = {__builtin_amdgcn_fmed3f(sy[0], -4.0f, yhi), __builtin_amdgcn_fmed3f(sy[1], -4.0f, yhi)};
+            const mv::f32x2 fx = {floorf(cx[0]), floorf(cx[1])}, fy = {floorf(cy[0]), floorf(cy[1])};
+            const mv::f32x2 wx1 = sub_rn2(cx, fx), wy1 = sub_rn2(cy, fy);
+            const mv::f32x2 wx0 = sub_rn2(splat2(1.0f), wx1), wy0 = sub_rn2(splat2(1.0f), wy1);
+            mv::f32x2 nw = mv::mul_rn2(wy0, wx0), ne = mv::mul_rn2(wy0, wx1);
+            mv::f32x2 sw = mv::mul_rn2(wy1, wx0), se = mv::mul_rn2(wy1, wx1);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int d = 2 * q + e;
+                const int x0 = (int)fx[e], y0 = (int)fy[e];
+                const bool vx0 = (unsigned)x0 < (unsigned)a.Ws, vx1 = (unsigned)(x0 + 1) < (unsigned)a.Ws;
+                const bool vy0 = (unsigned)y0 < (unsigned)a.Hs, vy1 = (unsigned)(y0 + 1) < (unsigned)a.Hs;
+                const float wnw = (vy0 && vx0) ? nw[e] : 0.0f, wne = (vy0 && vx1) ? ne[e] : 0.0f;
+                const float wsw = (vy1 && vx0) ? sw[e] : 0.0f, wse = (vy1 && vx1) ? se[e] : 0.0f;
+                // byte offset of tap (y0, x0); |y0 * Ws + x0| < 2^24 (checked by the launcher), the shift may wrap for
+                // negative corners: then the offset is out of the descriptor's range and the load returns 0
+                const unsigned o0 = ((unsigned)__mul24(y0, a.Ws) + (unsigned)x0) << SH;
+                const unsigned oa = o0 + (unsigned)(sub * 32), ob = oa + (unsigned)row_bytes;
+                const f32x4 q0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, oa, 0, 0));
+                const f32x4 q1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, oa + 16, 0, 0));
+                const f32x4 q2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, oa + (4 * C), 0, 0));
+                const f32x4 q3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, oa + (4 * C + 16), 0, 0));
+                const f32x4 q4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ob, 0, 0));
+                const f32x4 q5 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ob + 16, 0, 0));
+                const f32x4 q6 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ob + (4 * C), 0, 0));
+                const f32x4 q7 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ob + (4 * C + 16), 0, 0));
+                float part[GPL];
+#define MV_PAIR(c, A, B, Cq, Dq, R, j)                                                                         \
+                {                                                                                              \
+                    const mv::f32x2 wv = mv::blend2(wnw, wne, wsw, wse, (mv::f32x2){A[j], A[j + 1]},           \
+                                                    (mv::f32x2){B[j], B[j + 1]}, (mv::f32x2){Cq[j], Cq[j + 1]}, \
+                                                    (mv::f32x2){Dq[j], Dq[j + 1]});                            \
+                    const mv::f32x2 p2 = mv::mul_rn2(wv, (mv::f32x2){R[j], R[j + 1]});                         \
+                    part[(c) / CG] = ((c) % CG == 0) ? p2[0] : mv::add_rn(part[(c) / CG], p2[0]);              \
+                    part[((c) + 1) / CG] = (((c) + 1) % CG == 0) ? p2[1] : mv::add_rn(part[((c) + 1) / CG], p2[1]); \
+                }
+                MV_PAIR(0, q0, q2, q4, q6, R0, 0)
+                MV_PAIR(2, q0, q2, q4, q6, R0, 2)
+                MV_PAIR(4, q1, q3, q5, q7, R1, 0)
+                MV_PAIR(6, q1, q3, q5, q7, R1, 2)
+#undef MV_PAIR
+#pragma unroll
+                for (int k = 0; k < GPL; ++k) cg[d][k] = mv::div_rn(part[k], (float)CG);   // .mean(2)
+                // .sum(1): all groups of the pixel in group order (the LPP lanes of a pixel are neighbours)
+                float sc = 0.0f;
+                const int lane0 = (threadIdx.x & 63) - sub;
+#pragma unroll
+                for (int j = 0; j < LPP; ++j)
+#pragma unroll
+                    for (int k = 0; k < GPL; ++k) {
+                        const float val = LPP == 1 ? cg[d][k] : __shfl(cg[d][k], lane0 + j);
+                        sc = (j == 0 && k == 0) ? val : mv::add_rn(sc, val);
+                    }
+                score[d] = a.fuse_d ? mv::div_rn(sc, temp) : sc;
+            }
+        }
+        // softmax over depth, in registers (depth order, like the other launch forms)
+        float mx = score[0];
+#pragma unroll
+        for (int d = 1; d < D; ++d) mx = fmaxf(mx, score[d]);
+        float e[D], den = 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            e[d] = expf(mv::sub_rn(score[d], mx));
+            den = mv::add_rn(den, e[d]);
+        }
+        const mv::Recip rden = mv::make_recip(den);
+        const float wmax = mv::div_rn(1.0f, rden);   // attn_fuse_d = False: max_d softmax = exp(0) / sum
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float wgt = a.fuse_d ? mv::div_rn(mv::div_rn(e[d], rden), sqrt_c) : wmax;
+            wsum[d] = mv::add_rn(wsum[d], wgt);
+#pragma unroll
+            for (int k = 0; k < GPL; ++k) acc[d][k] = mv::add_rn(acc[d][k], mv::mul_rn(wgt, cg[d][k]));
+        }
+    }
+
+    if (valid) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const long o = (((long)b * D + d) * hw + p);
+            float* op = a.out + o * G + sub * GPL;
+            const mv::Recip rw = mv::make_recip(wsum[d]);
+            if (GPL == 4) {
+                st4(op, (f32x4){mv::div_rn(acc[d][0], rw), mv::div_rn(acc[d][GPL > 1 ? 1 : 0], rw),
+                                mv::div_rn(acc[d][GPL > 2 ? 2 : 0], rw), mv::div_rn(acc[d][GPL > 3 ? 3 : 0], rw)});
+            } else {
+#pragma unroll
+                for (int k = 0; k < GPL; ++k) op[k] = mv::div_rn(acc[d][k], rw);
+            }
+            if (a.wsum_out && sub == 0) a.wsum_out[o] = wsum[d];
+        }
+    }
+}
+
+// waves per workgroup of the pixel-major kernel: single-wave workgroups keep the tail of the launch fine-grained (a
+// 512x640 stage-4 launch is 5 waves per SIMD at 4 resident); MVSTER_PIX_NW = 1 / 2 / 4 for experiments
+static const int g_pix_nw = getenv("MVSTER_PIX_NW") ? atoi(getenv("MVSTER_PIX_NW")) : 1;
+
+template <int C, int G, int D, int NW>
+int launch_fwd_pix_nw(const WarpAggArgs& a, hipStream_t stream) {
+    constexpr int PPB = 64 * NW / (C / 8);
+    dim3 grid((a.h * a.w + PPB - 1) / PPB, a.B);
+    hipLaunchKernelGGL((warp_agg_fwd_pix_kernel<C, G, D, NW>), grid, dim3(64 * NW), 0, stream, a);
+    return mv_check_launch();
+}
+
+template <int C, int G, int D>
+int launch_fwd_pix(const WarpAggArgs& a, hipStream_t stream) {
+    // 24-bit multiply-add on texel indices, 32-bit byte offsets inside one (view, batch) map
+    if ((long)a.Hs * a.Ws >= (1L << 23) || (long)a.Hs * a.Ws * C * 4 >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    if (g_pix_nw == 4) return launch_fwd_pix_nw<C, G, D, 4>(a, stream);
+    if (g_pix_nw == 2) return launch_fwd_pix_nw<C, G, D, 2>(a, stream);
+    return launch_fwd_pix_nw<C, G, D, 1>(a, stream);
+}
+
+template <int C, int G>
+int dispatch_fwd_pix(const WarpAggArgs& a, hipStream_t stream) {
+    if (a.D == 4) return launch_fwd_pix<C, G, 4>(a, stream);
+    if (a.D == 8) return launch_fwd_pix<C, G, 8>(a, stream);
+    return MVSTER_ERR_UNSUPPORTED;
+}
+
 template <int C, int G, int D>
 int launch_fwd_wave(const WarpAggArgs& a, hipStream_t stream) {
     constexpr int PPB = 4 * (64 / ((C / 8) * D));
@@ -468,6 +702,7 @@ struct WarpAggBwdArgs {
 // LDS and stores once.
 constexpr int kWinX = 96, kWinY = 6;
 static const bool g_bwd_no_tiles = getenv("MVSTER_BWD_NO_TILES") != nullptr;   // experiment switch
+static const bool g_no_pix = getenv("MVSTER_NO_PIX") != nullptr;               // experiment switch: wave-local kernel at every stage
 
 template <int C, int G, bool GROUP, int DMAX>
 __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs ba) {
@@ -946,7 +1181,18 @@ extern "C" int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat,
     a.attn_temp = attn_temp; a.sqrt_c = sqrtf((float)C); a.fuse_d = attn_fuse_d;
     hipStream_t s = (hipStream_t)stream;
     // variant: 0 = choose; 1 = one thread per (pixel, d); 2 = workgroup-level lane split (C >= 16);
-    // 3 = wave-local kernel (what 0 picks whenever it applies)
+    // 3 = wave-local kernel (what 0 picks for C >= 32); 4 = pixel-major kernel (what 0 picks for C <= 16)
+    if (group_cor && (D == 4 || D == 8) && (variant == 4 || (variant == 0 && C <= 16 && !g_no_pix))) {
+        int rc = MVSTER_ERR_UNSUPPORTED;
+        if (C == 8 && G == 4) rc = dispatch_fwd_pix<8, 4>(a, s);
+        else if (C == 8 && G == 8) rc = dispatch_fwd_pix<8, 8>(a, s);
+        else if (C == 16 && G == 4) rc = dispatch_fwd_pix<16, 4>(a, s);
+        else if (C == 16 && G == 8) rc = dispatch_fwd_pix<16, 8>(a, s);
+        else if (C == 32 && G == 8 && variant == 4) rc = dispatch_fwd_pix<32, 8>(a, s);
+        else if (C == 32 && G == 4 && variant == 4) rc = dispatch_fwd_pix<32, 4>(a, s);
+        if (rc != MVSTER_ERR_UNSUPPORTED && !(rc == MVSTER_ERR_SHAPE && variant == 0)) return rc;
+        // (a map too large for the 24-bit index arithmetic falls through to the wave-local kernel)
+    }
     if (group_cor && (D == 4 || D == 8) && (variant == 0 || variant == 3)) {
         if (C == 8 && G == 4) return dispatch_fwd_wave<8, 4>(a, s);
         if (C == 8 && G == 8) return dispatch_fwd_wave<8, 8>(a, s);

@@ -20,7 +20,9 @@ args = ap.parse_args()
 dev = torch.device("cuda:0")
 _, proj, dv = make_inputs(nviews=args.views, H=args.height, W=args.width, seed=0)
 NV = args.views - 1
-print("%-28s %s" % ("stage (C,G,D,h,w)", "  ".join("v%d us / GB/s" % v for v in (1, 2, 3))))
+VARIANTS = (1, 2, 3, 4)
+print("MVSTER_PIX_NW=%s" % os.environ.get("MVSTER_PIX_NW", "1"))
+print("%-28s %s" % ("stage (C,G,D,h,w)", "  ".join("v%d us / GB/s" % v for v in VARIANTS)))
 for s, (C, G, D) in enumerate(((64, 8, 8), (32, 8, 8), (16, 4, 4), (8, 4, 4))):
     h, w = args.height >> (3 - s), args.width >> (3 - s)
     g = torch.Generator().manual_seed(s)
@@ -31,7 +33,10 @@ for s, (C, G, D) in enumerate(((64, 8, 8), (32, 8, 8), (16, 4, 4), (8, 4, 4))):
     rt = ops.relative_projection(proj["stage%d" % (s + 1)].to(dev))
     nbytes = 4 * (ref.numel() + src.numel() + hypo.numel() * (1 + G))
     cells = []
-    for variant in (1, 2, 3):
+    for variant in VARIANTS:
+        if variant == 4 and C > 32:
+            cells.append("      -        ")
+            continue
         for _ in range(3):
             ops.warp_agg_fwd_cl(ref, src, rt, hypo, G, True, True, 2.0, variant=variant)
         torch.cuda.synchronize()

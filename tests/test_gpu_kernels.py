@@ -154,8 +154,8 @@ def test_warp_agg_forward(golden, name):
     out = ops.warp_agg_fwd_cl(f_cl[0], f_cl[1:], _oracle_rt(pm).to(DEV), hypo.to(DEV), Gk, gc, fuse, temp, variant=1)
     got = out.permute(0, 4, 1, 2, 3).cpu()
     tight = (got - want).abs().max().item()
-    # the lane-split and wave-local kernels are bit-identical to the one-thread-per-(pixel, d) form
-    for variant in (0, 2, 3):
+    # the lane-split, wave-local and pixel-major kernels are bit-identical to the one-thread-per-(pixel, d) form
+    for variant in (0, 2, 3, 4):
         o2 = ops.warp_agg_fwd_cl(f_cl[0], f_cl[1:], _oracle_rt(pm).to(DEV), hypo.to(DEV), Gk, gc, fuse, temp,
                                  variant=variant)
         assert torch.equal(o2, out), (name, variant)
@@ -176,8 +176,8 @@ def test_warp_agg_forward(golden, name):
                                    (64, 8, 4), (8, 4, 8)])
 @pytest.mark.parametrize("fuse", [True, False])
 def test_warp_agg_kernel_variants_bit_identical(C, G, D, fuse):
-    """Every launch form of the fused kernel (one thread per (pixel, d); workgroup-level lane split; wave-local
-    ; the default choice) returns the same bits, incl. ragged pixel counts,
+    """Every launch form of the fused kernel (one thread per (pixel, d); workgroup-level lane split; wave-local;
+    pixel-major with packed hypothesis pairs and buffer loads; the default choice) returns the same bits, incl. ragged pixel counts,
     out-of-image taps, odd view counts and the saved softmax mass."""
     from mvster_amd.synthetic import make_inputs as mk
     for (h, w, nv, B) in ((37, 53, 3, 2), (16, 24, 4, 1), (5, 7, 2, 1)):
@@ -191,32 +191,43 @@ def test_warp_agg_kernel_variants_bit_identical(C, G, D, fuse):
         args = (ref.to(DEV), src.to(DEV), rt, hypo.to(DEV), G, True, fuse, 2.0)
         base, wbase = ops.warp_agg_fwd_cl(*args, want_wsum=True, variant=1)
         assert torch.isfinite(base).all() and base.abs().max() > 0
-        for variant in (0, 2, 3):
+        for variant in (0, 2, 3, 4):
             o, ws = ops.warp_agg_fwd_cl(*args, want_wsum=True, variant=variant)
             assert torch.equal(o, base), (C, G, D, h, w, variant)
             assert torch.equal(ws, wbase), (C, G, D, h, w, variant)
 
 
-def test_warp_agg_source_size_differs_and_oob(golden):
-    """Source map smaller than the reference map + far-away camera (mostly zero padding)."""
+@pytest.mark.parametrize("case", ["a", "b", "c", "d", "e"])
+def test_warp_agg_vs_reference_homo_warping(golden, case):
+    """The reference's homo_warping outputs (fixture G1) pushed through the rest of the stage arithmetic on the CPU, against
+    the fused kernel: a = DTU-like cameras, b = source map smaller than the reference map, c = far-away camera (mostly
+    zero padding), d = z == 0 exactly (-> 1e-9, mvs4net_utils.py:38-39), e = B=2 with per-sample cameras."""
     g = golden("g1_warp")
-    for case, src_k in (("b", "a_src"), ("c", "c_src")):
-        fea = g.t(case + "_fea")                                   # [1,8,Hs,Ws]
-        depth = g.t("a_depth")                                     # [1,4,32,40]
-        ref_p, src_p = g.t("a_ref"), g.t(src_k)
-        torch.manual_seed(3)
-        ref_fea = torch.randn(1, 8, 32, 40)
-        warped = g.t(case + "_out")                                # reference homo_warping output
-        cor = (warped.reshape(1, 4, 2, 4, 32, 40) * ref_fea.unsqueeze(2).repeat(1, 1, 4, 1, 1).reshape(1, 4, 2, 4, 32, 40)).mean(2)
-        wgt = torch.softmax(cor.sum(1) / 2.0, 1) / np.sqrt(8)
-        want = (wgt.unsqueeze(1) * cor) / (1e-8 + wgt).unsqueeze(1)
+    fea = g.t({"a": "a_fea", "b": "b_fea", "c": "c_fea", "d": "c_fea", "e": "e_fea"}[case])     # [B,8,Hs,Ws]
+    depth = g.t({"d": "d_depth", "e": "e_depth"}.get(case, "a_depth"))                          # [B,4,32,40]
+    warped = g.t(case + "_out")                                                                 # [B,8,4,32,40]
+    B = fea.shape[0]
+    if case == "d":
+        rt = torch.tensor([1., 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0]).view(1, 1, 12)
+    else:
+        ref_p = g.t("e_ref" if case == "e" else "a_ref")
+        src_p = g.t({"c": "c_src", "e": "e_src"}.get(case, "a_src"))
         P = torch.matmul(src_p, torch.inverse(ref_p))
         rt = torch.cat([P[:, :3, :3].reshape(-1, 9), P[:, :3, 3]], 1).unsqueeze(1).contiguous()
+    torch.manual_seed(3)
+    ref_fea = torch.randn(B, 8, 32, 40)
+    cor = (warped.reshape(B, 4, 2, 4, 32, 40) * ref_fea.unsqueeze(2).repeat(1, 1, 4, 1, 1).reshape(B, 4, 2, 4, 32, 40)).mean(2)
+    wgt = torch.softmax(cor.sum(1) / 2.0, 1) / np.sqrt(8)
+    want = (wgt.unsqueeze(1) * cor) / (1e-8 + wgt).unsqueeze(1)
+    base = None
+    for variant in (1, 0):
         out = ops.warp_agg_fwd_cl(ops.to_channels_last(ref_fea.to(DEV)), ops.to_channels_last(fea.to(DEV)).unsqueeze(0),
-                                  rt.to(DEV), depth.to(DEV), 4, True, True, 2.0)
+                                  rt.to(DEV), depth.to(DEV), 4, True, True, 2.0, variant=variant)
+        assert torch.isfinite(out).all()
         err = (out.permute(0, 4, 1, 2, 3).cpu() - want).abs().max().item()
-        note("warp_agg_g1_" + case, max_abs=err)
-        assert err <= 5e-6 * max(want.abs().max().item(), 1.0)
+        assert err <= 5e-6 * max(want.abs().max().item(), 1.0), (case, variant, err)
+        base = out if base is None else base
+    note("warp_agg_g1_" + case, max_abs=err)
 
 
 CONV_CASES = [
