@@ -681,7 +681,8 @@ int launch_fwd(const WarpAggArgs& a, hipStream_t stream) {
 // taps, redo the depth softmax, form dL/dcor, then re-gather once more to scatter
 //   d src[tap][c] += w_tap * dwarp[c]      (atomic, 4 taps x C)
 //   d ref[c]      += ...                   (atomic, summed over d and views)
-// Uses `out` and `wsum` saved by the forward.  attn_fuse_d only.
+// Uses `out` and `wsum` saved by the forward.  Both attention forms (attn_fuse_d on: a weight per (pixel, d); off: one
+// per pixel, the largest softmax value along depth, mvs4net_utils.py:1048-1051), up to 16 hypotheses.
 // ------------------------------------------------------------------------------------------
 struct WarpAggBwdArgs {
     WarpAggArgs f;
@@ -708,15 +709,13 @@ template <int C, int G, bool GROUP, int DMAX>
 __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs ba) {
     const WarpAggArgs& a = ba.f;
     constexpr int CG = C / G;
-    constexpr int CB = CG > 8 ? CG : 8;
-    constexpr int GB = CB / CG;
-    static_assert(CB == 8 || !GROUP, "the scatter window holds 8 channels");
-    constexpr int WC = CB < 8 ? CB : 8;                  // channels per window pass
+    constexpr int NB = C / 8;                // 8-channel blocks: one scatter-window pass each
+    constexpr bool GO_REG = G <= 8;          // the pixel's G output gradients live in registers (else they are re-read)
+    static_assert(C % 8 == 0 && (GROUP ? (C % G == 0 && G <= 8) : (C == G)), "layout");
     __shared__ float sc[2][DMAX][64];
     __shared__ float sd[2][DMAX][64];
-    __shared__ float corL[G][DMAX * 64];
     __shared__ float gref[C][64];
-    __shared__ float win[WC][kWinY][kWinX];
+    __shared__ float win[8][kWinY][kWinX];
     __shared__ int worg[2][2];
 
     const int tx = threadIdx.x;
@@ -736,16 +735,20 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
     const float* rp = a.ref + (long)b * a.ref_bs + (long)pc * C;
     const float W = ba.wsum[o];
     const float invW = 1.0f / W;
+    const float vmask = valid ? 1.0f : 0.0f;
+    const float* gop = ba.grad_out + o * G;
 
-    float go[G];
+    // go[g] = dL/d out[g] of this (pixel, d); common = sum_g go[g] * out[g]
+    float go[GO_REG ? G : 1];
     float common = 0.0f;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        go[g] = valid ? ba.grad_out[o * G + g] : 0.0f;
-        common = fmaf(go[g], ba.fwd_out[o * G + g], common);
+        const float gv = gop[g] * vmask;
+        common = fmaf(gv, ba.fwd_out[o * G + g], common);
+        if (GO_REG) go[g] = gv;
     }
     for (int i = tid; i < C * 64; i += nthr) (&gref[0][0])[i] = 0.0f;
-    for (int i = tid; i < WC * kWinY * kWinX; i += nthr) (&win[0][0][0])[i] = 0.0f;
+    for (int i = tid; i < 8 * kWinY * kWinX; i += nthr) (&win[0][0][0])[i] = 0.0f;
     __syncthreads();
 
     for (int v = 0; v < a.NV; ++v) {
@@ -767,37 +770,39 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
         const float* sp = a.src + voff;
         float* gsp = ba.grad_src + voff;
 
-        // pass 1: correlations and score (same arithmetic as the forward)
-        float score = 0.0f;
-        for (int cb = 0; cb < C / CB; ++cb) {
-            const int cbase = cb * CB;
-            float part[GB];
+        // pass 1: score (same arithmetic and order as the forward) and gdot = sum_g go[g] * cor[g]
+        float score = 0.0f, gdot = 0.0f, part = 0.0f;
 #pragma unroll
-            for (int c0 = 0; c0 < CB; c0 += 4) {
-                const f32x4 R = ld4(rp + cbase + c0);
-                const f32x4 A = ld4(sp + o00 + cbase + c0), Bq = ld4(sp + o01 + cbase + c0);
-                const f32x4 Cq = ld4(sp + o10 + cbase + c0), Dq = ld4(sp + o11 + cbase + c0);
+        for (int cb = 0; cb < NB; ++cb) {
+            f32x4 gq[2];
+            if (!GO_REG) { gq[0] = ld4(gop + cb * 8) * vmask; gq[1] = ld4(gop + cb * 8 + 4) * vmask; }
+#pragma unroll
+            for (int c0 = 0; c0 < 8; c0 += 4) {
+                const f32x4 R = ld4(rp + cb * 8 + c0);
+                const f32x4 A = ld4(sp + o00 + cb * 8 + c0), Bq = ld4(sp + o01 + cb * 8 + c0);
+                const f32x4 Cq = ld4(sp + o10 + cb * 8 + c0), Dq = ld4(sp + o11 + cb * 8 + c0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int c = c0 + j;
+                    const int c = cb * 8 + c0 + j;
                     const float wv = mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
                     if (GROUP) {
                         const float pr = mv::mul_rn(wv, R[j]);
-                        part[c / CG] = (c % CG == 0) ? pr : mv::add_rn(part[c / CG], pr);
+                        part = (c % CG == 0) ? pr : mv::add_rn(part, pr);
+                        if (c % CG == CG - 1) {
+                            const float cg = mv::div_rn(part, (float)CG);
+                            score = (c / CG == 0) ? cg : mv::add_rn(score, cg);
+                            gdot = fmaf(go[GO_REG ? c / CG : 0], cg, gdot);
+                        }
                     } else {
                         const float df = mv::sub_rn(R[j], wv);
-                        part[c] = mv::mul_rn(df, df);
+                        const float cg = mv::mul_rn(df, df);
+                        score = (c == 0) ? cg : mv::add_rn(score, cg);
+                        gdot = fmaf(GO_REG ? go[GO_REG ? c : 0] : gq[c0 / 4][j], cg, gdot);
                     }
                 }
             }
-#pragma unroll
-            for (int k = 0; k < GB; ++k) {
-                const float cg = GROUP ? mv::div_rn(part[k], (float)CG) : part[k];
-                corL[cb * GB + k][tid] = cg;
-                score = (cb == 0 && k == 0) ? cg : mv::add_rn(score, cg);
-            }
         }
-        score = mv::div_rn(score, a.attn_temp);
+        if (a.fuse_d) score = mv::div_rn(score, a.attn_temp);
         sc[v & 1][d][tx] = score;
         if (tid == 0) { worg[v & 1][0] = 0x7fffffff; worg[v & 1][1] = 0x7fffffff; }
         __syncthreads();
@@ -813,34 +818,48 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
             if (tx == 0) { atomicMin(&worg[v & 1][0], mnx); atomicMin(&worg[v & 1][1], mny); }
         }
         float mx = sc[v & 1][0][tx];
-        for (int j = 1; j < a.D; ++j) mx = fmaxf(mx, sc[v & 1][j][tx]);
+        int dstar = 0;
+        for (int j = 1; j < a.D; ++j) {
+            const float sj = sc[v & 1][j][tx];
+            if (sj > mx) { mx = sj; dstar = j; }          // first maximum
+        }
         float den = 0.0f;
         for (int j = 0; j < a.D; ++j) den += expf(sc[v & 1][j][tx] - mx);
         const float sig = expf(score - mx) / den;
-        const float wgt = sig / a.sqrt_c;
-        // dL/dw_v = (sum_g go[g]*cor[g] - sum_g go[g]*out[g]) / W
-        float dw = -common;
-#pragma unroll
-        for (int g = 0; g < G; ++g) dw = fmaf(go[g], corL[g][tid], dw);
-        dw *= invW;
-        const float dsig = dw / a.sqrt_c;
-        sd[v & 1][d][tx] = sig * dsig;
-        __syncthreads();
-        float dot = 0.0f;
-        for (int j = 0; j < a.D; ++j) dot += sd[v & 1][j][tx];
-        const float dscore = sig * (dsig - dot) / a.attn_temp;   // d/d(sum_g cor[g])
+        // dL/dw = (sum_g go[g]*cor[g] - sum_g go[g]*out[g]) / W  per (pixel, d); attn_fuse_d: one weight per (pixel, d),
+        // w = softmax_d(score / temp) / sqrt(C); otherwise one weight per pixel, w = max_d softmax_d(score) = 1 / den
+        float wgt, dscore;
+        if (a.fuse_d) {
+            wgt = sig / a.sqrt_c;
+            const float dsig = (gdot - common) * invW / a.sqrt_c;
+            sd[v & 1][d][tx] = sig * dsig;
+            __syncthreads();
+            float dot = 0.0f;
+            for (int j = 0; j < a.D; ++j) dot += sd[v & 1][j][tx];
+            dscore = sig * (dsig - dot) / a.attn_temp;   // d/d(sum_g cor[g])
+        } else {
+            wgt = 1.0f / den;
+            sd[v & 1][d][tx] = gdot - common;
+            __syncthreads();
+            float dws = 0.0f;
+            for (int j = 0; j < a.D; ++j) dws += sd[v & 1][j][tx];
+            dscore = dws * invW * wgt * ((d == dstar ? 1.0f : 0.0f) - sig);
+        }
         const int wx0 = worg[v & 1][0], wy0 = worg[v & 1][1];
         // window coordinates of the four taps (negative / too large = outside -> global atomics)
         const int ax = tc.xa - wx0, bx = tc.xb - wx0, ay = tc.ya - wy0, by = tc.yb - wy0;
         const bool iax = (unsigned)ax < (unsigned)kWinX, ibx = (unsigned)bx < (unsigned)kWinX;
         const bool iay = (unsigned)ay < (unsigned)kWinY, iby = (unsigned)by < (unsigned)kWinY;
 
-        // pass 2: re-gather, scatter the feature gradients, 8 channels per window pass
-        for (int cb = 0; cb < C / CB; ++cb) {
-            const int cbase = cb * CB;
-            if (valid) {
+        // pass 2: re-gather, scatter the feature gradients, 8 channels per window pass (unrolled: go[] stays in registers)
 #pragma unroll
-                for (int c0 = 0; c0 < CB; c0 += 4) {
+        for (int cb = 0; cb < NB; ++cb) {
+            const int cbase = cb * 8;
+            if (valid) {
+                f32x4 gq[2];
+                if (!GO_REG) { gq[0] = ld4(gop + cbase); gq[1] = ld4(gop + cbase + 4); }
+#pragma unroll
+                for (int c0 = 0; c0 < 8; c0 += 4) {
                     const f32x4 R = ld4(rp + cbase + c0);
                     const f32x4 A = ld4(sp + o00 + cbase + c0), Bq = ld4(sp + o01 + cbase + c0);
                     const f32x4 Cq = ld4(sp + o10 + cbase + c0), Dq = ld4(sp + o11 + cbase + c0);
@@ -848,8 +867,8 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
                     for (int j = 0; j < 4; ++j) {
                         const int cl = c0 + j;               // channel within the pass
                         const int c = cbase + cl;
-                        const int g = GROUP ? c / CG : c;
-                        const float dcor = fmaf(go[g] * invW, wgt, dscore);   // direct + through the softmax
+                        const float gv = GO_REG ? go[GO_REG ? (GROUP ? c / CG : c) : 0] : gq[c0 / 4][j];
+                        const float dcor = fmaf(gv * invW, wgt, dscore);   // direct + through the softmax
                         const float wv = mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
                         float dwv, dref;
                         if (GROUP) {
@@ -881,11 +900,10 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
                 }
             }
             __syncthreads();
-            // flush (and clear) the window: one global atomic per touched (texel, channel)
-            // channel-fastest order: the atomics of a wave go to 8 neighbouring texels x 8 channels = 256 contiguous
-            // bytes (2 cache lines) instead of 64 texels of one channel plane (16 lines)
-            for (int i = tid; i < WC * kWinY * kWinX; i += nthr) {
-                const int cl = i % WC, tex = i / WC;
+            // flush (and clear) the window: one global atomic per touched (texel, channel), channel-fastest: the
+            // atomics of a wave go to 8 neighbouring texels x 8 channels = 256 contiguous bytes
+            for (int i = tid; i < 8 * kWinY * kWinX; i += nthr) {
+                const int cl = i % 8, tex = i / 8;
                 const int wxx = tex % kWinX, wyy = tex / kWinX;
                 const float val = win[cl][wyy][wxx];
                 if (val != 0.0f) {
@@ -1149,9 +1167,8 @@ __global__ void __launch_bounds__(64 * 8) warp_agg_bwd_tile_kernel(WarpAggBwdArg
 template <int C, int G, bool GROUP>
 int launch_bwd(const WarpAggBwdArgs& ba, hipStream_t stream) {
     const WarpAggArgs& a = ba.f;
-    if (a.D > 8) return MVSTER_ERR_UNSUPPORTED;
     if constexpr (C == 8 && C / G <= 8) {
-        if (!g_bwd_no_tiles) {
+        if (!g_bwd_no_tiles && a.fuse_d && a.D <= 8) {      // the shipped full-resolution stage
             constexpr int R = 4;
             const int tiles_x = (a.w + 63) / 64, tiles_y = (a.h + R - 1) / R;
             hipLaunchKernelGGL((warp_agg_bwd_tile_kernel<C, G, GROUP, R>), dim3(tiles_x * tiles_y, a.B), dim3(64, a.D), 0, stream,
@@ -1161,7 +1178,8 @@ int launch_bwd(const WarpAggBwdArgs& ba, hipStream_t stream) {
     }
     dim3 block(64, a.D);
     dim3 grid((a.h * a.w + 63) / 64, a.B);
-    hipLaunchKernelGGL((warp_agg_bwd_kernel<C, G, GROUP, 8>), grid, block, 0, stream, ba);
+    if (a.D <= 8) hipLaunchKernelGGL((warp_agg_bwd_kernel<C, G, GROUP, 8>), grid, block, 0, stream, ba);
+    else hipLaunchKernelGGL((warp_agg_bwd_kernel<C, G, GROUP, kMaxD>), grid, block, 0, stream, ba);
     return mv_check_launch();
 }
 
@@ -1233,9 +1251,8 @@ extern "C" int mvster_warp_agg_bwd(const float* ref_feat, const float* src_feat,
                                    int attn_fuse_d, float attn_temp, void* stream) {
     if (!ref_feat || !src_feat || !rt || !hypo || !out || !wsum || !grad_out || !grad_ref || !grad_src)
         return MVSTER_ERR_NULL;
-    if (B <= 0 || NV <= 0 || D <= 0 || D > 8 || h <= 0 || w <= 0 || Hs <= 0 || Ws <= 0) return MVSTER_ERR_SHAPE;
+    if (B <= 0 || NV <= 0 || D <= 0 || D > kMaxD || h <= 0 || w <= 0 || Hs <= 0 || Ws <= 0) return MVSTER_ERR_SHAPE;
     if (!group_cor && G != C) return MVSTER_ERR_SHAPE;
-    if (!attn_fuse_d) return MVSTER_ERR_UNSUPPORTED;
     WarpAggBwdArgs ba;
     WarpAggArgs& a = ba.f;
     a.ref = ref_feat; a.src = src_feat; a.rt = rt; a.hypo = hypo; a.out = nullptr; a.wsum_out = nullptr;
@@ -1252,8 +1269,12 @@ extern "C" int mvster_warp_agg_bwd(const float* ref_feat, const float* src_feat,
     MV_CASE(8, 4, true)
     MV_CASE(16, 8, true)
     MV_CASE(8, 8, true)
+    MV_CASE(64, 4, true)
+    MV_CASE(32, 4, true)
     MV_CASE(8, 8, false)
     MV_CASE(16, 16, false)
+    MV_CASE(32, 32, false)
+    MV_CASE(64, 64, false)
 #undef MV_CASE
     return MVSTER_ERR_UNSUPPORTED;
 }

@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/device.txt
 for f in tests/test_gpu_kernels.py tests/test_gpu_model.py tests/test_gpu_train.py tests/test_gpu_fusion.py; do
-  /usr/bin/time -f "%e s" timeout 900 python -m pytest $f -m gpu -q --timeout=600 --durations=8 2>&1 | tail -40 > gpurun_out/$(basename $f .py).log
+  timeout 900 python -m pytest $f -m gpu -q --timeout=600 --durations=8 2>&1 | tail -40 > gpurun_out/$(basename $f .py).log
   echo "== $f exit ${PIPESTATUS[0]}"; tail -14 gpurun_out/$(basename $f .py).log
 done
 for nw in 1 4; do
