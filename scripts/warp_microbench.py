@@ -16,14 +16,19 @@ ap.add_argument("--height", type=int, default=512)
 ap.add_argument("--width", type=int, default=640)
 ap.add_argument("--views", type=int, default=5)
 ap.add_argument("--reps", type=int, default=50)
+ap.add_argument("--eager", action="store_true", help="plain launches, no hipGraph (for rocprofv3 counter passes)")
+ap.add_argument("--variants", type=str, default="1,2,3,4")
+ap.add_argument("--stages", type=str, default="1,2,3,4")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 _, proj, dv = make_inputs(nviews=args.views, H=args.height, W=args.width, seed=0)
 NV = args.views - 1
-VARIANTS = (1, 2, 3, 4)
+VARIANTS = tuple(int(v) for v in args.variants.split(","))
 print("MVSTER_PIX_NW=%s" % os.environ.get("MVSTER_PIX_NW", "1"))
 print("%-28s %s" % ("stage (C,G,D,h,w)", "  ".join("v%d us / GB/s" % v for v in VARIANTS)))
 for s, (C, G, D) in enumerate(((64, 8, 8), (32, 8, 8), (16, 4, 4), (8, 4, 4))):
+    if str(s + 1) not in args.stages.split(","):
+        continue
     h, w = args.height >> (3 - s), args.width >> (3 - s)
     g = torch.Generator().manual_seed(s)
     ref = torch.randn(1, h, w, C, generator=g).to(dev)
@@ -40,6 +45,12 @@ for s, (C, G, D) in enumerate(((64, 8, 8), (32, 8, 8), (16, 4, 4), (8, 4, 4))):
         for _ in range(3):
             ops.warp_agg_fwd_cl(ref, src, rt, hypo, G, True, True, 2.0, variant=variant)
         torch.cuda.synchronize()
+        if args.eager:
+            for _ in range(args.reps):
+                ops.warp_agg_fwd_cl(ref, src, rt, hypo, G, True, True, 2.0, variant=variant)
+            torch.cuda.synchronize()
+            cells.append("   eager       ")
+            continue
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             for _ in range(args.reps):

@@ -383,27 +383,48 @@ def test_fpn_tail_gather():
         assert err <= 1e-5 * want.abs().max().item()
 
 
-def test_warp_agg_backward_vs_autograd():
-    """HIP backward vs PyTorch autograd through the CPU oracle's aggregate_views."""
-    torch.manual_seed(5)
-    B, N, C, G, D, h, w = 1, 3, 8, 4, 4, 12, 16
+BWD_CASES = [
+    # C, G, D, group_cor, attn_fuse_d
+    (64, 8, 8, True, True), (32, 8, 8, True, True), (16, 4, 4, True, True), (8, 4, 4, True, True),       # the shipped stages
+    (8, 8, 8, True, True), (16, 8, 4, True, True), (32, 4, 8, True, True), (64, 4, 4, True, True),       # other group widths
+    (8, 8, 4, False, True), (16, 16, 4, False, True), (32, 32, 4, False, True), (64, 64, 3, False, True),  # squared differences
+    (16, 4, 4, True, False), (8, 4, 4, True, False), (8, 8, 5, False, False),                            # attn_fuse_d = False
+    (8, 4, 16, True, True), (16, 4, 12, True, False),                                                    # up to 16 hypotheses
+]
+
+
+@pytest.mark.parametrize("C,G,D,group_cor,fuse", BWD_CASES)
+def test_warp_agg_backward_vs_autograd(C, G, D, group_cor, fuse):
+    """HIP backward (both kernels: row blocks with a scatter window, 64x4 tiles at C=8) vs PyTorch autograd through the
+    CPU oracle's aggregate_views: B=2, a source map of another size than the reference map, a ragged pixel count, one
+    view rolled in-plane by half a radian so that its taps leave the scatter window (the direct-atomic path)."""
+    torch.manual_seed(C * 7 + D)
+    B, N, h, w, Hs, Ws = 2, 3, 12, 70, 10, 60
     _, proj, dv = make_inputs(N, h * 8, w * 8, seed=9, batch=B)
-    pm = proj["stage1"]
-    feats = [torch.randn(B, C, h, w, requires_grad=True) for _ in range(N)]
+    pm = proj["stage1"].clone()
+    c, s_ = float(np.cos(0.5)), float(np.sin(0.5))
+    roll = torch.tensor([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]])
+    pm[:, 2, 0, :3, :3] = roll @ pm[:, 2, 0, :3, :3]
+    feats = [torch.randn(B, C, h, w, requires_grad=True)] + [torch.randn(B, C, Hs, Ws, requires_grad=True) for _ in range(N - 1)]
     hypo = O.init_inverse_range(dv, D, h, w) * (1 + 0.02 * torch.rand(B, D, h, w))
-    cor = O.aggregate_views(feats, pm, hypo, True, G, attn_temp=2.0, attn_fuse_d=True)
+    cor = O.aggregate_views(feats, pm, hypo, group_cor, G, attn_temp=2.0, attn_fuse_d=fuse)
     gout = torch.randn_like(cor)
     cor.backward(gout)
-    f_cl = torch.stack([f.detach() for f in feats]).permute(0, 1, 3, 4, 2).contiguous().to(DEV)
+    ref_cl = feats[0].detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    src_cl = torch.stack([f.detach() for f in feats[1:]]).permute(0, 1, 3, 4, 2).contiguous().to(DEV)
     rt = _oracle_rt(pm).to(DEV)
-    out, wsum = ops.warp_agg_fwd_cl(f_cl[0], f_cl[1:], rt, hypo.to(DEV), G, True, True, 2.0, want_wsum=True)
-    g_ref, g_src = ops.warp_agg_bwd_cl(f_cl[0], f_cl[1:], rt, hypo.to(DEV), out, wsum,
-                                       gout.permute(0, 2, 3, 4, 1).contiguous().to(DEV), G, True, True, 2.0)
-    e_ref = (g_ref.permute(0, 3, 1, 2).cpu() - feats[0].grad).abs().max().item()
-    e_src = max((g_src[v].permute(0, 3, 1, 2).cpu() - feats[v + 1].grad).abs().max().item() for v in range(N - 1))
+    Gk = G if group_cor else C
+    out, wsum = ops.warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo.to(DEV), Gk, group_cor, fuse, 2.0, want_wsum=True)
+    e_fwd = (out.permute(0, 4, 1, 2, 3).cpu() - cor.detach()).abs().max().item() / max(cor.abs().max().item(), 1.0)
+    g_ref, g_src = ops.warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo.to(DEV), out, wsum,
+                                       gout.permute(0, 2, 3, 4, 1).contiguous().to(DEV), Gk, group_cor, fuse, 2.0)
     scale = max(f.grad.abs().max().item() for f in feats)
-    note("warp_agg_bwd", ref_max_abs=e_ref, src_max_abs=e_src, grad_absmax=scale)
-    assert e_ref <= 1e-4 * scale and e_src <= 1e-4 * scale      # atomics: summation order is not fixed
+    e_ref = (g_ref.permute(0, 3, 1, 2).cpu() - feats[0].grad).abs().max().item() / scale
+    e_src = max((g_src[v].permute(0, 3, 1, 2).cpu() - feats[v + 1].grad).abs().max().item() for v in range(N - 1)) / scale
+    note("warp_agg_bwd_C%d_G%d_D%d_%s_%s" % (C, G, D, "group" if group_cor else "sqdiff", "fuse" if fuse else "nofuse"),
+         fwd_rel=e_fwd, ref_rel=e_ref, src_rel=e_src, grad_absmax=scale)
+    assert e_fwd <= 1e-5
+    assert e_ref <= 1e-4 and e_src <= 1e-4      # atomics: summation order is not fixed
 
 
 def test_cpu_tensor_is_rejected():
