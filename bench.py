@@ -97,9 +97,10 @@ class KernelTimer:
             bytes_ = 4 * (ref_cl.numel() + src_cl.numel() + hypo.numel() + hypo.numel() * G)
             D = hypo.shape[1]
             variant = int(os.environ.get("MVSTER_WARP_VARIANT", "0"))
-            pix = variant == 4 or (variant == 0 and C <= 16 and not os.environ.get("MVSTER_NO_PIX"))
+            pix = variant == 4 or (variant == 0 and C <= 16 and os.environ.get("MVSTER_PIX"))
             if pix and C != G and D in (4, 8) and C <= 32:
-                kname = "warp_agg_fwd_pix_kernel<%d, %d, %d, %s>" % (C, G, D, os.environ.get("MVSTER_PIX_NW", "1"))
+                dpl = int(os.environ.get("MVSTER_PIX_DPL", "2")) or D
+                kname = "warp_agg_fwd_pix_kernel<%d, %d, %d, %d, %s>" % (C, G, D, dpl, os.environ.get("MVSTER_PIX_WPE", "4"))
             elif variant in (0, 3, 4) and C != G and D in (4, 8) and C <= 64:
                 kname = "warp_agg_fwd_wave_kernel<%d, %d, %d>" % (C, G, D)
             elif variant != 1 and C >= 16 and C != G and D <= 8:

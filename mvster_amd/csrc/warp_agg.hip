@@ -304,6 +304,10 @@ __global__ void __launch_bounds__(256) warp_agg_fwd_wave_kernel(WarpAggArgs a) {
     // per-launch divisors with their reciprocals (mvster_math.h: same bits as '/', 5 instead of 11 VALU ops)
     const mv::GridNorm gn = mv::make_grid_norm(a.Hs, a.Ws);
     const mv::Recip temp = mv::make_recip(a.attn_temp), sqrt_c = mv::make_recip(a.sqrt_c);
+    constexpr int SH = C == 8 ? 5 : (C == 16 ? 6 : (C == 32 ? 7 : 8));   // log2(bytes per texel)
+    const float xhi = (float)(a.Ws + 4), yhi = (float)(a.Hs + 4);
+    const unsigned src_bytes = (unsigned)a.Hs * (unsigned)a.Ws * (unsigned)(C * 4);
+    const int row_bytes = a.Ws << SH;
 
     float acc[GPL];
 #pragma unroll
@@ -319,17 +323,37 @@ __global__ void __launch_bounds__(256) warp_agg_fwd_wave_kernel(WarpAggArgs a) {
         for (int i = 0; i < 3; ++i) m.t[i] = r[9 + i];
         float sx, sy;
         mv::project(m, (float)x, (float)y, depth, gn, sx, sy);
-        mv::Taps t = mv::make_taps(sx, sy, a.Hs, a.Ws);
-        const mv::TapsClamped tc = mv::clamp_taps(t, a.Hs, a.Ws);
-        // wave-uniform base + 32-bit element offsets (the launcher checks Hs*Ws*C < 2^31)
-        const float* sp = a.src + (long)v * a.src_vs + (long)b * a.src_bs;
-        const unsigned ra = (unsigned)(tc.ya * a.Ws), rb = (unsigned)(tc.yb * a.Ws);
-        const float* p00 = sp + ((ra + (unsigned)tc.xa) * (unsigned)C + (unsigned)(sub * 8));
-        const float* p01 = sp + ((ra + (unsigned)tc.xb) * (unsigned)C + (unsigned)(sub * 8));
-        const float* p10 = sp + ((rb + (unsigned)tc.xa) * (unsigned)C + (unsigned)(sub * 8));
-        const float* p11 = sp + ((rb + (unsigned)tc.xb) * (unsigned)C + (unsigned)(sub * 8));
-        const f32x4 q0 = ld4(p00), q1 = ld4(p00 + 4), q2 = ld4(p01), q3 = ld4(p01 + 4);
-        const f32x4 q4 = ld4(p10), q5 = ld4(p10 + 4), q6 = ld4(p11), q7 = ld4(p11 + 4);
+        // make_taps() with a single clamp instruction per coordinate (v_med3_f32; a NaN position ends up at -4)
+        mv::Taps t;
+        {
+            const float cx = __builtin_amdgcn_fmed3f(sx, -4.0f, xhi), cy = __builtin_amdgcn_fmed3f(sy, -4.0f, yhi);
+            const float fx = floorf(cx), fy = floorf(cy);
+            t.x0 = (int)fx;
+            t.y0 = (int)fy;
+            const float wx1 = mv::sub_rn(cx, fx), wy1 = mv::sub_rn(cy, fy);
+            const float wx0 = mv::sub_rn(1.0f, wx1), wy0 = mv::sub_rn(1.0f, wy1);
+            const bool vx0 = (unsigned)t.x0 < (unsigned)a.Ws, vx1 = (unsigned)(t.x0 + 1) < (unsigned)a.Ws;
+            const bool vy0 = (unsigned)t.y0 < (unsigned)a.Hs, vy1 = (unsigned)(t.y0 + 1) < (unsigned)a.Hs;
+            t.nw = (vy0 && vx0) ? mv::mul_rn(wy0, wx0) : 0.0f;
+            t.ne = (vy0 && vx1) ? mv::mul_rn(wy0, wx1) : 0.0f;
+            t.sw = (vy1 && vx0) ? mv::mul_rn(wy1, wx0) : 0.0f;
+            t.se = (vy1 && vx1) ? mv::mul_rn(wy1, wx1) : 0.0f;
+        }
+        // raw buffer loads: one 32-bit byte offset per tap row (24-bit multiply-add on the texel index), the other
+        // addresses are immediate offsets; nothing is clamped -- a tap outside the map either falls outside the
+        // descriptor (the hardware returns 0) or reads some other texel, and its weight is 0 in both cases
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.src + (long)v * a.src_vs + (long)b * a.src_bs), (short)0, (int)src_bytes, 0x00020000);
+        const unsigned oa = (((unsigned)__mul24(t.y0, a.Ws) + (unsigned)t.x0) << SH) + (unsigned)(sub * 32);
+        const unsigned ob = oa + (unsigned)row_bytes;
+        const f32x4 q0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, oa, 0, 0));
+        const f32x4 q1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, oa + 16, 0, 0));
+        const f32x4 q2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, oa + (4 * C), 0, 0));
+        const f32x4 q3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, oa + (4 * C + 16), 0, 0));
+        const f32x4 q4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ob, 0, 0));
+        const f32x4 q5 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ob + 16, 0, 0));
+        const f32x4 q6 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ob + (4 * C), 0, 0));
+        const f32x4 q7 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ob + (4 * C + 16), 0, 0));
         // keep the eight loads together and ahead of their uses: left alone, the scheduler sinks each
         // load to its first use to save registers and the wave then eats eight memory latencies in a row
         __builtin_amdgcn_sched_barrier(0);
@@ -447,28 +471,34 @@ __device__ __forceinline__ mv::f32x2 sub_rn2(mv::f32x2 a, mv::f32x2 b) {
     return a - b;
 }
 
-template <int C, int G, int D, int NW>
-__global__ void __launch_bounds__(64 * NW) warp_agg_fwd_pix_kernel(WarpAggArgs a) {
-    constexpr int LPP = C / 8;           // lanes per pixel (channel slices of 8)
+// DPL = hypotheses per lane (even): DPL = D is the form described above; DPL = 2 spreads the D / 2 hypothesis pairs of a
+// pixel over QL = D / 2 lanes (twice / four times the waves, half / a quarter of the registers' worth of in-flight
+// taps per lane), with the softmax over depth as an in-wave all-gather like the wave-local kernel.
+template <int C, int G, int D, int DPL, int WPE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) warp_agg_fwd_pix_kernel(WarpAggArgs a) {
+    constexpr int LPP = C / 8;           // lanes per (pixel, hypothesis group): channel slices of 8
     constexpr int CG = C / G;            // channels per group
     constexpr int GPL = 8 / CG;          // whole groups per lane
-    constexpr int PPB = 64 * NW / LPP;   // pixels per workgroup (NW waves; waves never talk to each other)
+    constexpr int QL = D / DPL;          // lanes (hypothesis groups) per pixel and channel slice
+    constexpr int PPW = 64 / (LPP * QL); // pixels per wave (a workgroup is one wave: waves never talk to each other)
     constexpr int SH = C == 8 ? 5 : (C == 16 ? 6 : (C == 32 ? 7 : 8));   // log2(bytes per texel)
-    static_assert(C % 8 == 0 && CG <= 8 && 8 % CG == 0 && LPP >= 1 && LPP <= 4 && D % 2 == 0 && D <= 8, "pixel split");
+    static_assert(C % 8 == 0 && CG <= 8 && 8 % CG == 0 && DPL % 2 == 0 && D % DPL == 0 && PPW >= 1 &&
+                  PPW * LPP * QL == 64 && D <= 8, "pixel split");
 
-    const int sub = threadIdx.x % LPP;
+    const int lane = threadIdx.x;
+    const int sub = lane % LPP, pl = (lane / LPP) % PPW, qg = lane / (LPP * PPW);
     const int b = blockIdx.y;
     const int hw = a.h * a.w;
-    const int p = xcd_remap(blockIdx.x, gridDim.x) * PPB + threadIdx.x / LPP;
+    const int p = xcd_remap(blockIdx.x, gridDim.x) * PPW + pl;
     const bool valid = p < hw;
     const int pc = valid ? p : hw - 1;   // clamped: every lane takes part in the cross-lane sums
     const int y = pc / a.w;
     const int x = pc - y * a.w;
     const float xf = (float)x, yf = (float)y;
-    const float* hp = a.hypo + (long)b * D * hw + pc;
-    mv::f32x2 depth2[D / 2];
+    const float* hp = a.hypo + ((long)b * D + qg * DPL) * hw + pc;
+    mv::f32x2 depth2[DPL / 2];
 #pragma unroll
-    for (int q = 0; q < D / 2; ++q) depth2[q] = (mv::f32x2){hp[(long)(2 * q) * hw], hp[(long)(2 * q + 1) * hw]};
+    for (int q = 0; q < DPL / 2; ++q) depth2[q] = (mv::f32x2){hp[(long)(2 * q) * hw], hp[(long)(2 * q + 1) * hw]};
     const float* rp = a.ref + (long)b * a.ref_bs + (long)pc * C + sub * 8;
     const f32x4 R0 = ld4(rp), R1 = ld4(rp + 4);
     const mv::GridNorm gn = mv::make_grid_norm(a.Hs, a.Ws);
@@ -477,9 +507,9 @@ __global__ void __launch_bounds__(64 * NW) warp_agg_fwd_pix_kernel(WarpAggArgs a
     const unsigned src_bytes = (unsigned)a.Hs * (unsigned)a.Ws * (unsigned)(C * 4);
     const int row_bytes = a.Ws << SH;
 
-    float acc[D][GPL], wsum[D];
+    float acc[DPL][GPL], wsum[DPL];
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DPL; ++d) {
         wsum[d] = 1e-8f;
 #pragma unroll
         for (int k = 0; k < GPL; ++k) acc[d][k] = 0.0f;
@@ -494,9 +524,9 @@ __global__ void __launch_bounds__(64 * NW) warp_agg_fwd_pix_kernel(WarpAggArgs a
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.src + (long)v * a.src_vs + (long)b * a.src_bs), (short)0, (int)src_bytes, 0x00020000);
 
-        float cg[D][GPL], score[D];
+        float cg[DPL][GPL], score[DPL];
 #pragma unroll
-        for (int q = 0; q < D / 2; ++q) {
+        for (int q = 0; q < DPL / 2; ++q) {
             // two hypotheses at a time through the scalar chain, packed
             const mv::f32x2 dz = depth2[q];
             const mv::f32x2 px = mv::add_rn2(mv::mul_rn2(splat2(rx), dz), splat2(r[9]));
@@ -555,9 +585,9 @@ __global__ void __launch_bounds__(64 * NW) warp_agg_fwd_pix_kernel(WarpAggArgs a
 #undef MV_PAIR
 #pragma unroll
                 for (int k = 0; k < GPL; ++k) cg[d][k] = mv::div_rn(part[k], (float)CG);   // .mean(2)
-                // .sum(1): all groups of the pixel in group order (the LPP lanes of a pixel are neighbours)
+                // .sum(1): all groups of the (pixel, d) in group order (its LPP lanes are neighbours)
                 float sc = 0.0f;
-                const int lane0 = (threadIdx.x & 63) - sub;
+                const int lane0 = lane - sub;
 #pragma unroll
                 for (int j = 0; j < LPP; ++j)
 #pragma unroll
@@ -568,20 +598,28 @@ __global__ void __launch_bounds__(64 * NW) warp_agg_fwd_pix_kernel(WarpAggArgs a
                 score[d] = a.fuse_d ? mv::div_rn(sc, temp) : sc;
             }
         }
-        // softmax over depth, in registers (depth order, like the other launch forms)
+        // softmax over depth (depth order, like the other launch forms): in registers, plus an in-wave all-gather over the
+        // QL lanes that share the pixel when DPL < D
         float mx = score[0];
 #pragma unroll
-        for (int d = 1; d < D; ++d) mx = fmaxf(mx, score[d]);
-        float e[D], den = 0.0f;
+        for (int d = 1; d < DPL; ++d) mx = fmaxf(mx, score[d]);
+        if (QL > 1) {
+            const float own = mx;
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            e[d] = expf(mv::sub_rn(score[d], mx));
-            den = mv::add_rn(den, e[d]);
+            for (int j = 0; j < QL; ++j) mx = fmaxf(mx, __shfl(own, (j * PPW + pl) * LPP + sub));
         }
+        float e[DPL], den = 0.0f;
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) e[d] = expf(mv::sub_rn(score[d], mx));
+#pragma unroll
+        for (int j = 0; j < QL; ++j)
+#pragma unroll
+            for (int d = 0; d < DPL; ++d)
+                den = mv::add_rn(den, QL == 1 ? e[d] : __shfl(e[d], (j * PPW + pl) * LPP + sub));
         const mv::Recip rden = mv::make_recip(den);
         const float wmax = mv::div_rn(1.0f, rden);   // attn_fuse_d = False: max_d softmax = exp(0) / sum
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
+        for (int d = 0; d < DPL; ++d) {
             const float wgt = a.fuse_d ? mv::div_rn(mv::div_rn(e[d], rden), sqrt_c) : wmax;
             wsum[d] = mv::add_rn(wsum[d], wgt);
 #pragma unroll
@@ -591,8 +629,8 @@ __global__ void __launch_bounds__(64 * NW) warp_agg_fwd_pix_kernel(WarpAggArgs a
 
     if (valid) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const long o = (((long)b * D + d) * hw + p);
+        for (int d = 0; d < DPL; ++d) {
+            const long o = (((long)b * D + qg * DPL + d) * hw + p);
             float* op = a.out + o * G + sub * GPL;
             const mv::Recip rw = mv::make_recip(wsum[d]);
             if (GPL == 4) {
@@ -607,15 +645,16 @@ __global__ void __launch_bounds__(64 * NW) warp_agg_fwd_pix_kernel(WarpAggArgs a
     }
 }
 
-// waves per workgroup of the pixel-major kernel: single-wave workgroups keep the tail of the launch fine-grained (a
-// 512x640 stage-4 launch is 5 waves per SIMD at 4 resident); MVSTER_PIX_NW = 1 / 2 / 4 for experiments
-static const int g_pix_nw = getenv("MVSTER_PIX_NW") ? atoi(getenv("MVSTER_PIX_NW")) : 1;
+// launch shape of the pixel-major kernel: hypotheses per lane (0 = all D) and the occupancy target handed to the
+// register allocator; MVSTER_PIX_DPL / MVSTER_PIX_WPE override the defaults for experiments
+static const int g_pix_dpl = getenv("MVSTER_PIX_DPL") ? atoi(getenv("MVSTER_PIX_DPL")) : 2;
+static const int g_pix_wpe = getenv("MVSTER_PIX_WPE") ? atoi(getenv("MVSTER_PIX_WPE")) : 4;
 
-template <int C, int G, int D, int NW>
-int launch_fwd_pix_nw(const WarpAggArgs& a, hipStream_t stream) {
-    constexpr int PPB = 64 * NW / (C / 8);
-    dim3 grid((a.h * a.w + PPB - 1) / PPB, a.B);
-    hipLaunchKernelGGL((warp_agg_fwd_pix_kernel<C, G, D, NW>), grid, dim3(64 * NW), 0, stream, a);
+template <int C, int G, int D, int DPL, int WPE>
+int launch_fwd_pix_cfg(const WarpAggArgs& a, hipStream_t stream) {
+    constexpr int PPW = 64 / ((C / 8) * (D / DPL));
+    dim3 grid((a.h * a.w + PPW - 1) / PPW, a.B);
+    hipLaunchKernelGGL((warp_agg_fwd_pix_kernel<C, G, D, DPL, WPE>), grid, dim3(64), 0, stream, a);
     return mv_check_launch();
 }
 
@@ -623,9 +662,15 @@ template <int C, int G, int D>
 int launch_fwd_pix(const WarpAggArgs& a, hipStream_t stream) {
     // 24-bit multiply-add on texel indices, 32-bit byte offsets inside one (view, batch) map
     if ((long)a.Hs * a.Ws >= (1L << 23) || (long)a.Hs * a.Ws * C * 4 >= (1L << 31)) return MVSTER_ERR_SHAPE;
-    if (g_pix_nw == 4) return launch_fwd_pix_nw<C, G, D, 4>(a, stream);
-    if (g_pix_nw == 2) return launch_fwd_pix_nw<C, G, D, 2>(a, stream);
-    return launch_fwd_pix_nw<C, G, D, 1>(a, stream);
+    if (g_pix_dpl == 2 || (C / 8) * (D / 2) > 64) {
+        if constexpr ((C / 8) * (D / 2) <= 64) {
+            if (g_pix_wpe >= 6) return launch_fwd_pix_cfg<C, G, D, 2, 6>(a, stream);
+            if (g_pix_wpe == 5) return launch_fwd_pix_cfg<C, G, D, 2, 5>(a, stream);
+            return launch_fwd_pix_cfg<C, G, D, 2, 4>(a, stream);
+        }
+    }
+    if (g_pix_wpe >= 5) return launch_fwd_pix_cfg<C, G, D, D, 5>(a, stream);
+    return launch_fwd_pix_cfg<C, G, D, D, 4>(a, stream);
 }
 
 template <int C, int G>
@@ -638,7 +683,8 @@ int dispatch_fwd_pix(const WarpAggArgs& a, hipStream_t stream) {
 template <int C, int G, int D>
 int launch_fwd_wave(const WarpAggArgs& a, hipStream_t stream) {
     constexpr int PPB = 4 * (64 / ((C / 8) * D));
-    if ((long)a.Hs * a.Ws * C >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    // 24-bit multiply-add on texel indices, 32-bit byte offsets inside one (view, batch) map
+    if ((long)a.Hs * a.Ws >= (1L << 23) || (long)a.Hs * a.Ws * C * 4 >= (1L << 31)) return MVSTER_ERR_SHAPE;
     dim3 grid((a.h * a.w + PPB - 1) / PPB, a.B);
     hipLaunchKernelGGL((warp_agg_fwd_wave_kernel<C, G, D>), grid, dim3(256), 0, stream, a);
     return mv_check_launch();
@@ -703,7 +749,7 @@ struct WarpAggBwdArgs {
 // LDS and stores once.
 constexpr int kWinX = 96, kWinY = 6;
 static const bool g_bwd_no_tiles = getenv("MVSTER_BWD_NO_TILES") != nullptr;   // experiment switch
-static const bool g_no_pix = getenv("MVSTER_NO_PIX") != nullptr;               // experiment switch: wave-local kernel at every stage
+static const bool g_pix = getenv("MVSTER_PIX") != nullptr;   // experiment switch: pixel-major kernel at the fine stages
 
 template <int C, int G, bool GROUP, int DMAX>
 __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs ba) {
@@ -1199,8 +1245,9 @@ extern "C" int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat,
     a.attn_temp = attn_temp; a.sqrt_c = sqrtf((float)C); a.fuse_d = attn_fuse_d;
     hipStream_t s = (hipStream_t)stream;
     // variant: 0 = choose; 1 = one thread per (pixel, d); 2 = workgroup-level lane split (C >= 16);
-    // 3 = wave-local kernel (what 0 picks for C >= 32); 4 = pixel-major kernel (what 0 picks for C <= 16)
-    if (group_cor && (D == 4 || D == 8) && (variant == 4 || (variant == 0 && C <= 16 && !g_no_pix))) {
+    // 3 = wave-local kernel (what 0 picks whenever it applies); 4 = pixel-major kernel (faster on cache-resident inputs,
+    // slower inside the forward: kept as a tested alternative)
+    if (group_cor && (D == 4 || D == 8) && (variant == 4 || (variant == 0 && C <= 16 && g_pix))) {
         int rc = MVSTER_ERR_UNSUPPORTED;
         if (C == 8 && G == 4) rc = dispatch_fwd_pix<8, 4>(a, s);
         else if (C == 8 && G == 8) rc = dispatch_fwd_pix<8, 8>(a, s);
