@@ -82,10 +82,12 @@ def check_geometric_consistency(depth_ref, intrinsics_ref, extrinsics_ref, depth
     return tuple(t.cpu().numpy() for t in res)
 
 
-def filter_reference_view(ref_depth, ref_K, ref_E, confidence, src_depths, src_Ks, src_Es, conf_thres, thres_view):
+def filter_reference_view(ref_depth, ref_K, ref_E, confidence, src_depths, src_Ks, src_Es, conf_thres, thres_view,
+                          ref_img=None):
     """The per-reference-view part of the reference's ``filter_depth`` (test_mvs4.py:352-407): photometric, geometric
     and final masks, the averaged depth (float64, like NumPy's float32 / int32 division) and the fused world points
-    [M,3] of the pixels that pass.  Tensors stay on the GPU."""
+    [M,3] of the pixels that pass; with ``ref_img`` [H,W,3] (float, 0..1, as ``read_img`` returns it) also their
+    colours [M,3] uint8 (:395-396, :407).  Tensors stay on the GPU."""
     r = geometric_filter(ref_depth, ref_K, ref_E, src_depths, src_Ks, src_Es)
     dev = r["mask_sum"].device
     conf = _dev_depth(confidence, dev)
@@ -101,5 +103,50 @@ def filter_reference_view(ref_depth, ref_K, ref_E, confidence, src_depths, src_K
     pix = torch.stack([xs.double() * depth, ys.double() * depth, depth])   # (x, y, 1) * depth
     cam = kinv @ pix
     world = (einv @ torch.cat([cam, torch.ones_like(depth)[None]], 0))[:3]
-    return dict(photo_mask=photo_mask, geo_mask=geo_mask, final_mask=final_mask, geo_mask_sum=r["mask_sum"],
-                depth_est_averaged=avg, points=world.t().contiguous())
+    out = dict(photo_mask=photo_mask, geo_mask=geo_mask, final_mask=final_mask, geo_mask_sum=r["mask_sum"],
+               depth_est_averaged=avg, points=world.t().contiguous())
+    if ref_img is not None:
+        img = ref_img if isinstance(ref_img, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(ref_img))
+        img = img.to(dev)
+        if tuple(img.shape[:2]) != (H, W) or img.shape[-1] != 3:
+            raise RuntimeError("filter_reference_view: ref_img must be [H,W,3] at the depth map's resolution")
+        out["colors"] = (img[ys, xs] * 255).to(torch.uint8)              # (color * 255).astype(np.uint8): truncation
+    return out
+
+
+PLY_VERTEX_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+
+
+def fuse_views(per_view_results):
+    """Concatenate the ``points`` / ``colors`` of consecutive ``filter_reference_view`` results in reference-view order
+    into the structured vertex array the reference hands to plyfile (test_mvs4.py:409-418): x, y, z float32 (the float64
+    world points rounded once) and red, green, blue uint8."""
+    pts = torch.cat([r["points"] for r in per_view_results], 0).to(torch.float32).cpu().numpy()
+    cols = torch.cat([r["colors"] for r in per_view_results], 0).cpu().numpy()
+    v = np.empty(len(pts), dtype=PLY_VERTEX_DTYPE)
+    v["x"], v["y"], v["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+    v["red"], v["green"], v["blue"] = cols[:, 0], cols[:, 1], cols[:, 2]
+    return v
+
+
+def write_ply(filename, vertices):
+    """Binary little-endian PLY with one ``vertex`` element, the file ``PlyData([PlyElement.describe(v, 'vertex')])
+    .write(f)`` produces for the array above (test_mvs4.py:420-421)."""
+    v = np.ascontiguousarray(vertices, dtype=PLY_VERTEX_DTYPE)
+    header = ("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\n"
+              "property float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" % len(v))
+    with open(filename, "wb") as f:
+        f.write(header.encode("ascii"))
+        f.write(v.tobytes())
+
+
+def read_ply(filename):
+    """Inverse of ``write_ply`` (round-trip tests and downstream checks)."""
+    with open(filename, "rb") as f:
+        data = f.read()
+    end = data.index(b"end_header\n") + len(b"end_header\n")
+    head = data[:end].decode("ascii").split("\n")
+    n = int([l for l in head if l.startswith("element vertex")][0].split()[-1])
+    if "format binary_little_endian 1.0" not in head:
+        raise RuntimeError("read_ply: only the binary little-endian layout of write_ply is read")
+    return np.frombuffer(data[end:end + n * PLY_VERTEX_DTYPE.itemsize], dtype=PLY_VERTEX_DTYPE).copy()

@@ -94,7 +94,8 @@ def check_geometric_consistency(depth_ref, intrinsics_ref, extrinsics_ref, depth
     return mask, depth_back, x_src, y_src
 
 
-def filter_reference_view(ref_depth, ref_K, ref_E, confidence, src_depths, src_Ks, src_Es, conf_thres, thres_view):
+def filter_reference_view(ref_depth, ref_K, ref_E, confidence, src_depths, src_Ks, src_Es, conf_thres, thres_view,
+                          ref_img=None):
     """What filter_depth does for one reference view (test_mvs4.py:352-407): photometric mask from the confidence
     (:361), votes and reprojected depths of every source view (:369-383), their average with the reference depth
     (:385), the >= thres_view geometric mask (:387-388) and the surviving pixels lifted to world space (:399-407)."""
@@ -116,6 +117,23 @@ def filter_reference_view(ref_depth, ref_K, ref_E, confidence, src_depths, src_K
     sel_x, sel_y, sel_d = cols[final_mask], rows[final_mask], depth_est_averaged[final_mask]
     cam = np.matmul(np.linalg.inv(ref_K), np.vstack((sel_x, sel_y, np.ones_like(sel_x))) * sel_d)
     world = np.matmul(np.linalg.inv(ref_E), np.vstack((cam, np.ones_like(sel_x))))[:3]
-    return dict(photo_mask=photo_mask, geo_mask=geo_mask, final_mask=final_mask, geo_mask_sum=votes,
-                depth_est_averaged=depth_est_averaged, view_masks=view_masks, view_depths=view_depths,
-                points=world.transpose((1, 0)))
+    out = dict(photo_mask=photo_mask, geo_mask=geo_mask, final_mask=final_mask, geo_mask_sum=votes,
+               depth_est_averaged=depth_est_averaged, view_masks=view_masks, view_depths=view_depths,
+               points=world.transpose((1, 0)))
+    if ref_img is not None:
+        out["colors"] = (ref_img[final_mask] * 255).astype(np.uint8)          # test_mvs4.py:395-396, :407
+    return out
+
+
+def vertex_array(per_view):
+    """The structured array filter_depth builds for plyfile from all reference views (test_mvs4.py:409-418)."""
+    pts = np.concatenate([r["points"] for r in per_view], axis=0)
+    cols = np.concatenate([r["colors"] for r in per_view], axis=0)
+    xyz = np.array([tuple(v) for v in pts], dtype=[("x", "f4"), ("y", "f4"), ("z", "f4")])
+    rgb = np.array([tuple(v) for v in cols], dtype=[("red", "u1"), ("green", "u1"), ("blue", "u1")])
+    allv = np.empty(len(xyz), xyz.dtype.descr + rgb.dtype.descr)
+    for name in xyz.dtype.names:
+        allv[name] = xyz[name]
+    for name in rgb.dtype.names:
+        allv[name] = rgb[name]
+    return allv

@@ -33,3 +33,29 @@ def test_plane_scene_is_geometrically_consistent():
     res2 = GO.filter_reference_view(bad[0], Ks[0], Es[0], np.ones_like(depths[0]), bad[1:], Ks[1:], Es[1:], 0.5, 3)
     assert res2["view_masks"][1].mean() < 0.02
     assert (res2["view_masks"][0] == res["view_masks"][0]).all()
+
+
+def test_vertex_array_and_ply_round_trip(tmp_path):
+    """Colours are truncated to uint8 in reference-view order (test_mvs4.py:395-396, :407-418); the PLY writer of the
+    product stores exactly the structured array (host code, no GPU involved)."""
+    from mvster_amd import fusion
+    depths, Ks, Es = plane_depth_maps(3, 32, 48, seed=2)
+    rng = np.random.RandomState(0)
+    views = []
+    for ref in (0, 1):
+        order = [ref] + [v for v in range(3) if v != ref]
+        img = rng.rand(32, 48, 3).astype(np.float32)
+        r = GO.filter_reference_view(depths[order[0]], Ks[order[0]], Es[order[0]], np.ones((32, 48), np.float32),
+                                     depths[order[1:]], [Ks[v] for v in order[1:]], [Es[v] for v in order[1:]], 0.5, 1,
+                                     ref_img=img)
+        assert r["colors"].dtype == np.uint8 and r["colors"].shape == (int(r["final_mask"].sum()), 3)
+        assert np.array_equal(r["colors"], np.floor(img[r["final_mask"]] * 255).astype(np.uint8))
+        views.append(r)
+    v = GO.vertex_array(views)
+    assert len(v) == sum(len(r["points"]) for r in views) and v.dtype.names == ("x", "y", "z", "red", "green", "blue")
+    path = str(tmp_path / "scan.ply")
+    fusion.write_ply(path, v)
+    back = fusion.read_ply(path)
+    assert back.dtype == fusion.PLY_VERTEX_DTYPE and np.array_equal(back["x"], v["x"]) and np.array_equal(back["blue"], v["blue"])
+    head = open(path, "rb").read(200).decode("ascii", "ignore")
+    assert head.startswith("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x" % len(v))
