@@ -53,14 +53,20 @@ int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat, const floa
                         int attn_fuse_d, float attn_temp, int variant, void* stream);
 
 /* Backward of mvster_warp_agg_fwd w.r.t. the features (the sampling grid carries no gradient,
- * models/mvs4net_utils.py:23).  grad_out/out [B,D,h,w,G], wsum [B,D,h,w] from the forward;
- * grad_ref [B,h,w,C] and grad_src [NV][B,Hs,Ws,C] must be zero-initialised (atomic accumulate).
+ * models/mvs4net_utils.py:23).  grad_out/out [B,D,h,w,G], wsum [B,D,h,w] from the forward; both attention forms,
+ * D <= 16.  grad_ref [B,h,w,C] is written; grad_src [NV][B,Hs,Ws,C] must be zero-initialised.
+ * windows / win_org: scratch of the sizes mvster_warp_agg_bwd_scratch() reports (floats / ints, uninitialised).  With
+ * them the source gradient is accumulated without atomics for every tap inside a workgroup's scatter window (dense
+ * windows + a gather pass in fixed order: bit-reproducible); with both NULL the windows are flushed with global fp32
+ * atomics.  Taps outside a window (strongly rotated views) always use atomics.
  * Autograd of models/mvs4net_utils.py:1036-1060. */
 int mvster_warp_agg_bwd(const float* ref_feat, const float* src_feat, const float* rt, const float* hypo,
                         const float* out, const float* wsum, const float* grad_out, float* grad_ref,
-                        float* grad_src, int B, int NV, int C, int G, int D, int h, int w, int Hs, int Ws,
-                        long ref_batch_stride, long src_view_stride, long src_batch_stride, int group_cor,
+                        float* grad_src, float* windows, int* win_org, int B, int NV, int C, int G, int D, int h, int w,
+                        int Hs, int Ws, long ref_batch_stride, long src_view_stride, long src_batch_stride, int group_cor,
                         int attn_fuse_d, float attn_temp, void* stream);
+int mvster_warp_agg_bwd_scratch(int B, int NV, int C, int G, int D, int h, int w, int attn_fuse_d, long* window_floats,
+                                long* origin_ints);
 
 /* depth_values [B,ndv] (columns 0 and ndv-1 used) -> out [B,D,h,w].
  * inverse=1: models/mvs4net_utils.py:71-77 (init_inverse_range); inverse=0: :61-69 (init_range). */

@@ -737,6 +737,11 @@ struct WarpAggBwdArgs {
     const float* grad_out;  // [B, D, h, w, G]
     float* grad_ref;        // [B, h, w, C]
     float* grad_src;        // [NV][B, Hs, Ws, C]  (same strides as src)
+    // Deterministic, atomic-free accumulation of grad_src (both null: the window is flushed with global atomics):
+    // every workgroup stores its scatter windows densely, windows [B][nblk][NV][C/8][WY][kWinX][8] and their origins
+    // win_org [B][nblk][NV][2]; scatter_gather_kernel then sums, per source texel, the windows that cover it.
+    float* windows;
+    int* win_org;
 };
 
 // Scatter window: the source-view gradient of one workgroup (64 reference pixels of a row x all depths) and
@@ -946,15 +951,32 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
                 }
             }
             __syncthreads();
-            // flush (and clear) the window: one global atomic per touched (texel, channel), channel-fastest: the
-            // atomics of a wave go to 8 neighbouring texels x 8 channels = 256 contiguous bytes
-            for (int i = tid; i < 8 * kWinY * kWinX; i += nthr) {
-                const int cl = i % 8, tex = i / 8;
-                const int wxx = tex % kWinX, wyy = tex / kWinX;
-                const float val = win[cl][wyy][wxx];
-                if (val != 0.0f) {
+            if (ba.windows) {
+                // store (and clear) the window densely, texel-major / channel-fastest; scatter_gather_kernel sums the
+                // windows that cover a source texel in workgroup order: no atomics, the same bits on every run
+                const long slot = (((long)b * gridDim.x + blockIdx.x) * a.NV + v) * NB + cb;
+                float* wp = ba.windows + slot * (8 * kWinY * kWinX);
+                for (int i = tid; i < 8 * kWinY * kWinX; i += nthr) {
+                    const int cl = i % 8, tex = i / 8;
+                    const int wxx = tex % kWinX, wyy = tex / kWinX;
+                    wp[i] = win[cl][wyy][wxx];
                     win[cl][wyy][wxx] = 0.0f;
-                    unsafeAtomicAdd(gsp + ((long)(wy0 + wyy) * a.Ws + (wx0 + wxx)) * C + cbase + cl, val);
+                }
+                if (cb == 0 && tid == 0) {
+                    int* op = ba.win_org + (((long)b * gridDim.x + blockIdx.x) * a.NV + v) * 2;
+                    op[0] = wx0; op[1] = wy0;
+                }
+            } else {
+                // flush (and clear) the window: one global atomic per touched (texel, channel), channel-fastest: the
+                // atomics of a wave go to 8 neighbouring texels x 8 channels = 256 contiguous bytes
+                for (int i = tid; i < 8 * kWinY * kWinX; i += nthr) {
+                    const int cl = i % 8, tex = i / 8;
+                    const int wxx = tex % kWinX, wyy = tex / kWinX;
+                    const float val = win[cl][wyy][wxx];
+                    if (val != 0.0f) {
+                        win[cl][wyy][wxx] = 0.0f;
+                        unsafeAtomicAdd(gsp + ((long)(wy0 + wyy) * a.Ws + (wx0 + wxx)) * C + cbase + cl, val);
+                    }
                 }
             }
             __syncthreads();
@@ -1189,13 +1211,25 @@ __global__ void __launch_bounds__(64 * 8) warp_agg_bwd_tile_kernel(WarpAggBwdArg
             }
         }
         __syncthreads();
-        for (int i = tid; i < 8 * WY * kWinX; i += nthr) {
-            const int cl = i % 8, tex = i / 8;
-            const int wxx = tex % kWinX, wyy = tex / kWinX;
-            const float val = win[cl][wyy][wxx];
-            if (val != 0.0f) {
+        if (ba.windows) {
+            const long slot = ((long)b * gridDim.x + blockIdx.x) * a.NV + v;      // (C == 8: one channel block)
+            float* wp = ba.windows + slot * (8 * WY * kWinX);
+            for (int i = tid; i < 8 * WY * kWinX; i += nthr) {
+                const int cl = i % 8, tex = i / 8;
+                const int wxx = tex % kWinX, wyy = tex / kWinX;
+                wp[i] = win[cl][wyy][wxx];
                 win[cl][wyy][wxx] = 0.0f;
-                unsafeAtomicAdd(gsp + ((long)(wy0 + wyy) * a.Ws + (wx0 + wxx)) * C + cl, val);
+            }
+            if (tid == 0) { ba.win_org[slot * 2] = wx0; ba.win_org[slot * 2 + 1] = wy0; }
+        } else {
+            for (int i = tid; i < 8 * WY * kWinX; i += nthr) {
+                const int cl = i % 8, tex = i / 8;
+                const int wxx = tex % kWinX, wyy = tex / kWinX;
+                const float val = win[cl][wyy][wxx];
+                if (val != 0.0f) {
+                    win[cl][wyy][wxx] = 0.0f;
+                    unsafeAtomicAdd(gsp + ((long)(wy0 + wyy) * a.Ws + (wx0 + wxx)) * C + cl, val);
+                }
             }
         }
         __syncthreads();
@@ -1210,23 +1244,113 @@ __global__ void __launch_bounds__(64 * 8) warp_agg_bwd_tile_kernel(WarpAggBwdArg
     }
 }
 
+// Second pass of the atomic-free backward: one workgroup per 32 x 4 tile of one source map; lane = (texel, channel
+// quad).  The windows that overlap the tile are found by testing every workgroup's origin (a few thousand integer
+// compares per tile, in index order through a ballot prefix so that the summation order is fixed) and summed in
+// registers; the tile is then added onto grad_src, which holds what the first pass scattered directly (taps outside a
+// window).  WY = window rows (kWinY for the row kernel, R + 6 for the tile kernel).
+constexpr int kGatherList = 256;
+
+template <int WY, int NBLK>
+__global__ void __launch_bounds__(256) scatter_gather_kernel(const float* __restrict__ windows, const int* __restrict__ org,
+                                                             float* __restrict__ grad_src, int nblk, int NV, int Hs, int Ws,
+                                                             long src_vs, long src_bs, int tiles_x) {
+    constexpr int C = NBLK * 8;
+    __shared__ int list[kGatherList];
+    __shared__ int wcnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int v = blockIdx.y, b = blockIdx.z;
+    const int tx0 = (int)(blockIdx.x % tiles_x) * 32, ty0 = (int)(blockIdx.x / tiles_x) * 4;
+    const int half = tid & 1, tex = tid >> 1;
+    const int tx = tx0 + (tex & 31), ty = ty0 + (tex >> 5);
+    const bool inside = tx < Ws && ty < Hs;
+    f32x4 acc[NBLK];
+#pragma unroll
+    for (int cb = 0; cb < NBLK; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const long slot0 = (long)b * nblk;
+
+    int count = 0;                                   // entries in list (block-uniform)
+    for (int base = 0; base < nblk || count > 0; base += 256) {
+        if (base < nblk) {
+            const int k = base + tid;
+            bool hit = false;
+            if (k < nblk) {
+                const int* o = org + ((slot0 + k) * NV + v) * 2;
+                const int wx0 = o[0], wy0 = o[1];
+                hit = wx0 != 0x7fffffff && wx0 < tx0 + 32 && wx0 + kWinX > tx0 && wy0 < ty0 + 4 && wy0 + WY > ty0;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) wcnt[wave] = __popcll(m);
+            __syncthreads();
+            int off = count + __popcll(m & ((1ull << lane) - 1));
+            for (int w = 0; w < wave; ++w) off += wcnt[w];
+            if (hit) list[off] = k;                  // (count + 256 <= kGatherList is kept by draining below)
+            count += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            __syncthreads();
+        }
+        // drain when the next chunk might not fit, and at the end
+        if (count > kGatherList - 256 || base + 256 >= nblk) {
+            for (int li = 0; li < count; ++li) {
+                const int k = list[li];
+                const int* o = org + ((slot0 + k) * NV + v) * 2;
+                const int lx = tx - o[0], ly = ty - o[1];
+                if ((unsigned)lx < (unsigned)kWinX && (unsigned)ly < (unsigned)WY) {
+                    const float* wp = windows + ((slot0 + k) * NV + v) * ((long)NBLK * 8 * WY * kWinX) +
+                                      ((long)ly * kWinX + lx) * 8 + half * 4;
+#pragma unroll
+                    for (int cb = 0; cb < NBLK; ++cb) acc[cb] += ld4(wp + (long)cb * (8 * WY * kWinX));
+                }
+            }
+            __syncthreads();
+            count = 0;
+            if (base + 256 >= nblk) break;
+        }
+    }
+    if (inside) {
+        float* dst = grad_src + (long)v * src_vs + (long)b * src_bs + ((long)ty * Ws + tx) * C + half * 4;
+#pragma unroll
+        for (int cb = 0; cb < NBLK; ++cb) st4(dst + cb * 8, ld4(dst + cb * 8) + acc[cb]);
+    }
+}
+
+template <int WY, int NBLK>
+int launch_gather(const WarpAggBwdArgs& ba, int nblk, hipStream_t stream) {
+    const WarpAggArgs& a = ba.f;
+    const int tiles_x = (a.Ws + 31) / 32, tiles_y = (a.Hs + 3) / 4;
+    hipLaunchKernelGGL((scatter_gather_kernel<WY, NBLK>), dim3(tiles_x * tiles_y, a.NV, a.B), dim3(256), 0, stream, ba.windows,
+                       ba.win_org, ba.grad_src, nblk, a.NV, a.Hs, a.Ws, a.src_vs, a.src_bs, tiles_x);
+    return mv_check_launch();
+}
+
+constexpr int kTileR = 4;     // reference rows per workgroup of the tile kernel
+
+// which first-pass kernel a configuration takes, its workgroups per batch item and its window height
+static bool bwd_uses_tiles(int C, int G, int D, int fuse_d) {
+    return C == 8 && C / G <= 8 && !g_bwd_no_tiles && fuse_d && D <= 8;
+}
+static int bwd_blocks(int C, int G, int D, int fuse_d, int h, int w) {
+    return bwd_uses_tiles(C, G, D, fuse_d) ? ((w + 63) / 64) * ((h + kTileR - 1) / kTileR) : (h * w + 63) / 64;
+}
+
 template <int C, int G, bool GROUP>
 int launch_bwd(const WarpAggBwdArgs& ba, hipStream_t stream) {
     const WarpAggArgs& a = ba.f;
+    const int nblk = bwd_blocks(C, G, a.D, a.fuse_d, a.h, a.w);
     if constexpr (C == 8 && C / G <= 8) {
-        if (!g_bwd_no_tiles && a.fuse_d && a.D <= 8) {      // the shipped full-resolution stage
-            constexpr int R = 4;
-            const int tiles_x = (a.w + 63) / 64, tiles_y = (a.h + R - 1) / R;
-            hipLaunchKernelGGL((warp_agg_bwd_tile_kernel<C, G, GROUP, R>), dim3(tiles_x * tiles_y, a.B), dim3(64, a.D), 0, stream,
-                               ba, tiles_x);
-            return mv_check_launch();
+        if (bwd_uses_tiles(C, G, a.D, a.fuse_d)) {      // the shipped full-resolution stage
+            const int tiles_x = (a.w + 63) / 64;
+            hipLaunchKernelGGL((warp_agg_bwd_tile_kernel<C, G, GROUP, kTileR>), dim3(nblk, a.B), dim3(64, a.D), 0, stream, ba,
+                               tiles_x);
+            if (int rc = mv_check_launch()) return rc;
+            return ba.windows ? launch_gather<kTileR + 6, 1>(ba, nblk, stream) : MVSTER_OK;
         }
     }
     dim3 block(64, a.D);
-    dim3 grid((a.h * a.w + 63) / 64, a.B);
+    dim3 grid(nblk, a.B);
     if (a.D <= 8) hipLaunchKernelGGL((warp_agg_bwd_kernel<C, G, GROUP, 8>), grid, block, 0, stream, ba);
     else hipLaunchKernelGGL((warp_agg_bwd_kernel<C, G, GROUP, kMaxD>), grid, block, 0, stream, ba);
-    return mv_check_launch();
+    if (int rc = mv_check_launch()) return rc;
+    return ba.windows ? launch_gather<kWinY, C / 8>(ba, nblk, stream) : MVSTER_OK;
 }
 
 }  // namespace
@@ -1291,13 +1415,25 @@ extern "C" int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat,
     return MVSTER_ERR_UNSUPPORTED;
 }
 
+extern "C" int mvster_warp_agg_bwd_scratch(int B, int NV, int C, int G, int D, int h, int w, int attn_fuse_d,
+                                          long* window_floats, long* origin_ints) {
+    if (!window_floats || !origin_ints) return MVSTER_ERR_NULL;
+    if (B <= 0 || NV <= 0 || C <= 0 || C % 8 || G <= 0 || D <= 0 || h <= 0 || w <= 0) return MVSTER_ERR_SHAPE;
+    const long nblk = bwd_blocks(C, G, D, attn_fuse_d, h, w);
+    const int wy = bwd_uses_tiles(C, G, D, attn_fuse_d) ? kTileR + 6 : kWinY;
+    *window_floats = (long)B * nblk * NV * (C / 8) * 8 * wy * kWinX;
+    *origin_ints = (long)B * nblk * NV * 2;
+    return MVSTER_OK;
+}
+
 extern "C" int mvster_warp_agg_bwd(const float* ref_feat, const float* src_feat, const float* rt, const float* hypo,
                                    const float* out, const float* wsum, const float* grad_out, float* grad_ref,
-                                   float* grad_src, int B, int NV, int C, int G, int D, int h, int w, int Hs, int Ws,
-                                   long ref_batch_stride, long src_view_stride, long src_batch_stride, int group_cor,
-                                   int attn_fuse_d, float attn_temp, void* stream) {
+                                   float* grad_src, float* windows, int* win_org, int B, int NV, int C, int G, int D, int h,
+                                   int w, int Hs, int Ws, long ref_batch_stride, long src_view_stride,
+                                   long src_batch_stride, int group_cor, int attn_fuse_d, float attn_temp, void* stream) {
     if (!ref_feat || !src_feat || !rt || !hypo || !out || !wsum || !grad_out || !grad_ref || !grad_src)
         return MVSTER_ERR_NULL;
+    if ((windows == nullptr) != (win_org == nullptr)) return MVSTER_ERR_NULL;
     if (B <= 0 || NV <= 0 || D <= 0 || D > kMaxD || h <= 0 || w <= 0 || Hs <= 0 || Ws <= 0) return MVSTER_ERR_SHAPE;
     if (!group_cor && G != C) return MVSTER_ERR_SHAPE;
     WarpAggBwdArgs ba;
@@ -1307,6 +1443,7 @@ extern "C" int mvster_warp_agg_bwd(const float* ref_feat, const float* src_feat,
     a.B = B; a.NV = NV; a.D = D; a.h = h; a.w = w; a.Hs = Hs; a.Ws = Ws;
     a.attn_temp = attn_temp; a.sqrt_c = sqrtf((float)C); a.fuse_d = attn_fuse_d;
     ba.fwd_out = out; ba.wsum = wsum; ba.grad_out = grad_out; ba.grad_ref = grad_ref; ba.grad_src = grad_src;
+    ba.windows = windows; ba.win_org = win_org;
     hipStream_t s = (hipStream_t)stream;
 #define MV_CASE(CC, GG, GR) \
     if (C == CC && G == GG && (group_cor != 0) == GR) return launch_bwd<CC, GG, GR>(ba, s);

@@ -94,8 +94,14 @@ def warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, group_cor=True, attn_fuse_d=Tru
     return (out, wsum) if want_wsum else out
 
 
-def warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad_out, G, group_cor=True, attn_fuse_d=True, attn_temp=2.0):
-    """Gradients of warp_agg_fwd_cl w.r.t. ref_cl and src_cl."""
+def warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad_out, G, group_cor=True, attn_fuse_d=True, attn_temp=2.0,
+                    deterministic=None):
+    """Gradients of warp_agg_fwd_cl w.r.t. ref_cl and src_cl.  ``deterministic`` (default: on, unless the environment
+    sets MVSTER_BWD_ATOMIC): scatter windows are stored densely and summed by a gather pass in fixed order instead of
+    being flushed with global fp32 atomics -- faster (the atomics were what bounded this kernel) and bit-reproducible
+    for every tap inside a window."""
+    import ctypes
+    import os
     grad_out = grad_out.contiguous()
     for t, n in ((ref_cl, "ref"), (src_cl, "src"), (rt, "rt"), (hypo, "hypo"), (out, "out"), (wsum, "wsum"),
                  (grad_out, "grad_out")):
@@ -103,12 +109,22 @@ def warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad_out, G, group_cor=
     B, h, w, C = ref_cl.shape
     NV, _, Hs, Ws, _ = src_cl.shape
     D = hypo.shape[1]
-    g_ref = torch.zeros_like(ref_cl)
+    lib = _lib.load()
+    g_ref = torch.empty_like(ref_cl)
     g_src = torch.zeros_like(src_cl)
-    rc = _lib.load().mvster_warp_agg_bwd(_ptr(ref_cl), _ptr(src_cl), _ptr(rt), _ptr(hypo), _ptr(out), _ptr(wsum),
-                                         _ptr(grad_out), _ptr(g_ref), _ptr(g_src), B, NV, C, G, D, h, w, Hs, Ws,
-                                         h * w * C, B * Hs * Ws * C, Hs * Ws * C, int(group_cor), int(attn_fuse_d),
-                                         float(attn_temp), _stream())
+    if deterministic is None:
+        deterministic = not os.environ.get("MVSTER_BWD_ATOMIC")
+    windows = origins = None
+    if deterministic:
+        nf, ni = ctypes.c_long(0), ctypes.c_long(0)
+        _lib.check(lib.mvster_warp_agg_bwd_scratch(B, NV, C, G, D, h, w, int(attn_fuse_d), ctypes.addressof(nf),
+                                                   ctypes.addressof(ni)), "warp_agg_bwd_scratch")
+        windows = torch.empty(nf.value, device=ref_cl.device, dtype=torch.float32)
+        origins = torch.empty(ni.value, device=ref_cl.device, dtype=torch.int32)
+    rc = lib.mvster_warp_agg_bwd(_ptr(ref_cl), _ptr(src_cl), _ptr(rt), _ptr(hypo), _ptr(out), _ptr(wsum),
+                                 _ptr(grad_out), _ptr(g_ref), _ptr(g_src), _ptr(windows), _ptr(origins), B, NV, C, G, D, h,
+                                 w, Hs, Ws, h * w * C, B * Hs * Ws * C, Hs * Ws * C, int(group_cor), int(attn_fuse_d),
+                                 float(attn_temp), _stream())
     _lib.check(rc, "warp_agg_bwd")
     return g_ref, g_src
 

@@ -215,7 +215,10 @@ def test_full_size_windows_vs_oracle(model, checkpoint, shipped_cfg, H, W, N):
                 own_win = cor_own[:, :, :, y0:y1, x0:x1].cpu().contiguous()
                 e_o = (own_win - want).abs().max().item() / scale
                 worst["cor_tight"], worst["cor_own"] = max(worst["cor_tight"], e_t), max(worst["cor_own"], e_o)
-                assert e_t <= 5e-5, (name, (y0, x0), e_t)       # fp32 rounding at large coordinates; measured <= 1.5e-5
+                # one fp32 ulp of a sampling position is 1.2e-4 px at x ~ 1900 (the sgemm of rot @ pix may associate its
+                # three terms either way): measured 4e-6 at 640 columns, 6.4e-5 in the far corner of 1920 columns;
+                # an addressing or tile-edge bug shows up as O(1)
+                assert e_t <= 2e-4, (name, (y0, x0), e_t)
                 # (b) the U-Net on the kernel's own cost volume window
                 lo = oracle.reg[s](own_win)                                # [1,D,wh,ww]
                 iy, ix = _interior(y0, x0, y1, x1, h, w)
