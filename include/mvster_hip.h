@@ -55,10 +55,12 @@ int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat, const floa
 /* Backward of mvster_warp_agg_fwd w.r.t. the features (the sampling grid carries no gradient,
  * models/mvs4net_utils.py:23).  grad_out/out [B,D,h,w,G], wsum [B,D,h,w] from the forward; both attention forms,
  * D <= 16.  grad_ref [B,h,w,C] is written; grad_src [NV][B,Hs,Ws,C] must be zero-initialised.
- * windows / win_org: scratch of the sizes mvster_warp_agg_bwd_scratch() reports (floats / ints, uninitialised).  With
- * them the source gradient is accumulated without atomics for every tap inside a workgroup's scatter window (dense
- * windows + a gather pass in fixed order: bit-reproducible); with both NULL the windows are flushed with global fp32
- * atomics.  Taps outside a window (strongly rotated views) always use atomics.
+ * windows / win_org: scratch of the sizes mvster_warp_agg_bwd_scratch() reports (floats / ints, uninitialised).
+ * win_org is required (it also holds the operand maxima of the fixed-point scale of the LDS accumulators).  With
+ * `windows` the source gradient is accumulated without floating-point atomics for every tap inside a workgroup's
+ * scatter window (integer LDS accumulation, dense windows, a gather pass in fixed order: bit-reproducible); with
+ * windows == NULL the windows are flushed with global fp32 atomics.  Taps outside a window (strongly rotated views)
+ * always use global atomics.
  * Autograd of models/mvs4net_utils.py:1036-1060. */
 int mvster_warp_agg_bwd(const float* ref_feat, const float* src_feat, const float* rt, const float* hypo,
                         const float* out, const float* wsum, const float* grad_out, float* grad_ref,

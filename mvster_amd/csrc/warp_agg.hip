@@ -730,6 +730,52 @@ int launch_fwd(const WarpAggArgs& a, hipStream_t stream) {
 // Uses `out` and `wsum` saved by the forward.  Both attention forms (attn_fuse_d on: a weight per (pixel, d); off: one
 // per pixel, the largest softmax value along depth, mvs4net_utils.py:1048-1051), up to 16 hypotheses.
 // ------------------------------------------------------------------------------------------
+// LDS accumulators of the backward are 64-bit FIXED POINT: on gfx950 a wave64 ds_add_f32 costs ~190 LDS cycles
+// (scripts/probes/lds_atomic_probe.hip: it is executed lane by lane), ds_add_u64 ~7.  The scatter window and the
+// reference-gradient tile therefore accumulate round(v * 2^k) with integer atomics -- which are also associative, so the
+// sums no longer depend on the order in which the waves arrive -- and are converted back once.  2^k is chosen per
+// launch from upper bounds on the operands (the largest |grad_out|, |ref|, |src|, reduced on the device just before):
+// the largest single contribution lands near 2^36, leaving 27 bits of head room for the number of contributions per
+// texel and >= 29 bits below the largest value actually seen (fp32 atomics keep 24).
+typedef unsigned long long u64;
+
+struct FixScale {
+    float s, inv;
+};
+
+// maxima = {max |grad_out|, max |ref|, max |src|}
+__device__ __forceinline__ FixScale make_fix_scale(const float* maxima, int G, int D, int CG, bool group, bool fuse, float temp) {
+    const float gomax = maxima[0], fmax = fmaxf(maxima[1], maxima[2]);
+    // |cor| <= cormax; |d L / d cor| <= gomax * (1 + 2 G (1 + D) cormax / temp)  (softmax Jacobian: |sig * dsig| <= 2 G gomax
+    // cormax because W >= the view's own weight); a tap contribution is that times a feature value (/ CG), weights <= 1
+    const float cormax = group ? fmax * fmax : 4.0f * fmax * fmax;
+    const float dcor = gomax * (1.0f + 2.0f * (float)G * (float)(1 + D) * cormax / (fuse ? temp : 1.0f));
+    const float bound = group ? dcor * fmax / (float)CG : 4.0f * fmax * dcor;
+    FixScale f;
+    int e = 0;
+    if (bound > 0.0f && bound < INFINITY) frexpf(bound, &e);      // bound < 2^e
+    e = min(max(36 - e, -60), 100);
+    f.s = ldexpf(1.0f, e);
+    f.inv = ldexpf(1.0f, -e);
+    return f;
+}
+__device__ __forceinline__ void fix_add(u64* p, float v, float s) { atomicAdd(p, (u64)__float2ll_rn(v * s)); }
+__device__ __forceinline__ float fix_get(u64 v, float inv) { return (float)(long long)v * inv; }
+
+// max |x| over n floats into *out (a non-negative float orders like its bit pattern); *out must start at 0
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, long n, float* out) {
+    float m = 0.0f;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = ld4(x + i * 4);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reinterpret_cast<int*>(out), __float_as_int(m));
+}
+
 struct WarpAggBwdArgs {
     WarpAggArgs f;
     const float* fwd_out;   // [B, D, h, w, G]
@@ -742,6 +788,7 @@ struct WarpAggBwdArgs {
     // win_org [B][nblk][NV][2]; scatter_gather_kernel then sums, per source texel, the windows that cover it.
     float* windows;
     int* win_org;
+    const float* maxima;    // {max |grad_out|, max |ref|, max |src|} (device; written just before this launch)
 };
 
 // Scatter window: the source-view gradient of one workgroup (64 reference pixels of a row x all depths) and
@@ -765,9 +812,10 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
     static_assert(C % 8 == 0 && (GROUP ? (C % G == 0 && G <= 8) : (C == G)), "layout");
     __shared__ float sc[2][DMAX][64];
     __shared__ float sd[2][DMAX][64];
-    __shared__ float gref[C][64];
-    __shared__ float win[8][kWinY][kWinX];
+    __shared__ u64 gref[C][64];
+    __shared__ u64 win[8][kWinY][kWinX];
     __shared__ int worg[2][2];
+    const FixScale fx = make_fix_scale(ba.maxima, G, a.D, CG, GROUP, a.fuse_d != 0, a.attn_temp);
 
     const int tx = threadIdx.x;
     const int d = threadIdx.y;
@@ -798,8 +846,8 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
         common = fmaf(gv, ba.fwd_out[o * G + g], common);
         if (GO_REG) go[g] = gv;
     }
-    for (int i = tid; i < C * 64; i += nthr) (&gref[0][0])[i] = 0.0f;
-    for (int i = tid; i < 8 * kWinY * kWinX; i += nthr) (&win[0][0][0])[i] = 0.0f;
+    for (int i = tid; i < C * 64; i += nthr) (&gref[0][0])[i] = 0;
+    for (int i = tid; i < 8 * kWinY * kWinX; i += nthr) (&win[0][0][0])[i] = 0;
     __syncthreads();
 
     for (int v = 0; v < a.NV; ++v) {
@@ -930,21 +978,21 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
                             dref = 2.0f * df * dcor;
                             dwv = -dref;
                         }
-                        unsafeAtomicAdd(&gref[c][tx], dref);
+                        fix_add(&gref[c][tx], dref, fx.s);
                         if (t.nw != 0.0f) {
-                            if (iax && iay) unsafeAtomicAdd(&win[cl][ay][ax], t.nw * dwv);
+                            if (iax && iay) fix_add(&win[cl][ay][ax], t.nw * dwv, fx.s);
                             else unsafeAtomicAdd(gsp + o00 + c, t.nw * dwv);
                         }
                         if (t.ne != 0.0f) {
-                            if (ibx && iay) unsafeAtomicAdd(&win[cl][ay][bx], t.ne * dwv);
+                            if (ibx && iay) fix_add(&win[cl][ay][bx], t.ne * dwv, fx.s);
                             else unsafeAtomicAdd(gsp + o01 + c, t.ne * dwv);
                         }
                         if (t.sw != 0.0f) {
-                            if (iax && iby) unsafeAtomicAdd(&win[cl][by][ax], t.sw * dwv);
+                            if (iax && iby) fix_add(&win[cl][by][ax], t.sw * dwv, fx.s);
                             else unsafeAtomicAdd(gsp + o10 + c, t.sw * dwv);
                         }
                         if (t.se != 0.0f) {
-                            if (ibx && iby) unsafeAtomicAdd(&win[cl][by][bx], t.se * dwv);
+                            if (ibx && iby) fix_add(&win[cl][by][bx], t.se * dwv, fx.s);
                             else unsafeAtomicAdd(gsp + o11 + c, t.se * dwv);
                         }
                     }
@@ -959,8 +1007,8 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
                 for (int i = tid; i < 8 * kWinY * kWinX; i += nthr) {
                     const int cl = i % 8, tex = i / 8;
                     const int wxx = tex % kWinX, wyy = tex / kWinX;
-                    wp[i] = win[cl][wyy][wxx];
-                    win[cl][wyy][wxx] = 0.0f;
+                    wp[i] = fix_get(win[cl][wyy][wxx], fx.inv);
+                    win[cl][wyy][wxx] = 0;
                 }
                 if (cb == 0 && tid == 0) {
                     int* op = ba.win_org + (((long)b * gridDim.x + blockIdx.x) * a.NV + v) * 2;
@@ -972,10 +1020,10 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
                 for (int i = tid; i < 8 * kWinY * kWinX; i += nthr) {
                     const int cl = i % 8, tex = i / 8;
                     const int wxx = tex % kWinX, wyy = tex / kWinX;
-                    const float val = win[cl][wyy][wxx];
-                    if (val != 0.0f) {
-                        win[cl][wyy][wxx] = 0.0f;
-                        unsafeAtomicAdd(gsp + ((long)(wy0 + wyy) * a.Ws + (wx0 + wxx)) * C + cbase + cl, val);
+                    const u64 raw = win[cl][wyy][wxx];
+                    if (raw != 0) {
+                        win[cl][wyy][wxx] = 0;
+                        unsafeAtomicAdd(gsp + ((long)(wy0 + wyy) * a.Ws + (wx0 + wxx)) * C + cbase + cl, fix_get(raw, fx.inv));
                     }
                 }
             }
@@ -985,27 +1033,27 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
     // every reference pixel of this workgroup is complete: plain coalesced stores
     float* grp = ba.grad_ref + (long)b * a.ref_bs + (long)p0 * C;
     const int npix = min(64, hw - p0);
-    for (int i = tid; i < npix * C; i += nthr) grp[i] = gref[i % C][i / C];
+    for (int i = tid; i < npix * C; i += nthr) grp[i] = fix_get(gref[i % C][i / C], fx.inv);
 }
 
-// 2-D tile form for the narrow feature maps (C <= 16, the two fine stages, where this kernel's time is): one
-// workgroup owns 64 columns x R consecutive reference rows and keeps ONE scatter window per view for all of them.
-// The kernel runs at the memory-side atomic rate of the part (~18 G fp32 atomics/s whatever their pattern), and a
-// bilinear footprint makes neighbouring reference rows hit the same two source rows, so R rows need R + 2 window
-// rows instead of 3 R: about half the atomics.  Same arithmetic as warp_agg_bwd_kernel.
-template <int C, int G, bool GROUP, int R>
+// 2-D tile form for the full-resolution stage (C = 8, where this kernel's time is): one workgroup owns 64 columns x R
+// consecutive reference rows and keeps ONE scatter window per view for all of them -- a bilinear footprint makes
+// neighbouring reference rows hit the same two source rows, so R rows need R + 2 window rows instead of 3 R.  Same
+// arithmetic as warp_agg_bwd_kernel; kTileWinX columns (the 64-bit accumulators double the window's LDS footprint).
+constexpr int kTileWinX = 88;
+
+template <int G, bool GROUP, int R>
 __global__ void __launch_bounds__(64 * 8) warp_agg_bwd_tile_kernel(WarpAggBwdArgs ba, int tiles_x) {
     const WarpAggArgs& a = ba.f;
+    constexpr int C = 8;
     constexpr int CG = C / G;
-    static_assert(C <= 16 && (C == 8 || C == 16) && CG <= 8, "narrow maps: one or two 8-channel window passes");
-    constexpr int GB = 8 / CG;
     constexpr int WY = R + 6;
     __shared__ float sc[2][8][64];
     __shared__ float sd[2][8][64];
-    __shared__ float corL[G][8 * 64];
-    __shared__ float gref[R][C][64];
-    __shared__ float win[8][WY][kWinX];
+    __shared__ u64 gref[R][C][64];
+    __shared__ u64 win[8][WY][kTileWinX];
     __shared__ int worg[2];
+    const FixScale fx = make_fix_scale(ba.maxima, G, a.D, CG, GROUP, true, a.attn_temp);
 
     const int tx = threadIdx.x;
     const int d = threadIdx.y;
@@ -1018,8 +1066,8 @@ __global__ void __launch_bounds__(64 * 8) warp_agg_bwd_tile_kernel(WarpAggBwdArg
     const int x = min(x0 + tx, a.w - 1);
     const bool vcol = x0 + tx < a.w;
 
-    for (int i = tid; i < R * C * 64; i += nthr) (&gref[0][0][0])[i] = 0.0f;
-    for (int i = tid; i < 8 * WY * kWinX; i += nthr) (&win[0][0][0])[i] = 0.0f;
+    for (int i = tid; i < R * C * 64; i += nthr) (&gref[0][0][0])[i] = 0;
+    for (int i = tid; i < 8 * WY * kTileWinX; i += nthr) (&win[0][0][0])[i] = 0;
 
     for (int v = 0; v < a.NV; ++v) {
         mv::RT m;
@@ -1082,34 +1130,36 @@ __global__ void __launch_bounds__(64 * 8) warp_agg_bwd_tile_kernel(WarpAggBwdArg
             const long o00 = ((long)tc.ya * a.Ws + tc.xa) * C, o01 = ((long)tc.ya * a.Ws + tc.xb) * C;
             const long o10 = ((long)tc.yb * a.Ws + tc.xa) * C, o11 = ((long)tc.yb * a.Ws + tc.xb) * C;
 
-            // pass 1: correlations and score (same arithmetic as the forward)
-            float score = 0.0f;
+            // the eight channels of the reference pixel and of its warped source value stay in registers for both passes
+            float Rv[8], wv[8];
 #pragma unroll
-            for (int cb = 0; cb < C / 8; ++cb) {
-                float part[GB];
+            for (int c0 = 0; c0 < 8; c0 += 4) {
+                const f32x4 Rq = ld4(rp + c0);
+                const f32x4 A = ld4(sp + o00 + c0), Bq = ld4(sp + o01 + c0);
+                const f32x4 Cq = ld4(sp + o10 + c0), Dq = ld4(sp + o11 + c0);
 #pragma unroll
-                for (int c0 = 0; c0 < 8; c0 += 4) {
-                    const f32x4 Rv = ld4(rp + cb * 8 + c0);
-                    const f32x4 A = ld4(sp + o00 + cb * 8 + c0), Bq = ld4(sp + o01 + cb * 8 + c0);
-                    const f32x4 Cq = ld4(sp + o10 + cb * 8 + c0), Dq = ld4(sp + o11 + cb * 8 + c0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int c = c0 + j;
-                        const float wv = mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
-                        if (GROUP) {
-                            const float pr = mv::mul_rn(wv, Rv[j]);
-                            part[c / CG] = (c % CG == 0) ? pr : mv::add_rn(part[c / CG], pr);
-                        } else {
-                            const float df = mv::sub_rn(Rv[j], wv);
-                            part[c] = mv::mul_rn(df, df);
-                        }
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    Rv[c0 + j] = Rq[j];
+                    wv[c0 + j] = mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
                 }
+            }
+            // pass 1: score (same arithmetic and order as the forward) and gdot = sum_g go[g] * cor[g]
+            float score = 0.0f, gdot = 0.0f, part = 0.0f;
 #pragma unroll
-                for (int k = 0; k < GB; ++k) {
-                    const float cg = GROUP ? mv::div_rn(part[k], (float)CG) : part[k];
-                    corL[cb * GB + k][tid] = cg;
-                    score = (cb == 0 && k == 0) ? cg : mv::add_rn(score, cg);
+            for (int c = 0; c < 8; ++c) {
+                if (GROUP) {
+                    const float pr = mv::mul_rn(wv[c], Rv[c]);
+                    part = (c % CG == 0) ? pr : mv::add_rn(part, pr);
+                    if (c % CG == CG - 1) {
+                        const float cg = mv::div_rn(part, (float)CG);
+                        score = (c / CG == 0) ? cg : mv::add_rn(score, cg);
+                        gdot = fmaf(go[c / CG], cg, gdot);
+                    }
+                } else {
+                    const float df = mv::sub_rn(Rv[c], wv[c]);
+                    const float cg = mv::mul_rn(df, df);
+                    score = (c == 0) ? cg : mv::add_rn(score, cg);
+                    gdot = fmaf(go[GROUP ? 0 : c], cg, gdot);
                 }
             }
             score = mv::div_rn(score, a.attn_temp);
@@ -1122,113 +1172,71 @@ __global__ void __launch_bounds__(64 * 8) warp_agg_bwd_tile_kernel(WarpAggBwdArg
             for (int j = 0; j < a.D; ++j) den += expf(sc[par][j][tx] - mx);
             const float sig = expf(score - mx) / den;
             const float wgt = sig / a.sqrt_c;
-            float dw = -common;
-#pragma unroll
-            for (int g = 0; g < G; ++g) dw = fmaf(go[g], corL[g][tid], dw);
-            dw *= invW;
-            const float dsig = dw / a.sqrt_c;
+            const float dsig = (gdot - common) * invW / a.sqrt_c;
             sd[par][d][tx] = sig * dsig;
             __syncthreads();
             float dot = 0.0f;
             for (int j = 0; j < a.D; ++j) dot += sd[par][j][tx];
             const float dscore = sig * (dsig - dot) / a.attn_temp;
             const int ax = tc.xa - wx0, bx = tc.xb - wx0, ay = tc.ya - wy0, by = tc.yb - wy0;
-            const bool iax = (unsigned)ax < (unsigned)kWinX, ibx = (unsigned)bx < (unsigned)kWinX;
+            const bool iax = (unsigned)ax < (unsigned)kTileWinX, ibx = (unsigned)bx < (unsigned)kTileWinX;
             const bool iay = (unsigned)ay < (unsigned)WY, iby = (unsigned)by < (unsigned)WY;
 
-            // pass 2: scatter into the tile's window (first 8 channels; a 16-channel map takes a second window pass)
+            // pass 2: scatter into the tile's window (64-bit fixed-point LDS atomics; global atomics outside the window)
             if (valid) {
 #pragma unroll
-                for (int c0 = 0; c0 < 8; c0 += 4) {
-                    const f32x4 Rv = ld4(rp + c0);
-                    const f32x4 A = ld4(sp + o00 + c0), Bq = ld4(sp + o01 + c0);
-                    const f32x4 Cq = ld4(sp + o10 + c0), Dq = ld4(sp + o11 + c0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int c = c0 + j;
-                        const int g = GROUP ? c / CG : c;
-                        const float dcor = fmaf(go[g] * invW, wgt, dscore);
-                        const float wv = mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
-                        float dwv, dref;
-                        if (GROUP) {
-                            dwv = dcor * (1.0f / CG) * Rv[j];
-                            dref = dcor * (1.0f / CG) * wv;
-                        } else {
-                            const float df = Rv[j] - wv;
-                            dref = 2.0f * df * dcor;
-                            dwv = -dref;
-                        }
-                        unsafeAtomicAdd(&gref[r][c][tx], dref);
-                        if (t.nw != 0.0f) {
-                            if (iax && iay) unsafeAtomicAdd(&win[c][ay][ax], t.nw * dwv);
-                            else unsafeAtomicAdd(gsp + o00 + c, t.nw * dwv);
-                        }
-                        if (t.ne != 0.0f) {
-                            if (ibx && iay) unsafeAtomicAdd(&win[c][ay][bx], t.ne * dwv);
-                            else unsafeAtomicAdd(gsp + o01 + c, t.ne * dwv);
-                        }
-                        if (t.sw != 0.0f) {
-                            if (iax && iby) unsafeAtomicAdd(&win[c][by][ax], t.sw * dwv);
-                            else unsafeAtomicAdd(gsp + o10 + c, t.sw * dwv);
-                        }
-                        if (t.se != 0.0f) {
-                            if (ibx && iby) unsafeAtomicAdd(&win[c][by][bx], t.se * dwv);
-                            else unsafeAtomicAdd(gsp + o11 + c, t.se * dwv);
-                        }
+                for (int c = 0; c < 8; ++c) {
+                    const int g = GROUP ? c / CG : c;
+                    const float dcor = fmaf(go[g] * invW, wgt, dscore);
+                    float dwv, dref;
+                    if (GROUP) {
+                        dwv = dcor * (1.0f / CG) * Rv[c];
+                        dref = dcor * (1.0f / CG) * wv[c];
+                    } else {
+                        const float df = Rv[c] - wv[c];
+                        dref = 2.0f * df * dcor;
+                        dwv = -dref;
                     }
-                }
-                if (C == 16) {
-                    // channels 8..15 bypass the window (one window pass per view keeps the tile loop simple); they are the
-                    // minority of this kernel's time: stage 3 has a quarter of stage 4's pixels
-#pragma unroll
-                    for (int c0 = 8; c0 < C; c0 += 4) {
-                        const f32x4 Rv = ld4(rp + c0);
-                        const f32x4 A = ld4(sp + o00 + c0), Bq = ld4(sp + o01 + c0);
-                        const f32x4 Cq = ld4(sp + o10 + c0), Dq = ld4(sp + o11 + c0);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int c = c0 + j;
-                            const int g = GROUP ? c / CG : c;
-                            const float dcor = fmaf(go[g] * invW, wgt, dscore);
-                            const float wv = mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
-                            float dwv, dref;
-                            if (GROUP) {
-                                dwv = dcor * (1.0f / CG) * Rv[j];
-                                dref = dcor * (1.0f / CG) * wv;
-                            } else {
-                                const float df = Rv[j] - wv;
-                                dref = 2.0f * df * dcor;
-                                dwv = -dref;
-                            }
-                            unsafeAtomicAdd(&gref[r][c][tx], dref);
-                            if (t.nw != 0.0f) unsafeAtomicAdd(gsp + o00 + c, t.nw * dwv);
-                            if (t.ne != 0.0f) unsafeAtomicAdd(gsp + o01 + c, t.ne * dwv);
-                            if (t.sw != 0.0f) unsafeAtomicAdd(gsp + o10 + c, t.sw * dwv);
-                            if (t.se != 0.0f) unsafeAtomicAdd(gsp + o11 + c, t.se * dwv);
-                        }
+                    fix_add(&gref[r][c][tx], dref, fx.s);
+                    if (t.nw != 0.0f) {
+                        if (iax && iay) fix_add(&win[c][ay][ax], t.nw * dwv, fx.s);
+                        else unsafeAtomicAdd(gsp + o00 + c, t.nw * dwv);
+                    }
+                    if (t.ne != 0.0f) {
+                        if (ibx && iay) fix_add(&win[c][ay][bx], t.ne * dwv, fx.s);
+                        else unsafeAtomicAdd(gsp + o01 + c, t.ne * dwv);
+                    }
+                    if (t.sw != 0.0f) {
+                        if (iax && iby) fix_add(&win[c][by][ax], t.sw * dwv, fx.s);
+                        else unsafeAtomicAdd(gsp + o10 + c, t.sw * dwv);
+                    }
+                    if (t.se != 0.0f) {
+                        if (ibx && iby) fix_add(&win[c][by][bx], t.se * dwv, fx.s);
+                        else unsafeAtomicAdd(gsp + o11 + c, t.se * dwv);
                     }
                 }
             }
         }
         __syncthreads();
         if (ba.windows) {
-            const long slot = ((long)b * gridDim.x + blockIdx.x) * a.NV + v;      // (C == 8: one channel block)
-            float* wp = ba.windows + slot * (8 * WY * kWinX);
-            for (int i = tid; i < 8 * WY * kWinX; i += nthr) {
+            // dense, texel-major / channel-fastest window for scatter_gather_kernel (fixed summation order)
+            const long slot = ((long)b * gridDim.x + blockIdx.x) * a.NV + v;
+            float* wp = ba.windows + slot * (8 * WY * kTileWinX);
+            for (int i = tid; i < 8 * WY * kTileWinX; i += nthr) {
                 const int cl = i % 8, tex = i / 8;
-                const int wxx = tex % kWinX, wyy = tex / kWinX;
-                wp[i] = win[cl][wyy][wxx];
-                win[cl][wyy][wxx] = 0.0f;
+                const int wxx = tex % kTileWinX, wyy = tex / kTileWinX;
+                wp[i] = fix_get(win[cl][wyy][wxx], fx.inv);
+                win[cl][wyy][wxx] = 0;
             }
             if (tid == 0) { ba.win_org[slot * 2] = wx0; ba.win_org[slot * 2 + 1] = wy0; }
         } else {
-            for (int i = tid; i < 8 * WY * kWinX; i += nthr) {
+            for (int i = tid; i < 8 * WY * kTileWinX; i += nthr) {
                 const int cl = i % 8, tex = i / 8;
-                const int wxx = tex % kWinX, wyy = tex / kWinX;
-                const float val = win[cl][wyy][wxx];
-                if (val != 0.0f) {
-                    win[cl][wyy][wxx] = 0.0f;
-                    unsafeAtomicAdd(gsp + ((long)(wy0 + wyy) * a.Ws + (wx0 + wxx)) * C + cl, val);
+                const int wxx = tex % kTileWinX, wyy = tex / kTileWinX;
+                const u64 raw = win[cl][wyy][wxx];
+                if (raw != 0) {
+                    win[cl][wyy][wxx] = 0;
+                    unsafeAtomicAdd(gsp + ((long)(wy0 + wyy) * a.Ws + (wx0 + wxx)) * C + cl, fix_get(raw, fx.inv));
                 }
             }
         }
@@ -1240,7 +1248,7 @@ __global__ void __launch_bounds__(64 * 8) warp_agg_bwd_tile_kernel(WarpAggBwdArg
         if (y >= a.h) break;
         float* grp = ba.grad_ref + (long)b * a.ref_bs + ((long)y * a.w + x0) * C;
         const int npix = min(64, a.w - x0);
-        for (int i = tid; i < npix * C; i += nthr) grp[i] = gref[r][i % C][i / C];
+        for (int i = tid; i < npix * C; i += nthr) grp[i] = fix_get(gref[r][i % C][i / C], fx.inv);
     }
 }
 
@@ -1251,7 +1259,7 @@ __global__ void __launch_bounds__(64 * 8) warp_agg_bwd_tile_kernel(WarpAggBwdArg
 // window).  WY = window rows (kWinY for the row kernel, R + 6 for the tile kernel).
 constexpr int kGatherList = 256;
 
-template <int WY, int NBLK>
+template <int WY, int WX, int NBLK>
 __global__ void __launch_bounds__(256) scatter_gather_kernel(const float* __restrict__ windows, const int* __restrict__ org,
                                                              float* __restrict__ grad_src, int nblk, int NV, int Hs, int Ws,
                                                              long src_vs, long src_bs, int tiles_x) {
@@ -1277,7 +1285,7 @@ __global__ void __launch_bounds__(256) scatter_gather_kernel(const float* __rest
             if (k < nblk) {
                 const int* o = org + ((slot0 + k) * NV + v) * 2;
                 const int wx0 = o[0], wy0 = o[1];
-                hit = wx0 != 0x7fffffff && wx0 < tx0 + 32 && wx0 + kWinX > tx0 && wy0 < ty0 + 4 && wy0 + WY > ty0;
+                hit = wx0 != 0x7fffffff && wx0 < tx0 + 32 && wx0 + WX > tx0 && wy0 < ty0 + 4 && wy0 + WY > ty0;
             }
             const unsigned long long m = __ballot(hit);
             if (lane == 0) wcnt[wave] = __popcll(m);
@@ -1294,11 +1302,11 @@ __global__ void __launch_bounds__(256) scatter_gather_kernel(const float* __rest
                 const int k = list[li];
                 const int* o = org + ((slot0 + k) * NV + v) * 2;
                 const int lx = tx - o[0], ly = ty - o[1];
-                if ((unsigned)lx < (unsigned)kWinX && (unsigned)ly < (unsigned)WY) {
-                    const float* wp = windows + ((slot0 + k) * NV + v) * ((long)NBLK * 8 * WY * kWinX) +
-                                      ((long)ly * kWinX + lx) * 8 + half * 4;
+                if ((unsigned)lx < (unsigned)WX && (unsigned)ly < (unsigned)WY) {
+                    const float* wp = windows + ((slot0 + k) * NV + v) * ((long)NBLK * 8 * WY * WX) +
+                                      ((long)ly * WX + lx) * 8 + half * 4;
 #pragma unroll
-                    for (int cb = 0; cb < NBLK; ++cb) acc[cb] += ld4(wp + (long)cb * (8 * WY * kWinX));
+                    for (int cb = 0; cb < NBLK; ++cb) acc[cb] += ld4(wp + (long)cb * (8 * WY * WX));
                 }
             }
             __syncthreads();
@@ -1313,11 +1321,11 @@ __global__ void __launch_bounds__(256) scatter_gather_kernel(const float* __rest
     }
 }
 
-template <int WY, int NBLK>
+template <int WY, int WX, int NBLK>
 int launch_gather(const WarpAggBwdArgs& ba, int nblk, hipStream_t stream) {
     const WarpAggArgs& a = ba.f;
     const int tiles_x = (a.Ws + 31) / 32, tiles_y = (a.Hs + 3) / 4;
-    hipLaunchKernelGGL((scatter_gather_kernel<WY, NBLK>), dim3(tiles_x * tiles_y, a.NV, a.B), dim3(256), 0, stream, ba.windows,
+    hipLaunchKernelGGL((scatter_gather_kernel<WY, WX, NBLK>), dim3(tiles_x * tiles_y, a.NV, a.B), dim3(256), 0, stream, ba.windows,
                        ba.win_org, ba.grad_src, nblk, a.NV, a.Hs, a.Ws, a.src_vs, a.src_bs, tiles_x);
     return mv_check_launch();
 }
@@ -1339,10 +1347,10 @@ int launch_bwd(const WarpAggBwdArgs& ba, hipStream_t stream) {
     if constexpr (C == 8 && C / G <= 8) {
         if (bwd_uses_tiles(C, G, a.D, a.fuse_d)) {      // the shipped full-resolution stage
             const int tiles_x = (a.w + 63) / 64;
-            hipLaunchKernelGGL((warp_agg_bwd_tile_kernel<C, G, GROUP, kTileR>), dim3(nblk, a.B), dim3(64, a.D), 0, stream, ba,
+            hipLaunchKernelGGL((warp_agg_bwd_tile_kernel<G, GROUP, kTileR>), dim3(nblk, a.B), dim3(64, a.D), 0, stream, ba,
                                tiles_x);
             if (int rc = mv_check_launch()) return rc;
-            return ba.windows ? launch_gather<kTileR + 6, 1>(ba, nblk, stream) : MVSTER_OK;
+            return ba.windows ? launch_gather<kTileR + 6, kTileWinX, 1>(ba, nblk, stream) : MVSTER_OK;
         }
     }
     dim3 block(64, a.D);
@@ -1350,7 +1358,7 @@ int launch_bwd(const WarpAggBwdArgs& ba, hipStream_t stream) {
     if (a.D <= 8) hipLaunchKernelGGL((warp_agg_bwd_kernel<C, G, GROUP, 8>), grid, block, 0, stream, ba);
     else hipLaunchKernelGGL((warp_agg_bwd_kernel<C, G, GROUP, kMaxD>), grid, block, 0, stream, ba);
     if (int rc = mv_check_launch()) return rc;
-    return ba.windows ? launch_gather<kWinY, C / 8>(ba, nblk, stream) : MVSTER_OK;
+    return ba.windows ? launch_gather<kWinY, kWinX, C / 8>(ba, nblk, stream) : MVSTER_OK;
 }
 
 }  // namespace
@@ -1416,13 +1424,16 @@ extern "C" int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat,
 }
 
 extern "C" int mvster_warp_agg_bwd_scratch(int B, int NV, int C, int G, int D, int h, int w, int attn_fuse_d,
+                                          long* window_floats, long* origin_ints);   // (defined below, used by the launcher)
+
+extern "C" int mvster_warp_agg_bwd_scratch(int B, int NV, int C, int G, int D, int h, int w, int attn_fuse_d,
                                           long* window_floats, long* origin_ints) {
     if (!window_floats || !origin_ints) return MVSTER_ERR_NULL;
     if (B <= 0 || NV <= 0 || C <= 0 || C % 8 || G <= 0 || D <= 0 || h <= 0 || w <= 0) return MVSTER_ERR_SHAPE;
     const long nblk = bwd_blocks(C, G, D, attn_fuse_d, h, w);
-    const int wy = bwd_uses_tiles(C, G, D, attn_fuse_d) ? kTileR + 6 : kWinY;
-    *window_floats = (long)B * nblk * NV * (C / 8) * 8 * wy * kWinX;
-    *origin_ints = (long)B * nblk * NV * 2;
+    const bool tiles = bwd_uses_tiles(C, G, D, attn_fuse_d);
+    *window_floats = (long)B * nblk * NV * (C / 8) * 8 * (tiles ? (kTileR + 6) * kTileWinX : kWinY * kWinX);
+    *origin_ints = (long)B * nblk * NV * 2 + 4;      // + the three operand maxima of the fixed-point scale
     return MVSTER_OK;
 }
 
@@ -1433,7 +1444,7 @@ extern "C" int mvster_warp_agg_bwd(const float* ref_feat, const float* src_feat,
                                    long src_batch_stride, int group_cor, int attn_fuse_d, float attn_temp, void* stream) {
     if (!ref_feat || !src_feat || !rt || !hypo || !out || !wsum || !grad_out || !grad_ref || !grad_src)
         return MVSTER_ERR_NULL;
-    if ((windows == nullptr) != (win_org == nullptr)) return MVSTER_ERR_NULL;
+    if (!win_org) return MVSTER_ERR_NULL;
     if (B <= 0 || NV <= 0 || D <= 0 || D > kMaxD || h <= 0 || w <= 0 || Hs <= 0 || Ws <= 0) return MVSTER_ERR_SHAPE;
     if (!group_cor && G != C) return MVSTER_ERR_SHAPE;
     WarpAggBwdArgs ba;
@@ -1445,6 +1456,26 @@ extern "C" int mvster_warp_agg_bwd(const float* ref_feat, const float* src_feat,
     ba.fwd_out = out; ba.wsum = wsum; ba.grad_out = grad_out; ba.grad_ref = grad_ref; ba.grad_src = grad_src;
     ba.windows = windows; ba.win_org = win_org;
     hipStream_t s = (hipStream_t)stream;
+    {
+        // operand maxima for the fixed-point scale of the LDS accumulators: the last 4 ints of win_org
+        long nf = 0, ni = 0;
+        mvster_warp_agg_bwd_scratch(B, NV, C, G, D, h, w, attn_fuse_d, &nf, &ni);
+        float* mx = reinterpret_cast<float*>(win_org + (ni - 4));
+        if (hipMemsetAsync(mx, 0, 16, s) != hipSuccess) return MVSTER_ERR_LAUNCH;
+        const long n_go = (long)B * D * h * w * G, n_ref = (long)h * w * C, n_src = (long)Hs * Ws * C;
+        auto launch_max = [&](const float* p, long n, float* out) {
+            hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)min(1024L, n / 4096 + 1)), dim3(256), 0, s, p, n, out);
+        };
+        launch_max(grad_out, n_go, mx);
+        if (ref_batch_stride == n_ref) launch_max(ref_feat, n_ref * B, mx + 1);
+        else for (int bb = 0; bb < B; ++bb) launch_max(ref_feat + (long)bb * ref_batch_stride, n_ref, mx + 1);
+        if (src_batch_stride == n_src && src_view_stride == n_src * B) launch_max(src_feat, n_src * B * NV, mx + 2);
+        else
+            for (int v = 0; v < NV; ++v)
+                for (int bb = 0; bb < B; ++bb)
+                    launch_max(src_feat + (long)v * src_view_stride + (long)bb * src_batch_stride, n_src, mx + 2);
+        ba.maxima = mx;
+    }
 #define MV_CASE(CC, GG, GR) \
     if (C == CC && G == GG && (group_cor != 0) == GR) return launch_bwd<CC, GG, GR>(ba, s);
     MV_CASE(64, 8, true)

@@ -96,10 +96,11 @@ def warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, group_cor=True, attn_fuse_d=Tru
 
 def warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad_out, G, group_cor=True, attn_fuse_d=True, attn_temp=2.0,
                     deterministic=None):
-    """Gradients of warp_agg_fwd_cl w.r.t. ref_cl and src_cl.  ``deterministic`` (default: on, unless the environment
-    sets MVSTER_BWD_ATOMIC): scatter windows are stored densely and summed by a gather pass in fixed order instead of
-    being flushed with global fp32 atomics -- faster (the atomics were what bounded this kernel) and bit-reproducible
-    for every tap inside a window."""
+    """Gradients of warp_agg_fwd_cl w.r.t. ref_cl and src_cl.  Inside a workgroup the gradients accumulate in 64-bit
+    fixed-point LDS counters (integer atomics: 30x cheaper than ds_add_f32 on gfx950, and associative).
+    ``deterministic`` (default: on, unless the environment sets MVSTER_BWD_ATOMIC): the workgroups' scatter windows are
+    then stored densely and summed by a gather pass in fixed order instead of being flushed with global fp32 atomics,
+    which makes the source gradient bit-reproducible for every tap that falls inside a window."""
     import ctypes
     import os
     grad_out = grad_out.contiguous()
@@ -114,13 +115,11 @@ def warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad_out, G, group_cor=
     g_src = torch.zeros_like(src_cl)
     if deterministic is None:
         deterministic = not os.environ.get("MVSTER_BWD_ATOMIC")
-    windows = origins = None
-    if deterministic:
-        nf, ni = ctypes.c_long(0), ctypes.c_long(0)
-        _lib.check(lib.mvster_warp_agg_bwd_scratch(B, NV, C, G, D, h, w, int(attn_fuse_d), ctypes.addressof(nf),
-                                                   ctypes.addressof(ni)), "warp_agg_bwd_scratch")
-        windows = torch.empty(nf.value, device=ref_cl.device, dtype=torch.float32)
-        origins = torch.empty(ni.value, device=ref_cl.device, dtype=torch.int32)
+    nf, ni = ctypes.c_long(0), ctypes.c_long(0)
+    _lib.check(lib.mvster_warp_agg_bwd_scratch(B, NV, C, G, D, h, w, int(attn_fuse_d), ctypes.addressof(nf),
+                                               ctypes.addressof(ni)), "warp_agg_bwd_scratch")
+    windows = torch.empty(nf.value, device=ref_cl.device, dtype=torch.float32) if deterministic else None
+    origins = torch.empty(ni.value, device=ref_cl.device, dtype=torch.int32)
     rc = lib.mvster_warp_agg_bwd(_ptr(ref_cl), _ptr(src_cl), _ptr(rt), _ptr(hypo), _ptr(out), _ptr(wsum),
                                  _ptr(grad_out), _ptr(g_ref), _ptr(g_src), _ptr(windows), _ptr(origins), B, NV, C, G, D, h,
                                  w, Hs, Ws, h * w * C, B * Hs * Ws * C, Hs * Ws * C, int(group_cor), int(attn_fuse_d),

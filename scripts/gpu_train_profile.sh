@@ -6,7 +6,7 @@ REPO=$PWD
 rm -rf gpurun_out/prof_train; mkdir -p gpurun_out/prof_train
 export TMPDIR=/tmp
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_train" -o train -- python "$REPO/scripts/train_steps.py" 512 640 5 2 ${TRAIN_STEPS:-3} ${TRAIN_NATIVE:-1} > "$REPO/gpurun_out/prof_train/train.json" 2> "$REPO/gpurun_out/prof_train/rocprof.err"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_train" -o train -- python "$REPO/scripts/train_steps.py" 512 640 5 2 ${TRAIN_STEPS:-3} > "$REPO/gpurun_out/prof_train/train.json" 2> "$REPO/gpurun_out/prof_train/rocprof.err"
 echo "rocprof exit $?"
 cd "$REPO"
 cat gpurun_out/prof_train/train.json

@@ -7,5 +7,5 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gpu_configs import train  # noqa: E402
 
 a = [int(v) for v in sys.argv[1:]]
-H, W, N, B, steps, native = (a + [512, 640, 5, 2, 3, 1][len(a):])[:6]
-train(H, W, N, B, steps=steps, native=bool(native))
+H, W, N, B, steps = (a + [512, 640, 5, 2, 3][len(a):])[:5]
+train(H, W, N, B, steps=steps)
