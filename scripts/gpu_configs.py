@@ -44,7 +44,7 @@ def infer(H, W, N, steps=20):
     torch.cuda.reset_peak_memory_stats()
 
 
-def train(H, W, N, B, steps=5):
+def train(H, W, N, B, steps=5, graph=False):
     model = MVS4net(**SHIPPED)
     model.load_state_dict(load_weights(), strict=True)
     model.to(dev).train()
@@ -57,20 +57,37 @@ def train(H, W, N, B, steps=5):
         gt["stage%d" % s] = (500 + 300 * torch.rand(B, hs, ws, generator=g)).to(dev)
         mask["stage%d" % s] = (torch.rand(B, hs, ws, generator=g) > 0.2).float().to(dev)
     losses = []
-    for i in range(steps + 2):
-        if i == 2:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        opt.zero_grad()
-        out = model(imgs, proj, dv)
-        loss = MVS4net_loss(out, gt, mask, stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10,
-                            ot_eps=1, ot_continous=False, mono=True)[0]
-        loss.backward()
-        opt.step()
-        losses.append(loss.item())
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    print(json.dumps({"config": "train %dx%d N=%d B=%d (1 rank, Adam, OT loss), gfx950 kernels" % (H, W, N, B),
+    if graph:
+        from mvster_amd.graph import GraphedTrainStep
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+
+        def loss_fn(o, g_, m_):
+            return MVS4net_loss(o, g_, m_, stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10, ot_eps=1,
+                                ot_continous=False, mono=True)
+        step = GraphedTrainStep(model, opt, loss_fn, imgs, proj, dv, gt, mask, warmup=3)
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ls = [step().clone() for _ in range(steps)]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        losses = [l.item() for l in ls]
+    else:
+        for i in range(steps + 2):
+            if i == 2:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            opt.zero_grad()
+            out = model(imgs, proj, dv)
+            loss = MVS4net_loss(out, gt, mask, stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10,
+                                ot_eps=1, ot_continous=False, mono=True)[0]
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    print(json.dumps({"config": "train %dx%d N=%d B=%d (1 rank, Adam, OT loss), gfx950 kernels, %s" % (
+        H, W, N, B, "one hipGraph per step" if graph else "eager launches"),
                       "s_per_step": round(dt, 4), "loss_first": round(losses[0], 4), "loss_last": round(losses[-1], 4),
                       "finite": all(l == l for l in losses),
                       "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)

@@ -430,25 +430,32 @@ def test_warp_agg_backward_vs_autograd(C, G, D, group_cor, fuse):
         assert e_ref <= 1e-4 and e_src <= 1e-4, det
 
 
-@pytest.mark.parametrize("C,G,D,h,w", [(8, 4, 4, 64, 160), (16, 4, 4, 32, 80), (64, 8, 8, 8, 70)])
+@pytest.mark.parametrize("C,G,D,h,w", [(8, 4, 4, 64, 160), (16, 4, 4, 32, 80), (32, 8, 8, 16, 70)])
 def test_warp_agg_backward_is_reproducible(C, G, D, h, w):
-    """With the scatter windows stored densely and summed by the gather pass (the default), the source gradient has no
-    atomics on it for taps inside the windows: two runs return the same bits (DTU-like cameras: every tap is inside)."""
+    """Inside a workgroup the gradients accumulate in integer (fixed-point) LDS counters, so the reference gradient is the
+    same bits on every run; with ``deterministic=True`` the scatter windows are summed by the gather pass in fixed order
+    and the source gradient is reproducible too, as long as every tap falls inside its workgroup's window (translated
+    cameras here).  The default (windows flushed with global fp32 atomics) agrees to rounding."""
     torch.manual_seed(C + h)
     B, N = 2, 4
-    _, proj, dv = make_inputs(N, h * 8, w * 8, seed=3, batch=B)
+    _, proj, dv = make_inputs(N, h * 8, w * 8, seed=3, batch=B, rotate=False)
     rt = ops.relative_projection(proj["stage1"].to(DEV))
     ref = torch.randn(B, h, w, C, device=DEV)
     src = torch.randn(N - 1, B, h, w, C, device=DEV)
-    hypo = (O.init_inverse_range(dv, D, h, w) * (1 + 0.002 * torch.rand(B, D, h, w))).to(DEV)
+    hypo = (O.init_inverse_range(dv, D, h, w)[:, :1] * (1 + 0.002 * torch.arange(D).view(1, D, 1, 1)
+                                                          + 0.0005 * torch.rand(B, D, h, w))).contiguous().to(DEV)
     out, wsum = ops.warp_agg_fwd_cl(ref, src, rt, hypo, G, True, True, 2.0, want_wsum=True)
     gout = torch.randn_like(out)
     a = ops.warp_agg_bwd_cl(ref, src, rt, hypo, out, wsum, gout, G, True, True, 2.0, deterministic=True)
     b = ops.warp_agg_bwd_cl(ref, src, rt, hypo, out, wsum, gout, G, True, True, 2.0, deterministic=True)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[0], b[0]), "reference gradient"
+    assert torch.equal(a[1], b[1]), "source gradient (gather pass)"
     c = ops.warp_agg_bwd_cl(ref, src, rt, hypo, out, wsum, gout, G, True, True, 2.0, deterministic=False)
+    assert torch.equal(a[0], c[0])
     scale = c[1].abs().max().item()
-    assert (a[1] - c[1]).abs().max().item() <= 1e-5 * scale and torch.equal(a[0], c[0])
+    err = (a[1] - c[1]).abs().max().item() / scale
+    note("warp_agg_bwd_gather_vs_atomic_C%d" % C, rel=err)
+    assert err <= 1e-5
 
 
 def test_cpu_tensor_is_rejected():
