@@ -13,6 +13,8 @@
 // bounds logic is wave-uniform and the inner loop only moves along x).  The four waves' partial
 // tiles are summed through LDS and written to a per-workgroup slot of `partial`
 // [nblk][taps][COT*16][CIT*16]; the host sums the slots (deterministic, no atomics).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -209,6 +211,197 @@ int launch_wgrad(const WgradArgs& a, int nblk, int ntaps, hipStream_t s) {
     return mv_check_launch();
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-staged form (what mvster_conv_wgrad runs whenever the layer fits it).  The kernels above feed every MFMA operand
+// with its own 4-byte global load (a K step = four pixels x 16 channels = 256 B per wave instruction: a quarter of what
+// the texture path moves per cycle with 16-byte loads) and re-read gy and x once per kernel tap; measured, the weight
+// gradients of a training step run at 14 % of the fp32 MFMA peak.  Here one workgroup stages, per chunk of 64 output
+// columns of one output row, the gy chunk and the kd*kh input rows it meets -- coalesced 16-byte loads, zero padding
+// materialised -- and ALL kernel taps take their operands from LDS with conflict-free ds_read_b32 (pixel pitches chosen
+// so that the four pixels of a K step land 16 banks apart).  A workgroup owns MT x NT channel tiles (blockIdx.y) and
+// every tap: MT*NT*taps accumulator tiles live in registers across all rows the workgroup visits; the four waves split
+// the K steps of a chunk and are summed through LDS once, at the end.  Same `partial` layouts as above (host sum:
+// deterministic).  PCB = 0: one tap per N tile; PCB = 4 / 8: narrow B side, 16 / PCB taps share an N tile.
+// ------------------------------------------------------------------------------------------
+constexpr int kXC = 64;      // output columns per staged chunk
+
+__host__ __device__ constexpr int wg_pitch(int c, int s) {
+    // floats per staged pixel: >= c, a multiple of 4, and s * pitch = 16 (mod 32) so that consecutive pixels of a K step
+    // are 16 banks apart for ds_read_b32 (the two pixels a 32-lane group reads never collide)
+    int p = (c + 3) & ~3;
+    while ((s * p) % 32 != 16) p += 4;
+    return p;
+}
+
+template <int MT, int NT, int TY, int KW, int PCB>
+__global__ void __launch_bounds__(256) conv_wgrad_lds_kernel(WgradArgs a, int mgroups) {
+    constexpr int TAPS = TY * KW;
+    constexpr bool PACKED = PCB > 0;
+    constexpr int TPN = PACKED ? 16 / PCB : 1;
+    constexpr int NG = PACKED ? (TAPS + TPN - 1) / TPN : TAPS;      // N-tile groups per (mt, nt)
+    constexpr int NTT = PACKED ? 1 : NT;
+    constexpr int NACC = MT * NTT * NG;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int PA = wg_pitch(MT * 16, 1);
+    const int CBB = PACKED ? PCB : NT * 16;                          // B channels staged per pixel
+    const int PB = wg_pitch(CBB, a.sw);
+    const int XB = (kXC - 1) * a.sw + KW;
+    float* As = lds;                                                 // [kXC][PA]
+    float* Bs = lds + kXC * PA;                                      // [TY][XB][PB]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, k = lane >> 4;
+    const int m0 = (blockIdx.y % mgroups) * MT * 16, n0 = PACKED ? 0 : (blockIdx.y / mgroups) * NT * 16;
+
+    f32x4v acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane LDS offsets of the B operand (the taps of a packed tile differ per lane)
+    int boff[NG];
+    bool bval[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int tap = PACKED ? g * TPN + r / PCB : g;
+        const int tapc = tap < TAPS ? tap : TAPS - 1;
+        const int ty = tapc / KW, kx = tapc - ty * KW;
+        boff[g] = (ty * XB + kx) * PB + (PACKED ? r % PCB : 0);
+        bval[g] = tap < TAPS && (!PACKED || (r % PCB) < a.CI);
+    }
+
+    const int nrows = a.B * a.Do * a.Ho;
+    const int nchunks = (a.Wo + kXC - 1) / kXC;
+    const int qa = MT * 4, qb = CBB / 4;                             // float4 per staged pixel
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int yo = row % a.Ho, t = row / a.Ho;
+        const int zo = t % a.Do, b = t / a.Do;
+        const float* grow = a.gy + (long)row * a.Wo * a.CO;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int x1 = ch * kXC;
+            __syncthreads();                                         // the previous chunk's readers are done
+            // stage the gy chunk: [kXC][MT*16] (zeros beyond the row end / the channel count)
+            for (int i = threadIdx.x; i < kXC * qa; i += 256) {
+                const int px = i / qa, q = i - px * qa;
+                const int c = m0 + q * 4;
+                f32x4v v = {0.f, 0.f, 0.f, 0.f};
+                if (x1 + px < a.Wo && c < a.CO) v = *reinterpret_cast<const f32x4v*>(grow + (long)(x1 + px) * a.CO + c);
+                *reinterpret_cast<f32x4v*>(As + px * PA + q * 4) = v;
+            }
+            // stage the TY input rows: [TY][XB][CBB]
+            const int ix0 = x1 * a.sw - a.pw;
+            for (int i = threadIdx.x; i < TY * XB * qb; i += 256) {
+                const int q = i % qb;
+                int rest = i / qb;
+                const int px = rest % XB, ty = rest / XB;
+                const int kz = ty / a.kh, ky = ty - kz * a.kh;
+                const int iz = zo * a.sd - a.pd + kz, iy = yo * a.sh - a.ph + ky, ix = ix0 + px;
+                const int c = n0 + q * 4;
+                f32x4v v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi && c < a.CI)
+                    v = *reinterpret_cast<const f32x4v*>(a.x + ((((long)b * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.CI + c);
+                *reinterpret_cast<f32x4v*>(Bs + (ty * XB + px) * PB + q * 4) = v;
+            }
+            __syncthreads();
+            // K steps of this wave: four output columns each
+            for (int ks = wave; ks < kXC / 4; ks += 4) {
+                const int px = ks * 4 + k;
+                float av[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) av[i] = As[px * PA + i * 16 + r];
+                const float* bp = Bs + px * a.sw * PB + (PACKED ? 0 : r);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                    for (int j = 0; j < NTT; ++j) {
+                        float bv = bp[boff[g] + j * 16];
+                        if (PACKED) bv = bval[g] ? bv : 0.0f;
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+                            acc[(i * NTT + j) * NG + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[(i * NTT + j) * NG + g], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // cross-wave sum, one accumulator tile at a time through LDS (3 KB), then the workgroup's slot of `partial`
+    const int cop = (((a.CO + 15) / 16 == 3) ? 4 : (a.CO + 15) / 16) * 16;
+    const int cipw = PACKED ? 16 : (((a.CI + 15) / 16 == 3) ? 4 : (a.CI + 15) / 16) * 16;
+    float* slot = a.partial + (long)blockIdx.x * NG * cop * cipw;        // [NG][cop][cipw]
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTT; ++j)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const f32x4v mine = acc[(i * NTT + j) * NG + g];
+                if (wave > 0) *reinterpret_cast<f32x4v*>(lds + ((wave - 1) * 64 + lane) * 4) = mine;
+                __syncthreads();
+                if (wave == 0) {
+                    f32x4v sum = mine;
+#pragma unroll
+                    for (int w = 0; w < 3; ++w) sum += *reinterpret_cast<const f32x4v*>(lds + (w * 64 + lane) * 4);
+                    float* out = slot + (long)g * cop * cipw;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int mrow = m0 + i * 16 + 4 * k + q, ncol = n0 + j * 16 + r;
+                        if (mrow < cop && ncol < cipw) out[mrow * cipw + ncol] = sum[q];
+                    }
+                }
+                __syncthreads();
+            }
+}
+
+template <int MT, int NT, int TY, int KW, int PCB>
+int launch_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, hipStream_t s) {
+    const int PA = wg_pitch(MT * 16, 1), PB = wg_pitch(PCB > 0 ? PCB : NT * 16, a.sw);
+    const int XB = (kXC - 1) * a.sw + KW;
+    const size_t lds = sizeof(float) * ((size_t)kXC * PA + (size_t)TY * XB * PB);
+    if (lds > 64 * 1024) return MVSTER_ERR_UNSUPPORTED;
+    const int mgroups = cot / MT, ngroups = PCB > 0 ? 1 : cit / NT;
+    hipLaunchKernelGGL((conv_wgrad_lds_kernel<MT, NT, TY, KW, PCB>), dim3(nblk, mgroups * ngroups), dim3(256), lds, s, a, mgroups);
+    return mv_check_launch();
+}
+
+// tile shapes per tap count: MT*NT*taps accumulator tiles of 4 registers must stay well below the register file
+template <int TY, int KW>
+int dispatch_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, int packed, hipStream_t s) {
+    constexpr int TAPS = TY * KW;
+    if (packed) {
+        const int pcb = a.CI <= 4 ? 4 : 8;
+        if (TAPS == 1) return MVSTER_ERR_UNSUPPORTED;
+#define MV_LP(M_, P_) if (mt == M_ && pcb == P_) return launch_wgrad_lds<M_, 1, TY, KW, P_>(a, nblk, cot, cit, s);
+        const int ng8 = (TAPS + 1) / 2, ng4 = (TAPS + 3) / 4;
+        int mt = cot;
+        while (mt > 1 && mt * (pcb == 8 ? ng8 : ng4) > 40) mt /= 2;
+        MV_LP(1, 4) MV_LP(2, 4) MV_LP(4, 4) MV_LP(1, 8) MV_LP(2, 8) MV_LP(4, 8)
+#undef MV_LP
+        return MVSTER_ERR_UNSUPPORTED;
+    }
+    int mt = cot, nt = cit;
+    while (mt * nt * TAPS > 40 && (mt > 1 || nt > 1)) {
+        if (mt >= nt && mt > 1) mt /= 2; else nt /= 2;
+    }
+    if (mt * nt * TAPS > 40) return MVSTER_ERR_UNSUPPORTED;
+#define MV_LN(M_, N_) if (mt == M_ && nt == N_) { if constexpr (M_ * N_ * TAPS <= 40) return launch_wgrad_lds<M_, N_, TY, KW, 0>(a, nblk, cot, cit, s); }
+    MV_LN(1, 1) MV_LN(2, 1) MV_LN(1, 2) MV_LN(2, 2) MV_LN(4, 1) MV_LN(1, 4) MV_LN(4, 2) MV_LN(2, 4) MV_LN(4, 4)
+#undef MV_LN
+    return MVSTER_ERR_UNSUPPORTED;
+}
+
+static const bool g_wgrad_no_lds = getenv("MVSTER_WGRAD_NO_LDS") != nullptr;   // experiment switch: the per-tap kernels
+
+int try_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, int packed, hipStream_t s) {
+    if (g_wgrad_no_lds || (a.CO & 3) || (a.CI & 3)) return MVSTER_ERR_UNSUPPORTED;
+    const int ty = a.kd * a.kh;
+    if (ty == 1 && a.kw == 1) return dispatch_wgrad_lds<1, 1>(a, nblk, cot, cit, packed, s);
+    if (ty == 3 && a.kw == 3) return dispatch_wgrad_lds<3, 3>(a, nblk, cot, cit, packed, s);
+    if (ty == 9 && a.kw == 3) return dispatch_wgrad_lds<9, 3>(a, nblk, cot, cit, packed, s);
+    if (ty == 5 && a.kw == 5) return dispatch_wgrad_lds<5, 5>(a, nblk, cot, cit, packed, s);
+    return MVSTER_ERR_UNSUPPORTED;
+}
+
 }  // namespace
 
 // x [B,Di,Hi,Wi,CI], gy [B,Do,Ho,Wo,CO] (channels-last, contiguous); partial [nblk][kd*kh*kw][COP][CIP] with
@@ -234,8 +427,12 @@ extern "C" int mvster_conv_wgrad(const float* x, const float* gy, float* partial
     const int cot = (CO + 15) / 16 == 3 ? 4 : (CO + 15) / 16, cit = (CI + 15) / 16 == 3 ? 4 : (CI + 15) / 16;
     const int ntaps = kd * kh * kw;
     hipStream_t s = (hipStream_t)stream;
+    if (packed && CI > 8) return MVSTER_ERR_UNSUPPORTED;
+    {
+        const int rc = try_wgrad_lds(a, nblk, cot, cit, packed, s);
+        if (rc != MVSTER_ERR_UNSUPPORTED) return rc;
+    }
     if (packed) {
-        if (CI > 8) return MVSTER_ERR_UNSUPPORTED;
         const int cip = CI <= 4 ? 4 : 8;
 #define MV_P(A_, B_) if (cot == A_ && cip == B_) return launch_wgrad_packed<A_, B_>(a, nblk, ntaps, s);
         MV_P(1, 4) MV_P(1, 8) MV_P(2, 4) MV_P(2, 8) MV_P(4, 4) MV_P(4, 8)

@@ -44,11 +44,20 @@ def infer(H, W, N, steps=20):
     torch.cuda.reset_peak_memory_stats()
 
 
-def train(H, W, N, B, steps=5, graph=False):
+def train(H, W, N, B, steps=5, graph=False, coherent=False):
+    """``coherent``: zero the four ``prob`` heads, so that every pixel picks hypothesis 0 and the depth maps the cascade
+    hands from stage to stage are smooth, as they are for a network that has trained for a while.  The fixture weights
+    are random: their winner-take-all depths are unrelated between neighbouring pixels, which turns the scatter of the
+    warp backward into one global atomic per (tap, channel) -- the arithmetic per element is the same in both cases."""
     model = MVS4net(**SHIPPED)
     model.load_state_dict(load_weights(), strict=True)
+    if coherent:
+        with torch.no_grad():
+            for r in model.reg:
+                r.prob.weight.zero_()
+                r.prob.weight.requires_grad_(False)      # (an optimizer step would make the winners random again)
     model.to(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
     imgs, proj, dv = make_inputs(N, H, W, seed=0, device=dev, batch=B)
     g = torch.Generator().manual_seed(0)
     gt, mask = {}, {}
@@ -59,7 +68,7 @@ def train(H, W, N, B, steps=5, graph=False):
     losses = []
     if graph:
         from mvster_amd.graph import GraphedTrainStep
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, capturable=True)
 
         def loss_fn(o, g_, m_):
             return MVS4net_loss(o, g_, m_, stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10, ot_eps=1,
@@ -87,7 +96,8 @@ def train(H, W, N, B, steps=5, graph=False):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
     print(json.dumps({"config": "train %dx%d N=%d B=%d (1 rank, Adam, OT loss), gfx950 kernels, %s" % (
-        H, W, N, B, "one hipGraph per step" if graph else "eager launches"),
+        H, W, N, B, ("one hipGraph per step" if graph else "eager launches") + (", smooth depth maps (prob heads zeroed)" if coherent else
+                                                                                ", random-weight (incoherent) depth maps")),
                       "s_per_step": round(dt, 4), "loss_first": round(losses[0], 4), "loss_last": round(losses[-1], 4),
                       "finite": all(l == l for l in losses),
                       "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)

@@ -6,7 +6,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gpu_configs import train  # noqa: E402
 
-graph = "--graph" in sys.argv
-a = [int(v) for v in sys.argv[1:] if v != "--graph"]
+graph, coherent = "--graph" in sys.argv, "--coherent" in sys.argv
+a = [int(v) for v in sys.argv[1:] if not v.startswith("--")]
 H, W, N, B, steps = (a + [512, 640, 5, 2, 3][len(a):])[:5]
-train(H, W, N, B, steps=steps, graph=graph)
+train(H, W, N, B, steps=steps, graph=graph, coherent=coherent)
