@@ -166,11 +166,12 @@ int mvster_conv_wgrad(const float* x, const float* gy, float* partial, int nblk,
  * [groups, C] (batch statistics from the caller).
  *   stats:       partial[g][n][0][c] / [g][n][1][c] = workgroup n's share of sum d and sum d^2, d = x - x[first row of g]
  *                (mean = pivot + S1/rows, biased var = S2/rows - (S1/rows)^2, finished by the caller)
- *   fwd:         y = relu(x*scale + shift)                               (relu = 0: affine only)
+ *   fwd:         y = relu(x*scale + shift) (+ skip)                      (relu = 0: affine only; skip optional: the U-Net's
+ *                same-shape skip connection, added after the activation, models/mvs4net_utils.py:893-895)
  *   bwd_reduce:  partial[g][n][0][c] / [g][n][1][c] = workgroup n's share of sum g_ and sum g_*xh, n < mvster_bn_blocks()
  *   bwd_apply:   dx = scale * (g_ - sums[g][0]/rows - xh * sums[g][1]/rows),   g_ = gy * (y > 0), xh = (x - mean) * rstd */
-int mvster_bn_relu_fwd(const float* x, const float* scale, const float* shift, float* y, long rows, int C, int relu,
-                       int groups, void* stream);
+int mvster_bn_relu_fwd(const float* x, const float* scale, const float* shift, const float* skip, float* y, long rows,
+                       int C, int relu, int groups, void* stream);
 int mvster_bn_blocks(long rows, int C);
 int mvster_bn_stats(const float* x, float* partial, long rows, int C, int groups, void* stream);
 /* finalize: out [5][groups][C] = mean, biased var, rstd, scale, shift from the partial sums; running_mean / running_var

@@ -35,7 +35,7 @@ SIGNATURES = {
     "mvster_pack_conv_weights": [_f, _f] + [_i] * 6 + [_l] * 5 + [_i, _f],
     "mvster_pack_conv_weights_classes": [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f],
     "mvster_conv_wgrad": [_f, _f, _f] + [_i] * 20 + [_f],
-    "mvster_bn_relu_fwd": [_f, _f, _f, _f, _l, _i, _i, _i, _f],
+    "mvster_bn_relu_fwd": [_f, _f, _f, _f, _f, _l, _i, _i, _i, _f],
     "mvster_bn_blocks": [_l, _i],
     "mvster_bn_stats": [_f, _f, _l, _i, _i, _f],
     "mvster_bn_finalize": [_f] * 7 + [_l, _i, _i, _fl, _fl, _f],

@@ -23,9 +23,10 @@ __device__ __forceinline__ float relu_mask(int relu, float act) { return (relu =
 // blockIdx.y = statistics group (the reference normalises every view's batch separately): group g owns rows
 // [g*rows, (g+1)*rows) of x and row g of the per-channel parameter arrays.
 __global__ void __launch_bounds__(256) bn_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, float* __restrict__ y, long n4,
-                                                          int C, int relu) {
+                                                          const float* __restrict__ shift, const float* __restrict__ skip,
+                                                          float* __restrict__ y, long n4, int C, int relu) {
     x += (long)blockIdx.y * n4 * 4; y += (long)blockIdx.y * n4 * 4;
+    if (skip) skip += (long)blockIdx.y * n4 * 4;
     scale += blockIdx.y * C; shift += blockIdx.y * C;
     const int q = C >> 2;
     const long stride = (long)gridDim.x * 256;
@@ -40,6 +41,7 @@ __global__ void __launch_bounds__(256) bn_relu_fwd_kernel(const float* __restric
             const float t = bn_act(v[j], sc[j], sh[j]);
             o[j] = relu ? fmaxf(t, 0.0f) : t;
         }
+        if (skip) o += ld4(skip + i * 4);        // U-Net skip connection, added after the activation (mvs4net_utils.py:893-895)
         st4(y + i * 4, o);
     }
 }
@@ -207,14 +209,14 @@ int blocks_for(long n4) {
 }  // namespace
 
 // rows = rows PER GROUP; x, y [groups*rows, C]; scale, shift (mean, rstd) [groups, C]
-extern "C" int mvster_bn_relu_fwd(const float* x, const float* scale, const float* shift, float* y, long rows, int C, int relu,
-                                  int groups, void* stream) {
+extern "C" int mvster_bn_relu_fwd(const float* x, const float* scale, const float* shift, const float* skip, float* y,
+                                  long rows, int C, int relu, int groups, void* stream) {
     if (!x || !scale || !shift || !y) return MVSTER_ERR_NULL;
     if (int rc = check(rows, C)) return rc;
     if (groups < 1 || groups > 65535) return MVSTER_ERR_SHAPE;
     const long n4 = rows * (C / 4);
-    hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(blocks_for(n4), groups), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y,
-                       n4, C, relu);
+    hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(blocks_for(n4), groups), dim3(256), 0, (hipStream_t)stream, x, scale, shift, skip,
+                       y, n4, C, relu);
     return mv_check_launch();
 }
 

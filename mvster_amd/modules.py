@@ -56,9 +56,10 @@ def _deconv_bn_relu(cin, cout, kernel, pad, out_pad, stride):
         nn.BatchNorm3d(cout), nn.ReLU(inplace=True))
 
 
-def _deconv_bn_relu_cl(seq, x):
+def _deconv_bn_relu_cl(seq, x, skip=None):
+    """ConvTranspose3d -> BatchNorm -> ReLU (+ the U-Net skip connection, fused into the BatchNorm apply kernel)."""
     ct, bn = seq[0], seq[1]
-    return T.batch_norm_cl(T.conv_cl(x, ct.weight, None, ct.stride, ct.padding, transposed=True), bn, relu=True)
+    return T.batch_norm_cl(T.conv_cl(x, ct.weight, None, ct.stride, ct.padding, transposed=True), bn, relu=True, skip=skip)
 
 
 class reg2d(nn.Module):
@@ -92,9 +93,9 @@ class reg2d(nn.Module):
         c2 = self.conv2.forward_cl(self.conv1.forward_cl(c0))
         c4 = self.conv4.forward_cl(self.conv3.forward_cl(c2))
         x = self.conv6.forward_cl(self.conv5.forward_cl(c4))
-        x = c4 + _deconv_bn_relu_cl(self.conv7, x)
-        x = c2 + _deconv_bn_relu_cl(self.conv9, x)
-        x = c0 + _deconv_bn_relu_cl(self.conv11, x)
+        x = _deconv_bn_relu_cl(self.conv7, x, skip=c4)
+        x = _deconv_bn_relu_cl(self.conv9, x, skip=c2)
+        x = _deconv_bn_relu_cl(self.conv11, x, skip=c0)
         # 1x1x1 conv 8 -> 1 as multiply + 8-wide reduction (rocBLAS gemv takes 8 ms on this [2.6 M, 8] shape)
         return (x * self.prob.weight.reshape(-1)).sum(-1) + self.prob.bias
 
@@ -128,14 +129,14 @@ class reg3d(nn.Module):
         if self.down_size == 3:
             c4 = self.conv4.forward_cl(self.conv3.forward_cl(c2))
             x = self.conv6.forward_cl(self.conv5.forward_cl(c4))
-            x = c4 + _deconv_bn_relu_cl(self.conv7, x)
-            x = c2 + _deconv_bn_relu_cl(self.conv9, x)
+            x = _deconv_bn_relu_cl(self.conv7, x, skip=c4)
+            x = _deconv_bn_relu_cl(self.conv9, x, skip=c2)
         elif self.down_size == 2:
             x = self.conv4.forward_cl(self.conv3.forward_cl(c2))
-            x = c2 + _deconv_bn_relu_cl(self.conv9, x)
+            x = _deconv_bn_relu_cl(self.conv9, x, skip=c2)
         else:
             x = c2
-        x = c0 + _deconv_bn_relu_cl(self.conv11, x)
+        x = _deconv_bn_relu_cl(self.conv11, x, skip=c0)
         p = self.prob
         return T.conv_cl(x, p.weight, None, p.stride, p.padding).squeeze(-1)
 
@@ -196,18 +197,19 @@ class FPN4(nn.Module):
                 t = l.forward_cl(t, groups)
             return t
 
-        def plain(m, t):
-            return T.conv_cl(t, m.weight, m.bias, m.stride, m.padding)
+        def plain(m, t, up=None):
+            # (`up`: the coarser level, up-sampled x2 and added inside the convolution's epilogue)
+            return T.conv_cl(t, m.weight, m.bias, m.stride, m.padding, skip=up, skip_upsample=up is not None)
         c0 = seq(self.conv0, x)
         c1 = seq(self.conv1, c0)
         c2 = seq(self.conv2, c1)
         c3 = seq(self.conv3, c2)
         out = {"stage1": plain(self.out1, c3)}
-        f = T.upsample2x_cl(c3, "bilinear") + plain(self.inner1, c2)
+        f = plain(self.inner1, c2, up=c3)
         out["stage2"] = plain(self.out2, f)
-        f = T.upsample2x_cl(f, "bilinear") + plain(self.inner2, c1)
+        f = plain(self.inner2, c1, up=f)
         out["stage3"] = plain(self.out3, f)
-        f = T.upsample2x_cl(f, "bilinear") + plain(self.inner3, c0)
+        f = plain(self.inner3, c0, up=f)
         out["stage4"] = plain(self.out4, f)
         return out
 

@@ -298,14 +298,20 @@ def bn_batch_stats(x, weight, bias, running_mean, running_var, eps, momentum, gr
     return pack
 
 
-def bn_relu_fwd(x, scale, shift, relu, groups=1):
-    """y = relu(x*scale + shift) on a channels-last tensor [groups*n, ..., C] (training-mode BatchNorm apply); scale and
-    shift are [groups, C]: each of the `groups` equal slices along dim 0 has its own statistics."""
+def bn_relu_fwd(x, scale, shift, relu, groups=1, skip=None):
+    """y = relu(x*scale + shift) (+ skip) on a channels-last tensor [groups*n, ..., C] (training-mode BatchNorm apply);
+    scale and shift are [groups, C]: each of the `groups` equal slices along dim 0 has its own statistics; ``skip`` is
+    an optional tensor of x's shape added after the activation (the U-Net's skip connections)."""
     _chk(x, "bn_relu_fwd:x")
     C = x.shape[-1]
+    if skip is not None:
+        _chk(skip, "bn_relu_fwd:skip")
+        if tuple(skip.shape) != tuple(x.shape):
+            raise RuntimeError("bn_relu_fwd: skip must have the shape of x")
     y = torch.empty_like(x)
     rows = x.numel() // C // groups
-    rc = _lib.load().mvster_bn_relu_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), rows, C, int(relu), int(groups), _stream())
+    rc = _lib.load().mvster_bn_relu_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(skip), _ptr(y), rows, C, int(relu),
+                                        int(groups), _stream())
     _lib.check(rc, "bn_relu_fwd")
     return y
 

@@ -79,7 +79,7 @@ CACHE = _LayerCache()
 
 class _ConvCL(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, transposed):
+    def forward(ctx, x, weight, bias, stride, padding, transposed, skip=None, skip_upsample=False):
         w5 = weight if weight.dim() == 5 else weight.unsqueeze(2)
         cin = w5.shape[0] if transposed else w5.shape[1]
         if x.shape[-1] != cin:
@@ -90,7 +90,14 @@ class _ConvCL(torch.autograd.Function):
                           lambda L: L.repack_on_device(weight))
         if bias is not None:
             layer.shift[:layer.cout] = bias.detach()
-        y = layer(xp)
+        if skip is not None:
+            # y = conv(x) + skip, or + the bilinear x2 (align_corners) of a half-resolution skip, in the kernel's epilogue:
+            # the FPN's top-down sums (mvs4net_utils.py:488-496) without materialising the up-sampled 64-channel map
+            from .conv_plan import SKIP_ADD, SKIP_UPSAMPLE_ADD
+            y = layer(xp, skip=skip.contiguous(), skip_mode=SKIP_UPSAMPLE_ADD if skip_upsample else SKIP_ADD)
+        else:
+            y = layer(xp)
+        ctx.has_skip = (skip is not None, skip_upsample)
         ctx.save_for_backward(xp, weight, bias)
         ctx.cfg = (stride, padding, transposed, cin)
         return y
@@ -140,14 +147,21 @@ class _ConvCL(torch.autograd.Function):
                 gw = gw.squeeze(2)
         if bias is not None and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 1, 2, 3))
-        return gx, gw, gb, None, None, None
+        gskip = None
+        if ctx.has_skip[0]:
+            gskip = gy
+            if ctx.has_skip[1]:       # adjoint of the bilinear x2 (gather form, no atomics)
+                B_, D_, H_, W_, C_ = gy.shape
+                gskip = ops.upsample2x_cl(gy.reshape(B_ * D_, H_, W_, C_), backward=True).reshape(B_, D_, H_ // 2, W_ // 2, C_)
+        return gx, gw, gb, None, None, None, gskip, None
 
 
-def conv_cl(x, weight, bias=None, stride=1, padding=0, transposed=False):
+def conv_cl(x, weight, bias=None, stride=1, padding=0, transposed=False, skip=None, skip_upsample=False):
     """x [B,D,H,W,Cin] channels-last -> [B,Do,Ho,Wo,Cout]; weight in nn.Conv3d / nn.Conv2d / nn.ConvTranspose3d
-    layout (a 4-D weight is a depth-1 convolution)."""
+    layout (a 4-D weight is a depth-1 convolution).  ``skip`` is added in the kernel's epilogue: a tensor of the output's
+    shape, or with ``skip_upsample`` a [B,1,Ho/2,Wo/2,Cout] map that is bilinearly up-sampled x2 (align_corners) on the fly."""
     lead_s, lead_p = 1, 0
-    return _ConvCL.apply(x, weight, bias, _triple(stride, lead_s), _triple(padding, lead_p), transposed)
+    return _ConvCL.apply(x, weight, bias, _triple(stride, lead_s), _triple(padding, lead_p), transposed, skip, skip_upsample)
 
 
 class _BnReluCL(torch.autograd.Function):
@@ -156,26 +170,31 @@ class _BnReluCL(torch.autograd.Function):
     inside a training graph), which do not depend on x."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pack, relu, groups, frozen):
+    def forward(ctx, x, weight, bias, pack, relu, groups, frozen, skip=None):
         ctx.save_for_backward(x, pack)
-        ctx.cfg = (relu, groups, frozen)
-        return ops.bn_relu_fwd(x, pack[3], pack[4], relu, groups)
+        ctx.cfg = (relu, groups, frozen, skip is not None)
+        return ops.bn_relu_fwd(x, pack[3], pack[4], relu, groups, skip=None if skip is None else skip.contiguous())
 
     @staticmethod
     def backward(ctx, gy):
         x, pack = ctx.saved_tensors
-        relu, groups, frozen = ctx.cfg
-        dx, dbeta, dgamma = ops.bn_relu_bwd(x, gy.contiguous(), pack[3], pack[4], pack[0], pack[2], relu, groups, frozen)
-        return dx, dgamma.sum(0), dbeta.sum(0), None, None, None, None
+        relu, groups, frozen, has_skip = ctx.cfg
+        gy = gy.contiguous()
+        dx, dbeta, dgamma = ops.bn_relu_bwd(x, gy, pack[3], pack[4], pack[0], pack[2], relu, groups, frozen)
+        gskip = gy if has_skip else None          # the skip connection's gradient is the output gradient itself
+        if groups == 1:           # [1, C] -> [C]: a view, not a reduction launch
+            return dx, dgamma[0], dbeta[0], None, None, None, None, gskip
+        return dx, dgamma.sum(0), dbeta.sum(0), None, None, None, None, gskip
 
 
-def batch_norm_cl(x, bn, relu=False, groups=1):
+def batch_norm_cl(x, bn, relu=False, groups=1, skip=None):
     """nn.BatchNorm2d / 3d (+ optional ReLU) on a channels-last tensor, on the fused gfx950 kernels (mvster_bn_*):
     batch statistics + running-stat update in training (torch semantics: biased variance to normalise, unbiased in the
     running average), running statistics when the module is in eval mode.  ``groups`` > 1: x holds that many equal
     slices along dim 0 (the views of one sample batch) which are normalised separately and update the running
     statistics one after the other, exactly as ``groups`` separate calls of the module would (the reference runs its
-    FPN once per view).  Gradients flow to x, gamma, beta.  Configurations the kernels do not cover raise."""
+    FPN once per view).  ``skip``: a tensor of x's shape added after the activation, in the same kernel (the U-Net's skip
+    connections).  Gradients flow to x, gamma, beta (and skip).  Configurations the kernels do not cover raise."""
     C = x.shape[-1]
     if not x.is_cuda:
         raise RuntimeError("batch_norm_cl: expected a GPU tensor (the HIP path has no CPU fallback)")
@@ -194,13 +213,13 @@ def batch_norm_cl(x, bn, relu=False, groups=1):
                                       bn.running_var if track else None, bn.eps, bn.momentum or 0.0, groups)
             if track:
                 bn.num_batches_tracked += groups
-        return _BnReluCL.apply(x, bn.weight, bn.bias, pack, relu, groups, False)
+        return _BnReluCL.apply(x, bn.weight, bn.bias, pack, relu, groups, False, skip)
     with torch.no_grad():            # [C]-sized parameter preparation, like weight packing
         rstd = torch.rsqrt(bn.running_var + bn.eps)
         scale = bn.weight * rstd
         pack = torch.stack([bn.running_mean, bn.running_var, rstd, scale, bn.bias - bn.running_mean * scale])
         pack = pack.unsqueeze(1).expand(5, groups, C).contiguous()
-    return _BnReluCL.apply(x, bn.weight, bn.bias, pack, relu, groups, True)
+    return _BnReluCL.apply(x, bn.weight, bn.bias, pack, relu, groups, True, skip)
 
 
 class _Upsample2xCL(torch.autograd.Function):
