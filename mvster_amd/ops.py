@@ -265,7 +265,12 @@ def conv_wgrad(x_cl, gy_cl, kernel, stride, padding):
         ngrp, width = ntaps, cip
     rows = B * Do * Ho
     slot_bytes = ngrp * cop * width * 4
-    nblk = max(1, min((rows + 3) // 4, (32 << 20) // slot_bytes, 1024))
+    # workgroups = slots of `partial` (summed by the caller: deterministic).  Measured on the config-4 step: 1024 slots
+    # 26.0 ms, 512 26.4 ms, 256 27.9 ms -- the kernels want the parallelism more than the reduction minds the size.
+    # MVSTER_WGRAD_NBLK overrides (experiments).
+    import os
+    cap = int(os.environ.get("MVSTER_WGRAD_NBLK", "1024"))
+    nblk = max(1, min((rows + 3) // 4, (32 << 20) // slot_bytes, cap))
     partial = torch.empty(nblk, ngrp, cop, width, device=x_cl.device, dtype=torch.float32)
     rc = _lib.load().mvster_conv_wgrad(_ptr(x_cl), _ptr(gy_cl), _ptr(partial), nblk, B, Di, Hi, Wi, CI, Do, Ho, Wo, CO,
                                        kd, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],

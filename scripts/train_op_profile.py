@@ -41,5 +41,5 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step()
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=60))
-print(prof.key_averages().table(sort_by="count", row_limit=30, max_name_column_width=60))
+print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=400, max_name_column_width=70))
+print(prof.key_averages().table(sort_by="count", row_limit=5, max_name_column_width=70))
