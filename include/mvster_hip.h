@@ -134,6 +134,13 @@ int mvster_deconv_small(const float* in, const float* w, const float* scale, con
 int mvster_fpn_tail_gather(const float* G, const float* vb, float* P, float* workspace, int NB, int H, int W,
                            int CO, void* stream);
 
+/* Lateral 1x1 conv + top-down add of one FPN level, for a top-down map that is only held at the coarser
+ * resolution (models/mvs4net_utils.py:485, after pushing the next level's 1x1 "tap" conv through it):
+ * out [NB,H,W,CO] = bias [CO] + A [CO,CI] x [NB,H,W,CI] + bilinear x2 align_corners upsample of q [NB,H/2,W/2,CO].
+ * (CI, CO) in {(16,72), (8,72)}. */
+int mvster_fpn_lateral_up(const float* x, const float* A, const float* bias, const float* q, float* out, int NB,
+                          int H, int W, int CI, int CO, void* stream);
+
 /* Packed-weight refresh on the device (training, once per layer and optimizer step): writes the fragment order
  * [K/16][N/16][64][4] that mvster_conv_mfma reads, Bm[tap*cin_pad + ci][n] = w[n*s_n + ci*s_c + kz*s_z + ky*s_y + kx*s_x]
  * (element strides of the parameter tensor; flip = 1 mirrors the taps: the input-gradient form of a stride-1 layer),
@@ -164,25 +171,30 @@ int mvster_conv_wgrad(const float* x, const float* gy, float* partial, int nblk,
  * x [groups*rows, C]: `groups` independent statistics groups of `rows` rows each (the reference normalises every
  * view's batch on its own, MVS4Net.py:65-68); scale = gamma * rstd, shift = beta - mean * scale, mean, rstd are
  * [groups, C] (batch statistics from the caller).
- *   stats:       partial[g][n][0][c] / [g][n][1][c] = workgroup n's share of sum d and sum d^2, d = x - x[first row of g]
- *                (mean = pivot + S1/rows, biased var = S2/rows - (S1/rows)^2, finished by the caller)
+ *   stats:       per-workgroup slots partial[g][n][0][c] / [g][n][1][c] = sum d and sum d^2, d = x - x[first row of g];
+ *                a finishing kernel adds the slots in order (fp64) and writes out [5][groups][C] = mean, biased var, rstd,
+ *                scale, shift; running_mean / running_var (optional) get the groups' exponential-average updates in
+ *                order (momentum, unbiased variance) and num_batches_tracked (optional, device int64) += groups --
+ *                what `groups` sequential nn.BatchNorm calls would do
  *   fwd:         y = relu(x*scale + shift) (+ skip)                      (relu = 0: affine only; skip optional: the U-Net's
  *                same-shape skip connection, added after the activation, models/mvs4net_utils.py:893-895)
- *   bwd_reduce:  partial[g][n][0][c] / [g][n][1][c] = workgroup n's share of sum g_ and sum g_*xh, n < mvster_bn_blocks()
- *   bwd_apply:   dx = scale * (g_ - sums[g][0]/rows - xh * sums[g][1]/rows),   g_ = gy * (y > 0), xh = (x - mean) * rstd */
+ *   bwd_reduce:  slots as above of sum g_ and sum g_*xh; the finishing kernel writes sums [groups][2][C] and the parameter
+ *                gradients dbeta [C] = sum_g sum g_, dgamma [C] = sum_g sum g_*xh
+ *   bwd_apply:   dx = scale * (g_ - sums[g][0]/rows - xh * sums[g][1]/rows),   g_ = gy * (y > 0), xh = (x - mean) * rstd;
+ *                frozen = 1 (statistics are constants): dx = scale * g_
+ * partial: [groups][mvster_bn_slots(rows, C, groups)][2][C] floats of scratch. */
 int mvster_bn_relu_fwd(const float* x, const float* scale, const float* shift, const float* skip, float* y, long rows,
                        int C, int relu, int groups, void* stream);
-int mvster_bn_blocks(long rows, int C);
-int mvster_bn_stats(const float* x, float* partial, long rows, int C, int groups, void* stream);
-/* finalize: out [5][groups][C] = mean, biased var, rstd, scale, shift from the partial sums; running_mean / running_var
- * (optional) get the groups' exponential-average updates in order (momentum, unbiased variance) */
-int mvster_bn_finalize(const float* partial, const float* x, const float* weight, const float* bias, float* running_mean,
-                       float* running_var, float* out, long rows, int C, int groups, float eps, float momentum, void* stream);
+int mvster_bn_slots(long rows, int C, int groups);
+int mvster_bn_stats(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
+                    long* num_batches_tracked, float* partial, float* out, long rows, int C, int groups, float eps,
+                    float momentum, void* stream);
 int mvster_bn_relu_bwd_reduce(const float* x, const float* gy, const float* scale, const float* shift, const float* mean,
-                              const float* rstd, float* partial, long rows, int C, int relu, int groups, void* stream);
+                              const float* rstd, float* partial, float* sums, float* dgamma, float* dbeta, long rows, int C,
+                              int relu, int groups, void* stream);
 int mvster_bn_relu_bwd_apply(const float* x, const float* gy, const float* scale, const float* shift, const float* mean,
                              const float* rstd, const float* sums, float* dx, long rows, int C, int relu, int groups,
-                             void* stream);
+                             int frozen, void* stream);
 
 /* Bilinear x2 up-sampling (align_corners=True) of a channels-last map, in [B,h,w,C] -> out [B,2h,2w,C], and its
  * adjoint gout [B,2h,2w,C] -> gin [B,h,w,C] as a gather (no atomics): the FPN top-down path in training

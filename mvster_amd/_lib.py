@@ -32,15 +32,15 @@ SIGNATURES = {
     "mvster_conv_small": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f],
     "mvster_deconv_small": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f],
     "mvster_fpn_tail_gather": [_f, _f, _f, _f, _i, _i, _i, _i, _f],
+    "mvster_fpn_lateral_up": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f],
     "mvster_pack_conv_weights": [_f, _f] + [_i] * 6 + [_l] * 5 + [_i, _f],
     "mvster_pack_conv_weights_classes": [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f],
     "mvster_conv_wgrad": [_f, _f, _f] + [_i] * 20 + [_f],
     "mvster_bn_relu_fwd": [_f, _f, _f, _f, _f, _l, _i, _i, _i, _f],
-    "mvster_bn_blocks": [_l, _i],
-    "mvster_bn_stats": [_f, _f, _l, _i, _i, _f],
-    "mvster_bn_finalize": [_f] * 7 + [_l, _i, _i, _fl, _fl, _f],
-    "mvster_bn_relu_bwd_reduce": [_f] * 7 + [_l, _i, _i, _i, _f],
-    "mvster_bn_relu_bwd_apply": [_f] * 8 + [_l, _i, _i, _i, _f],
+    "mvster_bn_slots": [_l, _i, _i],
+    "mvster_bn_stats": [_f] * 8 + [_l, _i, _i, _fl, _fl, _f],
+    "mvster_bn_relu_bwd_reduce": [_f] * 10 + [_l, _i, _i, _i, _f],
+    "mvster_bn_relu_bwd_apply": [_f] * 8 + [_l, _i, _i, _i, _i, _f],
     "mvster_upsample2x_cl_fwd": [_f, _f, _i, _i, _i, _i, _f],
     "mvster_upsample2x_cl_bwd": [_f, _f, _i, _i, _i, _i, _f],
     "mvster_upsample2x_nearest_cl": [_f, _f, _i, _i, _i, _i, _i, _f],

@@ -90,7 +90,7 @@ def _lds_plan(B, Do, Ho, Wo, kernel, stride, ntile_total):
 def _tiles(M, ntile_total, nclass):
     """(MT, NT): biggest register tile that still fills the chip (>= 2048 waves), else the most waves."""
     best = None
-    for nt in (5, 4, 2, 1):
+    for nt in (5, 4, 3, 2, 1):
         if nt > ntile_total or ntile_total % nt:
             continue
         for mt in (4, 2, 1):
@@ -510,24 +510,38 @@ class FpnPlan:
         self.conv1 = [_cbr2d(l) for l in m.conv1]
         self.conv2 = [_cbr2d(l) for l in m.conv2]
         self.conv3 = [_cbr2d(l) for l in m.conv3]
-        self.inner1, self.inner2 = _plain2d(m.inner1), _plain2d(m.inner2)
-        self.out1, self.out2, self.out3 = _plain2d(m.out1), _plain2d(m.out2), _plain2d(m.out3)
-        # Last level, re-associated so that the full-resolution 64-channel map
-        #   f3 = F.interpolate(f2) + inner3(c0)            (419 MB at 5 x 512 x 640)
-        # is never formed.  out4 is linear and interpolation acts per channel, hence
-        #   out4(f3)[p] = sum_tap up(W4[tap] f2)[p+tap] + sum_tap W4[tap] (W3 c0[p+tap] + b3)
-        # = gather-sum of G = (1x1 conv 64 -> 9*8 of f2 at HALF resolution)   [tail_g + fpn_tail_gather]
-        # + 3x3 conv 8 -> 8 of c0 with composed weights W4[tap] @ W3          [tail_c, skip-add]
-        # + the bias pushed through the in-bounds taps                         [tail_vb]
-        w4 = m.out4.weight.detach().double()                    # [8, 64, 3, 3]
+        self.inner1 = _plain2d(m.inner1)
+        self.out1, self.out2 = _plain2d(m.out1), _plain2d(m.out2)
+        # The two fine levels, re-associated so that neither top-down map
+        #   f2 = F.interpolate(f1) + inner2(c1)            (105 MB at 5 x 512 x 640, half resolution)
+        #   f3 = F.interpolate(f2) + inner3(c0)            (419 MB, full resolution)
+        # is ever formed.  The output convs are linear and interpolation acts per channel, hence for level L
+        #   outL(f)[p] = sum_tap up(WL[tap] f_coarser)[p+tap] + sum_tap WL[tap] (Wi c[p+tap] + bi)
+        # = gather-sum of G = (1x1 conv 64 -> 9*co of the coarser map, at ITS resolution)  [*_g + fpn_tail_gather]
+        # + 3x3 conv of the bottom-up map c with composed weights WL[tap] @ Wi               [*_c, skip-add]
+        # + the bias pushed through the in-bounds taps                                        [*_vb]
+        # Level 4 needs G4 = Wg4 f2 at half resolution; f2 itself is a sum, so
+        #   G4 = up(Wg4 f1) + (Wg4 W2) c1 + Wg4 b2         [tail_g at QUARTER resolution + fpn_lateral_up]
+        w2 = m.inner2.weight.detach().double()[:, :, 0, 0]      # [64, 16]
+        b2 = m.inner2.bias.detach().double()                    # [64]
+        self.mid_g, self.mid_c, self.mid_vb, _ = self._reassociate(m.out3, w2, b2)
         w3 = m.inner3.weight.detach().double()[:, :, 0, 0]      # [64, 8]
         b3 = m.inner3.bias.detach().double()                    # [64]
-        co = w4.shape[0]
-        wg = w4.permute(2, 3, 0, 1).reshape(9 * co, w4.shape[1], 1, 1)           # row = tap*co + co_idx
-        wc = torch.einsum("ocyx,ci->oiyx", w4, w3)                               # [8, 8, 3, 3]
-        self.tail_g = ConvLayer(wg.float(), False, (1, 1), (0, 0))
-        self.tail_c = ConvLayer(wc.float(), False, (1, 1), (1, 1))
-        self.tail_vb = torch.einsum("ocyx,c->yxo", w4, b3).reshape(9, co).float().contiguous()
+        self.tail_g, self.tail_c, self.tail_vb, wg4 = self._reassociate(m.out4, w3, b3)      # wg4 [72, 64], fp64
+        self.tail_a = (wg4 @ w2).float().contiguous()           # [72, 16]   [ops.fpn_lateral_up]
+        self.tail_ab = (wg4 @ b2).float().contiguous()
+
+    @staticmethod
+    def _reassociate(out, wi, bi):
+        """out: the level's 3x3 output conv; wi [64, cin], bi [64]: the lateral 1x1 conv -> (g, c, vb, g's fp64 matrix)."""
+        wo = out.weight.detach().double()                                        # [co, 64, 3, 3]
+        co = wo.shape[0]
+        wg = wo.permute(2, 3, 0, 1).reshape(9 * co, wo.shape[1])                 # row = tap*co + co_idx
+        wc = torch.einsum("ocyx,ci->oiyx", wo, wi)                               # [co, cin, 3, 3]
+        g = ConvLayer(wg.float().reshape(9 * co, wo.shape[1], 1, 1), False, (1, 1), (0, 0))
+        c = ConvLayer(wc.float(), False, (1, 1), (1, 1), bias=out.bias)
+        vb = torch.einsum("ocyx,c->yxo", wo, bi).reshape(9, co).float().contiguous()
+        return g, c, vb, wg
 
     @staticmethod
     def _seq(layers, x):
@@ -556,11 +570,12 @@ class FpnPlan:
     def tail(self, c0, c1, f1):
         """The two fine levels (needed from stage 3 on); independent of the coarse outputs and of cascade
         stages 1-2, so the model runs it on a second HIP stream underneath them."""
-        f2 = self.inner2(c1, skip=f1, skip_mode=SKIP_UPSAMPLE_ADD)
-        o3 = self.out3(f2)
         H, W = c0.shape[2], c0.shape[3]
-        partial = ops.fpn_tail_gather(self.tail_g(f2), self.tail_vb, H, W)
-        o4 = self.tail_c(c0, skip=partial, skip_mode=SKIP_ADD)
+        p3 = ops.fpn_tail_gather(self.mid_g(f1), self.mid_vb, H // 2, W // 2)
+        o3 = self.mid_c(c1, skip=p3, skip_mode=SKIP_ADD)
+        g4 = ops.fpn_lateral_up(c1, self.tail_a, self.tail_ab, self.tail_g(f1))
+        p4 = ops.fpn_tail_gather(g4, self.tail_vb, H, W)
+        o4 = self.tail_c(c0, skip=p4, skip_mode=SKIP_ADD)
         return o3, o4
 
     def __call__(self, x):

@@ -8,7 +8,10 @@
 //   dbeta = sum g     dgamma = sum g * xh         dx = scale * (g - dbeta/N - xh * dgamma/N)
 // Every thread owns one float4 column group (blockDim*4 is a multiple of C), so per-channel sums stay in
 // registers along the grid-stride loop and are reduced once per workgroup through LDS into a per-workgroup
-// slot of `partial` [nblk][2][C]; the host adds the slots (deterministic).
+// slot of `partial` [groups][nblk][2][C].  A small second kernel adds the slots in a fixed order and in fp64
+// (deterministic) and writes the finished statistics / sums.  (Finishing in the last workgroup of the first kernel
+// instead -- a ticket counter -- needs an agent-scope fence per workgroup, which on gfx950 writes the XCD's L2 back:
+// measured +5 ms per training step.)
 #include "common.hpp"
 
 namespace {
@@ -48,7 +51,7 @@ __global__ void __launch_bounds__(256) bn_relu_fwd_kernel(const float* __restric
 
 // Batch statistics, one pass: per (group, channel) sums of (x - p) and (x - p)^2 with the pivot p = the group's
 // first row (keeps the E[d^2] - E[d]^2 subtraction well conditioned whatever the channel's mean is).  Same thread
-// mapping and per-workgroup partial slots as the backward reduction; the host finishes in fp64.
+// mapping and per-workgroup partial slots as the backward reduction.
 __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__ x, float* __restrict__ partial, long n4, int C) {
     __shared__ float red[256][8];
     x += (long)blockIdx.y * n4 * 4;
@@ -79,53 +82,80 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__
     }
 }
 
-// Finish the statistics on the device (two launches instead of ~20 tiny tensor ops per BatchNorm call): reduce the
-// per-workgroup partial sums in fp64 and form mean / biased variance / rstd / scale / shift per (group, channel)
-// [bn_finalize_kernel, one workgroup of 1024 threads per group: thread t owns channel t % C and every (1024 / C)-th
-// partial slot], then apply the running-average updates of the groups one after the other (what `groups` sequential
-// module calls would do) [bn_running_kernel, one thread per channel].
-__global__ void __launch_bounds__(1024) bn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ x,
-                                                           const float* __restrict__ weight, const float* __restrict__ bias,
-                                                           float* __restrict__ out, long rows, int C, int groups, int nblk,
-                                                           float eps) {
-    __shared__ double red[2][1024];
-    const int g = blockIdx.x;
-    const int c = threadIdx.x % C, sl = threadIdx.x / C, nsl = 1024 / C;
-    const float* pg = partial + (long)g * nblk * 2 * C;
-    double s1 = 0.0, s2 = 0.0;
-    for (int n = sl; n < nblk; n += nsl) {
-        s1 += (double)pg[((long)n * 2 + 0) * C + c];
-        s2 += (double)pg[((long)n * 2 + 1) * C + c];
-    }
-    red[0][threadIdx.x] = s1;
-    red[1][threadIdx.x] = s2;
+// The finishing kernels: workgroup b owns channels 4b..4b+3 (8 columns: both slot rows), 128 threads per column
+// strided over the slots, fp64, LDS tree; the groups are walked one after the other so that whatever depends on their
+// order -- the running averages, the sums over the groups -- is formed in registers by the column's first thread.
+constexpr int kFinishLanes = 128;
+
+__device__ __forceinline__ double column_sum(const float* __restrict__ pg, int nblk, int C, double* red) {
+    const int col = threadIdx.x & 7, lane = threadIdx.x >> 3;
+    const int off = (col >> 2) * C + blockIdx.x * 4 + (col & 3);
+    double s = 0.0;
+    for (int n = lane; n < nblk; n += kFinishLanes) s += (double)pg[(long)n * 2 * C + off];
+    __syncthreads();                       // (red is reused from group to group)
+    red[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x < C) {
-        for (int j = 1; j < nsl; ++j) { s1 += red[0][j * C + c]; s2 += red[1][j * C + c]; }
-        const double m1 = s1 / (double)rows, m2 = s2 / (double)rows;
-        const float mean = x[(long)g * rows * C + c] + (float)m1;
-        float var = (float)(m2 - m1 * m1);
-        var = var > 0.0f ? var : 0.0f;
-        const float rstd = 1.0f / sqrtf(var + eps);
-        const float scale = weight[c] * rstd;
-        float* o = out + (long)g * C + c;
-        const long gs = (long)groups * C;
-        o[0] = mean; o[gs] = var; o[2 * gs] = rstd; o[3 * gs] = scale; o[4 * gs] = bias[c] - mean * scale;
+    for (int w = kFinishLanes / 2; w > 0; w >>= 1) {
+        if (lane < w) red[threadIdx.x] += red[threadIdx.x + w * 8];
+        __syncthreads();
     }
+    return red[col];                       // every thread gets its column's total
 }
 
-__global__ void bn_running_kernel(const float* __restrict__ out, float* __restrict__ running_mean,
-                                  float* __restrict__ running_var, long rows, int C, int groups, float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float unbias = (float)rows / (float)(rows > 1 ? rows - 1 : 1);
-    float rm = running_mean[c], rv = running_var[c];
-    for (int g = 0; g < groups; ++g) {
-        rm = (1.0f - momentum) * rm + momentum * out[(long)g * C + c];
-        rv = (1.0f - momentum) * rv + momentum * (out[((long)groups + g) * C + c] * unbias);
+// Statistics: out [5][groups][C] = mean, biased variance, rstd, scale, shift; then the running-average updates of the
+// groups one after the other (what `groups` sequential module calls would do: momentum, unbiased variance) and
+// num_batches_tracked += groups.
+struct BnFinalizeArgs {
+    const float* partial; const float* x; const float* weight; const float* bias;
+    float* running_mean; float* running_var; long* num_batches_tracked; float* out;
+    long rows; int C, groups, nblk; float eps, momentum;
+};
+
+__global__ void __launch_bounds__(kFinishLanes * 8) bn_finalize_kernel(BnFinalizeArgs a) {
+    __shared__ double red[kFinishLanes * 8];
+    __shared__ double tot[8];
+    const int C = a.C, c = blockIdx.x * 4 + (threadIdx.x & 3);
+    const bool owner = threadIdx.x < 4, running = a.running_mean != nullptr;
+    const float unbias = (float)a.rows / (float)(a.rows > 1 ? a.rows - 1 : 1);
+    float rm = 0.0f, rv = 0.0f;
+    if (owner && running) { rm = a.running_mean[c]; rv = a.running_var[c]; }
+    for (int g = 0; g < a.groups; ++g) {
+        const double t = column_sum(a.partial + (long)g * a.nblk * 2 * C, a.nblk, C, red);
+        if (threadIdx.x < 8) tot[threadIdx.x] = t;
+        __syncthreads();
+        if (owner) {
+            const double m1 = tot[threadIdx.x] / (double)a.rows, m2 = tot[4 + threadIdx.x] / (double)a.rows;
+            const float mean = a.x[(long)g * a.rows * C + c] + (float)m1;
+            float var = (float)(m2 - m1 * m1);
+            var = var > 0.0f ? var : 0.0f;
+            const float rstd = 1.0f / sqrtf(var + a.eps);
+            const float scale = a.weight[c] * rstd;
+            float* o = a.out + (long)g * C + c;
+            const long gs = (long)a.groups * C;
+            o[0] = mean; o[gs] = var; o[2 * gs] = rstd; o[3 * gs] = scale; o[4 * gs] = a.bias[c] - mean * scale;
+            rm = (1.0f - a.momentum) * rm + a.momentum * mean;
+            rv = (1.0f - a.momentum) * rv + a.momentum * (var * unbias);
+        }
     }
-    running_mean[c] = rm;
-    running_var[c] = rv;
+    if (owner && running) { a.running_mean[c] = rm; a.running_var[c] = rv; }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.num_batches_tracked) *a.num_batches_tracked += a.groups;
+}
+
+// Backward sums: sums [groups][2][C] for the apply kernel and the parameter gradients summed over the groups,
+// dbeta [C] = sum_g sum g_, dgamma [C] = sum_g sum g_*xh.
+__global__ void __launch_bounds__(kFinishLanes * 8) bn_bwd_finish_kernel(const float* __restrict__ partial,
+                                                                         float* __restrict__ sums, float* __restrict__ dgamma,
+                                                                         float* __restrict__ dbeta, int C, int groups, int nblk) {
+    __shared__ double red[kFinishLanes * 8];
+    const int col = threadIdx.x & 7, c = blockIdx.x * 4 + (col & 3);
+    double total = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        const double t = column_sum(partial + (long)g * nblk * 2 * C, nblk, C, red);
+        if (threadIdx.x < 8) sums[((long)g * 2 + (col >> 2)) * C + c] = (float)t;
+        total += t;
+    }
+    if (threadIdx.x < 4) dbeta[c] = (float)total;
+    else if (threadIdx.x < 8) dgamma[c] = (float)total;
 }
 
 __global__ void __launch_bounds__(256) bn_relu_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ gy,
@@ -201,6 +231,16 @@ int check(long rows, int C) {
     return MVSTER_OK;
 }
 
+// Slots per group of `partial` for the two reductions: enough workgroups to stream at full rate, few enough that the
+// finishing kernel adds them up in a few microseconds.
+int slots_for(long rows, int C, int groups) {
+    const long n4 = rows * (C / 4);
+    long n = (n4 + 255) / 256;
+    const long cap = groups > 1 ? 512 : 1024;
+    if (n > cap) n = cap;
+    return (int)(n < 1 ? 1 : n);
+}
+
 int blocks_for(long n4) {
     const long want = (n4 + 255) / 256;
     return (int)(want < 2048 ? want : 2048);
@@ -220,63 +260,58 @@ extern "C" int mvster_bn_relu_fwd(const float* x, const float* scale, const floa
     return mv_check_launch();
 }
 
-// partial [nblk][2][C]; nblk is returned by mvster_bn_blocks(rows, C)
-extern "C" int mvster_bn_blocks(long rows, int C) {
-    if (check(rows, C)) return 0;
-    return blocks_for(rows * (C / 4));
-}
-
-// partial [groups][nblk][2][C]: sums of (x - x[first row of the group]) and of its square
-extern "C" int mvster_bn_stats(const float* x, float* partial, long rows, int C, int groups, void* stream) {
-    if (!x || !partial) return MVSTER_ERR_NULL;
-    if (int rc = check(rows, C)) return rc;
-    if (groups < 1 || groups > 65535) return MVSTER_ERR_SHAPE;
-    const long n4 = rows * (C / 4);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks_for(n4), groups), dim3(256), 0, (hipStream_t)stream, x, partial, n4, C);
-    return mv_check_launch();
+// partial [groups][mvster_bn_slots(rows, C, groups)][2][C] floats (scratch of stats and bwd_reduce)
+extern "C" int mvster_bn_slots(long rows, int C, int groups) {
+    if (check(rows, C) || groups < 1 || groups > 65535) return 0;
+    return slots_for(rows, C, groups);
 }
 
 // out [5][groups][C] = mean, biased var, rstd, scale = gamma*rstd, shift = beta - mean*scale; running_mean / running_var
-// (optional, [C]) receive the `groups` exponential-average updates in group order (unbiased variance, torch semantics).
-// partial as written by mvster_bn_stats with nblk = mvster_bn_blocks(rows, C).
-extern "C" int mvster_bn_finalize(const float* partial, const float* x, const float* weight, const float* bias,
-                                  float* running_mean, float* running_var, float* out, long rows, int C, int groups, float eps,
-                                  float momentum, void* stream) {
-    if (!partial || !x || !weight || !bias || !out) return MVSTER_ERR_NULL;
+// (optional, [C]) receive the `groups` exponential-average updates in group order (unbiased variance, torch semantics)
+// and num_batches_tracked (optional, int64 on the device) += groups.  Two launches.
+extern "C" int mvster_bn_stats(const float* x, const float* weight, const float* bias, float* running_mean,
+                               float* running_var, long* num_batches_tracked, float* partial, float* out, long rows, int C,
+                               int groups, float eps, float momentum, void* stream) {
+    if (!x || !weight || !bias || !partial || !out) return MVSTER_ERR_NULL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MVSTER_ERR_NULL;
     if (int rc = check(rows, C)) return rc;
     if (groups < 1 || groups > 65535) return MVSTER_ERR_SHAPE;
-    const int nblk = blocks_for(rows * (C / 4));
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(groups), dim3(1024), 0, (hipStream_t)stream, partial, x, weight, bias, out, rows,
-                       C, groups, nblk, eps);
-    if (running_mean)
-        hipLaunchKernelGGL(bn_running_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out, running_mean, running_var, rows, C,
-                           groups, momentum);
+    const int nblk = slots_for(rows, C, groups);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk, groups), dim3(256), 0, s, x, partial, rows * (C / 4), C);
+    BnFinalizeArgs a{partial, x, weight, bias, running_mean, running_var, num_batches_tracked, out,
+                     rows, C, groups, nblk, eps, momentum};
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 4), dim3(kFinishLanes * 8), 0, s, a);
     return mv_check_launch();
 }
 
-// partial [groups][nblk][2][C]
+// sums [groups][2][C] (for bwd_apply), dgamma [C], dbeta [C]; partial as for mvster_bn_stats.  Two launches.
 extern "C" int mvster_bn_relu_bwd_reduce(const float* x, const float* gy, const float* scale, const float* shift,
-                                         const float* mean, const float* rstd, float* partial, long rows, int C, int relu,
-                                         int groups, void* stream) {
-    if (!x || !gy || !scale || !shift || !mean || !rstd || !partial) return MVSTER_ERR_NULL;
+                                         const float* mean, const float* rstd, float* partial, float* sums, float* dgamma,
+                                         float* dbeta, long rows, int C, int relu, int groups, void* stream) {
+    if (!x || !gy || !scale || !shift || !mean || !rstd || !partial || !sums || !dgamma || !dbeta) return MVSTER_ERR_NULL;
     if (int rc = check(rows, C)) return rc;
     if (groups < 1 || groups > 65535) return MVSTER_ERR_SHAPE;
     const long n4 = rows * (C / 4);
-    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(blocks_for(n4), groups), dim3(256), 0, (hipStream_t)stream, x, gy, scale,
-                       shift, mean, rstd, partial, n4, C, relu);
+    const int nblk = slots_for(rows, C, groups);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(nblk, groups), dim3(256), 0, s, x, gy, scale, shift, mean, rstd, partial,
+                       n4, C, relu);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(C / 4), dim3(kFinishLanes * 8), 0, s, partial, sums, dgamma, dbeta, C, groups,
+                       nblk);
     return mv_check_launch();
 }
 
-// sums [groups][2][C] = (sum g, sum g*xh) over the group's rows; dx [groups*rows, C]
+// sums [groups][2][C] = (sum g, sum g*xh) over the group's rows; dx [groups*rows, C].  frozen = 1: mean / rstd are
+// constants (running statistics of a BatchNorm in eval mode), so dx = g * scale and the sums are not applied.
 extern "C" int mvster_bn_relu_bwd_apply(const float* x, const float* gy, const float* scale, const float* shift,
                                         const float* mean, const float* rstd, const float* sums, float* dx, long rows, int C,
-                                        int relu, int groups, void* stream) {
+                                        int relu, int groups, int frozen, void* stream) {
     if (!x || !gy || !scale || !shift || !mean || !rstd || !sums || !dx) return MVSTER_ERR_NULL;
     if (int rc = check(rows, C)) return rc;
     if (groups < 1 || groups > 65535) return MVSTER_ERR_SHAPE;
     const long n4 = rows * (C / 4);
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(blocks_for(n4), groups), dim3(256), 0, (hipStream_t)stream, x, gy, scale,
-                       shift, mean, rstd, sums, dx, n4, C, relu, 1.0f / (float)rows);
+                       shift, mean, rstd, sums, dx, n4, C, relu, frozen ? 0.0f : 1.0f / (float)rows);
     return mv_check_launch();
 }

@@ -344,8 +344,9 @@ int dispatch_tiles(const ConvArgs& a, int MT, int NT, bool splitk, hipStream_t s
     }
 #define MV_T(M_, N_) if (MT == M_ && NT == N_) return launch<CIN, M_, N_, false>(a, s);
     MV_T(1, 1) MV_T(2, 1) MV_T(4, 1) MV_T(1, 2) MV_T(2, 2) MV_T(4, 2) MV_T(1, 4) MV_T(2, 4) MV_T(4, 4)
-    if constexpr (CIN == 64) {   // 72 = 9 x 8 output channels of the re-associated FPN tail (5 N tiles)
+    if constexpr (CIN == 64) {   // 72 = 9 x 8 and 144 = 9 x 16 output channels of the re-associated FPN levels
         MV_T(1, 5) MV_T(2, 5) MV_T(4, 5)
+        MV_T(1, 3) MV_T(2, 3) MV_T(4, 3) MV_T(1, 9) MV_T(2, 9)
     }
 #undef MV_T
     return MVSTER_ERR_UNSUPPORTED;

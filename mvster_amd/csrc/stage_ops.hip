@@ -151,14 +151,18 @@ __global__ void fpn_tail_gather_kernel(const float* __restrict__ G, const float*
 // formed once per pixel and applied to channel pairs with v_pk_fma_f32 (3x fewer instructions than
 // nine bilerp() trees per channel); taps outside the image get zero weights instead of a branch, and the
 // bias pushed through the in-bounds taps depends only on the pixel's border class (9 sums, built in LDS).
-template <int CO>
+// COT = total output channels; a workgroup does 8 of them (blockIdx.y picks which), so CO = 16 keeps the same patch size.
+template <int COT>
 __global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* __restrict__ G,
                                                                   const float* __restrict__ vb,
                                                                   float* __restrict__ P, int NB, int H, int W,
                                                                   int tiles_x, int tiles_y) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    constexpr int CG = 9 * CO, Q = CG / 4;     // float4 per half-resolution pixel
+    constexpr int CO = 8;
+    constexpr int CGT = 9 * COT;               // channels of G per half-resolution pixel
+    constexpr int CG = 9 * CO, Q = CG / 4;     // float4 of them staged per pixel (this workgroup's 8 outputs x 9 taps)
     constexpr int PR = 8, PC = 20;             // patch capacity (rows, cols)
+    const int cbase = blockIdx.y * CO;
     __shared__ f32x4 patch[PR * PC * Q];
     __shared__ float vbsum[9][CO];             // [3*yclass + xclass][c]: sum of vb over the in-bounds taps
     const int Hh = H / 2, Wh = W / 2;
@@ -172,11 +176,11 @@ __global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* _
     const int r0 = mv::make_lerp(ylo, Hh, H).i0, r1 = mv::make_lerp(yhi, Hh, H).i1;
     const int c0 = mv::make_lerp(xlo, Wh, W).i0, c1 = mv::make_lerp(xhi, Wh, W).i1;
     const int nr = r1 - r0 + 1, nc = c1 - c0 + 1;       // <= PR, <= PC
-    const float* g = G + (long)b * Hh * Wh * CG;
+    const float* g = G + (long)b * Hh * Wh * CGT + cbase;
     for (int i = threadIdx.x; i < nr * nc * Q; i += 256) {
         const int q = i % Q, pix = i / Q;
         const int pc = pix % nc, pr = pix / nc;
-        patch[(pr * PC + pc) * Q + q] = ld4(g + ((long)(r0 + pr) * Wh + (c0 + pc)) * CG + q * 4);
+        patch[(pr * PC + pc) * Q + q] = ld4(g + ((long)(r0 + pr) * Wh + (c0 + pc)) * CGT + (q >> 1) * COT + (q & 1) * 4);
     }
     if (threadIdx.x < 9 * CO) {
         const int cls = threadIdx.x / CO, c = threadIdx.x % CO;
@@ -185,7 +189,7 @@ __global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* _
         for (int ky = 0; ky < 3; ++ky)
             for (int kx = 0; kx < 3; ++kx) {
                 const bool in = !(yc == 0 && ky == 0) && !(yc == 2 && ky == 2) && !(xc == 0 && kx == 0) && !(xc == 2 && kx == 2);
-                if (in) sacc += vb[(ky * 3 + kx) * CO + c];
+                if (in) sacc += vb[(ky * 3 + kx) * COT + cbase + c];
             }
         vbsum[cls][c] = sacc;
     }
@@ -235,9 +239,75 @@ __global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* _
             }
         }
     }
-    float* o = P + (((long)b * H + y) * W + x) * CO;
+    float* o = P + (((long)b * H + y) * W + x) * COT + cbase;
 #pragma unroll
     for (int c = 0; c < CO; c += 4) st4(o + c, (f32x4){acc[c / 2][0], acc[c / 2][1], acc[c / 2 + 1][0], acc[c / 2 + 1][1]});
+}
+
+// Lateral 1x1 conv + top-down add of the FPN (models/mvs4net_utils.py:485) for a top-down map that only exists at
+// the coarser level:   out[p][co] = bias[co] + sum_ci A[co][ci] x[p][ci] + up2(q)[p][co]
+// with x [NB,H,W,CI] the bottom-up map, q [NB,H/2,W/2,CO] and up2 = the reference's x2 align_corners interpolation.
+// K = CI = 16 is one MFMA step, so the GEMM form is all epilogue (4-byte corner gathers per accumulator element:
+// 127 us at 5 x 256 x 320 x 72), and a thread-per-pixel form reads and writes 16-byte slices 288 bytes apart, which
+// thrashes the 32 KB L1 (122 us).  Here a thread owns one float4 of output channels (its 4 x CI weights stay in
+// registers) and consecutive threads consecutive channels, so every corner read and every store of a wavefront is a
+// contiguous run of whole cache lines; a workgroup of (CO/4) x 14 threads walks 14 pixels at a time.
+constexpr int kLateralSlots = 14, kLateralIters = 16, kLateralPix = 1;   // 18 x 14 = 252 threads
+
+template <int CI, int CO>
+__global__ void __launch_bounds__(CO / 4 * kLateralSlots)
+fpn_lateral_up_kernel(const float* __restrict__ x, const float* __restrict__ A, const float* __restrict__ bias,
+                      const float* __restrict__ q, float* __restrict__ out, int H, int W) {
+    constexpr int NCH = CO / 4;
+    const int chunk = threadIdx.x % NCH, slot = threadIdx.x / NCH;
+    const int b = blockIdx.y;
+    const int Hh = H / 2, Wh = W / 2;
+    float a[4][CI];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < CI; c += 4) {
+            const f32x4 v = ld4(A + (chunk * 4 + j) * CI + c);
+            a[j][c] = v[0]; a[j][c + 1] = v[1]; a[j][c + 2] = v[2]; a[j][c + 3] = v[3];
+        }
+    const f32x4 bv = ld4(bias + chunk * 4);
+    const float* qb = q + (long)b * Hh * Wh * CO + chunk * 4;
+    const int base = xcd_remap(blockIdx.x, gridDim.x) * (kLateralSlots * kLateralIters);
+    // kLateralPix pixels per trip, all their loads issued first (measured: 1 -> 54 us, 2 -> 59 us, 4 -> 59 us; the
+    // kernel moves 173 MB, i.e. 3.2 TB/s, like the MFMA layers that write a tensor of this size)
+    for (int it = 0; it < kLateralIters; it += kLateralPix) {
+        mv::Lerp ly[kLateralPix], lx[kLateralPix];
+        f32x4 xv[kLateralPix][CI / 4], q00[kLateralPix], q01[kLateralPix], q10[kLateralPix], q11[kLateralPix];
+        int pp[kLateralPix];
+#pragma unroll
+        for (int u = 0; u < kLateralPix; ++u) {
+            const int p = base + (it + u) * kLateralSlots + slot;
+            pp[u] = p;
+            const int pc = min(p, H * W - 1);
+            const int y = pc / W, xx = pc - y * W;
+            ly[u] = mv::make_lerp(y, Hh, H);
+            lx[u] = mv::make_lerp(xx, Wh, W);
+            const float* xp = x + ((long)b * H * W + pc) * CI;
+#pragma unroll
+            for (int c = 0; c < CI / 4; ++c) xv[u][c] = ld4(xp + 4 * c);
+            q00[u] = ld4(qb + ((long)ly[u].i0 * Wh + lx[u].i0) * CO);
+            q01[u] = ld4(qb + ((long)ly[u].i0 * Wh + lx[u].i1) * CO);
+            q10[u] = ld4(qb + ((long)ly[u].i1 * Wh + lx[u].i0) * CO);
+            q11[u] = ld4(qb + ((long)ly[u].i1 * Wh + lx[u].i1) * CO);
+        }
+#pragma unroll
+        for (int u = 0; u < kLateralPix; ++u) {
+            f32x4 r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float acc = bv[j];
+#pragma unroll
+                for (int c = 0; c < CI; ++c) acc = fmaf(a[j][c], xv[u][c / 4][c % 4], acc);
+                r[j] = mv::bilerp(ly[u], lx[u], q00[u][j], q01[u][j], q10[u][j], q11[u][j]) + acc;
+            }
+            if (pp[u] < H * W) st4(out + ((long)b * H * W + pp[u]) * CO + chunk * 4, r);
+        }
+    }
 }
 
 // Separable form of fpn_tail_gather (2.4x fewer loads): bilinear interpolation factorises into a
@@ -436,15 +506,33 @@ extern "C" int mvster_fpn_tail_gather(const float* G, const float* vb, float* P,
         }
         return mv_check_launch();
     }
-    if (CO == 8 && H >= 16 && W >= 64) {   // LDS-tiled gather (8 x 32 output tiles)
+    if (H >= 16 && W >= 64) {   // LDS-tiled gather (8 x 32 output tiles, 8 channels per workgroup)
         const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
-        hipLaunchKernelGGL(fpn_tail_gather_lds_kernel<8>, dim3(tiles_x * tiles_y * NB), block, 0, s, G, vb, P, NB, H, W,
-                           tiles_x, tiles_y);
+        if (CO == 8)
+            hipLaunchKernelGGL(fpn_tail_gather_lds_kernel<8>, dim3(tiles_x * tiles_y * NB), block, 0, s, G, vb, P, NB, H, W,
+                               tiles_x, tiles_y);
+        else
+            hipLaunchKernelGGL(fpn_tail_gather_lds_kernel<16>, dim3(tiles_x * tiles_y * NB, 2), block, 0, s, G, vb, P, NB, H,
+                               W, tiles_x, tiles_y);
         return mv_check_launch();
     }
     dim3 grid((H * W + 255) / 256, NB);
     if (CO == 8) hipLaunchKernelGGL(fpn_tail_gather_kernel<8>, grid, block, 0, s, G, vb, P, NB, H, W);
     else hipLaunchKernelGGL(fpn_tail_gather_kernel<16>, grid, block, 0, s, G, vb, P, NB, H, W);
+    return mv_check_launch();
+}
+
+// x [NB,H,W,CI], A [CO,CI], bias [CO], q [NB,H/2,W/2,CO] -> out [NB,H,W,CO]; (CI, CO) in {(16,72), (8,72)}.
+extern "C" int mvster_fpn_lateral_up(const float* x, const float* A, const float* bias, const float* q, float* out, int NB,
+                                     int H, int W, int CI, int CO, void* stream) {
+    if (!x || !A || !bias || !q || !out) return MVSTER_ERR_NULL;
+    if (NB <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1)) return MVSTER_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int per_block = kLateralSlots * kLateralIters;
+    dim3 grid((H * W + per_block - 1) / per_block, NB), block(72 / 4 * kLateralSlots);
+    if (CI == 16 && CO == 72) hipLaunchKernelGGL((fpn_lateral_up_kernel<16, 72>), grid, block, 0, s, x, A, bias, q, out, H, W);
+    else if (CI == 8 && CO == 72) hipLaunchKernelGGL((fpn_lateral_up_kernel<8, 72>), grid, block, 0, s, x, A, bias, q, out, H, W);
+    else return MVSTER_ERR_UNSUPPORTED;
     return mv_check_launch();
 }
 

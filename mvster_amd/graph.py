@@ -79,7 +79,9 @@ class GraphedTrainStep:
             self.loss = self._step()
 
     def _step(self):
-        self.optimizer.zero_grad(set_to_none=False)
+        # grads are re-created by every backward: inside the capture they come from the graph's private pool, so a replay
+        # writes them in place and no zero-fill / accumulate kernels are recorded
+        self.optimizer.zero_grad(set_to_none=True)
         out = self.model(self.imgs, self.proj, self.depth_values)
         res = self.loss_fn(out, self.gt, self.mask)
         loss = res[0] if isinstance(res, (tuple, list)) else res

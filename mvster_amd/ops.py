@@ -229,6 +229,20 @@ def fpn_tail_gather(G, vb, H, W, separable=False):
     return P
 
 
+def fpn_lateral_up(x, A, bias, q):
+    """x [NB,1,H,W,CI], A [CO,CI], bias [CO], q [NB,1,H/2,W/2,CO] -> bias + A x + up2(q) as [NB,1,H,W,CO]."""
+    for t, n in ((x, "x"), (A, "A"), (bias, "bias"), (q, "q")):
+        _chk(t, "fpn_lateral_up:" + n)
+    NB, _, H, W, CI = x.shape
+    CO = A.shape[0]
+    if tuple(A.shape) != (CO, CI) or bias.numel() != CO or tuple(q.shape) != (NB, 1, H // 2, W // 2, CO):
+        raise RuntimeError("fpn_lateral_up: inconsistent shapes")
+    out = torch.empty(NB, 1, H, W, CO, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().mvster_fpn_lateral_up(_ptr(x), _ptr(A), _ptr(bias), _ptr(q), _ptr(out), NB, H, W, CI, CO,
+                                                 _stream()), "fpn_lateral_up")
+    return out
+
+
 def mfma_probe(A, Bm):
     """A [16,4] @ B [4,16] on one v_mfma_f32_16x16x4_f32 (layout test hook)."""
     A, Bm = A.contiguous(), Bm.contiguous()
@@ -283,23 +297,24 @@ def conv_wgrad(x_cl, gy_cl, kernel, stride, padding):
     return dw.reshape(kd, kh, kw, CO, CI).permute(3, 4, 0, 1, 2).contiguous()
 
 
-def bn_batch_stats(x, weight, bias, running_mean, running_var, eps, momentum, groups=1):
-    """Statistics kernel + device-side finish in two launches: -> pack [5, groups, C] = (mean, biased var, rstd, scale,
-    shift); running_mean / running_var (or None) are updated in place, one exponential-average step per group."""
+def bn_batch_stats(x, weight, bias, running_mean, running_var, eps, momentum, groups=1, num_batches_tracked=None):
+    """-> pack [5, groups, C] = (mean, biased var, rstd, scale, shift); running_mean / running_var (or None) are
+    updated in place, one exponential-average step per group, and num_batches_tracked (or None) += groups."""
     _chk(x, "bn_batch_stats:x")
     C = x.shape[-1]
     rows = x.numel() // C // groups
     lib = _lib.load()
-    nblk = lib.mvster_bn_blocks(rows, C)
+    nblk = lib.mvster_bn_slots(rows, C, groups)
     if nblk <= 0:
         raise RuntimeError("bn_batch_stats: unsupported channel count %d" % C)
     partial = torch.empty(groups, nblk, 2, C, device=x.device, dtype=torch.float32)
-    rc = lib.mvster_bn_stats(_ptr(x), _ptr(partial), rows, C, int(groups), _stream())
-    _lib.check(rc, "bn_stats")
     pack = torch.empty(5, groups, C, device=x.device, dtype=torch.float32)
-    rc = lib.mvster_bn_finalize(_ptr(partial), _ptr(x), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
-                                _ptr(pack), rows, C, int(groups), float(eps), float(momentum), _stream())
-    _lib.check(rc, "bn_finalize")
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
+        raise RuntimeError("bn_batch_stats: num_batches_tracked must be an int64 tensor on the device")
+    rc = lib.mvster_bn_stats(_ptr(x), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                             _ptr(num_batches_tracked), _ptr(partial), _ptr(pack), rows, C, int(groups),
+                             float(eps), float(momentum), _stream())
+    _lib.check(rc, "bn_stats")
     return pack
 
 
@@ -322,28 +337,28 @@ def bn_relu_fwd(x, scale, shift, relu, groups=1, skip=None):
 
 
 def bn_relu_bwd(x, gy, scale, shift, mean, rstd, relu, groups=1, frozen=False):
-    """-> (dx, sum g [groups,C], sum g*xh [groups,C]) with g = gy*(y>0), xh = (x-mean)*rstd (BatchNorm + ReLU backward,
-    batch statistics per group).  ``frozen``: mean / rstd are constants (running statistics), so dx = g * scale: the
-    apply kernel is run with zero sums."""
+    """-> (dx, dbeta [C] = sum g, dgamma [C] = sum g*xh) with g = gy*(y>0), xh = (x-mean)*rstd (BatchNorm + ReLU backward,
+    batch statistics per group; the parameter gradients are summed over the groups).  ``frozen``: mean /
+    rstd are constants (running statistics), so dx = g * scale."""
     _chk(x, "bn_relu_bwd:x")
     _chk(gy, "bn_relu_bwd:gy")
     C = x.shape[-1]
     rows = x.numel() // C // groups
     lib = _lib.load()
-    nblk = lib.mvster_bn_blocks(rows, C)
+    nblk = lib.mvster_bn_slots(rows, C, groups)
     if nblk <= 0:
         raise RuntimeError("bn_relu_bwd: unsupported channel count %d" % C)
     partial = torch.empty(groups, nblk, 2, C, device=x.device, dtype=torch.float32)
+    sums = torch.empty(groups, 2, C, device=x.device, dtype=torch.float32)
+    dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
     rc = lib.mvster_bn_relu_bwd_reduce(_ptr(x), _ptr(gy), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(partial),
-                                       rows, C, int(relu), int(groups), _stream())
+                                       _ptr(sums), _ptr(dgb[0]), _ptr(dgb[1]), rows, C, int(relu), int(groups), _stream())
     _lib.check(rc, "bn_relu_bwd_reduce")
-    sums = partial.sum(1)                                   # [groups, 2, C]
     dx = torch.empty_like(x)
-    rc = lib.mvster_bn_relu_bwd_apply(_ptr(x), _ptr(gy), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
-                                      _ptr(torch.zeros_like(sums) if frozen else sums),
-                                      _ptr(dx), rows, C, int(relu), int(groups), _stream())
+    rc = lib.mvster_bn_relu_bwd_apply(_ptr(x), _ptr(gy), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(sums),
+                                      _ptr(dx), rows, C, int(relu), int(groups), int(frozen), _stream())
     _lib.check(rc, "bn_relu_bwd_apply")
-    return dx, sums[:, 0], sums[:, 1]
+    return dx, dgb[1], dgb[0]
 
 
 def sinkhorn_pixels(attn, hypo, gt, iters, eps, mask=None, continuous=False):

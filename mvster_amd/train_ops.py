@@ -182,9 +182,7 @@ class _BnReluCL(torch.autograd.Function):
         gy = gy.contiguous()
         dx, dbeta, dgamma = ops.bn_relu_bwd(x, gy, pack[3], pack[4], pack[0], pack[2], relu, groups, frozen)
         gskip = gy if has_skip else None          # the skip connection's gradient is the output gradient itself
-        if groups == 1:           # [1, C] -> [C]: a view, not a reduction launch
-            return dx, dgamma[0], dbeta[0], None, None, None, None, gskip
-        return dx, dgamma.sum(0), dbeta.sum(0), None, None, None, None, gskip
+        return dx, dgamma, dbeta, None, None, None, None, gskip
 
 
 def batch_norm_cl(x, bn, relu=False, groups=1, skip=None):
@@ -210,9 +208,8 @@ def batch_norm_cl(x, bn, relu=False, groups=1, skip=None):
             raise NotImplementedError("batch_norm_cl: cumulative-average running statistics (momentum=None)")
         with torch.no_grad():
             pack = ops.bn_batch_stats(x, bn.weight, bn.bias, bn.running_mean if track else None,
-                                      bn.running_var if track else None, bn.eps, bn.momentum or 0.0, groups)
-            if track:
-                bn.num_batches_tracked += groups
+                                      bn.running_var if track else None, bn.eps, bn.momentum or 0.0, groups,
+                                      num_batches_tracked=bn.num_batches_tracked if track else None)
         return _BnReluCL.apply(x, bn.weight, bn.bias, pack, relu, groups, False, skip)
     with torch.no_grad():            # [C]-sized parameter preparation, like weight packing
         rstd = torch.rsqrt(bn.running_var + bn.eps)

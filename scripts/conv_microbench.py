@@ -43,10 +43,10 @@ def timeit(fn, n=20):
 def candidates(layer, B, Di, Hi, Wi, sm):
     """Every (variant, mt, nt) the kernels support for this layer."""
     out = []
-    nts = [n for n in (1, 2, 4, 5) if n <= layer.ntile_total and layer.ntile_total % n == 0]
+    nts = [n for n in (1, 2, 3, 4, 5, 9) if n <= layer.ntile_total and layer.ntile_total % n == 0]
     for m in (1, 2, 4):
         for n in nts:
-            if n == 5 and layer.cin != 64:
+            if n in (3, 5, 9) and (layer.cin != 64 or (m, n) == (4, 9)):
                 continue
             out.append(("d%d,%d" % (m, n), (m, n, 0)))
     if not layer.transposed and layer.cin % 16 == 0 and layer.kernel[2] in (3, 5) and sm in (0, 1):

@@ -44,6 +44,9 @@ def infer(H, W, N, steps=20):
     torch.cuda.reset_peak_memory_stats()
 
 
+FUSED_ADAM = os.environ.get("MVSTER_UNFUSED_ADAM") is None     # torch.optim.Adam(fused=True): one multi-tensor kernel
+
+
 def train(H, W, N, B, steps=5, graph=False, coherent=False):
     """``coherent``: zero the four ``prob`` heads, so that every pixel picks hypothesis 0 and the depth maps the cascade
     hands from stage to stage are smooth, as they are for a network that has trained for a while.  The fixture weights
@@ -57,7 +60,7 @@ def train(H, W, N, B, steps=5, graph=False, coherent=False):
                 r.prob.weight.zero_()
                 r.prob.weight.requires_grad_(False)      # (an optimizer step would make the winners random again)
     model.to(dev).train()
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, fused=FUSED_ADAM)
     imgs, proj, dv = make_inputs(N, H, W, seed=0, device=dev, batch=B)
     g = torch.Generator().manual_seed(0)
     gt, mask = {}, {}
@@ -68,7 +71,7 @@ def train(H, W, N, B, steps=5, graph=False, coherent=False):
     losses = []
     if graph:
         from mvster_amd.graph import GraphedTrainStep
-        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, capturable=True)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, capturable=True, fused=FUSED_ADAM)
 
         def loss_fn(o, g_, m_):
             return MVS4net_loss(o, g_, m_, stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10, ot_eps=1,
@@ -95,8 +98,8 @@ def train(H, W, N, B, steps=5, graph=False, coherent=False):
             losses.append(loss.item())
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-    print(json.dumps({"config": "train %dx%d N=%d B=%d (1 rank, Adam, OT loss), gfx950 kernels, %s" % (
-        H, W, N, B, ("one hipGraph per step" if graph else "eager launches") + (", smooth depth maps (prob heads zeroed)" if coherent else
+    print(json.dumps({"config": "train %dx%d N=%d B=%d (1 rank, %s, OT loss), gfx950 kernels, %s" % (
+        H, W, N, B, "Adam(fused=True)" if FUSED_ADAM else "Adam", ("one hipGraph per step" if graph else "eager launches") + (", smooth depth maps (prob heads zeroed)" if coherent else
                                                                                 ", random-weight (incoherent) depth maps")),
                       "s_per_step": round(dt, 4), "loss_first": round(losses[0], 4), "loss_last": round(losses[-1], 4),
                       "finite": all(l == l for l in losses),

@@ -105,6 +105,14 @@ def fpn_tail_gather_reference(G, vb, H, W, separable=True):
     return out.permute(0, 2, 3, 1).reshape(NB, 1, H, W, CO).contiguous()
 
 
+def fpn_lateral_up_reference(x, A, bias, q):
+    """PyTorch restatement of mvster_fpn_lateral_up (CPU tests)."""
+    import torch.nn.functional as F
+    NB, _, H, W, _ = x.shape
+    up = F.interpolate(q[:, 0].permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    return (up + x[:, 0] @ A.t() + bias).unsqueeze(1).contiguous()
+
+
 class Emulated:
     """Wraps a plan so that every ConvLayer call goes through run_layer()."""
 
@@ -117,8 +125,11 @@ class Emulated:
         cp.ConvLayer.__call__ = lambda self_, x_, skip=None, skip_mode=SKIP_NONE, tiles=None: run_layer(self_, x_, skip, skip_mode)
         orig_gather = cp.ops.fpn_tail_gather
         cp.ops.fpn_tail_gather = fpn_tail_gather_reference
+        orig_lateral = cp.ops.fpn_lateral_up
+        cp.ops.fpn_lateral_up = fpn_lateral_up_reference
         try:
             return self.plan(x)
         finally:
             cp.ConvLayer.__call__ = orig
             cp.ops.fpn_tail_gather = orig_gather
+            cp.ops.fpn_lateral_up = orig_lateral

@@ -372,7 +372,8 @@ def test_fpn_plan_vs_oracle():
 def test_fpn_tail_gather():
     from tests.conv_emulator import fpn_tail_gather_reference
     g = torch.Generator().manual_seed(2)
-    for (NB, H, W, CO) in ((2, 12, 20, 8), (1, 64, 34, 8), (1, 8, 8, 16), (2, 40, 96, 8), (1, 18, 70, 8)):
+    for (NB, H, W, CO) in ((2, 12, 20, 8), (1, 64, 34, 8), (1, 8, 8, 16), (2, 40, 96, 8), (1, 18, 70, 8),
+                           (2, 40, 96, 16), (1, 18, 70, 16)):
         G = torch.randn(NB, 1, H // 2, W // 2, 9 * CO, generator=g)
         vb = torch.randn(9, CO, generator=g)
         want = fpn_tail_gather_reference(G, vb, H, W)
@@ -380,6 +381,21 @@ def test_fpn_tail_gather():
         got2 = ops.fpn_tail_gather(G.to(DEV), vb.to(DEV), H, W, separable=True).cpu()
         err = max((got - want).abs().max().item(), (got2 - want).abs().max().item())
         note("fpn_tail_gather_%dx%d" % (H, W), max_abs=err, ref_absmax=want.abs().max().item())
+        assert err <= 1e-5 * want.abs().max().item()
+
+
+def test_fpn_lateral_up():
+    from tests.conv_emulator import fpn_lateral_up_reference
+    g = torch.Generator().manual_seed(3)
+    for (NB, H, W, CI, CO) in ((2, 12, 20, 16, 72), (1, 64, 34, 16, 72), (2, 6, 130, 8, 72)):
+        x = torch.randn(NB, 1, H, W, CI, generator=g)
+        A = torch.randn(CO, CI, generator=g)
+        bias = torch.randn(CO, generator=g)
+        q = torch.randn(NB, 1, H // 2, W // 2, CO, generator=g)
+        want = fpn_lateral_up_reference(x, A, bias, q)
+        got = ops.fpn_lateral_up(x.to(DEV), A.to(DEV), bias.to(DEV), q.to(DEV)).cpu()
+        err = (got - want).abs().max().item()
+        note("fpn_lateral_up_%dx%d" % (H, W), max_abs=err, ref_absmax=want.abs().max().item())
         assert err <= 1e-5 * want.abs().max().item()
 
 
