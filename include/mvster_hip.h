@@ -134,6 +134,11 @@ int mvster_deconv_small(const float* in, const float* w, const float* scale, con
 int mvster_fpn_tail_gather(const float* G, const float* vb, float* P, float* workspace, int NB, int H, int W,
                            int CO, void* stream);
 
+/* Adjoint of mvster_fpn_tail_gather with respect to G (training): gP [NB,H,W,CO] -> gG [NB,H/2,W/2,pitch], channels
+ * 9*CO..pitch-1 zero-filled (pitch >= 9*CO, multiple of 4); a gather over the <= 6x6 full-resolution positions that read
+ * a half-resolution pixel, no atomics.  CO in {8, 16}. */
+int mvster_fpn_tail_gather_bwd(const float* gP, float* gG, int NB, int H, int W, int CO, int pitch, void* stream);
+
 /* Lateral 1x1 conv + top-down add of one FPN level, for a top-down map that is only held at the coarser
  * resolution (models/mvs4net_utils.py:485, after pushing the next level's 1x1 "tap" conv through it):
  * out [NB,H,W,CO] = bias [CO] + A [CO,CI] x [NB,H,W,CI] + bilinear x2 align_corners upsample of q [NB,H/2,W/2,CO].

@@ -120,7 +120,7 @@ class ConvLayer:
         else:
             cout, cin = w.shape[0], w.shape[1]
         self.cin = cin_pad or cin
-        if self.cin not in (4, 8, 16, 32, 64):
+        if self.cin not in (4, 8, 16, 32, 64, 80):        # (80: the FPN gather's 72 gradient channels, padded)
             raise RuntimeError("conv_mfma: unsupported input channel count %d" % self.cin)
         self.cout = cout
         self.relu = relu

@@ -657,6 +657,7 @@ extern "C" int mvster_conv_mfma(const float* in, const float* wpk, const float* 
         case 16: return dispatch_tiles<16>(a, mt, nt, splitk, s);
         case 32: return dispatch_tiles<32>(a, mt, nt, splitk, s);
         case 64: return dispatch_tiles<64>(a, mt, nt, splitk, s);
+        case 80: return dispatch_tiles<80>(a, mt, nt, splitk, s);   // 72 gradient channels of the FPN gather, zero-padded
         default: return MVSTER_ERR_UNSUPPORTED;
     }
 }

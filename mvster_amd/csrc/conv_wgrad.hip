@@ -380,12 +380,14 @@ int dispatch_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, int packe
         return MVSTER_ERR_UNSUPPORTED;
     }
     int mt = cot, nt = cit;
+    if (cot == 5 && TAPS != 1) return MVSTER_ERR_UNSUPPORTED;        // 5 M tiles do not halve
     while (mt * nt * TAPS > 40 && (mt > 1 || nt > 1)) {
         if (mt >= nt && mt > 1) mt /= 2; else nt /= 2;
     }
     if (mt * nt * TAPS > 40) return MVSTER_ERR_UNSUPPORTED;
 #define MV_LN(M_, N_) if (mt == M_ && nt == N_) { if constexpr (M_ * N_ * TAPS <= 40) return launch_wgrad_lds<M_, N_, TY, KW, 0>(a, nblk, cot, cit, s); }
     MV_LN(1, 1) MV_LN(2, 1) MV_LN(1, 2) MV_LN(2, 2) MV_LN(4, 1) MV_LN(1, 4) MV_LN(4, 2) MV_LN(2, 4) MV_LN(4, 4)
+    if constexpr (TAPS == 1) { MV_LN(5, 4) }      // 72 (+8) x 64: the FPN gather's 1x1 conv
 #undef MV_LN
     return MVSTER_ERR_UNSUPPORTED;
 }
@@ -405,7 +407,7 @@ int try_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, int packed, hi
 }  // namespace
 
 // x [B,Di,Hi,Wi,CI], gy [B,Do,Ho,Wo,CO] (channels-last, contiguous); partial [nblk][kd*kh*kw][COP][CIP] with
-// COP / CIP = CO / CI rounded up to 16 (<= 64).  Do/Ho/Wo must be the conv's output size for (k, s, p).
+// COP / CIP = CO / CI rounded up to 16 (CI <= 64, CO <= 80).  Do/Ho/Wo must be the conv's output size for (k, s, p).
 // packed = 0: partial [nblk][taps][COP][CIP16] (one kernel tap per N tile).
 // packed = 1 (CI <= 8): partial [nblk][ceil(taps/TPN)][COP][16] with TPN = 16/CIP taps per tile, CIP = 4 or 8 (CI rounded
 // up); column n of a tile = (tap % TPN) * CIP + ci.
@@ -416,7 +418,7 @@ extern "C" int mvster_conv_wgrad(const float* x, const float* gy, float* partial
     if (B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || nblk <= 0 || kd <= 0 || kh <= 0 ||
         kw <= 0 || sd <= 0 || sh <= 0 || sw <= 0 || pd < 0 || ph < 0 || pw < 0)
         return MVSTER_ERR_SHAPE;
-    if (CI <= 0 || CI > 64 || CO <= 0 || CO > 64) return MVSTER_ERR_UNSUPPORTED;
+    if (CI <= 0 || CI > 64 || CO <= 0 || CO > 80) return MVSTER_ERR_UNSUPPORTED;
     if (Do != (Di + 2 * pd - kd) / sd + 1 || Ho != (Hi + 2 * ph - kh) / sh + 1 || Wo != (Wi + 2 * pw - kw) / sw + 1)
         return MVSTER_ERR_SHAPE;
     if ((long)Wo * CO >= (1L << 31) || (long)Wi * CI >= (1L << 31) || (long)kd * kh * kw > 65535) return MVSTER_ERR_SHAPE;
@@ -440,7 +442,7 @@ extern "C" int mvster_conv_wgrad(const float* x, const float* gy, float* partial
         return MVSTER_ERR_UNSUPPORTED;
     }
 #define MV_W(A_, B_) if (cot == A_ && cit == B_) return launch_wgrad<A_, B_>(a, nblk, ntaps, s);
-    MV_W(1, 1) MV_W(1, 2) MV_W(1, 4) MV_W(2, 1) MV_W(2, 2) MV_W(2, 4) MV_W(4, 1) MV_W(4, 2) MV_W(4, 4)
+    MV_W(1, 1) MV_W(1, 2) MV_W(1, 4) MV_W(2, 1) MV_W(2, 2) MV_W(2, 4) MV_W(4, 1) MV_W(4, 2) MV_W(4, 4) MV_W(5, 4)
 #undef MV_W
     return MVSTER_ERR_UNSUPPORTED;
 }

@@ -244,6 +244,61 @@ __global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* _
     for (int c = 0; c < CO; c += 4) st4(o + c, (f32x4){acc[c / 2][0], acc[c / 2][1], acc[c / 2 + 1][0], acc[c / 2 + 1][1]});
 }
 
+// Adjoint of the gather-sum above with respect to G (training): gG [NB, H/2, W/2, pitch] <- gP [NB, H, W, CO],
+//   gG[q][tap*CO + co] = sum over full-resolution positions r = p + tap (both p and r inside the image) of
+//                        w(r -> q) * gP[p][co],     w = the bilinear x2 weight with which r reads q,
+// as a gather over the <= 6 x 6 positions r that can touch q (same make_lerp() as the forward; no atomics).  One
+// thread per (q, tap): the nine taps of a pixel write one contiguous run.  Channels 9*CO .. pitch-1 are zeroed (the
+// input-gradient convolution that follows wants a multiple of 16 channels).
+template <int CO>
+__global__ void __launch_bounds__(256) fpn_tail_gather_bwd_kernel(const float* __restrict__ gP, float* __restrict__ gG,
+                                                                  int NB, int H, int W, int pitch) {
+    const int Hh = H / 2, Wh = W / 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)NB * Hh * Wh * 9) return;
+    const int tap = (int)(i % 9);
+    long q = i / 9;
+    const int xi = (int)(q % Wh), yi = (int)((q / Wh) % Hh), b = (int)(q / ((long)Wh * Hh));
+    const int ty = tap / 3 - 1, tx = tap % 3 - 1;
+    float wy[6], wx[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int ro = 2 * yi - 2 + k, co = 2 * xi - 2 + k;
+        const bool vy = ro >= 0 && ro < H && ro - ty >= 0 && ro - ty < H;
+        const bool vx = co >= 0 && co < W && co - tx >= 0 && co - tx < W;
+        const mv::Lerp ly = mv::make_lerp(vy ? ro : 0, Hh, H), lx = mv::make_lerp(vx ? co : 0, Wh, W);
+        wy[k] = vy ? (ly.i0 == yi ? ly.w0 : 0.0f) + (ly.i1 == yi ? ly.w1 : 0.0f) : 0.0f;
+        wx[k] = vx ? (lx.i0 == xi ? lx.w0 : 0.0f) + (lx.i1 == xi ? lx.w1 : 0.0f) : 0.0f;
+    }
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.0f;
+    const float* base = gP + (long)b * H * W * CO;
+#pragma unroll
+    for (int ky = 0; ky < 6; ++ky) {
+        if (wy[ky] == 0.0f) continue;
+        const int py = 2 * yi - 2 + ky - ty;
+#pragma unroll
+        for (int kx = 0; kx < 6; ++kx) {
+            if (wx[kx] == 0.0f) continue;
+            const int px = 2 * xi - 2 + kx - tx;
+            const float w = wy[ky] * wx[kx];
+            const float* g = base + ((long)py * W + px) * CO;
+#pragma unroll
+            for (int c = 0; c < CO; c += 4) {
+                const f32x4 v = ld4(g + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[c + j] = fmaf(w, v[j], acc[c + j]);
+            }
+        }
+    }
+    float* o = gG + q * pitch + tap * CO;
+#pragma unroll
+    for (int c = 0; c < CO; c += 4) st4(o + c, (f32x4){acc[c], acc[c + 1], acc[c + 2], acc[c + 3]});
+    if (tap == 0)
+        for (int c = 9 * CO; c < pitch; c += 4) st4(gG + q * pitch + c, (f32x4){0.f, 0.f, 0.f, 0.f});
+}
+
 // Lateral 1x1 conv + top-down add of the FPN (models/mvs4net_utils.py:485) for a top-down map that only exists at
 // the coarser level:   out[p][co] = bias[co] + sum_ci A[co][ci] x[p][ci] + up2(q)[p][co]
 // with x [NB,H,W,CI] the bottom-up map, q [NB,H/2,W/2,CO] and up2 = the reference's x2 align_corners interpolation.
@@ -519,6 +574,21 @@ extern "C" int mvster_fpn_tail_gather(const float* G, const float* vb, float* P,
     dim3 grid((H * W + 255) / 256, NB);
     if (CO == 8) hipLaunchKernelGGL(fpn_tail_gather_kernel<8>, grid, block, 0, s, G, vb, P, NB, H, W);
     else hipLaunchKernelGGL(fpn_tail_gather_kernel<16>, grid, block, 0, s, G, vb, P, NB, H, W);
+    return mv_check_launch();
+}
+
+// gP [NB,H,W,CO] -> gG [NB,H/2,W/2,pitch]: the adjoint of mvster_fpn_tail_gather with respect to G; pitch >= 9*CO, a
+// multiple of 4 (the channels beyond 9*CO are zero-filled).  CO in {8, 16}.
+extern "C" int mvster_fpn_tail_gather_bwd(const float* gP, float* gG, int NB, int H, int W, int CO, int pitch, void* stream) {
+    if (!gP || !gG) return MVSTER_ERR_NULL;
+    if (NB <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || pitch < 9 * CO || (pitch & 3)) return MVSTER_ERR_SHAPE;
+    if (CO != 8 && CO != 16) return MVSTER_ERR_UNSUPPORTED;
+    const long total = (long)NB * (H / 2) * (W / 2) * 9;
+    if ((total + 255) / 256 >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (CO == 8) hipLaunchKernelGGL(fpn_tail_gather_bwd_kernel<8>, grid, block, 0, s, gP, gG, NB, H, W, pitch);
+    else hipLaunchKernelGGL(fpn_tail_gather_bwd_kernel<16>, grid, block, 0, s, gP, gG, NB, H, W, pitch);
     return mv_check_launch();
 }
 

@@ -209,8 +209,8 @@ class FPN4(nn.Module):
         out["stage2"] = plain(self.out2, f)
         f = plain(self.inner2, c1, up=f)
         out["stage3"] = plain(self.out3, f)
-        f = plain(self.inner3, c0, up=f)
-        out["stage4"] = plain(self.out4, f)
+        # finest level: re-associated, the full-resolution 64-channel map is never formed (train_ops.fpn_fine_level)
+        out["stage4"] = T.fpn_fine_level(c0, f, self.inner3, self.out4)
         return out
 
 

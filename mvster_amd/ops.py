@@ -229,6 +229,17 @@ def fpn_tail_gather(G, vb, H, W, separable=False):
     return P
 
 
+def fpn_tail_gather_bwd(gP, pitch=None):
+    """gP [NB,1,H,W,CO] -> gG [NB,1,H/2,W/2,pitch]: adjoint of fpn_tail_gather w.r.t. G (channels 9*CO.. are zero)."""
+    _chk(gP, "fpn_tail_gather_bwd")
+    NB, _, H, W, CO = gP.shape
+    pitch = 9 * CO if pitch is None else pitch
+    gG = torch.empty(NB, 1, H // 2, W // 2, pitch, device=gP.device, dtype=torch.float32)
+    _lib.check(_lib.load().mvster_fpn_tail_gather_bwd(_ptr(gP), _ptr(gG), NB, H, W, CO, pitch, _stream()),
+               "fpn_tail_gather_bwd")
+    return gG
+
+
 def fpn_lateral_up(x, A, bias, q):
     """x [NB,1,H,W,CI], A [CO,CI], bias [CO], q [NB,1,H/2,W/2,CO] -> bias + A x + up2(q) as [NB,1,H,W,CO]."""
     for t, n in ((x, "x"), (A, "A"), (bias, "bias"), (q, "q")):

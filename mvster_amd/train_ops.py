@@ -56,13 +56,18 @@ class _LayerCache:
         self._d = {}
         self.always_repack = False
 
-    def get(self, weight, role, build, refresh):
-        """``build()`` makes the layer; ``refresh(layer)`` re-packs it from the updated parameter."""
+    def get(self, weight, role, build, refresh, owner=None):
+        """``build()`` makes the layer; ``refresh(layer)`` re-packs it from the updated parameter.  ``owner``: the
+        parameter a derived weight (a product of parameters, a new tensor every step) is cached under; such layers are
+        re-packed on every call."""
+        derived = owner is not None
+        if derived:
+            weight = owner
         key = (id(weight), role)
         hit = self._d.get(key)
         stamp = (weight._version, weight.data_ptr())
         if hit is not None and hit[0] is weight and hit[2].wpk.device == weight.device:
-            if hit[1] != stamp or self.always_repack or torch.cuda.is_current_stream_capturing():
+            if derived or hit[1] != stamp or self.always_repack or torch.cuda.is_current_stream_capturing():
                 refresh(hit[2])
                 self._d[key] = (weight, stamp, hit[2])
             return hit[2]
@@ -79,15 +84,16 @@ CACHE = _LayerCache()
 
 class _ConvCL(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, transposed, skip=None, skip_upsample=False):
+    def forward(ctx, x, weight, bias, stride, padding, transposed, skip=None, skip_upsample=False, owner=None):
         w5 = weight if weight.dim() == 5 else weight.unsqueeze(2)
+        own, tag = owner if owner is not None else (None, "")
         cin = w5.shape[0] if transposed else w5.shape[1]
         if x.shape[-1] != cin:
             raise RuntimeError("conv_cl: input has %d channels, weight expects %d" % (x.shape[-1], cin))
         cin_p = _cin_for(cin)
         xp = _pad_last(x, cin_p).contiguous()
-        layer = CACHE.get(weight, "fwd", lambda: ConvLayer(w5, transposed, stride, padding, cin_pad=cin_p),
-                          lambda L: L.repack_on_device(weight))
+        layer = CACHE.get(weight, "fwd" + tag, lambda: ConvLayer(w5, transposed, stride, padding, cin_pad=cin_p),
+                          lambda L: L.repack_on_device(weight), owner=own)
         if bias is not None:
             layer.shift[:layer.cout] = bias.detach()
         if skip is not None:
@@ -100,12 +106,14 @@ class _ConvCL(torch.autograd.Function):
         ctx.has_skip = (skip is not None, skip_upsample)
         ctx.save_for_backward(xp, weight, bias)
         ctx.cfg = (stride, padding, transposed, cin)
+        ctx.owner = (own, tag)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         xp, weight, bias = ctx.saved_tensors
         stride, padding, transposed, cin = ctx.cfg
+        own, tag = ctx.owner
         w5 = weight if weight.dim() == 5 else weight.unsqueeze(2)
         kernel = tuple(w5.shape[2:])
         gy = gy.contiguous()
@@ -116,18 +124,18 @@ class _ConvCL(torch.autograd.Function):
             gyp = _pad_last(gy, co_p).contiguous()
             if transposed:
                 # y = convT(x; W[cin,cout]) : dx = conv(gy; W read as [out=cin, in=cout], same stride / padding)
-                layer = CACHE.get(weight, "dgrad", lambda: ConvLayer(w5, False, stride, padding, cin_pad=co_p),
-                                  lambda L: L.repack_on_device(weight))
+                layer = CACHE.get(weight, "dgrad" + tag, lambda: ConvLayer(w5, False, stride, padding, cin_pad=co_p),
+                                  lambda L: L.repack_on_device(weight), owner=own)
             elif stride == (1, 1, 1):
                 def flipped():
                     return w5.detach().flip(2, 3, 4).transpose(0, 1).contiguous()
                 pad = tuple(k - 1 - p for k, p in zip(kernel, padding))
-                layer = CACHE.get(weight, "dgrad", lambda: ConvLayer(flipped(), False, stride, pad, cin_pad=co_p),
-                                  lambda L: L.repack_on_device(weight, swap=True, flip=True))
+                layer = CACHE.get(weight, "dgrad" + tag, lambda: ConvLayer(flipped(), False, stride, pad, cin_pad=co_p),
+                                  lambda L: L.repack_on_device(weight, swap=True, flip=True), owner=own)
             else:
                 # stride 2: the adjoint is the transposed conv with the same weights (parity classes)
-                layer = CACHE.get(weight, "dgrad", lambda: ConvLayer(w5, True, stride, padding, cin_pad=co_p),
-                                  lambda L: L.repack_on_device(weight))
+                layer = CACHE.get(weight, "dgrad" + tag, lambda: ConvLayer(w5, True, stride, padding, cin_pad=co_p),
+                                  lambda L: L.repack_on_device(weight), owner=own)
             gx = layer(gyp)
             if tuple(gx.shape[:4]) != tuple(xp.shape[:4]):
                 raise RuntimeError("conv_cl: input gradient of a strided layer needs even input sizes (%s -> %s)"
@@ -153,15 +161,81 @@ class _ConvCL(torch.autograd.Function):
             if ctx.has_skip[1]:       # adjoint of the bilinear x2 (gather form, no atomics)
                 B_, D_, H_, W_, C_ = gy.shape
                 gskip = ops.upsample2x_cl(gy.reshape(B_ * D_, H_, W_, C_), backward=True).reshape(B_, D_, H_ // 2, W_ // 2, C_)
-        return gx, gw, gb, None, None, None, gskip, None
+        return gx, gw, gb, None, None, None, gskip, None, None
 
 
-def conv_cl(x, weight, bias=None, stride=1, padding=0, transposed=False, skip=None, skip_upsample=False):
+def conv_cl(x, weight, bias=None, stride=1, padding=0, transposed=False, skip=None, skip_upsample=False, owner=None):
     """x [B,D,H,W,Cin] channels-last -> [B,Do,Ho,Wo,Cout]; weight in nn.Conv3d / nn.Conv2d / nn.ConvTranspose3d
     layout (a 4-D weight is a depth-1 convolution).  ``skip`` is added in the kernel's epilogue: a tensor of the output's
     shape, or with ``skip_upsample`` a [B,1,Ho/2,Wo/2,Cout] map that is bilinearly up-sampled x2 (align_corners) on the fly."""
     lead_s, lead_p = 1, 0
-    return _ConvCL.apply(x, weight, bias, _triple(stride, lead_s), _triple(padding, lead_p), transposed, skip, skip_upsample)
+    return _ConvCL.apply(x, weight, bias, _triple(stride, lead_s), _triple(padding, lead_p), transposed, skip, skip_upsample,
+                         owner)
+
+
+class _FpnGather(torch.autograd.Function):
+    """P = gather-sum of the nine shifted bilinear x2 up-samplings of G = conv1x1(f; wg) (+ the bias terms vb): the
+    top-down half of a re-associated FPN level (see ``fpn_fine_level``).  All passes on the gfx950 kernels; the 72-channel
+    gradient of G is written with an 80-channel pitch so that the input-gradient conv and the weight gradient read it
+    as it is."""
+
+    PITCH = {8: 80}          # 9*co rounded up to the input-gradient conv's channel granularity
+
+    @staticmethod
+    def forward(ctx, f, wg, vb, H, W, owner):
+        w5 = wg.unsqueeze(2)
+        layer = CACHE.get(wg, "fpn_g", lambda: ConvLayer(w5, False, (1, 1, 1), (0, 0, 0)), lambda L: L.repack_on_device(wg),
+                          owner=owner)
+        f = f.contiguous()
+        P = ops.fpn_tail_gather(layer(f), vb.detach().contiguous(), H, W)
+        ctx.save_for_backward(f, wg)
+        ctx.owner = owner
+        return P
+
+    @staticmethod
+    def backward(ctx, gP):
+        f, wg = ctx.saved_tensors
+        gP = gP.contiguous()
+        co = gP.shape[-1]
+        if co not in _FpnGather.PITCH:
+            raise NotImplementedError("fpn_fine_level: %d output channels (the path's finest level has 8)" % co)
+        pitch = _FpnGather.PITCH[co]
+        gG = ops.fpn_tail_gather_bwd(gP, pitch=pitch)                       # [NB,1,h,w,pitch]
+        gf = gwg = gvb = None
+        if ctx.needs_input_grad[0]:
+            def transposed_weight():                                        # [64 out, 9co in] -> padded to `pitch` inputs
+                return wg.detach()[:, :, 0, 0].t().reshape(wg.shape[1], wg.shape[0], 1, 1, 1).contiguous()
+            layer = CACHE.get(wg, "fpn_g_dgrad", lambda: ConvLayer(transposed_weight(), False, (1, 1, 1), (0, 0, 0), cin_pad=pitch),
+                              lambda L: L.repack_on_device(wg, swap=True), owner=ctx.owner)
+            gf = layer(gG)
+        if ctx.needs_input_grad[1]:
+            gwg = ops.conv_wgrad(f, gG, (1, 1, 1), (1, 1, 1), (0, 0, 0))[:wg.shape[0]].reshape(wg.shape)
+        if ctx.needs_input_grad[2]:
+            # d/d vb[tap] = sum of gP over the pixels whose tap is inside the image: all, minus the first / last row / column
+            g = gP[:, 0]
+            rows = g.sum(2)                                                              # over x: [NB,H,co]
+            xs = torch.stack([rows - g[:, :, 0], rows, rows - g[:, :, -1]])             # kx = 0, 1, 2
+            tot = xs.sum(2)                                                              # over y: [3,NB,co]
+            gvb = torch.stack([tot - xs[:, :, 0], tot, tot - xs[:, :, -1]]).sum(2).reshape(9, co)   # [ky,kx] -> [9,co]
+        return gf, gwg, gvb, None, None, None
+
+
+def fpn_fine_level(c_low, f_coarse, inner, out):
+    """out(F.interpolate(f_coarse, x2 bilinear, align_corners) + inner(c_low)) of the FPN's top-down path
+    (models/mvs4net_utils.py:488-489) WITHOUT forming the 64-channel map at c_low's resolution (839 MB for ten 512x640
+    views, plus its gradient): ``out`` is linear and interpolation acts per channel, so
+        out(f)[p] = sum_tap up(W_out[tap] f_coarse)[p + tap] + sum_tap W_out[tap] (W_in c_low[p + tap] + b_in)
+    = the gather-sum of a 1x1 conv of f_coarse (_FpnGather) + a 3x3 conv of c_low with the composed weights; the composed
+    weights are differentiable functions of the parameters, so autograd carries the gradients back to ``out.weight``,
+    ``inner.weight`` and ``inner.bias``.  Same re-association as the inference plan (conv_plan.FpnPlan)."""
+    wo = out.weight                                                       # [co, 64, 3, 3]
+    co = wo.shape[0]
+    wg = wo.permute(2, 3, 0, 1).reshape(9 * co, wo.shape[1], 1, 1)        # row = tap*co + co_idx
+    wc = torch.einsum("ocyx,ci->oiyx", wo, inner.weight[:, :, 0, 0])      # [co, cin, 3, 3]
+    vb = torch.einsum("ocyx,c->yxo", wo, inner.bias).reshape(9, co)
+    H, W = c_low.shape[2], c_low.shape[3]
+    P = _FpnGather.apply(f_coarse, wg, vb, H, W, out.weight)
+    return conv_cl(c_low, wc, out.bias, out.stride, out.padding, skip=P, owner=(out.weight, "_fine_c"))
 
 
 class _BnReluCL(torch.autograd.Function):

@@ -384,6 +384,23 @@ def test_fpn_tail_gather():
         assert err <= 1e-5 * want.abs().max().item()
 
 
+@pytest.mark.parametrize("NB,H,W,CO,pitch", [(2, 12, 20, 8, 80), (1, 64, 34, 8, 72), (1, 8, 8, 16, 144), (1, 18, 70, 8, 80)])
+def test_fpn_tail_gather_adjoint(NB, H, W, CO, pitch):
+    """mvster_fpn_tail_gather_bwd against autograd through the PyTorch restatement of the gather."""
+    from tests.conv_emulator import fpn_tail_gather_reference
+    g = torch.Generator().manual_seed(4)
+    G = torch.randn(NB, 1, H // 2, W // 2, 9 * CO, generator=g, dtype=torch.float64, requires_grad=True)
+    vb = torch.randn(9, CO, generator=g, dtype=torch.float64)
+    gP = torch.randn(NB, 1, H, W, CO, generator=g)
+    fpn_tail_gather_reference(G, vb, H, W).backward(gP.double())
+    got = ops.fpn_tail_gather_bwd(gP.to(DEV), pitch=pitch).cpu()
+    assert tuple(got.shape) == (NB, 1, H // 2, W // 2, pitch)
+    err = (got[..., :9 * CO].double() - G.grad).abs().max().item()
+    note("fpn_tail_gather_bwd_%dx%d" % (H, W), max_abs=err, ref_absmax=G.grad.abs().max().item())
+    assert err <= 1e-5 * G.grad.abs().max().item()
+    assert (got[..., 9 * CO:] == 0).all()
+
+
 def test_fpn_lateral_up():
     from tests.conv_emulator import fpn_lateral_up_reference
     g = torch.Generator().manual_seed(3)
