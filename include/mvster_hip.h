@@ -171,6 +171,14 @@ int mvster_conv_wgrad(const float* x, const float* gy, float* partial, int nblk,
                       int Do, int Ho, int Wo, int CO, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph,
                       int pw, int packed, void* stream);
 
+/* Finish of the weight gradient: adds the nblk slots (fixed order) and writes dW in the parameter's layout in one launch.
+ * Slot element (g, row, col) of [ngrp][cop][width]: co = row; cip = 0: tap = g, ci = col; cip = 4 / 8 (packed): tap =
+ * g*(16/cip) + col/cip, ci = col % cip.  Kept when tap < ntaps, co < co_lim, ci < ci_lim; flip mirrors the taps
+ * (tap -> ntaps-1-tap); dw is [co_lim][ci_lim][ntaps], or [ci_lim][co_lim][ntaps] with swap (the mirrored narrow-output
+ * form and nothing else needs both). */
+int mvster_conv_wgrad_finish(const float* partial, float* dw, int nblk, int ngrp, int cop, int width, int ntaps, int cip,
+                             int co_lim, int ci_lim, int swap, int flip, void* stream);
+
 /* Training-mode BatchNorm + ReLU on channels-last activations (C a power of two, 4..64): the elementwise half of the
  * reference's conv -> BatchNorm -> ReLU blocks (models/mvs4net_utils.py:116-123, :224-251) and its autograd.
  * x [groups*rows, C]: `groups` independent statistics groups of `rows` rows each (the reference normalises every

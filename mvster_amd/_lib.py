@@ -38,6 +38,7 @@ SIGNATURES = {
     "mvster_pack_conv_weights_classes": [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f],
     "mvster_conv_wgrad": [_f, _f, _f] + [_i] * 20 + [_f],
     "mvster_bn_relu_fwd": [_f, _f, _f, _f, _f, _l, _i, _i, _i, _f],
+    "mvster_conv_wgrad_finish": [_f, _f] + [_i] * 10 + [_f],
     "mvster_bn_slots": [_l, _i, _i],
     "mvster_bn_stats": [_f] * 8 + [_l, _i, _i, _fl, _fl, _f],
     "mvster_bn_relu_bwd_reduce": [_f] * 10 + [_l, _i, _i, _i, _f],

@@ -404,6 +404,43 @@ int try_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, int packed, hi
     return MVSTER_ERR_UNSUPPORTED;
 }
 
+// ------------------------------------------------------------------------------------------
+// Finish: add the nblk slots of `partial` (fixed order: deterministic) and write the gradient in the parameter's own
+// layout -- one launch instead of a tensor reduction plus a permuting copy (plus flips / transposes for the mirrored
+// form).  A workgroup owns 64 consecutive elements of a slot; its 16 wavefronts stride over the slots (every load is a
+// 256-byte run), meet in LDS, and the first wavefront scatters the 64 sums.
+//   element e = (g, row, col) of a slot [ngrp][cop][width]:
+//     co = row;  not packed: tap = g, ci = col;  packed (cip = 4 / 8): tap = g * (16 / cip) + col / cip, ci = col % cip
+//   kept when tap < ntaps, co < co_lim, ci < ci_lim; flip: tap -> ntaps - 1 - tap;
+//   dw[co][ci][tap] ([co_lim][ci_lim][ntaps]), or with swap dw[ci][co][tap] ([ci_lim][co_lim][ntaps]).
+// ------------------------------------------------------------------------------------------
+struct FinishArgs {
+    const float* partial; float* dw;
+    int nblk, ngrp, cop, width, ntaps, cip, co_lim, ci_lim, swap, flip;
+};
+
+__global__ void __launch_bounds__(1024) conv_wgrad_finish_kernel(FinishArgs a) {
+    __shared__ float red[16][64];
+    const int el = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const long E = (long)a.ngrp * a.cop * a.width;
+    const long e = (long)blockIdx.x * 64 + el;
+    float s = 0.0f;
+    if (e < E)
+        for (int n = lane; n < a.nblk; n += 16) s += a.partial[(long)n * E + e];
+    red[lane][el] = s;
+    __syncthreads();
+    if (lane != 0 || e >= E) return;
+#pragma unroll
+    for (int w = 1; w < 16; ++w) s += red[w][el];
+    const int col = (int)(e % a.width), row = (int)((e / a.width) % a.cop), g = (int)(e / ((long)a.width * a.cop));
+    int tap = g, ci = col;
+    if (a.cip) { tap = g * (16 / a.cip) + col / a.cip; ci = col % a.cip; }
+    if (tap >= a.ntaps || row >= a.co_lim || ci >= a.ci_lim) return;
+    if (a.flip) tap = a.ntaps - 1 - tap;
+    const long o = a.swap ? ((long)ci * a.co_lim + row) * a.ntaps + tap : ((long)row * a.ci_lim + ci) * a.ntaps + tap;
+    a.dw[o] = s;
+}
+
 }  // namespace
 
 // x [B,Di,Hi,Wi,CI], gy [B,Do,Ho,Wo,CO] (channels-last, contiguous); partial [nblk][kd*kh*kw][COP][CIP] with
@@ -445,4 +482,20 @@ extern "C" int mvster_conv_wgrad(const float* x, const float* gy, float* partial
     MV_W(1, 1) MV_W(1, 2) MV_W(1, 4) MV_W(2, 1) MV_W(2, 2) MV_W(2, 4) MV_W(4, 1) MV_W(4, 2) MV_W(4, 4) MV_W(5, 4)
 #undef MV_W
     return MVSTER_ERR_UNSUPPORTED;
+}
+
+// partial [nblk][ngrp][cop][width] as written by mvster_conv_wgrad -> dw in parameter layout (see the kernel): ntaps =
+// kd*kh*kw, cip = 0 (one tap per group) or 4 / 8 (packed), co_lim <= cop and ci_lim = the channel counts to keep.
+extern "C" int mvster_conv_wgrad_finish(const float* partial, float* dw, int nblk, int ngrp, int cop, int width, int ntaps,
+                                        int cip, int co_lim, int ci_lim, int swap, int flip, void* stream) {
+    if (!partial || !dw) return MVSTER_ERR_NULL;
+    if (nblk <= 0 || ngrp <= 0 || cop <= 0 || width <= 0 || ntaps <= 0 || co_lim <= 0 || ci_lim <= 0 || co_lim > cop)
+        return MVSTER_ERR_SHAPE;
+    if (cip != 0 && cip != 4 && cip != 8) return MVSTER_ERR_UNSUPPORTED;
+    if (cip ? (width != 16 || ci_lim > cip || (long)ngrp * (16 / cip) < ntaps) : (ci_lim > width || ngrp != ntaps))
+        return MVSTER_ERR_SHAPE;
+    FinishArgs a{partial, dw, nblk, ngrp, cop, width, ntaps, cip, co_lim, ci_lim, swap, flip};
+    const long E = (long)ngrp * cop * width;
+    hipLaunchKernelGGL(conv_wgrad_finish_kernel, dim3((unsigned)((E + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, a);
+    return mv_check_launch();
 }

@@ -267,10 +267,12 @@ def _wgrad_tiles(c):
     return 4 if t == 3 else t
 
 
-def conv_wgrad(x_cl, gy_cl, kernel, stride, padding):
+def conv_wgrad(x_cl, gy_cl, kernel, stride, padding, co_keep=None, ci_keep=None, mirrored=False):
     """Weight gradient of the channels-last convolution y = conv(x; W[CO,CI,kd,kh,kw], stride, padding):
-    x_cl [B,Di,Hi,Wi,CI], gy_cl [B,Do,Ho,Wo,CO] -> dW [CO,CI,kd,kh,kw].  With the roles of x and gy swapped it is
-    the gradient of a ConvTranspose weight [cin,cout,...].  Autograd of models/mvs4net_utils.py:116-123 etc."""
+    x_cl [B,Di,Hi,Wi,CI], gy_cl [B,Do,Ho,Wo,CO] -> dW [co_keep,ci_keep,kd,kh,kw] (the leading channels; default all).
+    With the roles of x and gy swapped it is the gradient of a ConvTranspose weight [cin,cout,...].  ``mirrored``: return
+    dW with the taps mirrored and the two channel axes exchanged, [ci_keep,co_keep,kd,kh,kw] (the narrow-output form of
+    train_ops).  Two launches: the slot kernel and the finish.  Autograd of models/mvs4net_utils.py:116-123 etc."""
     _chk(x_cl, "conv_wgrad:x")
     _chk(gy_cl, "conv_wgrad:gy")
     B, Di, Hi, Wi, CI = x_cl.shape
@@ -290,22 +292,28 @@ def conv_wgrad(x_cl, gy_cl, kernel, stride, padding):
         ngrp, width = ntaps, cip
     rows = B * Do * Ho
     slot_bytes = ngrp * cop * width * 4
-    # workgroups = slots of `partial` (summed by the caller: deterministic).  Measured on the config-4 step: 1024 slots
-    # 26.0 ms, 512 26.4 ms, 256 27.9 ms -- the kernels want the parallelism more than the reduction minds the size.
-    # MVSTER_WGRAD_NBLK overrides (experiments).
+    # workgroups = slots of `partial` (added in a fixed order by the finish kernel: deterministic).  Measured on the
+    # config-4 step: 1024 slots 26.0 ms, 512 26.4 ms, 256 27.9 ms -- the kernels want the parallelism more than the
+    # reduction minds the size.  MVSTER_WGRAD_NBLK overrides (experiments).
     import os
     cap = int(os.environ.get("MVSTER_WGRAD_NBLK", "1024"))
     nblk = max(1, min((rows + 3) // 4, (32 << 20) // slot_bytes, cap))
     partial = torch.empty(nblk, ngrp, cop, width, device=x_cl.device, dtype=torch.float32)
-    rc = _lib.load().mvster_conv_wgrad(_ptr(x_cl), _ptr(gy_cl), _ptr(partial), nblk, B, Di, Hi, Wi, CI, Do, Ho, Wo, CO,
-                                       kd, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
-                                       int(packed), _stream())
+    lib = _lib.load()
+    rc = lib.mvster_conv_wgrad(_ptr(x_cl), _ptr(gy_cl), _ptr(partial), nblk, B, Di, Hi, Wi, CI, Do, Ho, Wo, CO,
+                               kd, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
+                               int(packed), _stream())
     _lib.check(rc, "conv_wgrad")
-    dw = partial.sum(0)                                                   # [groups, COP, width]
-    if packed:
-        dw = dw.reshape(ngrp, cop, tpn, cip).permute(0, 2, 1, 3).reshape(ngrp * tpn, cop, cip)[:ntaps]
-    dw = dw[:, :CO, :CI]                                                  # [taps, CO, CI]
-    return dw.reshape(kd, kh, kw, CO, CI).permute(3, 4, 0, 1, 2).contiguous()
+    co_keep = CO if co_keep is None else co_keep
+    ci_keep = CI if ci_keep is None else ci_keep
+    if co_keep > CO or ci_keep > CI:
+        raise RuntimeError("conv_wgrad: cannot keep more channels than the tensors have")
+    dw = torch.empty((ci_keep, co_keep, kd, kh, kw) if mirrored else (co_keep, ci_keep, kd, kh, kw), device=x_cl.device,
+                     dtype=torch.float32)
+    rc = lib.mvster_conv_wgrad_finish(_ptr(partial), _ptr(dw), nblk, ngrp, cop, width, ntaps, cip if packed else 0,
+                                      co_keep, ci_keep, int(mirrored), int(mirrored), _stream())
+    _lib.check(rc, "conv_wgrad_finish")
+    return dw
 
 
 def bn_batch_stats(x, weight, bias, running_mean, running_var, eps, momentum, groups=1, num_batches_tracked=None):

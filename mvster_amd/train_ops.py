@@ -143,14 +143,14 @@ class _ConvCL(torch.autograd.Function):
             gx = gx[..., :cin]
         if ctx.needs_input_grad[1]:
             if transposed:
-                gw = ops.conv_wgrad(gy, xp, kernel, stride, padding)[:cin]          # [cin, cout, k]
+                gw = ops.conv_wgrad(gy, xp, kernel, stride, padding, co_keep=cin)           # [cin, cout, k]
             elif stride == (1, 1, 1) and gy.shape[-1] <= 8 < xp.shape[-1] and kernel != (1, 1, 1):
                 # narrow OUTPUT side: the mirrored sum  dW[co][ci][t] = sum_q x[q][ci] * gy[q + p - t][co]  has gy as the
                 # shifted tensor, so the tap-packed kernel applies with the roles swapped (taps and padding mirrored)
                 mirror = tuple(k - 1 - p for k, p in zip(kernel, padding))
-                gw = ops.conv_wgrad(gy, xp, kernel, stride, mirror).flip(2, 3, 4).transpose(0, 1)[:, :cin]
+                gw = ops.conv_wgrad(gy, xp, kernel, stride, mirror, co_keep=cin, mirrored=True)
             else:
-                gw = ops.conv_wgrad(xp, gy, kernel, stride, padding)[:, :cin]       # [cout, cin, k]
+                gw = ops.conv_wgrad(xp, gy, kernel, stride, padding, ci_keep=cin)           # [cout, cin, k]
             if weight.dim() == 4:
                 gw = gw.squeeze(2)
         if bias is not None and ctx.needs_input_grad[2]:
@@ -209,7 +209,7 @@ class _FpnGather(torch.autograd.Function):
                               lambda L: L.repack_on_device(wg, swap=True), owner=ctx.owner)
             gf = layer(gG)
         if ctx.needs_input_grad[1]:
-            gwg = ops.conv_wgrad(f, gG, (1, 1, 1), (1, 1, 1), (0, 0, 0))[:wg.shape[0]].reshape(wg.shape)
+            gwg = ops.conv_wgrad(f, gG, (1, 1, 1), (1, 1, 1), (0, 0, 0), co_keep=wg.shape[0]).reshape(wg.shape)
         if ctx.needs_input_grad[2]:
             # d/d vb[tap] = sum of gP over the pixels whose tap is inside the image: all, minus the first / last row / column
             g = gP[:, 0]
