@@ -799,6 +799,73 @@ struct WarpAggBwdArgs {
 // that fall outside the window (strongly rotated views) go to global memory directly.  grad_ref needs no
 // atomics at all: each reference pixel belongs to exactly one workgroup, which sums over depths and views in
 // LDS and stores once.
+// Taps that fall outside the scatter window go to global memory with atomics.  Issued lane = pixel they would be 8
+// successive instructions per tap, each lane walking its own texel's channels: the L2 atomic units then see one 4-byte
+// request per lane and instruction, ~20 G adds/s whatever the address pattern (scripts/probes/global_atomic_probe.hip).
+// Eight neighbouring lanes covering one texel's 32 contiguous bytes are merged into one request: 169 G adds/s.  So a
+// wavefront parks the (offset, 8 values) records of its out-of-window lanes in LDS and drains them with
+// lane = (record, channel).  Wave-local: no workgroup barrier, 64 records of 36 bytes per wavefront.
+struct TapQueue {
+    int off[64];
+    float val[64][8];
+};
+
+__device__ __forceinline__ void queue_tap(TapQueue& q, float* __restrict__ gsp, bool outside, long off, float wt,
+                                          const float (&dw8)[8]) {
+    const unsigned long long mask = __ballot(outside);
+    if (mask == 0) return;                                   // wave-uniform
+    const int lane = threadIdx.x & 63;
+    if (outside) {
+        const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        q.off[slot] = (int)off;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) q.val[slot][c] = wt * dw8[c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n = __popcll(mask) * 8;
+    for (int i = lane; i < n; i += 64) unsafeAtomicAdd(gsp + q.off[i >> 3] + (i & 7), q.val[i >> 3][i & 7]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                         // the records are consumed before the next tap overwrites them
+}
+
+// The four taps of one pixel for one 8-channel pass: into the window (64-bit fixed-point LDS atomics) where they fall
+// inside it, queued for the coalesced global atomics otherwise.  win = &window[0][0][0] with channel pitch `cpitch` and
+// row pitch `rpitch` (u64 units).
+struct TapPlace {
+    int ax, bx, ay, by;
+    bool iax, ibx, iay, iby;
+    long o00, o01, o10, o11;
+};
+
+__device__ __forceinline__ void scatter_taps(u64* win, int cpitch, int rpitch, TapQueue& q, float* __restrict__ gsp, bool valid,
+                                             const mv::Taps& t, const TapPlace& w, int cbase, const float (&dw8)[8],
+                                             float fxs) {
+    const bool wnw = valid && t.nw != 0.0f, wne = valid && t.ne != 0.0f;
+    const bool wsw = valid && t.sw != 0.0f, wse = valid && t.se != 0.0f;
+    if (wnw && w.iax && w.iay) {
+#pragma unroll
+        for (int cl = 0; cl < 8; ++cl) fix_add(win + cl * cpitch + w.ay * rpitch + w.ax, t.nw * dw8[cl], fxs);
+    }
+    if (wne && w.ibx && w.iay) {
+#pragma unroll
+        for (int cl = 0; cl < 8; ++cl) fix_add(win + cl * cpitch + w.ay * rpitch + w.bx, t.ne * dw8[cl], fxs);
+    }
+    if (wsw && w.iax && w.iby) {
+#pragma unroll
+        for (int cl = 0; cl < 8; ++cl) fix_add(win + cl * cpitch + w.by * rpitch + w.ax, t.sw * dw8[cl], fxs);
+    }
+    if (wse && w.ibx && w.iby) {
+#pragma unroll
+        for (int cl = 0; cl < 8; ++cl) fix_add(win + cl * cpitch + w.by * rpitch + w.bx, t.se * dw8[cl], fxs);
+    }
+    queue_tap(q, gsp, wnw && !(w.iax && w.iay), w.o00 + cbase, t.nw, dw8);
+    queue_tap(q, gsp, wne && !(w.ibx && w.iay), w.o01 + cbase, t.ne, dw8);
+    queue_tap(q, gsp, wsw && !(w.iax && w.iby), w.o10 + cbase, t.sw, dw8);
+    queue_tap(q, gsp, wse && !(w.ibx && w.iby), w.o11 + cbase, t.se, dw8);
+}
+
 constexpr int kWinX = 96, kWinY = 6;
 static const bool g_bwd_no_tiles = getenv("MVSTER_BWD_NO_TILES") != nullptr;   // experiment switch
 static const bool g_pix = getenv("MVSTER_PIX") != nullptr;   // experiment switch: pixel-major kernel at the fine stages
@@ -815,6 +882,7 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
     __shared__ u64 gref[C][64];
     __shared__ u64 win[8][kWinY][kWinX];
     __shared__ int worg[2][2];
+    __shared__ TapQueue tapq[DMAX];          // one per wavefront
     const FixScale fx = make_fix_scale(ba.maxima, G, a.D, CG, GROUP, a.fuse_d != 0, a.attn_temp);
 
     const int tx = threadIdx.x;
@@ -946,14 +1014,19 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
         }
         const int wx0 = worg[v & 1][0], wy0 = worg[v & 1][1];
         // window coordinates of the four taps (negative / too large = outside -> global atomics)
-        const int ax = tc.xa - wx0, bx = tc.xb - wx0, ay = tc.ya - wy0, by = tc.yb - wy0;
-        const bool iax = (unsigned)ax < (unsigned)kWinX, ibx = (unsigned)bx < (unsigned)kWinX;
-        const bool iay = (unsigned)ay < (unsigned)kWinY, iby = (unsigned)by < (unsigned)kWinY;
+        TapPlace tp;
+        tp.ax = tc.xa - wx0; tp.bx = tc.xb - wx0; tp.ay = tc.ya - wy0; tp.by = tc.yb - wy0;
+        tp.iax = (unsigned)tp.ax < (unsigned)kWinX; tp.ibx = (unsigned)tp.bx < (unsigned)kWinX;
+        tp.iay = (unsigned)tp.ay < (unsigned)kWinY; tp.iby = (unsigned)tp.by < (unsigned)kWinY;
+        tp.o00 = o00; tp.o01 = o01; tp.o10 = o10; tp.o11 = o11;
 
         // pass 2: re-gather, scatter the feature gradients, 8 channels per window pass (unrolled: go[] stays in registers)
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
             const int cbase = cb * 8;
+            float dw8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dw8[j] = 0.0f;
             if (valid) {
                 f32x4 gq[2];
                 if (!GO_REG) { gq[0] = ld4(gop + cbase); gq[1] = ld4(gop + cbase + 4); }
@@ -969,35 +1042,20 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
                         const float gv = GO_REG ? go[GO_REG ? (GROUP ? c / CG : c) : 0] : gq[c0 / 4][j];
                         const float dcor = fmaf(gv * invW, wgt, dscore);   // direct + through the softmax
                         const float wv = mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
-                        float dwv, dref;
+                        float dref;
                         if (GROUP) {
-                            dwv = dcor * (1.0f / CG) * R[j];
+                            dw8[cl] = dcor * (1.0f / CG) * R[j];
                             dref = dcor * (1.0f / CG) * wv;
                         } else {
                             const float df = R[j] - wv;
                             dref = 2.0f * df * dcor;
-                            dwv = -dref;
+                            dw8[cl] = -dref;
                         }
                         fix_add(&gref[c][tx], dref, fx.s);
-                        if (t.nw != 0.0f) {
-                            if (iax && iay) fix_add(&win[cl][ay][ax], t.nw * dwv, fx.s);
-                            else unsafeAtomicAdd(gsp + o00 + c, t.nw * dwv);
-                        }
-                        if (t.ne != 0.0f) {
-                            if (ibx && iay) fix_add(&win[cl][ay][bx], t.ne * dwv, fx.s);
-                            else unsafeAtomicAdd(gsp + o01 + c, t.ne * dwv);
-                        }
-                        if (t.sw != 0.0f) {
-                            if (iax && iby) fix_add(&win[cl][by][ax], t.sw * dwv, fx.s);
-                            else unsafeAtomicAdd(gsp + o10 + c, t.sw * dwv);
-                        }
-                        if (t.se != 0.0f) {
-                            if (ibx && iby) fix_add(&win[cl][by][bx], t.se * dwv, fx.s);
-                            else unsafeAtomicAdd(gsp + o11 + c, t.se * dwv);
-                        }
                     }
                 }
             }
+            scatter_taps(&win[0][0][0], kWinY * kWinX, kWinX, tapq[d], gsp, valid, t, tp, cbase, dw8, fx.s);
             __syncthreads();
             if (ba.windows) {
                 // store (and clear) the window densely, texel-major / channel-fastest; scatter_gather_kernel sums the
@@ -1053,6 +1111,7 @@ __global__ void __launch_bounds__(64 * 8) warp_agg_bwd_tile_kernel(WarpAggBwdArg
     __shared__ u64 gref[R][C][64];
     __shared__ u64 win[8][WY][kTileWinX];
     __shared__ int worg[2];
+    __shared__ TapQueue tapq[8];             // one per wavefront
     const FixScale fx = make_fix_scale(ba.maxima, G, a.D, CG, GROUP, true, a.attn_temp);
 
     const int tx = threadIdx.x;
@@ -1178,44 +1237,30 @@ __global__ void __launch_bounds__(64 * 8) warp_agg_bwd_tile_kernel(WarpAggBwdArg
             float dot = 0.0f;
             for (int j = 0; j < a.D; ++j) dot += sd[par][j][tx];
             const float dscore = sig * (dsig - dot) / a.attn_temp;
-            const int ax = tc.xa - wx0, bx = tc.xb - wx0, ay = tc.ya - wy0, by = tc.yb - wy0;
-            const bool iax = (unsigned)ax < (unsigned)kTileWinX, ibx = (unsigned)bx < (unsigned)kTileWinX;
-            const bool iay = (unsigned)ay < (unsigned)WY, iby = (unsigned)by < (unsigned)WY;
+            TapPlace tp;
+            tp.ax = tc.xa - wx0; tp.bx = tc.xb - wx0; tp.ay = tc.ya - wy0; tp.by = tc.yb - wy0;
+            tp.iax = (unsigned)tp.ax < (unsigned)kTileWinX; tp.ibx = (unsigned)tp.bx < (unsigned)kTileWinX;
+            tp.iay = (unsigned)tp.ay < (unsigned)WY; tp.iby = (unsigned)tp.by < (unsigned)WY;
+            tp.o00 = o00; tp.o01 = o01; tp.o10 = o10; tp.o11 = o11;
 
-            // pass 2: scatter into the tile's window (64-bit fixed-point LDS atomics; global atomics outside the window)
-            if (valid) {
+            // pass 2: scatter into the tile's window (64-bit fixed-point LDS atomics; coalesced global atomics outside it)
+            float dw8[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int g = GROUP ? c / CG : c;
-                    const float dcor = fmaf(go[g] * invW, wgt, dscore);
-                    float dwv, dref;
-                    if (GROUP) {
-                        dwv = dcor * (1.0f / CG) * Rv[c];
-                        dref = dcor * (1.0f / CG) * wv[c];
-                    } else {
-                        const float df = Rv[c] - wv[c];
-                        dref = 2.0f * df * dcor;
-                        dwv = -dref;
-                    }
-                    fix_add(&gref[r][c][tx], dref, fx.s);
-                    if (t.nw != 0.0f) {
-                        if (iax && iay) fix_add(&win[c][ay][ax], t.nw * dwv, fx.s);
-                        else unsafeAtomicAdd(gsp + o00 + c, t.nw * dwv);
-                    }
-                    if (t.ne != 0.0f) {
-                        if (ibx && iay) fix_add(&win[c][ay][bx], t.ne * dwv, fx.s);
-                        else unsafeAtomicAdd(gsp + o01 + c, t.ne * dwv);
-                    }
-                    if (t.sw != 0.0f) {
-                        if (iax && iby) fix_add(&win[c][by][ax], t.sw * dwv, fx.s);
-                        else unsafeAtomicAdd(gsp + o10 + c, t.sw * dwv);
-                    }
-                    if (t.se != 0.0f) {
-                        if (ibx && iby) fix_add(&win[c][by][bx], t.se * dwv, fx.s);
-                        else unsafeAtomicAdd(gsp + o11 + c, t.se * dwv);
-                    }
+            for (int c = 0; c < 8; ++c) {
+                const int g = GROUP ? c / CG : c;
+                const float dcor = fmaf(go[g] * invW, wgt, dscore);
+                float dref;
+                if (GROUP) {
+                    dw8[c] = dcor * (1.0f / CG) * Rv[c];
+                    dref = dcor * (1.0f / CG) * wv[c];
+                } else {
+                    const float df = Rv[c] - wv[c];
+                    dref = 2.0f * df * dcor;
+                    dw8[c] = -dref;
                 }
+                if (valid) fix_add(&gref[r][c][tx], dref, fx.s);
             }
+            scatter_taps(&win[0][0][0], WY * kTileWinX, kTileWinX, tapq[d], gsp, valid, t, tp, 0, dw8, fx.s);
         }
         __syncthreads();
         if (ba.windows) {
