@@ -18,7 +18,7 @@ H, W, N, B = 512, 640, 5, 2
 model = MVS4net(**SHIPPED)
 model.load_state_dict(load_weights(), strict=True)
 model.to(dev).train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
 imgs, proj, dv = make_inputs(N, H, W, seed=0, device=dev, batch=B)
 g = torch.Generator().manual_seed(0)
 gt, mask = {}, {}
@@ -53,5 +53,8 @@ for ev in prof.events():
     a[1] += ev.self_device_time_total
 tot = sum(v[1] for v in agg.values())
 print("aten kernels: %d launches, %.2f ms" % (sum(v[0] for v in agg.values()), tot / 1e3))
-for (name, where), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:110]:
+only = sys.argv[1:]          # optional: aten op names to list in full
+for (name, where), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:(1000 if only else 110)]:
+    if only and name.split("::")[1] not in only:
+        continue
     print("%7.1f us %4d x  %-28s %s" % (t, n, name, where))
