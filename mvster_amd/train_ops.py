@@ -118,10 +118,12 @@ class _ConvCL(torch.autograd.Function):
         kernel = tuple(w5.shape[2:])
         gy = gy.contiguous()
         gx = gw = gb = None
+        co = gy.shape[-1]
+        co_p = _cin_for(co)
+        # the output gradient padded to a channel count the kernels take (1 -> 4 for the depth heads); also what the
+        # weight gradient reads: with a multiple of 4 channels it runs on the LDS-staged kernel
+        gyp = _pad_last(gy, co_p).contiguous() if co != co_p else gy
         if ctx.needs_input_grad[0]:
-            co = gy.shape[-1]
-            co_p = _cin_for(co)
-            gyp = _pad_last(gy, co_p).contiguous()
             if transposed:
                 # y = convT(x; W[cin,cout]) : dx = conv(gy; W read as [out=cin, in=cout], same stride / padding)
                 layer = CACHE.get(weight, "dgrad" + tag, lambda: ConvLayer(w5, False, stride, padding, cin_pad=co_p),
@@ -143,14 +145,14 @@ class _ConvCL(torch.autograd.Function):
             gx = gx[..., :cin]
         if ctx.needs_input_grad[1]:
             if transposed:
-                gw = ops.conv_wgrad(gy, xp, kernel, stride, padding, co_keep=cin)           # [cin, cout, k]
-            elif stride == (1, 1, 1) and gy.shape[-1] <= 8 < xp.shape[-1] and kernel != (1, 1, 1):
+                gw = ops.conv_wgrad(gyp, xp, kernel, stride, padding, co_keep=cin, ci_keep=co)   # [cin, cout, k]
+            elif stride == (1, 1, 1) and co <= 8 < xp.shape[-1] and kernel != (1, 1, 1):
                 # narrow OUTPUT side: the mirrored sum  dW[co][ci][t] = sum_q x[q][ci] * gy[q + p - t][co]  has gy as the
                 # shifted tensor, so the tap-packed kernel applies with the roles swapped (taps and padding mirrored)
                 mirror = tuple(k - 1 - p for k, p in zip(kernel, padding))
-                gw = ops.conv_wgrad(gy, xp, kernel, stride, mirror, co_keep=cin, mirrored=True)
+                gw = ops.conv_wgrad(gyp, xp, kernel, stride, mirror, co_keep=cin, ci_keep=co, mirrored=True)
             else:
-                gw = ops.conv_wgrad(xp, gy, kernel, stride, padding, ci_keep=cin)           # [cout, cin, k]
+                gw = ops.conv_wgrad(xp, gyp, kernel, stride, padding, co_keep=co, ci_keep=cin)   # [cout, cin, k]
             if weight.dim() == 4:
                 gw = gw.squeeze(2)
         if bias is not None and ctx.needs_input_grad[2]:
