@@ -433,6 +433,91 @@ def test_upsample2x_cl_forward_and_adjoint(B, h, w, C):
     assert (xb.grad.cpu()[:, 0] - xa.grad.permute(0, 2, 3, 1)).abs().max() <= 1e-5
 
 
+@pytest.mark.parametrize("B,h,w,C", [(2, 8, 12, 32), (1, 5, 7, 8), (1, 1, 3, 4)])
+def test_upsample2x_nearest_cl_forward_and_adjoint(B, h, w, C):
+    """The mono head's nearest x2 (mvs4net_utils.py:858) and its adjoint (2x2 block sums) against F.interpolate."""
+    g = torch.Generator().manual_seed(B * 10 + h)
+    x = torch.randn(B, 1, h, w, C, generator=g)
+    xa = x[:, 0].permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ya = F.interpolate(xa, scale_factor=2, mode="nearest")
+    gy = torch.randn(ya.shape, generator=g)
+    ya.backward(gy)
+    xb = x.to(DEV).requires_grad_(True)
+    yb = T.upsample2x_cl(xb, "nearest")
+    yb.backward(gy.permute(0, 2, 3, 1).unsqueeze(1).contiguous().to(DEV))
+    assert torch.equal(yb.detach().cpu()[:, 0], ya.detach().permute(0, 2, 3, 1))
+    assert (xb.grad.cpu()[:, 0] - xa.grad.permute(0, 2, 3, 1)).abs().max() <= 1e-6
+
+
+@pytest.mark.parametrize("C,groups", [(8, 1), (32, 5), (64, 3)])
+def test_batch_norm_cl_groups_skip_and_frozen(C, groups):
+    """What the first BatchNorm test leaves out: statistics per view group (parameter gradients summed over the groups,
+    running statistics updated group after group, the counter advanced by the number of groups), the skip tensor added
+    in the same kernel, and a BatchNorm in eval mode inside a training graph (running statistics, dx = g * scale)."""
+    g = torch.Generator().manual_seed(C + groups)
+    x = torch.randn(groups * 2, 1, 6, 10, C, generator=g) * 1.5 + 0.3
+    skip = torch.randn(x.shape, generator=g)
+    gy = torch.randn(x.shape, generator=g)
+    ref, ours = torch.nn.BatchNorm3d(C), torch.nn.BatchNorm3d(C)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5, generator=g)
+        ref.bias.uniform_(-0.5, 0.5, generator=g)
+    ours.load_state_dict(ref.state_dict())
+    ours.to(DEV)
+
+    def torch_form(x_, skip_):
+        outs = []
+        for v in range(groups):                      # `groups` sequential calls of the module, like the reference's FPN
+            xv = x_[2 * v:2 * v + 2].permute(0, 4, 1, 2, 3)
+            outs.append(torch.relu(ref(xv)).permute(0, 2, 3, 4, 1))
+        return torch.cat(outs) + skip_
+
+    for mode in ("train", "eval"):
+        ref.train(mode == "train")
+        ours.train(mode == "train")
+        ref.zero_grad()
+        ours.zero_grad()
+        xa, sa = x.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+        ya = torch_form(xa, sa)
+        ya.backward(gy)
+        xb, sb = x.to(DEV).requires_grad_(True), skip.to(DEV).requires_grad_(True)
+        yb = T.batch_norm_cl(xb, ours, relu=True, groups=groups, skip=sb)
+        yb.backward(gy.to(DEV))
+        assert (yb.detach().cpu() - ya.detach()).abs().max() <= 2e-5, mode
+        assert (xb.grad.cpu() - xa.grad).abs().max() <= 2e-5, mode
+        assert torch.equal(sb.grad.cpu(), sa.grad), mode
+        for pa, pb in ((ref.weight, ours.weight), (ref.bias, ours.bias)):
+            assert (pb.grad.cpu() - pa.grad).abs().max() <= 1e-4 * max(1.0, pa.grad.abs().max().item()), mode
+    assert (ours.running_mean.cpu() - ref.running_mean).abs().max() <= 1e-5
+    assert (ours.running_var.cpu() - ref.running_var).abs().max() <= 1e-5
+    assert int(ours.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+def test_layer_cache_sees_replaced_storage_and_always_repack():
+    """ADVICE r1: updates that do not bump ``_version``.  ``p.data = t`` moves the storage (seen through data_ptr);
+    an in-place write through ``p.data`` is invisible unless ``always_repack`` is set."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 1, 8, 16, 8, generator=g).to(DEV)
+    w = torch.nn.Parameter(torch.randn(8, 8, 1, 3, 3, generator=g).to(DEV))
+
+    def run():
+        with torch.no_grad():
+            return T.conv_cl(x, w, None, 1, (0, 1, 1))
+
+    def want():
+        return F.conv3d(x.permute(0, 4, 1, 2, 3), w.detach(), None, padding=(0, 1, 1)).permute(0, 2, 3, 4, 1)
+
+    assert (run() - want()).abs().max() <= 1e-4
+    w.data = (w.detach() * 2.0).clone()                      # new storage, same version
+    assert (run() - want()).abs().max() <= 1e-4
+    T.CACHE.always_repack = True
+    try:
+        w.data.mul_(0.5)                                     # same storage, same version
+        assert (run() - want()).abs().max() <= 1e-4
+    finally:
+        T.CACHE.always_repack = False
+
+
 def test_graphed_train_step_follows_the_eager_trajectory():
     """GraphedTrainStep (forward + loss + backward + Adam in one hipGraph) against the same steps issued eagerly: same
     losses step by step and the same parameter movement (the scatter atomics of the warp backward make two eager runs
