@@ -164,13 +164,17 @@ __global__ void __launch_bounds__(256) deconv_small_kernel(DeconvArgs a) {
     const unsigned o10 = in_ ? base + (unsigned)a.Wi * CIN * 4u : 0xFFFFFFF0u;
     const unsigned o11 = (jn && in_) ? base + (unsigned)(a.Wi + 1) * CIN * 4u : 0xFFFFFFF0u;
 
-    float acc[4][COUT];   // [dy*2+dx][co]
+    // packed fp32 FMAs (two output channels per instruction), weights as wave-uniform scalar pairs.  The channel loop
+    // stays rolled (4 channels per trip): fully unrolled, the 1152 scalar weights and 576 packed FMAs of (16, 8) ran
+    // 45.8 us at stage 4 against 24.3 us rolled (25.9 us with unpacked FMAs).
+    f32x2v acc[4][COUT / 2];   // [dy*2+dx][co pair]
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[q][c] = 0.0f;
+        for (int c = 0; c < COUT / 2; ++c) acc[q][c] = (f32x2v){0.f, 0.f};
 
-    auto wrow = [&](int ky, int kx, int ci) { return a.w + ((ky * 3 + kx) * CIN + ci) * COUT; };   // wave-uniform
+    const f32x2v* w2 = reinterpret_cast<const f32x2v*>(a.w);
+    auto wrow = [&](int ky, int kx, int ci) { return w2 + ((ky * 3 + kx) * CIN + ci) * (COUT / 2); };   // wave-uniform
 #pragma unroll 1
     for (int c4 = 0; c4 < CIN; c4 += 4) {
         const f32x4v x00 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + c4 * 4u, 0, 0));
@@ -180,18 +184,18 @@ __global__ void __launch_bounds__(256) deconv_small_kernel(DeconvArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int ci = c4 + k;
-            const float a00 = x00[k], a01 = x01[k], a10 = x10[k], a11 = x11[k];
+            const f32x2v a00 = {x00[k], x00[k]}, a01 = {x01[k], x01[k]}, a10 = {x10[k], x10[k]}, a11 = {x11[k], x11[k]};
 #pragma unroll
-            for (int co = 0; co < COUT; ++co) {
-                acc[0][co] = fmaf(a00, wrow(1, 1, ci)[co], acc[0][co]);
-                acc[1][co] = fmaf(a00, wrow(1, 2, ci)[co], acc[1][co]);
-                acc[1][co] = fmaf(a01, wrow(1, 0, ci)[co], acc[1][co]);
-                acc[2][co] = fmaf(a00, wrow(2, 1, ci)[co], acc[2][co]);
-                acc[2][co] = fmaf(a10, wrow(0, 1, ci)[co], acc[2][co]);
-                acc[3][co] = fmaf(a00, wrow(2, 2, ci)[co], acc[3][co]);
-                acc[3][co] = fmaf(a01, wrow(2, 0, ci)[co], acc[3][co]);
-                acc[3][co] = fmaf(a10, wrow(0, 2, ci)[co], acc[3][co]);
-                acc[3][co] = fmaf(a11, wrow(0, 0, ci)[co], acc[3][co]);
+            for (int co = 0; co < COUT / 2; ++co) {
+                acc[0][co] = __builtin_elementwise_fma(a00, wrow(1, 1, ci)[co], acc[0][co]);
+                acc[1][co] = __builtin_elementwise_fma(a00, wrow(1, 2, ci)[co], acc[1][co]);
+                acc[1][co] = __builtin_elementwise_fma(a01, wrow(1, 0, ci)[co], acc[1][co]);
+                acc[2][co] = __builtin_elementwise_fma(a00, wrow(2, 1, ci)[co], acc[2][co]);
+                acc[2][co] = __builtin_elementwise_fma(a10, wrow(0, 1, ci)[co], acc[2][co]);
+                acc[3][co] = __builtin_elementwise_fma(a00, wrow(2, 2, ci)[co], acc[3][co]);
+                acc[3][co] = __builtin_elementwise_fma(a01, wrow(2, 0, ci)[co], acc[3][co]);
+                acc[3][co] = __builtin_elementwise_fma(a10, wrow(0, 2, ci)[co], acc[3][co]);
+                acc[3][co] = __builtin_elementwise_fma(a11, wrow(0, 0, ci)[co], acc[3][co]);
             }
         }
     }
@@ -204,7 +208,7 @@ __global__ void __launch_bounds__(256) deconv_small_kernel(DeconvArgs a) {
         float v[COUT];
 #pragma unroll
         for (int c = 0; c < COUT; ++c) {
-            v[c] = fmaf(acc[q][c], a.scale[c], a.shift[c]);
+            v[c] = fmaf(acc[q][c >> 1][c & 1], a.scale[c], a.shift[c]);
             if (a.relu) v[c] = fmaxf(v[c], 0.0f);
         }
         if (a.skip) {
