@@ -366,6 +366,14 @@ int launch_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, hipStream_t
     return mv_check_launch();
 }
 
+// Accumulator tiles (MT * NT * tap groups) a wavefront may hold.  Small tiles win: the staging of a chunk is not
+// overlapped with its own math, so it is occupancy that hides it -- measured over the 64 weight gradients of a config-4
+// step: limit 40 -> 6.09 ms, 20 -> 5.49 ms, 12 -> 5.28 ms, 4 -> 5.22 ms.  MVSTER_WGRAD_ACC overrides (experiments).
+static int wgrad_acc_limit() {
+    static const int v = getenv("MVSTER_WGRAD_ACC") ? atoi(getenv("MVSTER_WGRAD_ACC")) : 12;
+    return v;
+}
+
 // tile shapes per tap count: MT*NT*taps accumulator tiles of 4 registers must stay well below the register file
 template <int TY, int KW>
 int dispatch_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, int packed, hipStream_t s) {
@@ -376,20 +384,22 @@ int dispatch_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, int packe
 #define MV_LP(M_, P_) if (mt == M_ && pcb == P_) return launch_wgrad_lds<M_, 1, TY, KW, P_>(a, nblk, cot, cit, s);
         const int ng8 = (TAPS + 1) / 2, ng4 = (TAPS + 3) / 4;
         int mt = cot;
-        while (mt > 1 && mt * (pcb == 8 ? ng8 : ng4) > 40) mt /= 2;
+        while (mt > 1 && mt * (pcb == 8 ? ng8 : ng4) > wgrad_acc_limit()) mt /= 2;
         MV_LP(1, 4) MV_LP(2, 4) MV_LP(4, 4) MV_LP(1, 8) MV_LP(2, 8) MV_LP(4, 8)
 #undef MV_LP
         return MVSTER_ERR_UNSUPPORTED;
     }
     int mt = cot, nt = cit;
     if (cot == 5 && TAPS != 1) return MVSTER_ERR_UNSUPPORTED;        // 5 M tiles do not halve
-    while (mt * nt * TAPS > 40 && (mt > 1 || nt > 1)) {
-        if (mt >= nt && mt > 1) mt /= 2; else nt /= 2;
+    while (mt * nt * TAPS > wgrad_acc_limit() && (mt > 1 || nt > 1)) {
+        if (mt >= nt && mt > 1 && mt != 5) mt /= 2;
+        else if (nt > 1) nt /= 2;
+        else break;
     }
     if (mt * nt * TAPS > 40) return MVSTER_ERR_UNSUPPORTED;
 #define MV_LN(M_, N_) if (mt == M_ && nt == N_) { if constexpr (M_ * N_ * TAPS <= 40) return launch_wgrad_lds<M_, N_, TY, KW, 0>(a, nblk, cot, cit, s); }
     MV_LN(1, 1) MV_LN(2, 1) MV_LN(1, 2) MV_LN(2, 2) MV_LN(4, 1) MV_LN(1, 4) MV_LN(4, 2) MV_LN(2, 4) MV_LN(4, 4)
-    if constexpr (TAPS == 1) { MV_LN(5, 4) }      // 72 (+8) x 64: the FPN gather's 1x1 conv
+    if constexpr (TAPS == 1) { MV_LN(5, 4) MV_LN(5, 2) MV_LN(5, 1) }      // 72 (+8) x 64: the FPN gather's 1x1 conv
 #undef MV_LN
     return MVSTER_ERR_UNSUPPORTED;
 }
