@@ -220,7 +220,8 @@ int launch_wgrad(const WgradArgs& a, int nblk, int ntaps, hipStream_t s) {
 // materialised -- and ALL kernel taps take their operands from LDS with conflict-free ds_read_b32 (pixel pitches chosen
 // so that the four pixels of a K step land 16 banks apart).  A workgroup owns MT x NT channel tiles (blockIdx.y) and
 // every tap: MT*NT*taps accumulator tiles live in registers across all rows the workgroup visits; the four waves split
-// the K steps of a chunk and are summed through LDS once, at the end.  Same `partial` layouts as above (host sum:
+// the K steps of a chunk and are summed through LDS once, at the end.  Chunks are register-double-buffered (the next
+// chunk's global loads fly under this chunk's MFMAs).  Same `partial` layouts as above (host sum:
 // deterministic).  PCB = 0: one tap per N tile; PCB = 4 / 8: narrow B side, 16 / PCB taps share an N tile.
 // ------------------------------------------------------------------------------------------
 constexpr int kXC = 64;      // output columns per staged chunk
@@ -232,6 +233,9 @@ __host__ __device__ constexpr int wg_pitch(int c, int s) {
     while ((s * p) % 32 != 16) p += 4;
     return p;
 }
+
+// largest x stride the prefetch registers are sized for: the 3x3x3 layers (TY = 9) are all stride 1
+__host__ __device__ constexpr int wgrad_stride_bound(int ty) { return ty == 9 ? 1 : 2; }
 
 template <int MT, int NT, int TY, int KW, int PCB>
 __global__ void __launch_bounds__(256) conv_wgrad_lds_kernel(WgradArgs a, int mgroups) {
@@ -271,57 +275,91 @@ __global__ void __launch_bounds__(256) conv_wgrad_lds_kernel(WgradArgs a, int mg
 
     const int nrows = a.B * a.Do * a.Ho;
     const int nchunks = (a.Wo + kXC - 1) / kXC;
-    const int qa = MT * 4, qb = CBB / 4;                             // float4 per staged pixel
-    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+    constexpr int qa = MT * 4, qb = (PACKED ? PCB : NT * 16) / 4;    // float4 per staged pixel
+    // A staging unit = one chunk of one output row.  Units are register-double-buffered: the global loads of unit u+1
+    // are issued before the MFMAs of unit u and written to LDS after them (measured over the 64 weight gradients of a
+    // config-4 step: 5.26 -> 4.40 ms; the 27-tap layers gain too, although the nine staged rows cost them 40 registers).
+    constexpr int NA = (kXC * qa + 255) / 256;
+    constexpr int NBX = (TY * (63 * wgrad_stride_bound(TY) + KW) * qb + 255) / 256;
+    f32x4v ra[NA], rb[NBX];
+    const int nb4 = TY * XB * qb;                                    // float4 of the B patch (<= NBX * 256)
+    const int my_rows = blockIdx.x < nrows ? (nrows - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int nunits = my_rows * nchunks;
+    auto unit_row = [&](int u) { return blockIdx.x + (u / nchunks) * gridDim.x; };
+    auto load_a = [&](int row, int x1, int idx) {
+        const int px = idx / qa, q = idx - px * qa;
+        const int c = m0 + q * 4;
+        f32x4v v = {0.f, 0.f, 0.f, 0.f};
+        if (idx < kXC * qa && x1 + px < a.Wo && c < a.CO)
+            v = *reinterpret_cast<const f32x4v*>(a.gy + ((long)row * a.Wo + (x1 + px)) * a.CO + c);
+        return v;
+    };
+    auto load_b = [&](int row, int x1, int idx) {
         const int yo = row % a.Ho, t = row / a.Ho;
         const int zo = t % a.Do, b = t / a.Do;
-        const float* grow = a.gy + (long)row * a.Wo * a.CO;
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const int x1 = ch * kXC;
-            __syncthreads();                                         // the previous chunk's readers are done
-            // stage the gy chunk: [kXC][MT*16] (zeros beyond the row end / the channel count)
-            for (int i = threadIdx.x; i < kXC * qa; i += 256) {
-                const int px = i / qa, q = i - px * qa;
-                const int c = m0 + q * 4;
-                f32x4v v = {0.f, 0.f, 0.f, 0.f};
-                if (x1 + px < a.Wo && c < a.CO) v = *reinterpret_cast<const f32x4v*>(grow + (long)(x1 + px) * a.CO + c);
-                *reinterpret_cast<f32x4v*>(As + px * PA + q * 4) = v;
-            }
-            // stage the TY input rows: [TY][XB][CBB]
-            const int ix0 = x1 * a.sw - a.pw;
-            for (int i = threadIdx.x; i < TY * XB * qb; i += 256) {
-                const int q = i % qb;
-                int rest = i / qb;
-                const int px = rest % XB, ty = rest / XB;
-                const int kz = ty / a.kh, ky = ty - kz * a.kh;
-                const int iz = zo * a.sd - a.pd + kz, iy = yo * a.sh - a.ph + ky, ix = ix0 + px;
-                const int c = n0 + q * 4;
-                f32x4v v = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi && c < a.CI)
-                    v = *reinterpret_cast<const f32x4v*>(a.x + ((((long)b * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.CI + c);
-                *reinterpret_cast<f32x4v*>(Bs + (ty * XB + px) * PB + q * 4) = v;
-            }
-            __syncthreads();
-            // K steps of this wave: four output columns each
-            for (int ks = wave; ks < kXC / 4; ks += 4) {
-                const int px = ks * 4 + k;
-                float av[MT];
+        const int q = idx % qb;
+        const int rest = idx / qb;
+        const int px = rest % XB, ty = rest / XB;
+        const int kz = ty / a.kh, ky = ty - kz * a.kh;
+        const int iz = zo * a.sd - a.pd + kz, iy = yo * a.sh - a.ph + ky, ix = x1 * a.sw - a.pw + px;
+        const int c = n0 + q * 4;
+        f32x4v v = {0.f, 0.f, 0.f, 0.f};
+        if (idx < nb4 && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi && c < a.CI)
+            v = *reinterpret_cast<const f32x4v*>(a.x + ((((long)b * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.CI + c);
+        return v;
+    };
+    auto store_a = [&](int idx, const f32x4v& v) {
+        const int px = idx / qa, q = idx - px * qa;
+        if (idx < kXC * qa) *reinterpret_cast<f32x4v*>(As + px * PA + q * 4) = v;
+    };
+    auto store_b = [&](int idx, const f32x4v& v) {
+        const int q = idx % qb;
+        const int rest = idx / qb;
+        const int px = rest % XB, ty = rest / XB;
+        if (idx < nb4) *reinterpret_cast<f32x4v*>(Bs + (ty * XB + px) * PB + q * 4) = v;
+    };
+    auto compute = [&]() {
+        // K steps of this wave: four output columns each
+        for (int ks = wave; ks < kXC / 4; ks += 4) {
+            const int px = ks * 4 + k;
+            float av[MT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) av[i] = As[px * PA + i * 16 + r];
-                const float* bp = Bs + px * a.sw * PB + (PACKED ? 0 : r);
+            for (int i = 0; i < MT; ++i) av[i] = As[px * PA + i * 16 + r];
+            const float* bp = Bs + px * a.sw * PB + (PACKED ? 0 : r);
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
+            for (int g = 0; g < NG; ++g) {
 #pragma unroll
-                    for (int j = 0; j < NTT; ++j) {
-                        float bv = bp[boff[g] + j * 16];
-                        if (PACKED) bv = bval[g] ? bv : 0.0f;
+                for (int j = 0; j < NTT; ++j) {
+                    float bv = bp[boff[g] + j * 16];
+                    if (PACKED) bv = bval[g] ? bv : 0.0f;
 #pragma unroll
-                        for (int i = 0; i < MT; ++i)
-                            acc[(i * NTT + j) * NG + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[(i * NTT + j) * NG + g], 0, 0, 0);
-                    }
+                    for (int i = 0; i < MT; ++i)
+                        acc[(i * NTT + j) * NG + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[(i * NTT + j) * NG + g], 0, 0, 0);
                 }
             }
         }
+    };
+    auto fetch = [&](int u) {
+        const int row = unit_row(u), x1 = (u % nchunks) * kXC;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = load_a(row, x1, threadIdx.x + i * 256);
+#pragma unroll
+        for (int i = 0; i < NBX; ++i) rb[i] = load_b(row, x1, threadIdx.x + i * 256);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) store_a(threadIdx.x + i * 256, ra[i]);
+#pragma unroll
+        for (int i = 0; i < NBX; ++i) store_b(threadIdx.x + i * 256, rb[i]);
+    };
+    if (nunits > 0) { fetch(0); commit(); }
+    __syncthreads();
+    for (int u = 0; u < nunits; ++u) {
+        if (u + 1 < nunits) fetch(u + 1);
+        compute();
+        __syncthreads();                                             // this unit's readers are done
+        if (u + 1 < nunits) commit();
+        __syncthreads();
     }
 
     // cross-wave sum, one accumulator tile at a time through LDS (3 KB), then the workgroup's slot of `partial`
@@ -360,7 +398,7 @@ int launch_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, hipStream_t
     const size_t lds = sizeof(float) * ((size_t)kXC * PA + (size_t)TY * XB * PB);
     // (layers that need more -- stride-2 3x3 from 32 channels, 3x3 from 64 -- were measured no faster here with the limit
     //  raised to 128 KB, one workgroup per CU, than on the per-tap kernels below: 105 vs 47+ us, 642 vs 588 us)
-    if (lds > 64 * 1024) return MVSTER_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024 || a.sw > wgrad_stride_bound(TY)) return MVSTER_ERR_UNSUPPORTED;   // (prefetch register budget)
     const int mgroups = cot / MT, ngroups = PCB > 0 ? 1 : cit / NT;
     hipLaunchKernelGGL((conv_wgrad_lds_kernel<MT, NT, TY, KW, PCB>), dim3(nblk, mgroups * ngroups), dim3(256), lds, s, a, mgroups);
     return mv_check_launch();
