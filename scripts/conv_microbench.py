@@ -64,8 +64,31 @@ def candidates(layer, B, Di, Hi, Wi, sm):
     return out
 
 
-def emit_table(shapes, path):
-    """Time every candidate on the layer shapes of the given workloads; write the winners as JSON."""
+def _tune(calls, table, dev):
+    """Time every candidate of every recorded call that is not in the table yet; keep the winners."""
+    for layer, xs, ss, sm in calls:
+        B, Di, Hi, Wi, _ = xs
+        sig = cp.layer_signature(layer, B, Di, Hi, Wi, sm)
+        if sig in table:
+            continue
+        x = torch.randn(*xs, device=dev)
+        skip = torch.randn(*ss, device=dev) if ss else None
+        best = None
+        for name, tiles in candidates(layer, B, Di, Hi, Wi, sm):
+            try:
+                us = min(timeit(lambda: layer(x, skip=skip, skip_mode=sm, tiles=tiles), n=10) for _ in range(2))
+            except RuntimeError:
+                continue
+            if best is None or us < best[0]:
+                best = (us, tiles)
+        table[sig] = [best[1][2], best[1][0], best[1][1]]
+        print("%-48s -> v%d mt%d nt%d  %.1f us" % (sig, best[1][2], best[1][0], best[1][1], best[0]), flush=True)
+        del x, skip
+
+
+def emit_table(shapes, path, train_shapes=((512, 640, 5, 2),)):
+    """Time every candidate on the layer shapes of the given workloads -- eval forwards, and the forward + input-gradient
+    layers of a training step -- and write the winners as JSON."""
     import json
     dev = torch.device("cuda:0")
     model = MVS4net(**SHIPPED)
@@ -74,35 +97,35 @@ def emit_table(shapes, path):
     table = {}
     orig = cp.ConvLayer.__call__
     cp.FORCE_VARIANT = None
+    calls = []
+
+    def rec(layer, x, skip=None, skip_mode=0, tiles=None):
+        calls.append((layer, tuple(x.shape), None if skip is None else tuple(skip.shape), skip_mode if skip is not None else 0))
+        return orig(layer, x, skip, skip_mode, tiles)
     for (H, W, N) in shapes:
         imgs, proj, dv = make_inputs(N, H, W, seed=0, device=dev)
-        calls = []
-
-        def rec(layer, x, skip=None, skip_mode=0, tiles=None):
-            calls.append((layer, tuple(x.shape), None if skip is None else tuple(skip.shape), skip_mode if skip is not None else 0))
-            return orig(layer, x, skip, skip_mode, tiles)
+        del calls[:]
         cp.ConvLayer.__call__ = rec
         model(imgs, proj, dv)
         cp.ConvLayer.__call__ = orig
         torch.cuda.synchronize()
-        for layer, xs, ss, sm in calls:
-            B, Di, Hi, Wi, _ = xs
-            sig = cp.layer_signature(layer, B, Di, Hi, Wi, sm)
-            if sig in table:
-                continue
-            x = torch.randn(*xs, device=dev)
-            skip = torch.randn(*ss, device=dev) if ss else None
-            best = None
-            for name, tiles in candidates(layer, B, Di, Hi, Wi, sm):
-                try:
-                    us = min(timeit(lambda: layer(x, skip=skip, skip_mode=sm, tiles=tiles), n=10) for _ in range(2))
-                except RuntimeError:
-                    continue
-                if best is None or us < best[0]:
-                    best = (us, tiles)
-            table[sig] = [best[1][2], best[1][0], best[1][1]]
-            print("%-48s -> v%d mt%d nt%d  %.1f us" % (sig, best[1][2], best[1][0], best[1][1], best[0]), flush=True)
-            del x, skip
+        _tune(list(calls), table, dev)
+    from mvster_amd import MVS4net_loss
+    model.train()
+    for (H, W, N, B) in train_shapes:
+        imgs, proj, dv = make_inputs(N, H, W, seed=0, device=dev, batch=B)
+        gt = {"stage%d" % s: 500 + 300 * torch.rand(B, H // 2 ** (4 - s), W // 2 ** (4 - s), device=dev) for s in range(1, 5)}
+        mask = {k: torch.ones_like(v) for k, v in gt.items()}
+        del calls[:]
+        cp.ConvLayer.__call__ = rec
+        out = model(imgs, proj, dv)
+        MVS4net_loss(out, gt, mask, stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10, ot_eps=1,
+                     ot_continous=False, mono=True)[0].backward()
+        cp.ConvLayer.__call__ = orig
+        torch.cuda.synchronize()
+        model.zero_grad(set_to_none=True)
+        print("-- training step %dx%d N=%d B=%d: %d layer calls" % (H, W, N, B, len(calls)), flush=True)
+        _tune(list(calls), table, dev)
     with open(path, "w") as f:
         json.dump(table, f, indent=0, sort_keys=True)
     print("wrote", path, len(table), "entries")
