@@ -809,11 +809,19 @@ struct TapQueue {
     int off[64];
     float val[64][8];
 };
+constexpr int kQueueDirect = 4;      // up to this many out-of-window lanes of a wavefront issue their atomics themselves
 
 __device__ __forceinline__ void queue_tap(TapQueue& q, float* __restrict__ gsp, bool outside, long off, float wt,
                                           const float (&dw8)[8]) {
     const unsigned long long mask = __ballot(outside);
     if (mask == 0) return;                                   // wave-uniform
+    if (__popcll(mask) <= kQueueDirect) {                    // a few stragglers (smooth depth maps): not worth the detour
+        if (outside) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) unsafeAtomicAdd(gsp + off + c, wt * dw8[c]);
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63;
     if (outside) {
         const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
@@ -1097,21 +1105,25 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
 // 2-D tile form for the full-resolution stage (C = 8, where this kernel's time is): one workgroup owns 64 columns x R
 // consecutive reference rows and keeps ONE scatter window per view for all of them -- a bilinear footprint makes
 // neighbouring reference rows hit the same two source rows, so R rows need R + 2 window rows instead of 3 R.  Same
-// arithmetic as warp_agg_bwd_kernel; kTileWinX columns (the 64-bit accumulators double the window's LDS footprint).
-constexpr int kTileWinX = 88;
+// arithmetic as warp_agg_bwd_kernel; kTileWinX columns (the 64-bit accumulators double the window's LDS footprint; 80 is
+// what leaves room for two workgroups per CU).
+constexpr int kTileWinX = 80;
 
-template <int G, bool GROUP, int R>
-__global__ void __launch_bounds__(64 * 8) warp_agg_bwd_tile_kernel(WarpAggBwdArgs ba, int tiles_x) {
+// NW = wavefronts (depth hypotheses) the LDS is sized for.  With NW = 4 (the shipped full-resolution stage) the kernel
+// needs 80.7 KB: two workgroups per CU -- it is latency-bound, and at one workgroup per CU (99 KB, when the tap queues
+// were first added with an 88-wide window) the smooth-depth case ran 1.07 instead of 0.77 ms.
+template <int G, bool GROUP, int R, int NW>
+__global__ void __launch_bounds__(64 * NW) warp_agg_bwd_tile_kernel(WarpAggBwdArgs ba, int tiles_x) {
     const WarpAggArgs& a = ba.f;
     constexpr int C = 8;
     constexpr int CG = C / G;
     constexpr int WY = R + 6;
-    __shared__ float sc[2][8][64];
-    __shared__ float sd[2][8][64];
+    __shared__ float sc[2][NW][64];
+    __shared__ float sd[2][NW][64];
     __shared__ u64 gref[R][C][64];
     __shared__ u64 win[8][WY][kTileWinX];
     __shared__ int worg[2];
-    __shared__ TapQueue tapq[8];             // one per wavefront
+    __shared__ TapQueue tapq[NW];            // one per wavefront
     const FixScale fx = make_fix_scale(ba.maxima, G, a.D, CG, GROUP, true, a.attn_temp);
 
     const int tx = threadIdx.x;
@@ -1392,8 +1404,12 @@ int launch_bwd(const WarpAggBwdArgs& ba, hipStream_t stream) {
     if constexpr (C == 8 && C / G <= 8) {
         if (bwd_uses_tiles(C, G, a.D, a.fuse_d)) {      // the shipped full-resolution stage
             const int tiles_x = (a.w + 63) / 64;
-            hipLaunchKernelGGL((warp_agg_bwd_tile_kernel<G, GROUP, kTileR>), dim3(nblk, a.B), dim3(64, a.D), 0, stream, ba,
-                               tiles_x);
+            if (a.D <= 4)
+                hipLaunchKernelGGL((warp_agg_bwd_tile_kernel<G, GROUP, kTileR, 4>), dim3(nblk, a.B), dim3(64, a.D), 0, stream,
+                                   ba, tiles_x);
+            else
+                hipLaunchKernelGGL((warp_agg_bwd_tile_kernel<G, GROUP, kTileR, 8>), dim3(nblk, a.B), dim3(64, a.D), 0, stream,
+                                   ba, tiles_x);
             if (int rc = mv_check_launch()) return rc;
             return ba.windows ? launch_gather<kTileR + 6, kTileWinX, 1>(ba, nblk, stream) : MVSTER_OK;
         }

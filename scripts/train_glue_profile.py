@@ -53,7 +53,15 @@ for ev in prof.events():
     a[1] += ev.self_device_time_total
 tot = sum(v[1] for v in agg.values())
 print("aten kernels: %d launches, %.2f ms" % (sum(v[0] for v in agg.values()), tot / 1e3))
-only = sys.argv[1:]          # optional: aten op names to list in full
+by_count = "--by-count" in sys.argv
+only = [a for a in sys.argv[1:] if not a.startswith("--")]          # optional: aten op names to list in full
+if by_count:
+    names = collections.defaultdict(lambda: [0, 0.0])
+    for (name, where), (n, t) in agg.items():
+        names[name][0] += n
+        names[name][1] += t
+    for name, (n, t) in sorted(names.items(), key=lambda kv: -kv[1][0]):
+        print("%5d x %8.1f us  %s" % (n, t, name))
 for (name, where), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:(1000 if only else 110)]:
     if only and name.split("::")[1] not in only:
         continue
