@@ -18,16 +18,20 @@ f1 = torch.randn(NB, 1, H // 4, W // 4, 64, device=dev)
 
 
 def timeit(name, fn, reps=30):
-    for _ in range(3):
-        out = fn()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        out = fn()
-    b.record()
-    torch.cuda.synchronize()
-    print("%-44s %8.1f us" % (name, a.elapsed_time(b) / reps * 1e3), flush=True)
+    best = None
+    for _ in range(3):                 # best of three rounds (the first round of a new shape also pays the allocator)
+        for _ in range(5):
+            out = fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            out = fn()
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) / reps * 1e3
+        best = us if best is None else min(best, us)
+    print("%-44s %8.1f us" % (name, best), flush=True)
     return out
 
 
