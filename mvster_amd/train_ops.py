@@ -175,6 +175,17 @@ def conv_cl(x, weight, bias=None, stride=1, padding=0, transposed=False, skip=No
                          owner)
 
 
+def tap_bias_grad(gP):
+    """Gradient of the gather-sum's per-tap bias terms vb [9, co] given gP [NB,1,H,W,co]: d/d vb[tap] = the sum of gP over
+    the pixels whose tap lies inside the image -- everything, minus the first / last row and / or column."""
+    g = gP[:, 0]
+    co = g.shape[-1]
+    rows = g.sum(2)                                                              # over x: [NB,H,co]
+    xs = torch.stack([rows - g[:, :, 0], rows, rows - g[:, :, -1]])             # kx = 0, 1, 2
+    tot = xs.sum(2)                                                              # over y: [3,NB,co]
+    return torch.stack([tot - xs[:, :, 0], tot, tot - xs[:, :, -1]]).sum(2).reshape(9, co)   # [ky,kx] -> [9,co]
+
+
 class _FpnGather(torch.autograd.Function):
     """P = gather-sum of the nine shifted bilinear x2 up-samplings of G = conv1x1(f; wg) (+ the bias terms vb): the
     top-down half of a re-associated FPN level (see ``fpn_fine_level``).  All passes on the gfx950 kernels; the 72-channel
@@ -213,12 +224,7 @@ class _FpnGather(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gwg = ops.conv_wgrad(f, gG, (1, 1, 1), (1, 1, 1), (0, 0, 0), co_keep=wg.shape[0]).reshape(wg.shape)
         if ctx.needs_input_grad[2]:
-            # d/d vb[tap] = sum of gP over the pixels whose tap is inside the image: all, minus the first / last row / column
-            g = gP[:, 0]
-            rows = g.sum(2)                                                              # over x: [NB,H,co]
-            xs = torch.stack([rows - g[:, :, 0], rows, rows - g[:, :, -1]])             # kx = 0, 1, 2
-            tot = xs.sum(2)                                                              # over y: [3,NB,co]
-            gvb = torch.stack([tot - xs[:, :, 0], tot, tot - xs[:, :, -1]]).sum(2).reshape(9, co)   # [ky,kx] -> [9,co]
+            gvb = tap_bias_grad(gP)
         return gf, gwg, gvb, None, None, None
 
 

@@ -148,3 +148,17 @@ def test_transposed_layer_is_the_input_gradient_of_a_strided_conv(cin, cout, k, 
     layer.repack(conv.weight)
     fresh = cp.ConvLayer(conv.weight, True, conv.stride, conv.padding)
     assert torch.equal(layer.wpk, fresh.wpk)
+
+
+def test_tap_bias_gradient_of_the_fpn_gather():
+    """train_ops.tap_bias_grad (the bias part of the re-associated FPN level's backward) against autograd through the
+    PyTorch restatement of the gather-sum."""
+    from mvster_amd.train_ops import tap_bias_grad
+    from tests.conv_emulator import fpn_tail_gather_reference
+    g = torch.Generator().manual_seed(11)
+    NB, H, W, co = 2, 6, 10, 8
+    G = torch.randn(NB, 1, H // 2, W // 2, 9 * co, generator=g, dtype=torch.float64)
+    vb = torch.randn(9, co, generator=g, dtype=torch.float64, requires_grad=True)
+    gP = torch.randn(NB, 1, H, W, co, generator=g, dtype=torch.float64)
+    fpn_tail_gather_reference(G, vb, H, W).backward(gP)
+    assert (tap_bias_grad(gP) - vb.grad).abs().max() <= 1e-10
