@@ -122,11 +122,15 @@ class KernelTimer:
     def summary(self):
         agg = {}
         for name, e0, e1, flops, bytes_ in self.records:
-            a = agg.setdefault(name, dict(ms=0.0, n=0, flops=0, bytes=0))
-            a["ms"] += e0.elapsed_time(e1)
+            a = agg.setdefault(name, dict(ms=0.0, n=0, flops=0, bytes=0, shapes={}))
+            ms = e0.elapsed_time(e1)
+            a["ms"] += ms
             a["n"] += 1
             a["flops"] += flops
             a["bytes"] += bytes_
+            sh = a["shapes"].setdefault((flops, bytes_), [0.0, 0])       # one entry per distinct layer shape
+            sh[0] += ms
+            sh[1] += 1
         return agg
 
 
@@ -415,6 +419,11 @@ def main():
                      "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                      "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": a["n"] // ninstr,
                      "flops_per_launch": a["flops"] // a["n"]}
+                if len(a["shapes"]) > 1:      # the kernel serves several layer shapes: the fraction of each
+                    e["per_shape"] = [{"flops_per_launch": fl, "avg_launch_us": round(ms / n * 1e3, 2),
+                                       "launches_per_step": n // ninstr,
+                                       "frac": round(fl / (ms / n * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+                                      for (fl, _), (ms, n) in sorted(a["shapes"].items(), key=lambda kv: -kv[0][0])]
             else:
                 achieved = a["bytes"] / (a["ms"] * 1e-3) / 1e9
                 e = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
