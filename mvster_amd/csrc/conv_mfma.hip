@@ -371,6 +371,12 @@ int dispatch_tiles(const ConvArgs& a, int MT, int NT, bool splitk, hipStream_t s
 // for stride-1 layers at any tap offset (the previous [pixel][4 quads] layout put m and m + 4 on the same banks: 30-40 %
 // of the LDS cycles were conflicts, r01_o PMC).  patch_plane() pads a plane to 4 mod 8 slots, which keeps the two planes
 // 16 banks apart for the staging stores (a thread quartet writes quads 0..3 of one pixel).
+// Multiply-shift forms of the prologue's divisions (tile decode, patch pixel -> row / column): with plain `/` and `%` the
+// prologue spent 11 reciprocal-based division sequences (~220 of its ~570 instructions) per wavefront -- on a one-chunk
+// layer the MFMA phase is only 72 instructions long, so the prologue and epilogue are what the MFMA pipes wait for.
+struct LdsDivs {
+    unsigned mul[5], shr[5];     // tiles_x, tiles_y, Do, PW, PH
+};
 constexpr int kMaxStage = 12;   // float4 loads per thread per chunk (patch <= 48 KB)
 __device__ __forceinline__ int patch_plane(int npix) { return ((npix * 2 + 7) & ~7) + 4; }   // float4 units, = 4 mod 8
 static const bool g_no_wlds = getenv("MVSTER_NO_WLDS") != nullptr;   // experiment switch: weights from L1 again
@@ -378,7 +384,7 @@ static const bool g_no_wlds = getenv("MVSTER_NO_WLDS") != nullptr;   // experime
 // WN > 0: the chunk's weights are staged in LDS too, WN float4 per thread (taps * NT * 64 <= WN * 256).
 // Used with WN = 3 (2-D 3x3, NT = 1); WN = 7 (3x3x3, 28 KB) was measured slower: it costs a workgroup of occupancy.
 template <int MT, int NT, int KW, int NG, int WN>
-__global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, int tiles_y) {
+__global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, int tiles_y, LdsDivs dv) {
     extern __shared__ __attribute__((aligned(16))) float patch_raw[];
     f32x4v* patch_base = reinterpret_cast<f32x4v*>(patch_raw);
     f32x4v* wl = patch_base + NG * 1024 + 32;     // WL: this chunk's packed weights [tap][nt][lane] (after the plane pads)
@@ -390,10 +396,13 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     const int plane = patch_plane(KD * PH * PW);
 
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_x = bid % tiles_x; bid /= tiles_x;
-    const int tile_y = bid % tiles_y; bid /= tiles_y;
-    const int zo = bid % a.Do;
-    const int b = bid / a.Do;
+    unsigned q = fast_div(bid, tiles_x, dv.mul[0], dv.shr[0]);
+    const int tile_x = bid - q * tiles_x; bid = q;
+    q = fast_div(bid, tiles_y, dv.mul[1], dv.shr[1]);
+    const int tile_y = bid - q * tiles_y; bid = q;
+    q = fast_div(bid, a.Do, dv.mul[2], dv.shr[2]);
+    const int zo = bid - q * a.Do;
+    const int b = q;
     const int ty0 = tile_y * TY, tx0 = tile_x * 32;
     const int nt0 = blockIdx.y * NT;
 
@@ -408,10 +417,11 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
         int off = -1;
         if (idx < nstage) {
             const int quad = idx & 3;
-            int pix = idx >> 2;
-            const int px = pix % PW; pix /= PW;
-            const int py = pix % PH;
-            const int pz = pix / PH;
+            const unsigned pix = idx >> 2;
+            const unsigned prow = fast_div(pix, PW, dv.mul[3], dv.shr[3]);       // = pz * PH + py
+            const int px = pix - prow * PW;
+            const int pz = fast_div(prow, PH, dv.mul[4], dv.shr[4]);
+            const int py = prow - pz * PH;
             const int iz = zo * a.sd - a.pd[0] + pz, iy = ty0 * a.sh - a.ph[0] + py, ix = tx0 * a.sw - a.pw[0] + px;
             if ((unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
                 off = ((((b * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * CIN) + quad * 4;
@@ -551,13 +561,17 @@ int launch_lds_ng(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
     const long blocks = (long)tiles_x * tiles_y * a.Do * a.B;
     if (blocks >= (1L << 31) || (long)a.B * a.Di * a.Hi * a.Wi * a.cin >= (1L << 31)) return MVSTER_ERR_SHAPE;
     dim3 grid((unsigned)blocks, a.ntile_total / NT, 1);
+    LdsDivs dv;
+    const unsigned divisors[5] = {(unsigned)tiles_x, (unsigned)tiles_y, (unsigned)a.Do, (unsigned)(31 * a.sw + KW),
+                                  (unsigned)((2 * MT - 1) * a.sh + a.kh[0])};
+    for (int i = 0; i < 5; ++i) find_divisor(divisors[i], dv.mul[i], dv.shr[i]);
     const int nw = a.kd[0] * a.kh[0] * KW * NT * 64;       // weight float4 per chunk
     if (nw <= 3 * 256 && !g_no_wlds) {
         const size_t lds = (size_t)(NG * 1024 + 32) * 16 + 3 * 256 * 16;
-        hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW, NG, 3>), grid, dim3(256), lds, s, a, tiles_x, tiles_y);
+        hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW, NG, 3>), grid, dim3(256), lds, s, a, tiles_x, tiles_y, dv);
     } else {
         const size_t lds = (size_t)(NG * 1024 + 32) * 16;
-        hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW, NG, 0>), grid, dim3(256), lds, s, a, tiles_x, tiles_y);
+        hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW, NG, 0>), grid, dim3(256), lds, s, a, tiles_x, tiles_y, dv);
     }
     return mv_check_launch();
 }
