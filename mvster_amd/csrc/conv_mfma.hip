@@ -85,11 +85,10 @@ static void find_divisor(unsigned d, unsigned& mul, unsigned& shr) {
 }
 
 // Fused epilogue for 4 consecutive output channels n0..n0+3 of one output voxel.
-__device__ __forceinline__ void epilogue_store(const ConvArgs& a, f32x4v v, int n0, long opix, int b, int oy, int ox) {
+// (scale / shift are padded to 16 * ntiles floats: one 16-byte load each; callers that can, load them ahead of the MFMAs)
+__device__ __forceinline__ void epilogue_store(const ConvArgs& a, f32x4v v, int n0, long opix, int b, int oy, int ox,
+                                               const f32x4v sc, const f32x4v sh) {
     const bool vec = (n0 + 3 < a.cout) && ((a.cout & 3) == 0);
-    float sc[4], sh[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { sc[j] = a.scale[n0 + j]; sh[j] = a.shift[n0 + j]; }   // padded to 16*ntiles
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         v[j] = fmaf(v[j], sc[j], sh[j]);
@@ -138,6 +137,11 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& a, f32x4v v, int 
             op[j] = r;
         }
     }
+}
+
+__device__ __forceinline__ void epilogue_store(const ConvArgs& a, f32x4v v, int n0, long opix, int b, int oy, int ox) {
+    epilogue_store(a, v, n0, opix, b, oy, ox, *reinterpret_cast<const f32x4v*>(a.scale + n0),
+                   *reinterpret_cast<const f32x4v*>(a.shift + n0));
 }
 
 // SPLITK: the 4 waves of a workgroup share ONE set of MT x NT tiles and each takes every 4th K step; the
@@ -430,21 +434,6 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     }
     const long zero_off = a.zeros - a.in;
 
-    // LDS float4 index of this lane's A operand for tap (0,0,0) of each of its M tiles
-    int abase[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int t = wave * MT + mt;
-        const int row = t >> 1, xs = t & 1;
-        abase[mt] = ((row * a.sh) * PW + (xs * 16 + lm) * a.sw) * 2 + (lq >> 1) * plane + (lq & 1);
-    }
-
-    f32x4v acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-
     const float* wp = a.wpk + ((long)nt0 * 64 + lane) * 4;
     const long wstep = (long)a.ntile_total * 256;
 
@@ -486,6 +475,30 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
         }
     };
     stage_load(0);
+    // everything below up to the LDS store is independent of the loads just issued and runs under their latency
+    // LDS float4 index of this lane's A operand for tap (0,0,0) of each of its M tiles
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int t = wave * MT + mt;
+        const int row = t >> 1, xs = t & 1;
+        abase[mt] = ((row * a.sh) * PW + (xs * 16 + lm) * a.sw) * 2 + (lq >> 1) * plane + (lq & 1);
+    }
+
+    f32x4v acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    // BatchNorm scale / shift of this lane's output channels, fetched ahead of the MFMAs instead of after them
+    f32x4v scv[NT], shv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n0 = min((nt0 + nt) * 16 + lq * 4, a.ntile_total * 16 - 4);
+        scv[nt] = *reinterpret_cast<const f32x4v*>(a.scale + n0);
+        shv[nt] = *reinterpret_cast<const f32x4v*>(a.shift + n0);
+    }
     stage_store(patch_base);
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -551,7 +564,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
         for (int nt = 0; nt < NT; ++nt) {
             const int n0 = (nt0 + nt) * 16 + lq * 4;
             if (n0 >= a.cout) continue;
-            epilogue_store(a, acc[mt][nt], n0, opix, b, y, x);
+            epilogue_store(a, acc[mt][nt], n0, opix, b, y, x, scv[nt], shv[nt]);
         }
     }
 }
