@@ -26,14 +26,12 @@ struct SmallArgs {
 };
 
 template <int CIN>
-__global__ void __launch_bounds__(256) conv_small_kernel(SmallArgs a, int tiles_x, int tiles_y) {
+__global__ void __launch_bounds__(256) conv_small_kernel(SmallArgs a, FastDiv tiles_x, FastDiv tiles_y) {
     constexpr int TY = 8, TX = 32, PH = TY + 2, PW = TX + 2, Q = CIN / 4;
     __shared__ f32x4v patch[PH * PW * Q];
-    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_x = bid % tiles_x; bid /= tiles_x;
-    const int tile_y = bid % tiles_y;
-    const int nb = bid / tiles_y;
-    const int y0 = tile_y * TY, x0 = tile_x * TX;
+    unsigned txu, tyu;
+    const int nb = (int)fdivmod(fdivmod(xcd_remap(blockIdx.x, gridDim.x), tiles_x, txu), tiles_y, tyu);
+    const int y0 = (int)tyu * TY, x0 = (int)txu * TX;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 
     const __amdgpu_buffer_rsrc_t rsrc =
@@ -117,8 +115,8 @@ extern "C" int mvster_conv_small(const float* in, const float* w, const float* s
     const long blocks = (long)tiles_x * tiles_y * NB;
     if (blocks >= (1L << 31)) return MVSTER_ERR_SHAPE;
     dim3 grid((unsigned)blocks), block(256);
-    if (cin == 8) hipLaunchKernelGGL(conv_small_kernel<8>, grid, block, 0, (hipStream_t)stream, a, tiles_x, tiles_y);
-    else if (cin == 4) hipLaunchKernelGGL(conv_small_kernel<4>, grid, block, 0, (hipStream_t)stream, a, tiles_x, tiles_y);
+    if (cin == 8) hipLaunchKernelGGL(conv_small_kernel<8>, grid, block, 0, (hipStream_t)stream, a, mv_fastdiv(tiles_x), mv_fastdiv(tiles_y));
+    else if (cin == 4) hipLaunchKernelGGL(conv_small_kernel<4>, grid, block, 0, (hipStream_t)stream, a, mv_fastdiv(tiles_x), mv_fastdiv(tiles_y));
     else return MVSTER_ERR_UNSUPPORTED;
     return mv_check_launch();
 }

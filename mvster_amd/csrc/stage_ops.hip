@@ -156,7 +156,7 @@ template <int COT>
 __global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* __restrict__ G,
                                                                   const float* __restrict__ vb,
                                                                   float* __restrict__ P, int NB, int H, int W,
-                                                                  int tiles_x, int tiles_y) {
+                                                                  FastDiv tiles_x, FastDiv tiles_y) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     constexpr int CO = 8;
     constexpr int CGT = 9 * COT;               // channels of G per half-resolution pixel
@@ -166,21 +166,22 @@ __global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* _
     __shared__ f32x4 patch[PR * PC * Q];
     __shared__ float vbsum[9][CO];             // [3*yclass + xclass][c]: sum of vb over the in-bounds taps
     const int Hh = H / 2, Wh = W / 2;
-    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_x = bid % tiles_x; bid /= tiles_x;
-    const int tile_y = bid % tiles_y;
-    const int b = bid / tiles_y;
-    const int y0 = tile_y * 8, x0 = tile_x * 32;
+    unsigned txu, tyu;
+    const int b = (int)fdivmod(fdivmod(xcd_remap(blockIdx.x, gridDim.x), tiles_x, txu), tiles_y, tyu);
+    const int y0 = (int)tyu * 8, x0 = (int)txu * 32;
     // half-resolution footprint of output rows y0-1 .. y0+8 and columns x0-1 .. x0+32 (clamped to the image)
     const int ylo = max(y0 - 1, 0), yhi = min(y0 + 8, H - 1), xlo = max(x0 - 1, 0), xhi = min(x0 + 32, W - 1);
     const int r0 = mv::make_lerp(ylo, Hh, H).i0, r1 = mv::make_lerp(yhi, Hh, H).i1;
     const int c0 = mv::make_lerp(xlo, Wh, W).i0, c1 = mv::make_lerp(xhi, Wh, W).i1;
     const int nr = r1 - r0 + 1, nc = c1 - c0 + 1;       // <= PR, <= PC
     const float* g = G + (long)b * Hh * Wh * CGT + cbase;
-    for (int i = threadIdx.x; i < nr * nc * Q; i += 256) {
+    // (walks the PC-wide patch, compile-time divisors, and skips the unused columns: a runtime `% nc` per element was
+    //  half of this loop's instructions)
+    for (int i = threadIdx.x; i < nr * PC * Q; i += 256) {
         const int q = i % Q, pix = i / Q;
-        const int pc = pix % nc, pr = pix / nc;
-        patch[(pr * PC + pc) * Q + q] = ld4(g + ((long)(r0 + pr) * Wh + (c0 + pc)) * CGT + (q >> 1) * COT + (q & 1) * 4);
+        const int pc = pix % PC, pr = pix / PC;
+        if (pc < nc)
+            patch[(pr * PC + pc) * Q + q] = ld4(g + ((long)(r0 + pr) * Wh + (c0 + pc)) * CGT + (q >> 1) * COT + (q & 1) * 4);
     }
     if (threadIdx.x < 9 * CO) {
         const int cls = threadIdx.x / CO, c = threadIdx.x % CO;
@@ -252,13 +253,15 @@ __global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* _
 // input-gradient convolution that follows wants a multiple of 16 channels).
 template <int CO>
 __global__ void __launch_bounds__(256) fpn_tail_gather_bwd_kernel(const float* __restrict__ gP, float* __restrict__ gG,
-                                                                  int NB, int H, int W, int pitch) {
+                                                                  int NB, int H, int W, int pitch, FastDiv wdiv, FastDiv hdiv) {
     const int Hh = H / 2, Wh = W / 2;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)NB * Hh * Wh * 9) return;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (unsigned)NB * Hh * Wh * 9) return;
     const int tap = (int)(i % 9);
-    long q = i / 9;
-    const int xi = (int)(q % Wh), yi = (int)((q / Wh) % Hh), b = (int)(q / ((long)Wh * Hh));
+    const unsigned q = i / 9;
+    unsigned xu, yu;
+    const int b = (int)fdivmod(fdivmod(q, wdiv, xu), hdiv, yu);
+    const int xi = (int)xu, yi = (int)yu;
     const int ty = tap / 3 - 1, tx = tap % 3 - 1;
     float wy[6], wx[6];
 #pragma unroll
@@ -292,11 +295,11 @@ __global__ void __launch_bounds__(256) fpn_tail_gather_bwd_kernel(const float* _
             }
         }
     }
-    float* o = gG + q * pitch + tap * CO;
+    float* o = gG + (long)q * pitch + tap * CO;
 #pragma unroll
     for (int c = 0; c < CO; c += 4) st4(o + c, (f32x4){acc[c], acc[c + 1], acc[c + 2], acc[c + 3]});
     if (tap == 0)
-        for (int c = 9 * CO; c < pitch; c += 4) st4(gG + q * pitch + c, (f32x4){0.f, 0.f, 0.f, 0.f});
+        for (int c = 9 * CO; c < pitch; c += 4) st4(gG + (long)q * pitch + c, (f32x4){0.f, 0.f, 0.f, 0.f});
 }
 
 // Lateral 1x1 conv + top-down add of the FPN (models/mvs4net_utils.py:485) for a top-down map that only exists at
@@ -312,7 +315,7 @@ constexpr int kLateralSlots = 14, kLateralIters = 16, kLateralPix = 1;   // 18 x
 template <int CI, int CO>
 __global__ void __launch_bounds__(CO / 4 * kLateralSlots)
 fpn_lateral_up_kernel(const float* __restrict__ x, const float* __restrict__ A, const float* __restrict__ bias,
-                      const float* __restrict__ q, float* __restrict__ out, int H, int W) {
+                      const float* __restrict__ q, float* __restrict__ out, int H, int W, FastDiv wdiv) {
     constexpr int NCH = CO / 4;
     const int chunk = threadIdx.x % NCH, slot = threadIdx.x / NCH;
     const int b = blockIdx.y;
@@ -339,7 +342,9 @@ fpn_lateral_up_kernel(const float* __restrict__ x, const float* __restrict__ A, 
             const int p = base + (it + u) * kLateralSlots + slot;
             pp[u] = p;
             const int pc = min(p, H * W - 1);
-            const int y = pc / W, xx = pc - y * W;
+            unsigned xu;
+            const int y = (int)fdivmod((unsigned)pc, wdiv, xu);
+            const int xx = (int)xu;
             ly[u] = mv::make_lerp(y, Hh, H);
             lx[u] = mv::make_lerp(xx, Wh, W);
             const float* xp = x + ((long)b * H * W + pc) * CI;
@@ -565,10 +570,10 @@ extern "C" int mvster_fpn_tail_gather(const float* G, const float* vb, float* P,
         const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
         if (CO == 8)
             hipLaunchKernelGGL(fpn_tail_gather_lds_kernel<8>, dim3(tiles_x * tiles_y * NB), block, 0, s, G, vb, P, NB, H, W,
-                               tiles_x, tiles_y);
+                               mv_fastdiv(tiles_x), mv_fastdiv(tiles_y));
         else
             hipLaunchKernelGGL(fpn_tail_gather_lds_kernel<16>, dim3(tiles_x * tiles_y * NB, 2), block, 0, s, G, vb, P, NB, H,
-                               W, tiles_x, tiles_y);
+                               W, mv_fastdiv(tiles_x), mv_fastdiv(tiles_y));
         return mv_check_launch();
     }
     dim3 grid((H * W + 255) / 256, NB);
@@ -584,11 +589,11 @@ extern "C" int mvster_fpn_tail_gather_bwd(const float* gP, float* gG, int NB, in
     if (NB <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || pitch < 9 * CO || (pitch & 3)) return MVSTER_ERR_SHAPE;
     if (CO != 8 && CO != 16) return MVSTER_ERR_UNSUPPORTED;
     const long total = (long)NB * (H / 2) * (W / 2) * 9;
-    if ((total + 255) / 256 >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    if (total >= (1L << 31)) return MVSTER_ERR_SHAPE;
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (CO == 8) hipLaunchKernelGGL(fpn_tail_gather_bwd_kernel<8>, grid, block, 0, s, gP, gG, NB, H, W, pitch);
-    else hipLaunchKernelGGL(fpn_tail_gather_bwd_kernel<16>, grid, block, 0, s, gP, gG, NB, H, W, pitch);
+    if (CO == 8) hipLaunchKernelGGL(fpn_tail_gather_bwd_kernel<8>, grid, block, 0, s, gP, gG, NB, H, W, pitch, mv_fastdiv(W / 2), mv_fastdiv(H / 2));
+    else hipLaunchKernelGGL(fpn_tail_gather_bwd_kernel<16>, grid, block, 0, s, gP, gG, NB, H, W, pitch, mv_fastdiv(W / 2), mv_fastdiv(H / 2));
     return mv_check_launch();
 }
 
@@ -600,8 +605,8 @@ extern "C" int mvster_fpn_lateral_up(const float* x, const float* A, const float
     hipStream_t s = (hipStream_t)stream;
     constexpr int per_block = kLateralSlots * kLateralIters;
     dim3 grid((H * W + per_block - 1) / per_block, NB), block(72 / 4 * kLateralSlots);
-    if (CI == 16 && CO == 72) hipLaunchKernelGGL((fpn_lateral_up_kernel<16, 72>), grid, block, 0, s, x, A, bias, q, out, H, W);
-    else if (CI == 8 && CO == 72) hipLaunchKernelGGL((fpn_lateral_up_kernel<8, 72>), grid, block, 0, s, x, A, bias, q, out, H, W);
+    if (CI == 16 && CO == 72) hipLaunchKernelGGL((fpn_lateral_up_kernel<16, 72>), grid, block, 0, s, x, A, bias, q, out, H, W, mv_fastdiv(W));
+    else if (CI == 8 && CO == 72) hipLaunchKernelGGL((fpn_lateral_up_kernel<8, 72>), grid, block, 0, s, x, A, bias, q, out, H, W, mv_fastdiv(W));
     else return MVSTER_ERR_UNSUPPORTED;
     return mv_check_launch();
 }

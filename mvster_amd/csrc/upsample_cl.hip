@@ -8,16 +8,14 @@ namespace {
 
 // out [B, 2h, 2w, C] <- in [B, h, w, C]; one thread per (output pixel, 4 channels)
 __global__ void __launch_bounds__(256) upsample2x_cl_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
-                                                                int h, int w, int C) {
+                                                                int h, int w, int C, FastDiv qd, FastDiv wd, FastDiv hd) {
     const int q = C >> 2, H = 2 * h, W = 2 * w;
-    const long total = (long)B * H * W * q;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned total = (unsigned)B * H * W * q;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= total) return;
-    const int c4 = (int)(i % q);
-    long p = i / q;
-    const int x = (int)(p % W); p /= W;
-    const int y = (int)(p % H);
-    const int b = (int)(p / H);
+    unsigned c4u, xu, yu;
+    const int b = (int)fdivmod(fdivmod(fdivmod(i, qd, c4u), wd, xu), hd, yu);      // divisors q, W = 2w, H = 2h
+    const int c4 = (int)c4u, x = (int)xu, y = (int)yu;
     const mv::Lerp ly = mv::make_lerp(y, h, H), lx = mv::make_lerp(x, w, W);
     const float* base = in + (long)b * h * w * C + c4 * 4;
     const f32x4 v00 = ld4(base + ((long)ly.i0 * w + lx.i0) * C), v01 = ld4(base + ((long)ly.i0 * w + lx.i1) * C);
@@ -25,7 +23,7 @@ __global__ void __launch_bounds__(256) upsample2x_cl_fwd_kernel(const float* __r
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = mv::bilerp(ly, lx, v00[j], v01[j], v10[j], v11[j]);
-    st4(out + i * 4, o);
+    st4(out + (long)i * 4, o);
 }
 
 // weight with which output index o contributes to input index i along one axis
@@ -36,16 +34,14 @@ __device__ __forceinline__ float axis_weight(int o, int i, int in_size, int out_
 
 // gin [B, h, w, C] <- gout [B, 2h, 2w, C]; one thread per (input pixel, 4 channels)
 __global__ void __launch_bounds__(256) upsample2x_cl_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gin, int B,
-                                                                int h, int w, int C) {
+                                                                int h, int w, int C, FastDiv qd, FastDiv wd, FastDiv hd) {
     const int q = C >> 2, H = 2 * h, W = 2 * w;
-    const long total = (long)B * h * w * q;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned total = (unsigned)B * h * w * q;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= total) return;
-    const int c4 = (int)(i % q);
-    long p = i / q;
-    const int xi = (int)(p % w); p /= w;
-    const int yi = (int)(p % h);
-    const int b = (int)(p / h);
+    unsigned c4u, xu, yu;
+    const int b = (int)fdivmod(fdivmod(fdivmod(i, qd, c4u), wd, xu), hd, yu);      // divisors q, w, h
+    const int c4 = (int)c4u, xi = (int)xu, yi = (int)yu;
     // output rows / columns whose source coordinate lies within one pixel of (yi, xi): o * (in-1)/(out-1) in (i-1, i+1)
     float wy[6], wx[6];
 #pragma unroll
@@ -70,7 +66,7 @@ __global__ void __launch_bounds__(256) upsample2x_cl_bwd_kernel(const float* __r
             for (int j = 0; j < 4; ++j) acc[j] = fmaf(wgt, g[j], acc[j]);
         }
     }
-    st4(gin + i * 4, acc);
+    st4(gin + (long)i * 4, acc);
 }
 
 // nearest x2 (F.interpolate(scale_factor=2, mode="nearest"), the mono head's up-sampling, mvs4net_utils.py:858) and its
@@ -115,9 +111,9 @@ extern "C" int mvster_upsample2x_cl_fwd(const float* in, float* out, int B, int 
     if (!in || !out) return MVSTER_ERR_NULL;
     if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || (C & 3)) return MVSTER_ERR_SHAPE;
     const long total = (long)B * 4 * h * w * (C / 4);
-    if ((total + 255) / 256 >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    if (total >= (1L << 31)) return MVSTER_ERR_SHAPE;
     hipLaunchKernelGGL(upsample2x_cl_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out,
-                       B, h, w, C);
+                       B, h, w, C, mv_fastdiv(C / 4), mv_fastdiv(2 * w), mv_fastdiv(2 * h));
     return mv_check_launch();
 }
 
@@ -126,7 +122,8 @@ extern "C" int mvster_upsample2x_cl_bwd(const float* gout, float* gin, int B, in
     if (!gout || !gin) return MVSTER_ERR_NULL;
     if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || (C & 3)) return MVSTER_ERR_SHAPE;
     const long total = (long)B * h * w * (C / 4);
+    if (total >= (1L << 31)) return MVSTER_ERR_SHAPE;
     hipLaunchKernelGGL(upsample2x_cl_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gout,
-                       gin, B, h, w, C);
+                       gin, B, h, w, C, mv_fastdiv(C / 4), mv_fastdiv(w), mv_fastdiv(h));
     return mv_check_launch();
 }
