@@ -396,7 +396,6 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     const int KD = a.kd[0], KH = a.kh[0];
     const int PW = 31 * a.sw + KW, PH = (TY - 1) * a.sh + KH;
     const int CIN = a.cin, nchunks = CIN >> 4;
-    const int nstage = KD * PH * PW * 4;     // float4 per chunk (<= NG * 1024)
     const int plane = patch_plane(KD * PH * PW);
 
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -413,24 +412,24 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lm = lane & 15, lq = lane >> 4;
 
-    // chunk-independent global element offsets of the float4s this thread stages (-1 = zero padding)
-    int goff[NG * 4];
+    // chunk-independent global element offset of each patch pixel this thread stages (-1 = zero padding): a thread owns
+    // all four quads of its pixels, so the pixel -> (row, column) arithmetic and the bounds checks are done once per pixel
+    const int npix = KD * PH * PW;
+    int goff[NG];
 #pragma unroll
-    for (int i = 0; i < NG * 4; ++i) {
-        const int idx = threadIdx.x + i * 256;
+    for (int g = 0; g < NG; ++g) {
+        const unsigned pix = threadIdx.x + g * 256;
         int off = -1;
-        if (idx < nstage) {
-            const int quad = idx & 3;
-            const unsigned pix = idx >> 2;
+        if ((int)pix < npix) {
             const unsigned prow = fast_div(pix, PW, dv.mul[3], dv.shr[3]);       // = pz * PH + py
             const int px = pix - prow * PW;
             const int pz = fast_div(prow, PH, dv.mul[4], dv.shr[4]);
             const int py = prow - pz * PH;
             const int iz = zo * a.sd - a.pd[0] + pz, iy = ty0 * a.sh - a.ph[0] + py, ix = tx0 * a.sw - a.pw[0] + px;
             if ((unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
-                off = ((((b * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * CIN) + quad * 4;
+                off = (((b * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * CIN;
         }
-        goff[i] = off;
+        goff[g] = off;
     }
     const long zero_off = a.zeros - a.in;
 
@@ -450,8 +449,8 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     auto stage_load = [&](int ch) {
 #pragma unroll
         for (int i = 0; i < NG * 4; ++i) {
-            const int o = goff[i];
-            const long off = o >= 0 ? (long)o + ch * 16 : zero_off;
+            const int o = goff[i >> 2];
+            const long off = o >= 0 ? (long)o + ch * 16 + (i & 3) * 4 : zero_off;
             stg[i] = *reinterpret_cast<const f32x4v*>(a.in + off);
         }
         if (WL) {
@@ -466,8 +465,8 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     auto stage_store = [&](f32x4v* dst) {
 #pragma unroll
         for (int i = 0; i < NG * 4; ++i) {
-            const int idx = threadIdx.x + i * 256, quad = idx & 3;       // idx = pixel * 4 + quad, as loaded
-            if (idx < nstage) dst[(quad >> 1) * plane + (idx >> 2) * 2 + (quad & 1)] = stg[i];
+            const int pix = threadIdx.x + (i >> 2) * 256, quad = i & 3;
+            if (pix < npix) dst[(quad >> 1) * plane + pix * 2 + (quad & 1)] = stg[i];
         }
         if (WL) {
 #pragma unroll
