@@ -244,7 +244,7 @@ class ConvLayer:
         kd, kh, kw = self.kernel
         rc = _lib.load().mvster_pack_conv_weights(w.data_ptr(), self.wpk.data_ptr(), self.cout, self._cin_raw, self.cin, kd,
                                                   kh, kw, s_n, s_c, st[2], st[3], st[4], int(flip),
-                                                  torch.cuda.current_stream().cuda_stream)
+                                                  ops._stream())
         _lib.check(rc, "pack_conv_weights")
         if self.w_small is not None:
             wv = w.transpose(0, 1) if swap else w
@@ -274,7 +274,7 @@ class ConvLayer:
         rc = _lib.load().mvster_pack_conv_weights_classes(
             w.data_ptr(), self.wpk.data_ptr(), self.cout, self._cin_raw, self.cin, kd * kh * kw, len(self.classes),
             ntaps.ctypes.data_as(ctypes.c_void_p), woff.ctypes.data_as(ctypes.c_void_p), taps.ctypes.data_as(ctypes.c_void_p),
-            torch.cuda.current_stream().cuda_stream)
+            ops._stream())
         _lib.check(rc, "pack_conv_weights_classes")
         if self.w_deconv is not None:
             self.w_deconv.copy_(w[:, :, 0].permute(2, 3, 0, 1))
@@ -367,7 +367,7 @@ class ConvLayer:
                 x.data_ptr(), self.w_deconv.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
                 None if skip is None else skip.data_ptr(),
                 None if self.prob is None else self.prob[0].data_ptr(), None if self.prob is None else self.prob[1].data_ptr(),
-                out.data_ptr(), B * Di, Hi, Wi, self.cin, self.cout, int(self.relu), torch.cuda.current_stream().cuda_stream)
+                out.data_ptr(), B * Di, Hi, Wi, self.cin, self.cout, int(self.relu), ops._stream())
             _lib.check(rc, "deconv_small")
             return out
         if self.prob is not None and variant in (1, 3):
@@ -386,7 +386,7 @@ class ConvLayer:
             rc = _lib.load().mvster_conv_small(
                 x.data_ptr(), self.w_small.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
                 None if skip is None else skip.data_ptr(), out.data_ptr(), B * Di, Hi, Wi, self.cin, int(self.relu),
-                torch.cuda.current_stream().cuda_stream)
+                ops._stream())
             _lib.check(rc, "conv_small")
             return out
         rc = _lib.load().mvster_conv_mfma(
@@ -394,7 +394,7 @@ class ConvLayer:
             None if skip is None else skip.data_ptr(), self.zeros.data_ptr(),
             None if self.prob is None else self.prob[0].data_ptr(), None if self.prob is None else self.prob[1].data_ptr(),
             out.data_ptr(), geom.ctypes.data_as(ctypes.c_void_p), int(geom.size), self.woff.ctypes.data_as(ctypes.c_void_p), self.cin,
-            mt, nt, variant, torch.cuda.current_stream().cuda_stream)
+            mt, nt, variant, ops._stream())
         _lib.check(rc, "conv_mfma")
         return out
 

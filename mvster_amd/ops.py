@@ -15,7 +15,9 @@ def _ptr(t):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current stream on the current device (the C accessors: ``torch.cuda.current_stream()`` builds
+    a Python Stream object per call, ~9 us each and ~200 calls per training step)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _chk(t, name):
@@ -316,6 +318,17 @@ def conv_wgrad(x_cl, gy_cl, kernel, stride, padding, co_keep=None, ci_keep=None,
     return dw
 
 
+_BN_SLOTS = {}
+
+
+def _bn_slots(rows, C, groups):
+    key = (rows, C, groups)
+    n = _BN_SLOTS.get(key)
+    if n is None:
+        n = _BN_SLOTS[key] = _lib.load().mvster_bn_slots(rows, C, groups)
+    return n
+
+
 def bn_batch_stats(x, weight, bias, running_mean, running_var, eps, momentum, groups=1, num_batches_tracked=None):
     """-> pack [5, groups, C] = (mean, biased var, rstd, scale, shift); running_mean / running_var (or None) are
     updated in place, one exponential-average step per group, and num_batches_tracked (or None) += groups."""
@@ -323,7 +336,7 @@ def bn_batch_stats(x, weight, bias, running_mean, running_var, eps, momentum, gr
     C = x.shape[-1]
     rows = x.numel() // C // groups
     lib = _lib.load()
-    nblk = lib.mvster_bn_slots(rows, C, groups)
+    nblk = _bn_slots(rows, C, groups)
     if nblk <= 0:
         raise RuntimeError("bn_batch_stats: unsupported channel count %d" % C)
     partial = torch.empty(groups, nblk, 2, C, device=x.device, dtype=torch.float32)
@@ -364,7 +377,7 @@ def bn_relu_bwd(x, gy, scale, shift, mean, rstd, relu, groups=1, frozen=False):
     C = x.shape[-1]
     rows = x.numel() // C // groups
     lib = _lib.load()
-    nblk = lib.mvster_bn_slots(rows, C, groups)
+    nblk = _bn_slots(rows, C, groups)
     if nblk <= 0:
         raise RuntimeError("bn_relu_bwd: unsupported channel count %d" % C)
     partial = torch.empty(groups, nblk, 2, C, device=x.device, dtype=torch.float32)
