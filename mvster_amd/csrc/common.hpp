@@ -32,30 +32,3 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
-
-// Division by a launch-time constant as multiply-high + shift (exact for n < 2^31).  A runtime `/` or `%` costs a
-// wavefront ~20-40 instructions (reciprocal + fix-ups); the small kernels of this path do a handful per thread, which is
-// a sizeable share of their instruction count.  The host fills the struct (mv_fastdiv), kernels take it by value.
-struct FastDiv {
-    unsigned d, mul, shr;
-};
-
-static inline FastDiv mv_fastdiv(unsigned d) {
-    FastDiv f;
-    f.d = d;
-    if (d <= 1) { f.mul = 0; f.shr = 0; return f; }
-    int lg = 31 - __builtin_clz(d);
-    if (d & (d - 1)) ++lg;                       // ceil(log2 d)
-    const int p = 31 + lg;
-    f.mul = (unsigned)(((1ull << p) + d - 1) / d);
-    f.shr = (unsigned)(p - 32);
-    return f;
-}
-
-__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.shr); }
-// quotient and remainder
-__device__ __forceinline__ unsigned fdivmod(unsigned n, const FastDiv& f, unsigned& rem) {
-    const unsigned q = fdiv(n, f);
-    rem = n - q * f.d;
-    return q;
-}

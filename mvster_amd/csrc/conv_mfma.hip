@@ -379,7 +379,7 @@ int dispatch_tiles(const ConvArgs& a, int MT, int NT, bool splitk, hipStream_t s
 // prologue spent 11 reciprocal-based division sequences (~220 of its ~570 instructions) per wavefront -- on a one-chunk
 // layer the MFMA phase is only 72 instructions long, so the prologue and epilogue are what the MFMA pipes wait for.
 struct LdsDivs {
-    unsigned mul[5], shr[5];     // tiles_x, tiles_y, Do, PW, PH
+    unsigned mul[6], shr[6];     // tiles_x, tiles_y, Do, PW, PH, KH
 };
 constexpr int kMaxStage = 12;   // float4 loads per thread per chunk (patch <= 48 KB)
 __device__ __forceinline__ int patch_plane(int npix) { return ((npix * 2 + 7) & ~7) + 4; }   // float4 units, = 4 mod 8
@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
         const int kz_lo = max(0, a.pd[0] - zo * a.sd), kz_hi = min(KD, a.Di + a.pd[0] - zo * a.sd);
         const int r_first = kz_lo * KH, nrows = kz_hi * KH;
         auto load_row = [&](int r, f32x4v (&A)[KW][MT], f32x4v (&Bv)[KW][NT]) {
-            const int kz = r / KH, ky = r - kz * KH;
+            const int kz = fast_div(r, KH, dv.mul[5], dv.shr[5]), ky = r - kz * KH;   // (no division sequence per row of taps)
             const int rowoff = (kz * PH + ky) * PW * 2;
             const float* w = wp + (long)(r * KW * nchunks + ch) * wstep;
 #pragma unroll
@@ -574,9 +574,9 @@ int launch_lds_ng(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
     if (blocks >= (1L << 31) || (long)a.B * a.Di * a.Hi * a.Wi * a.cin >= (1L << 31)) return MVSTER_ERR_SHAPE;
     dim3 grid((unsigned)blocks, a.ntile_total / NT, 1);
     LdsDivs dv;
-    const unsigned divisors[5] = {(unsigned)tiles_x, (unsigned)tiles_y, (unsigned)a.Do, (unsigned)(31 * a.sw + KW),
-                                  (unsigned)((2 * MT - 1) * a.sh + a.kh[0])};
-    for (int i = 0; i < 5; ++i) find_divisor(divisors[i], dv.mul[i], dv.shr[i]);
+    const unsigned divisors[6] = {(unsigned)tiles_x, (unsigned)tiles_y, (unsigned)a.Do, (unsigned)(31 * a.sw + KW),
+                                  (unsigned)((2 * MT - 1) * a.sh + a.kh[0]), (unsigned)a.kh[0]};
+    for (int i = 0; i < 6; ++i) find_divisor(divisors[i], dv.mul[i], dv.shr[i]);
     const int nw = a.kd[0] * a.kh[0] * KW * NT * 64;       // weight float4 per chunk
     if (nw <= 3 * 256 && !g_no_wlds) {
         const size_t lds = (size_t)(NG * 1024 + 32) * 16 + 3 * 256 * 16;

@@ -18,6 +18,40 @@
 #define MV_HD inline
 #endif
 
+// Division by a launch-time constant as multiply-high + shift (exact for n < 2^31; tests/test_hostmath.py checks it
+// against `/` on the host build).  A runtime `/` or `%` costs a wavefront ~20-40 instructions (reciprocal + fix-ups); the
+// small kernels of this path do a handful per thread, and in the LDS convolution's prologue they were a third of all
+// instructions.  The host fills the struct (mv_fastdiv), kernels take it by value.
+struct FastDiv {
+    unsigned d, mul, shr;
+};
+
+static inline FastDiv mv_fastdiv(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    if (d <= 1) { f.mul = 0; f.shr = 0; return f; }
+    int lg = 31 - __builtin_clz(d);
+    if (d & (d - 1)) ++lg;                       // ceil(log2 d)
+    const int p = 31 + lg;
+    f.mul = (unsigned)(((1ull << p) + d - 1) / d);
+    f.shr = (unsigned)(p - 32);
+    return f;
+}
+
+MV_HD unsigned fdiv(unsigned n, const FastDiv& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.shr);
+#else
+    return f.d == 1 ? n : ((unsigned)(((unsigned long long)n * f.mul) >> 32) >> f.shr);
+#endif
+}
+// quotient and remainder
+MV_HD unsigned fdivmod(unsigned n, const FastDiv& f, unsigned& rem) {
+    const unsigned q = fdiv(n, f);
+    rem = n - q * f.d;
+    return q;
+}
+
 namespace mv {
 
 // fp32 ops that must not be contracted into FMAs (the reference materialises the

@@ -5,6 +5,24 @@
 
 extern "C" {
 
+// quotient of the multiply-shift division the kernels use (mvster_math.h FastDiv)
+unsigned hm_fastdiv(unsigned n, unsigned d) {
+    const FastDiv f = mv_fastdiv(d);
+    return fdiv(n, f);
+}
+// number of n in [lo, hi) (stepping by `step`) whose quotient / remainder differ from the plain operators
+long hm_fastdiv_mismatches(unsigned d, unsigned lo, unsigned hi, unsigned step) {
+    const FastDiv f = mv_fastdiv(d);
+    long bad = 0;
+    for (unsigned long long n = lo; n < hi; n += step) {
+        unsigned rem;
+        const unsigned q = fdivmod((unsigned)n, f, rem);
+        if (q != (unsigned)n / d || rem != (unsigned)n % d) ++bad;
+    }
+    return bad;
+}
+
+
 // ref_pm/src_pm: [2,4,4] each; out: 12 floats (r[9], t[3])
 int hm_relative_projection(const float* ref_pm, const float* src_pm, float* out) {
     mv::RT m;

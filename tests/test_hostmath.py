@@ -155,3 +155,20 @@ def test_select_with_prob_head(hm):
     want = feat @ w + 0.3
     assert np.abs(lo - want).max() <= 1e-5
     assert np.abs(attn - torch.softmax(torch.from_numpy(want), 0).numpy()).max() <= 1e-6
+
+
+def test_multiply_shift_division(hm):
+    """FastDiv (mvster_math.h), the division by launch constants used in the kernels' index arithmetic: exact for every
+    dividend below 2^31 -- checked here for the divisors the path produces (tile counts, patch widths, image sizes) and
+    awkward ones, over dense low ranges, strided sweeps of the whole range and the top end."""
+    hm.hm_fastdiv_mismatches.restype = ctypes.c_long
+    hm.hm_fastdiv_mismatches.argtypes = [ctypes.c_uint] * 4
+    hm.hm_fastdiv.restype = ctypes.c_uint
+    hm.hm_fastdiv.argtypes = [ctypes.c_uint] * 2
+    top = 2 ** 31
+    for d in (1, 2, 3, 5, 6, 7, 9, 10, 18, 19, 20, 34, 35, 36, 40, 64, 80, 100, 131, 160, 200, 240, 320, 400, 480, 640, 800,
+              960, 1600, 1920, 4096, 65535, 65537, 1000003, 2 ** 30 - 1, 2 ** 30 + 1, 2 ** 31 - 1):
+        assert hm.hm_fastdiv_mismatches(d, 0, 200000, 1) == 0, d
+        assert hm.hm_fastdiv_mismatches(d, 0, top, 104729) == 0, d
+        assert hm.hm_fastdiv_mismatches(d, top - 200000, top, 1) == 0, d
+    assert hm.hm_fastdiv(2 ** 31 - 1, 7) == (2 ** 31 - 1) // 7
