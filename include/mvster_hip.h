@@ -219,7 +219,7 @@ int mvster_upsample2x_cl_bwd(const float* gout, float* gin, int B, int h, int w,
 int mvster_upsample2x_nearest_cl(const float* in, float* out, int B, int h, int w, int C, int backward, void* stream);
 
 /* Sinkhorn optimal-transport loss per pixel and its gradient, fused (discrete form, ot_continous=False):
- * attn, hypo [B,D,HW], gt [B,HW] -> loss_pix [B,HW], jac [B,D,HW] = d loss_pix / d attn.  2 <= D <= 8,
+ * attn, hypo [B,D,HW], gt [B,HW] -> loss_pix [B,HW], jac [B,D,HW] = d loss_pix / d attn.  2 <= D <= 16,
  * iters <= 16.  Replaces the per-pixel part of `sinkhorn` (models/mvs4net_utils.py:1096-1142) and its autograd;
  * the masked mean over pixels stays with the caller. */
 int mvster_sinkhorn(const float* attn, const float* hypo, const float* gt, float* loss_pix, float* jac, int B, int D,

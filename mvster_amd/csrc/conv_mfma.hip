@@ -71,6 +71,29 @@ struct ConvArgs {
 
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
+// Probe build only (make timeline -> libmvster_hip_tl.so, scripts/conv_timeline.py): lane 0 of every wavefront stamps
+// s_memtime at the kernel's phase boundaries into a debug buffer.  The product library is compiled without it.
+#ifdef MVSTER_TIMELINE
+__device__ unsigned long long* g_tl = nullptr;
+#define MV_TL(k)                                                                                              \
+    do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (g_tl && (threadIdx.x & 63) == 0)                                                                  \
+            g_tl[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime();     \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
+#define MV_TL_ID()                                                                                            \
+    do {                                                                                                      \
+        if (g_tl && (threadIdx.x & 63) == 0) {                                                                \
+            g_tl[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 6] = __builtin_amdgcn_s_getreg(63492);   \
+            g_tl[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 7] = __builtin_amdgcn_s_getreg(63508);   \
+        }                                                                                                     \
+    } while (0)
+#else
+#define MV_TL(k)
+#define MV_TL_ID()
+#endif
+
 __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, unsigned mul, unsigned shr) {
     return d == 1 ? n : (__umulhi(n, mul) >> shr);
 }
@@ -390,6 +413,8 @@ static const bool g_no_wlds = getenv("MVSTER_NO_WLDS") != nullptr;   // experime
 template <int MT, int NT, int KW, int NG, int WN>
 __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, int tiles_y, LdsDivs dv) {
     extern __shared__ __attribute__((aligned(16))) float patch_raw[];
+    MV_TL(0);
+    MV_TL_ID();
     f32x4v* patch_base = reinterpret_cast<f32x4v*>(patch_raw);
     f32x4v* wl = patch_base + NG * 1024 + 32;     // WL: this chunk's packed weights [tap][nt][lane] (after the plane pads)
     constexpr int TY = 2 * MT;
@@ -498,8 +523,11 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
         scv[nt] = *reinterpret_cast<const f32x4v*>(a.scale + n0);
         shv[nt] = *reinterpret_cast<const f32x4v*>(a.shift + n0);
     }
+    MV_TL(1);
     stage_store(patch_base);
+    MV_TL(2);
     __syncthreads();
+    MV_TL(3);
     for (int ch = 0; ch < nchunks; ++ch) {
         const f32x4v* patch = patch_base;
         if (ch + 1 < nchunks) stage_load(ch + 1);
@@ -552,6 +580,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
         }
     }
 
+    MV_TL(4);
     // epilogue (swapped operands: this lane holds channels 4*lq..4*lq+3 of its own voxel, see above)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -566,6 +595,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
             epilogue_store(a, acc[mt][nt], n0, opix, b, y, x, scv[nt], shv[nt]);
         }
     }
+    MV_TL(5);
 }
 
 template <int MT, int NT, int KW, int NG>
@@ -687,6 +717,12 @@ extern "C" int mvster_conv_mfma(const float* in, const float* wpk, const float* 
         default: return MVSTER_ERR_UNSUPPORTED;
     }
 }
+
+#ifdef MVSTER_TIMELINE
+extern "C" int mvster_debug_timeline(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &buf, sizeof(buf)) == hipSuccess ? MVSTER_OK : MVSTER_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int mvster_mfma_probe(const float* A, const float* B, float* D, void* stream) {
     if (!A || !B || !D) return MVSTER_ERR_NULL;

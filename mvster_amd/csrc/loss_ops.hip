@@ -2,7 +2,7 @@
 //
 // The reference (models/mvs4net_utils.py:1096-1142) materialises the [B, HW, D, D] cost and runs `iters`
 // log-domain Sinkhorn updates as ~8 tensor passes each, all kept alive for autograd: ~0.6 GB of
-// intermediates per stage-4 call and dozens of launches.  D <= 8, so one thread can hold the whole problem
+// intermediates per stage-4 call and dozens of launches.  D <= 8 (shipped), so one thread can hold the whole problem
 // of one pixel in registers: both potentials, the |i-j| cost analytically, the transport plan, and the
 // reverse sweep through the iterations.  One launch returns the per-pixel loss AND its gradient with
 // respect to the predicted distribution (the only differentiable input), so backward is a multiply.
@@ -151,13 +151,16 @@ int launch_sinkhorn(const float* attn, const float* hypo, const float* gt, const
 #define MV_S(D_) if (D == D_) { hipLaunchKernelGGL((sinkhorn_kernel<D_, CONT>), grid, block, 0, s, attn, hypo, gt, mask, loss_pix, jac, B, HW, iters, inv_eps); return mv_check_launch(); }
     if (!CONT) { MV_S(2) }
     MV_S(3) MV_S(4) MV_S(5) MV_S(6) MV_S(7) MV_S(8)
+    // 9..16 hypotheses (MVS4net accepts stage_splits up to 16): same code; the potentials' history no longer fits the
+    // register file and lives in scratch memory, so these instances are slower per pixel -- not a shipped configuration
+    MV_S(9) MV_S(10) MV_S(11) MV_S(12) MV_S(13) MV_S(14) MV_S(15) MV_S(16)
 #undef MV_S
     return MVSTER_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
-// attn, hypo [B,D,HW]; gt [B,HW] -> loss_pix [B,HW], jac [B,D,HW] = d loss_pix / d attn.  D in {2,...,8}, iters <= 16.
+// attn, hypo [B,D,HW]; gt [B,HW] -> loss_pix [B,HW], jac [B,D,HW] = d loss_pix / d attn.  D in {2,...,16}, iters <= 16.
 extern "C" int mvster_sinkhorn(const float* attn, const float* hypo, const float* gt, float* loss_pix, float* jac, int B,
                                int D, long HW, int iters, float eps, void* stream) {
     if (!attn || !hypo || !gt || !loss_pix || !jac) return MVSTER_ERR_NULL;
@@ -166,7 +169,7 @@ extern "C" int mvster_sinkhorn(const float* attn, const float* hypo, const float
     return launch_sinkhorn<false>(attn, hypo, gt, nullptr, loss_pix, jac, B, D, HW, iters, eps, (hipStream_t)stream);
 }
 
-// The continuous form (ot_continous=True): as above with mask [B,HW] (> 0.5 = valid); D in {3,...,8}.
+// The continuous form (ot_continous=True): as above with mask [B,HW] (> 0.5 = valid); D in {3,...,16}.
 extern "C" int mvster_sinkhorn_continuous(const float* attn, const float* hypo, const float* gt, const float* mask,
                                           float* loss_pix, float* jac, int B, int D, long HW, int iters, float eps,
                                           void* stream) {

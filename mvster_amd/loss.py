@@ -1,48 +1,13 @@
-"""Training losses with the reference's signatures.  On the GPU the Sinkhorn term of ``MVS4net_loss`` /
-``Blend_loss`` runs as one fused kernel (``mvster_sinkhorn``: per-pixel loss + its gradient, no [B,HW,D,D]
-intermediates); ``sinkhorn`` itself is the tensor-level form with the reference's return values.
+"""Training losses with the reference's signatures.  The Sinkhorn term of ``MVS4net_loss`` / ``Blend_loss`` runs as
+one fused kernel (``mvster_sinkhorn``: per-pixel loss + its gradient, no [B,HW,D,D] intermediates).
 
-``MVS4net_loss`` / ``Blend_loss`` follow models/MVS4Net.py:113-206, ``sinkhorn`` follows
-models/mvs4net_utils.py:1096-1142: an entropy-regularised optimal-transport distance between
-the one-hot ground-truth depth bin and the predicted ``attn_weight`` distribution, solved by
-``iters`` log-domain Sinkhorn updates with the |i-j| bin-distance cost.
+``MVS4net_loss`` / ``Blend_loss`` follow models/MVS4Net.py:113-206; the OT term is the loss value of the reference's
+``sinkhorn`` (models/mvs4net_utils.py:1096-1142): an entropy-regularised optimal-transport distance between the one-hot
+ground-truth depth bin and the predicted ``attn_weight`` distribution, solved by ``iters`` log-domain Sinkhorn
+updates with the |i-j| bin-distance cost.  (The tensor-level restatement that also returns the transport plan is test
+infrastructure and lives with the other checkers, not in this package.)
 """
 import torch
-import torch.nn.functional as F
-
-
-def sinkhorn(gt_depth, hypo_depth, attn_weight, mask, iters, eps=1, continuous=False):
-    B, D, H, W = attn_weight.shape
-    dev = gt_depth.device
-    pred = attn_weight.permute(0, 2, 3, 1).reshape(B, H * W, D)
-    if not continuous:
-        ar = torch.arange(D, dtype=torch.float32, device=dev)
-        cost = (ar[None, :] - ar[:, None]).abs()[None, None].repeat(B, H * W, 1, 1)           # [B,HW,D,D]
-        nearest = (hypo_depth - gt_depth[:, None]).abs().min(1)[1].reshape(B * H * W, 1)
-        target = torch.zeros(B * H * W, D, dtype=hypo_depth.dtype, device=dev)
-        target.scatter_add_(1, nearest, torch.ones(B * H * W, 1, dtype=hypo_depth.dtype, device=dev))
-        target = target.reshape(B, H * W, D)
-    else:
-        target = torch.zeros((B, H * W, D + 1), dtype=torch.float32, device=dev)
-        target[:, :, -1] = 1
-        ar = torch.arange(D, dtype=torch.float32, device=dev)
-        cost = torch.zeros((B, D, D + 1), dtype=torch.float32, device=dev)
-        cost[:, :D, :D] = (ar[None, :] - ar[:, None]).abs()[None]
-        cost = cost[:, None, None].repeat(1, H, W, 1, 1)
-        itv = 1 / hypo_depth[:, 2] - 1 / hypo_depth[:, 1]
-        off = (1 / gt_depth - 1 / hypo_depth[:, 0]) / itv
-        off[~mask] = 10
-        cost[..., -1] = torch.stack([(off - i).abs() for i in range(D)], dim=1).permute(0, 2, 3, 1)
-        cost = cost.reshape(B, H * W, D, D + 1)
-    log_mu = (target + 1e-12).log()
-    log_nu = (pred + 1e-12).log()
-    u, v = torch.zeros_like(log_nu), torch.zeros_like(log_mu)
-    for _ in range(iters):
-        v = log_mu - torch.logsumexp(cost / eps + u.unsqueeze(3), dim=2)
-        u = log_nu - torch.logsumexp(cost / eps + v.unsqueeze(2), dim=3)
-    plan = (cost / eps + u.unsqueeze(3) + v.unsqueeze(2)).exp()
-    loss = (plan * cost).reshape(B * H * W, -1)[mask.reshape(-1)].sum(-1).mean()
-    return plan, loss
 
 
 class _SinkhornLoss(torch.autograd.Function):
@@ -70,15 +35,14 @@ class _SinkhornLoss(torch.autograd.Function):
 
 def sinkhorn_loss(gt_depth, hypo_depth, attn_weight, mask, iters, eps=1, continuous=False):
     """The loss value of ``sinkhorn`` (its second return) on the fused gfx950 kernel (``mvster_sinkhorn`` /
-    ``mvster_sinkhorn_continuous``): GPU tensors, D <= 8 hypotheses, iters <= 16 -- the range of the reference's
-    configurations.  There is no tensor-level fallback: other inputs raise (``sinkhorn`` above is the explicit
-    reference-shaped form that also returns the transport plan)."""
+    ``mvster_sinkhorn_continuous``): GPU tensors, D <= 16 hypotheses (what ``MVS4net`` accepts as ``stage_splits``; the shipped 4/8 keep a
+    pixel's whole problem in registers, 9..16 spill the iteration history to scratch), iters <= 16.  There is no tensor-level fallback: other inputs raise."""
     D = attn_weight.shape[1]
     if not attn_weight.is_cuda:
         raise RuntimeError("mvster_amd.loss.sinkhorn_loss runs on MI355X only (there is no CPU fallback)")
-    if not ((3 if continuous else 2) <= D <= 8 and 0 <= iters <= 16):
+    if not ((3 if continuous else 2) <= D <= 16 and 0 <= iters <= 16):
         raise NotImplementedError("sinkhorn_loss: D=%d hypotheses / %d iterations (the fused kernel holds a pixel's whole "
-                                  "problem in registers: D <= 8, iters <= 16)" % (D, iters))
+                                  "problem in one thread: D <= 16, iters <= 16)" % (D, iters))
     return _SinkhornLoss.apply(attn_weight, hypo_depth, gt_depth, mask, int(iters), float(eps), bool(continuous))
 
 

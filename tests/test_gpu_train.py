@@ -283,7 +283,8 @@ def test_reg_module_gradients_native_vs_pytorch_rocm(kind):
 
 
 @pytest.mark.parametrize("D,iters,eps,cont", [(4, 10, 1.0, False), (8, 10, 1.0, False), (8, 3, 0.5, False), (5, 16, 2.0, False),
-                                              (4, 10, 1.0, True), (8, 10, 1.0, True), (3, 3, 0.5, True), (5, 16, 2.0, True)])
+                                              (4, 10, 1.0, True), (8, 10, 1.0, True), (3, 3, 0.5, True), (5, 16, 2.0, True),
+                                              (12, 10, 1.0, False), (16, 3, 1.0, False), (9, 5, 1.0, True), (16, 10, 1.0, True)])
 def test_fused_sinkhorn_vs_tensor_form(D, iters, eps, cont):
     """mvster_sinkhorn / mvster_sinkhorn_continuous (one thread per pixel, loss + gradient in one launch) against the
     oracle's tensor-level restatement of models/mvs4net_utils.py:1096-1142 under autograd, in fp64 on the CPU."""
