@@ -102,7 +102,9 @@ int mvster_upsample_bilinear(const float* in, float* out, int B, int hi, int wi,
  * (models/mvs4net_utils.py:900) -- `out` is then the [B,Do,Ho,Wo] logits volume instead of the feature volume.
  * variant 0 = direct (operands from L1), 1 = LDS-staged input patch (ordinary convs, cin % 16 == 0,
  * mt in {2,4}: the workgroup tile is 2*mt rows x 32 columns), 2 = direct with the 4 waves of a workgroup
- * splitting K (small deep layers; cin >= 16, mt*nt <= 4).
+ * splitting K (small deep layers; cin >= 16, mt*nt <= 4), 5 = persistent workgroups with LDS-DMA double-buffered
+ * input patches and workgroup-resident weights (ordinary convs, cin in {16, 32}, cout % 16 == 0, kernels
+ * (1|3)x3x3 and 1x5x5, in-plane stride 1 or 2, mt = 2; bits 8.. of `variant` = workgroups per CU, 0 = default).
  * Conv3d/ConvTranspose3d/BatchNorm3d/ReLU of reg2d/reg3d (models/mvs4net_utils.py:870-965) and
  * Conv2d/BatchNorm2d/ReLU/upsample-add of FPN4 (:419-502). */
 int mvster_conv_mfma(const float* in, const float* wpk, const float* scale, const float* shift, const float* skip,

@@ -27,47 +27,11 @@
 // (1,3,3) layers are HBM/L2-bound.  FLOPs per launch = 2 * M * Cout * taps * Cin.
 #include <stdlib.h>
 
-#include "common.hpp"
+#include "conv_args.hpp"
 
 namespace {
 
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-
-constexpr int kMaxTaps = 128;
-constexpr int kMaxClasses = 8;
-
-struct ConvArgs {
-    const float* in;      // [B, Di, Hi, Wi, CIN]
-    const float* wpk;     // packed weights, all classes
-    const float* scale;   // [Np]
-    const float* shift;   // [Np]
-    const float* skip;    // optional
-    const float* zeros;   // >= 16 bytes of zeros: the "address" of every padded tap
-    const float* prob_w;  // optional fused 1x1x1 head (cout == 8): out becomes [voxels] logits
-    const float* prob_b;
-    float* out;           // [B, DoF, HoF, WoF, COUT]
-    int B, Di, Hi, Wi;
-    int Do, Ho, Wo;       // output lattice walked by M (per class)
-    int DoF, HoF, WoF;    // full output dims
-    int sd, sh, sw;       // input step per lattice step
-    int cin;              // input channels (LDS-staged variant; the direct kernel has it as a template argument)
-    int cout;             // real output channels
-    int ntile_total;      // Np / 16
-    int relu;
-    int skip_mode;        // 0 none, 1 same-resolution add, 2 bilinear x2 upsample-add (2-D, half resolution)
-    int nclass;
-    // per class
-    int kd[kMaxClasses], kh[kMaxClasses], kw[kMaxClasses];   // sub-kernel extent
-    int pd[kMaxClasses], ph[kMaxClasses], pw[kMaxClasses];   // input offset: i = o*s - p + k
-    int od[kMaxClasses], oh[kMaxClasses], ow[kMaxClasses];   // output phase
-    int osd, osh, osw;                                       // output lattice stride
-    int nsteps[kMaxClasses];
-    int all_inside[kMaxClasses];                             // no tap of any lattice voxel needs padding
-    long woff[kMaxClasses];                                  // float offset of the class's packed weights
-    // filled by the C entry point: multiply-shift division by Wo, Ho, Do (valid for dividends < 2^31)
-    unsigned div_mul[3], div_shr[3];
-    unsigned in_bytes;                                       // size of `in` (< 4 GB): buffer-load range check
-};
+using namespace mvconv;
 
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
@@ -93,19 +57,6 @@ __device__ unsigned long long* g_tl = nullptr;
 #define MV_TL(k)
 #define MV_TL_ID()
 #endif
-
-__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, unsigned mul, unsigned shr) {
-    return d == 1 ? n : (__umulhi(n, mul) >> shr);
-}
-
-static void find_divisor(unsigned d, unsigned& mul, unsigned& shr) {
-    if (d <= 1) { mul = 0; shr = 0; return; }
-    int lg = 31 - __builtin_clz(d);
-    if (d & (d - 1)) ++lg;                       // ceil(log2 d)
-    const int p = 31 + lg;
-    mul = (unsigned)(((1ull << p) + d - 1) / d);
-    shr = (unsigned)(p - 32);
-}
 
 // Fused epilogue for 4 consecutive output channels n0..n0+3 of one output voxel.
 // (scale / shift are padded to 16 * ntiles floats: one 16-byte load each; callers that can, load them ahead of the MFMAs)
@@ -703,6 +654,7 @@ extern "C" int mvster_conv_mfma(const float* in, const float* wpk, const float* 
     if (a.ntile_total % nt != 0) return MVSTER_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     a.cin = cin;
+    if ((variant & 0xff) == 5) return dispatch_pers(a, mt, nt, variant >> 8, s);   // persistent LDS-DMA family (conv_pers.hip)
     if (prob_w && (a.cout != 8 || a.skip_mode == 2 || variant == 1)) return MVSTER_ERR_UNSUPPORTED;
     if (variant == 1) return dispatch_lds(a, mt, nt, s);
     if (variant != 0 && variant != 2) return MVSTER_ERR_UNSUPPORTED;
