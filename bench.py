@@ -61,31 +61,20 @@ class KernelTimer:
     def install(self):
         import mvster_amd.conv_plan as cp
         import mvster_amd.ops as ops
+        from mvster_amd import _lib
         timer = self
         self._orig_conv = cp.ConvLayer.__call__
         self._orig_warp = ops.warp_agg_fwd_cl
 
         def conv_call(layer, x, skip=None, skip_mode=0, tiles=None):
             B, Di, Hi, Wi, _ = x.shape
-            _, mt, nt, _, variant = layer._geom(B, Di, Hi, Wi, skip_mode if skip is not None else 0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = timer._orig_conv(layer, x, skip, skip_mode, tiles)
             e1.record()
             bytes_ = 4 * (x.numel() + out.numel() + layer.wpk.numel() + (skip.numel() if skip is not None else 0))
-            if variant == 1:
-                kd, kh, kw = layer.kernel
-                nstage = kd * ((2 * mt - 1) * layer.stride[1] + kh) * (31 * layer.stride[2] + kw) * 4
-                wl = kd * kh * kw * nt * 64 <= 768 and not os.environ.get("MVSTER_NO_WLDS")
-                kname = "conv_lds_kernel<%d, %d, %d, %d, %d>" % (mt, nt, kw, -(-nstage // 1024), 3 if wl else 0)
-            elif variant == 3:
-                kname = "conv_small_kernel<%d>" % layer.cin
-            elif variant == 4:
-                kname = "deconv_small_kernel<%d, %d>" % (layer.cin, layer.cout)
-            else:
-                kname = "conv_mfma_kernel<%d, %d, %d, %s>" % (layer.cin, mt, nt, "true" if variant == 2 else "false")
-            timer.records.append((kname, e0, e1,
-                                  layer.flops(B, Di, Hi, Wi), bytes_))
+            # the library reports what it dispatched (mvster_last_kernel): no second copy of the dispatch rules here
+            timer.records.append((_lib.last_kernel(), e0, e1, layer.flops(B, Di, Hi, Wi), bytes_))
             return out
 
         def warp_call(ref_cl, src_cl, rt, hypo, G, *a, **k):
@@ -93,21 +82,8 @@ class KernelTimer:
             e0.record()
             out = timer._orig_warp(ref_cl, src_cl, rt, hypo, G, *a, **k)
             e1.record()
-            C = ref_cl.shape[-1]
             bytes_ = 4 * (ref_cl.numel() + src_cl.numel() + hypo.numel() + hypo.numel() * G)
-            D = hypo.shape[1]
-            variant = int(os.environ.get("MVSTER_WARP_VARIANT", "0"))
-            pix = variant == 4 or (variant == 0 and C <= 16 and os.environ.get("MVSTER_PIX"))
-            if pix and C != G and D in (4, 8) and C <= 32:
-                dpl = int(os.environ.get("MVSTER_PIX_DPL", "2")) or D
-                kname = "warp_agg_fwd_pix_kernel<%d, %d, %d, %d, %s>" % (C, G, D, dpl, os.environ.get("MVSTER_PIX_WPE", "4"))
-            elif variant in (0, 3, 4) and C != G and D in (4, 8) and C <= 64:
-                kname = "warp_agg_fwd_wave_kernel<%d, %d, %d>" % (C, G, D)
-            elif variant != 1 and C >= 16 and C != G and D <= 8:
-                kname = "warp_agg_fwd_lanes_kernel<%d, %d, 8>" % (C, G)
-            else:
-                kname = "warp_agg_fwd_kernel<%d, %d, %s, %d>" % (C, G, "true" if C != G else "false", 8 if D <= 8 else 16)
-            timer.records.append((kname, e0, e1, 0, bytes_))
+            timer.records.append((_lib.last_kernel(), e0, e1, 0, bytes_))
             return out
 
         cp.ConvLayer.__call__ = conv_call
@@ -413,7 +389,7 @@ def main():
 
         def entry(name, a):
             avg_ms = a["ms"] / a["n"]
-            if a["flops"] > 0 and name.startswith("conv") and not name.startswith("conv_small"):
+            if a["flops"] > 0 and name.startswith("conv") and not name.startswith("conv_small"):      # (MFMA kernels)
                 achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
                 e = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,

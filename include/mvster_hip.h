@@ -104,7 +104,9 @@ int mvster_upsample_bilinear(const float* in, float* out, int B, int hi, int wi,
  * mt in {2,4}: the workgroup tile is 2*mt rows x 32 columns), 2 = direct with the 4 waves of a workgroup
  * splitting K (small deep layers; cin >= 16, mt*nt <= 4), 5 = persistent workgroups with LDS-DMA double-buffered
  * input patches and workgroup-resident weights (ordinary convs, cin in {16, 32}, cout % 16 == 0, kernels
- * (1|3)x3x3 and 1x5x5, in-plane stride 1 or 2, mt = 2; bits 8.. of `variant` = workgroups per CU, 0 = default).
+ * (1|3)x3x3 and 1x5x5, in-plane stride 1 or 2, mt = 2; bits 8.. of `variant` = workgroups per CU, 0 = default),
+ * 6 = persistent 1x1x1 kernel with all packed weights resident in LDS and the input read once (cin in {32, 64},
+ * cout % 4 == 0, optional same-shape skip; nt is ignored: a wave walks all N tiles).
  * Conv3d/ConvTranspose3d/BatchNorm3d/ReLU of reg2d/reg3d (models/mvs4net_utils.py:870-965) and
  * Conv2d/BatchNorm2d/ReLU/upsample-add of FPN4 (:419-502). */
 int mvster_conv_mfma(const float* in, const float* wpk, const float* scale, const float* shift, const float* skip,
@@ -242,6 +244,12 @@ int mvster_sinkhorn_continuous(const float* attn, const float* hypo, const float
 int mvster_geo_filter(const float* depth_ref, const float* depth_src, const double* ref_mats, const double* view_mats,
                       int* mask_sum, float* depth_sum, unsigned char* view_mask, float* view_depth, float* x_src,
                       float* y_src, int NS, int H, int W, float pix_thres, float rel_thres, void* stream);
+
+/* Name of the kernel the most recent mvster_conv_mfma / mvster_conv_small / mvster_deconv_small / mvster_conv_wgrad /
+ * mvster_warp_agg_fwd / mvster_warp_agg_bwd (first pass) call on the calling host thread launched, in the profiler's spelling with template arguments (e.g. "conv_lds_kernel<2, 1, 3, 1, 3>");
+ * "" before the first call.  The pointer stays valid for the life of the library.  (bench.py attributes HIP-event timings
+ * with it; there is no reference counterpart -- the reference's dispatch lives inside cuDNN.) */
+const char* mvster_last_kernel(void);
 
 /* One v_mfma_f32_16x16x4_f32: A [16,4], B [4,16] -> D [16,16] (row major).  Test hook that pins the
  * fragment layout the convolution kernels assume. */

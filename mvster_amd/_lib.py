@@ -50,7 +50,9 @@ SIGNATURES = {
     "mvster_sinkhorn_continuous": [_f, _f, _f, _f, _f, _f, _i, _i, _l, _i, _fl, _f],
     "mvster_geo_filter": [_f] * 10 + [_i, _i, _i, _fl, _fl, _f],
     "mvster_mfma_probe": [_f, _f, _f, _f],
+    "mvster_last_kernel": [],
 }
+RESTYPES = {"mvster_last_kernel": ctypes.c_char_p}     # everything else returns an int status
 
 _lib = None
 
@@ -70,7 +72,7 @@ def load():
                 continue
             fn = getattr(lib, name)        # AttributeError if the library does not export it
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = RESTYPES.get(name, ctypes.c_int)
         _lib = lib
     return _lib
 
@@ -78,3 +80,8 @@ def load():
 def check(rc, what):
     if rc != 0:
         raise RuntimeError("%s failed: %s (code %d)" % (what, ERRORS.get(rc, "unknown error"), rc))
+
+
+def last_kernel():
+    """Kernel name (profiler spelling) the most recent convolution / fused-warp launch of this thread dispatched."""
+    return load().mvster_last_kernel().decode()

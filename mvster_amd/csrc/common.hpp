@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "mvster_math.h"
 
@@ -16,6 +17,21 @@ static inline int mv_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MVSTER_OK : MVSTER_ERR_LAUNCH;
 }
+
+// What the last launcher called on this host thread dispatched, spelled like the profiler spells the kernel
+// ("conv_lds_kernel<2, 1, 3, 1, 3>"): mvster_last_kernel() hands it to the caller, so that bench.py attributes its
+// event timings to the kernel the library really chose instead of re-deriving the dispatch rules.
+extern thread_local const char* mv_last_kernel;
+#define MV_NOTE_KERNEL(...)                              \
+    do {                                                 \
+        static char nm_[96];                             \
+        static bool init_ = false;                       \
+        if (!init_) {                                    \
+            snprintf(nm_, sizeof nm_, __VA_ARGS__);      \
+            init_ = true;                                \
+        }                                                \
+        mv_last_kernel = nm_;                            \
+    } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -306,6 +306,7 @@ int launch(const ConvArgs& a, hipStream_t s) {
     // (a capped, persistent grid was measured slower on every layer: 436 vs 452 depth-maps/s; the
     //  grid-stride loop in the kernel therefore runs exactly once)
     dim3 grid((unsigned)gx, a.ntile_total / NT, a.nclass);
+    MV_NOTE_KERNEL("conv_mfma_kernel<%d, %d, %d, %s>", CIN, MT, NT, SPLITK ? "true" : "false");
     hipLaunchKernelGGL((conv_mfma_kernel<CIN, MT, NT, SPLITK>), grid, dim3(256), 0, s, a);
     return mv_check_launch();
 }
@@ -561,9 +562,11 @@ int launch_lds_ng(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
     const int nw = a.kd[0] * a.kh[0] * KW * NT * 64;       // weight float4 per chunk
     if (nw <= 3 * 256 && !g_no_wlds) {
         const size_t lds = (size_t)(NG * 1024 + 32) * 16 + 3 * 256 * 16;
+        MV_NOTE_KERNEL("conv_lds_kernel<%d, %d, %d, %d, 3>", MT, NT, KW, NG);
         hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW, NG, 3>), grid, dim3(256), lds, s, a, tiles_x, tiles_y, dv);
     } else {
         const size_t lds = (size_t)(NG * 1024 + 32) * 16;
+        MV_NOTE_KERNEL("conv_lds_kernel<%d, %d, %d, %d, 0>", MT, NT, KW, NG);
         hipLaunchKernelGGL((conv_lds_kernel<MT, NT, KW, NG, 0>), grid, dim3(256), lds, s, a, tiles_x, tiles_y, dv);
     }
     return mv_check_launch();
@@ -655,6 +658,7 @@ extern "C" int mvster_conv_mfma(const float* in, const float* wpk, const float* 
     hipStream_t s = (hipStream_t)stream;
     a.cin = cin;
     if ((variant & 0xff) == 5) return dispatch_pers(a, mt, nt, variant >> 8, s);   // persistent LDS-DMA family (conv_pers.hip)
+    if ((variant & 0xff) == 6) return dispatch_1x1(a, mt, variant >> 8, s);        // persistent 1x1, weights in LDS
     if (prob_w && (a.cout != 8 || a.skip_mode == 2 || variant == 1)) return MVSTER_ERR_UNSUPPORTED;
     if (variant == 1) return dispatch_lds(a, mt, nt, s);
     if (variant != 0 && variant != 2) return MVSTER_ERR_UNSUPPORTED;

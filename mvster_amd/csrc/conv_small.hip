@@ -115,9 +115,15 @@ extern "C" int mvster_conv_small(const float* in, const float* w, const float* s
     const long blocks = (long)tiles_x * tiles_y * NB;
     if (blocks >= (1L << 31)) return MVSTER_ERR_SHAPE;
     dim3 grid((unsigned)blocks), block(256);
-    if (cin == 8) hipLaunchKernelGGL(conv_small_kernel<8>, grid, block, 0, (hipStream_t)stream, a, mv_fastdiv(tiles_x), mv_fastdiv(tiles_y));
-    else if (cin == 4) hipLaunchKernelGGL(conv_small_kernel<4>, grid, block, 0, (hipStream_t)stream, a, mv_fastdiv(tiles_x), mv_fastdiv(tiles_y));
-    else return MVSTER_ERR_UNSUPPORTED;
+    if (cin == 8) {
+        MV_NOTE_KERNEL("conv_small_kernel<8>");
+        hipLaunchKernelGGL(conv_small_kernel<8>, grid, block, 0, (hipStream_t)stream, a, mv_fastdiv(tiles_x), mv_fastdiv(tiles_y));
+    } else if (cin == 4) {
+        MV_NOTE_KERNEL("conv_small_kernel<4>");
+        hipLaunchKernelGGL(conv_small_kernel<4>, grid, block, 0, (hipStream_t)stream, a, mv_fastdiv(tiles_x), mv_fastdiv(tiles_y));
+    } else {
+        return MVSTER_ERR_UNSUPPORTED;
+    }
     return mv_check_launch();
 }
 
@@ -245,8 +251,14 @@ extern "C" int mvster_deconv_small(const float* in, const float* w, const float*
     a.out = out; a.NB = NB; a.Hi = Hi; a.Wi = Wi; a.relu = relu; a.in_bytes = (unsigned)(in_elems * 4);
     dim3 grid((Hi * Wi + 255) / 256, NB), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (cin == 16 && cout == 8) hipLaunchKernelGGL((deconv_small_kernel<16, 8>), grid, block, 0, s, a);
-    else if (cin == 32 && cout == 16) hipLaunchKernelGGL((deconv_small_kernel<32, 16>), grid, block, 0, s, a);
-    else return MVSTER_ERR_UNSUPPORTED;
+    if (cin == 16 && cout == 8) {
+        MV_NOTE_KERNEL("deconv_small_kernel<16, 8>");
+        hipLaunchKernelGGL((deconv_small_kernel<16, 8>), grid, block, 0, s, a);
+    } else if (cin == 32 && cout == 16) {
+        MV_NOTE_KERNEL("deconv_small_kernel<32, 16>");
+        hipLaunchKernelGGL((deconv_small_kernel<32, 16>), grid, block, 0, s, a);
+    } else {
+        return MVSTER_ERR_UNSUPPORTED;
+    }
     return mv_check_launch();
 }

@@ -200,6 +200,7 @@ template <int COT, int CIP>
 int launch_wgrad_packed(const WgradArgs& a, int nblk, int ntaps, hipStream_t s) {
     constexpr int TPN = 16 / CIP;
     const size_t lds = (size_t)3 * COT * 256 * sizeof(float);
+    MV_NOTE_KERNEL("conv_wgrad_packed_kernel<%d, %d>", COT, CIP);
     hipLaunchKernelGGL((conv_wgrad_packed_kernel<COT, CIP>), dim3(nblk, (ntaps + TPN - 1) / TPN), dim3(256), lds, s, a, ntaps);
     return mv_check_launch();
 }
@@ -207,6 +208,7 @@ int launch_wgrad_packed(const WgradArgs& a, int nblk, int ntaps, hipStream_t s) 
 template <int COT, int CIT>
 int launch_wgrad(const WgradArgs& a, int nblk, int ntaps, hipStream_t s) {
     const size_t lds = (size_t)3 * COT * CIT * 256 * sizeof(float);
+    MV_NOTE_KERNEL("conv_wgrad_kernel<%d, %d>", COT, CIT);
     hipLaunchKernelGGL((conv_wgrad_kernel<COT, CIT>), dim3(nblk, ntaps), dim3(256), lds, s, a);
     return mv_check_launch();
 }
@@ -400,6 +402,7 @@ int launch_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, hipStream_t
     //  raised to 128 KB, one workgroup per CU, than on the per-tap kernels below: 105 vs 47+ us, 642 vs 588 us)
     if (lds > 64 * 1024 || a.sw > wgrad_stride_bound(TY)) return MVSTER_ERR_UNSUPPORTED;   // (prefetch register budget)
     const int mgroups = cot / MT, ngroups = PCB > 0 ? 1 : cit / NT;
+    MV_NOTE_KERNEL("conv_wgrad_lds_kernel<%d, %d, %d, %d, %d>", MT, NT, TY, KW, PCB);
     hipLaunchKernelGGL((conv_wgrad_lds_kernel<MT, NT, TY, KW, PCB>), dim3(nblk, mgroups * ngroups), dim3(256), lds, s, a, mgroups);
     return mv_check_launch();
 }

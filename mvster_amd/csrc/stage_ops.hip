@@ -638,3 +638,9 @@ extern "C" int mvster_relative_projection_multi(const float* const* proj_matrice
     hipLaunchKernelGGL(relative_projection_multi_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
     return mv_check_launch();
 }
+
+thread_local const char* mv_last_kernel = "";
+
+// Name (profiler spelling, template arguments included) of the kernel the most recent mvster_conv_mfma / mvster_conv_small /
+// mvster_deconv_small / mvster_warp_agg_fwd call on this thread launched; "" before the first one.
+extern "C" const char* mvster_last_kernel() { return mv_last_kernel; }

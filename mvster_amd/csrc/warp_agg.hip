@@ -654,6 +654,7 @@ template <int C, int G, int D, int DPL, int WPE>
 int launch_fwd_pix_cfg(const WarpAggArgs& a, hipStream_t stream) {
     constexpr int PPW = 64 / ((C / 8) * (D / DPL));
     dim3 grid((a.h * a.w + PPW - 1) / PPW, a.B);
+    MV_NOTE_KERNEL("warp_agg_fwd_pix_kernel<%d, %d, %d, %d, %d>", C, G, D, DPL, WPE);
     hipLaunchKernelGGL((warp_agg_fwd_pix_kernel<C, G, D, DPL, WPE>), grid, dim3(64), 0, stream, a);
     return mv_check_launch();
 }
@@ -686,6 +687,7 @@ int launch_fwd_wave(const WarpAggArgs& a, hipStream_t stream) {
     // 24-bit multiply-add on texel indices, 32-bit byte offsets inside one (view, batch) map
     if ((long)a.Hs * a.Ws >= (1L << 23) || (long)a.Hs * a.Ws * C * 4 >= (1L << 31)) return MVSTER_ERR_SHAPE;
     dim3 grid((a.h * a.w + PPB - 1) / PPB, a.B);
+    MV_NOTE_KERNEL("warp_agg_fwd_wave_kernel<%d, %d, %d>", C, G, D);
     hipLaunchKernelGGL((warp_agg_fwd_wave_kernel<C, G, D>), grid, dim3(256), 0, stream, a);
     return mv_check_launch();
 }
@@ -703,6 +705,7 @@ int launch_fwd_lanes(const WarpAggArgs& a, hipStream_t stream) {
     if (a.D > 8) return MVSTER_ERR_UNSUPPORTED;
     dim3 block(64, a.D);
     dim3 grid((a.h * a.w + PPB - 1) / PPB, a.B);
+    MV_NOTE_KERNEL("warp_agg_fwd_lanes_kernel<%d, %d, 8>", C, G);
     hipLaunchKernelGGL((warp_agg_fwd_lanes_kernel<C, G, 8>), grid, block, 0, stream, a);
     return mv_check_launch();
 }
@@ -712,11 +715,15 @@ int launch_fwd(const WarpAggArgs& a, hipStream_t stream) {
     dim3 block(64, a.D);
     dim3 grid((a.h * a.w + 63) / 64, a.B);
     if (a.D <= 8) {
+        MV_NOTE_KERNEL("warp_agg_fwd_kernel<%d, %d, %s, 8>", C, G, GROUP ? "true" : "false");
         hipLaunchKernelGGL((warp_agg_fwd_kernel<C, G, GROUP, 8>), grid, block, 0, stream, a);
     } else {
         // 1024-thread blocks; the per-thread correlations of the widest ungrouped case do not fit LDS
         if constexpr (G * kMaxD * 64 * 4 > 120 * 1024) return MVSTER_ERR_UNSUPPORTED;
-        else hipLaunchKernelGGL((warp_agg_fwd_kernel<C, G, GROUP, kMaxD>), grid, block, 0, stream, a);
+        else {
+            MV_NOTE_KERNEL("warp_agg_fwd_kernel<%d, %d, %s, %d>", C, G, GROUP ? "true" : "false", kMaxD);
+            hipLaunchKernelGGL((warp_agg_fwd_kernel<C, G, GROUP, kMaxD>), grid, block, 0, stream, a);
+        }
     }
     return mv_check_launch();
 }
@@ -757,6 +764,11 @@ __device__ __forceinline__ FixScale make_fix_scale(const float* maxima, int G, i
     e = min(max(36 - e, -60), 100);
     f.s = ldexpf(1.0f, e);
     f.inv = ldexpf(1.0f, -e);
+    // A non-finite operand (absmax_kernel reports NaN for it) has no fixed-point image: integer conversion would turn it
+    // into finite garbage.  Every value converted back then reads NaN instead -- the gradients of such a step are NaN, like
+    // the reference's, never silently finite.  (Resolution otherwise: absolute, bound * 2^-36 per contribution, i.e. the
+    // smallest gradients of a launch keep fewer bits than its largest; fp32 atomics would keep 24 relative to the running sum.)
+    if (!(bound < INFINITY)) { f.s = 0.0f; f.inv = __builtin_nanf(""); }
     return f;
 }
 __device__ __forceinline__ void fix_add(u64* p, float v, float s) { atomicAdd(p, (u64)__float2ll_rn(v * s)); }
@@ -765,15 +777,22 @@ __device__ __forceinline__ float fix_get(u64 v, float inv) { return (float)(long
 // max |x| over n floats into *out (a non-negative float orders like its bit pattern); *out must start at 0
 __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, long n, float* out) {
     float m = 0.0f;
+    bool bad = false;           // fmaxf drops NaN: non-finite elements are tracked separately and reported as NaN
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const f32x4 v = ld4(x + i * 4);
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        bad = bad || !(fabsf(v[0]) < INFINITY) || !(fabsf(v[1]) < INFINITY) || !(fabsf(v[2]) < INFINITY) || !(fabsf(v[3]) < INFINITY);
     }
-    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        m = fmaxf(m, fabsf(x[i]));
+        bad = bad || !(fabsf(x[i]) < INFINITY);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reinterpret_cast<int*>(out), __float_as_int(m));
+    const bool any_bad = __any(bad);
+    // (as integers, positive floats order like their values and the quiet-NaN pattern lies above +Inf)
+    if ((threadIdx.x & 63) == 0 && (m > 0.0f || any_bad)) atomicMax(reinterpret_cast<int*>(out), any_bad ? 0x7fc00000 : __float_as_int(m));
 }
 
 struct WarpAggBwdArgs {
@@ -1404,20 +1423,28 @@ int launch_bwd(const WarpAggBwdArgs& ba, hipStream_t stream) {
     if constexpr (C == 8 && C / G <= 8) {
         if (bwd_uses_tiles(C, G, a.D, a.fuse_d)) {      // the shipped full-resolution stage
             const int tiles_x = (a.w + 63) / 64;
-            if (a.D <= 4)
+            if (a.D <= 4) {
+                MV_NOTE_KERNEL("warp_agg_bwd_tile_kernel<%d, %s, %d, 4>", G, GROUP ? "true" : "false", kTileR);
                 hipLaunchKernelGGL((warp_agg_bwd_tile_kernel<G, GROUP, kTileR, 4>), dim3(nblk, a.B), dim3(64, a.D), 0, stream,
                                    ba, tiles_x);
-            else
+            } else {
+                MV_NOTE_KERNEL("warp_agg_bwd_tile_kernel<%d, %s, %d, 8>", G, GROUP ? "true" : "false", kTileR);
                 hipLaunchKernelGGL((warp_agg_bwd_tile_kernel<G, GROUP, kTileR, 8>), dim3(nblk, a.B), dim3(64, a.D), 0, stream,
                                    ba, tiles_x);
+            }
             if (int rc = mv_check_launch()) return rc;
             return ba.windows ? launch_gather<kTileR + 6, kTileWinX, 1>(ba, nblk, stream) : MVSTER_OK;
         }
     }
     dim3 block(64, a.D);
     dim3 grid(nblk, a.B);
-    if (a.D <= 8) hipLaunchKernelGGL((warp_agg_bwd_kernel<C, G, GROUP, 8>), grid, block, 0, stream, ba);
-    else hipLaunchKernelGGL((warp_agg_bwd_kernel<C, G, GROUP, kMaxD>), grid, block, 0, stream, ba);
+    if (a.D <= 8) {
+        MV_NOTE_KERNEL("warp_agg_bwd_kernel<%d, %d, %s, 8>", C, G, GROUP ? "true" : "false");
+        hipLaunchKernelGGL((warp_agg_bwd_kernel<C, G, GROUP, 8>), grid, block, 0, stream, ba);
+    } else {
+        MV_NOTE_KERNEL("warp_agg_bwd_kernel<%d, %d, %s, %d>", C, G, GROUP ? "true" : "false", kMaxD);
+        hipLaunchKernelGGL((warp_agg_bwd_kernel<C, G, GROUP, kMaxD>), grid, block, 0, stream, ba);
+    }
     if (int rc = mv_check_launch()) return rc;
     return ba.windows ? launch_gather<kWinY, kWinX, C / 8>(ba, nblk, stream) : MVSTER_OK;
 }

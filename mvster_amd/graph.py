@@ -50,18 +50,26 @@ class GraphedTrainStep:
     a fixed sequence of ~3 000 launches; issued eagerly it is launch-bound on the host (41 ms of enqueue for ~35 ms
     of kernels at 512x640x5, B=2).  Captured once on static input buffers, a step is one ``replay()``.
 
-    Single process only (DistributedDataParallel issues its collectives from autograd hooks and needs its own capture
-    protocol).  The optimizer must be built with ``capturable=True`` (torch.optim.Adam / AdamW); the loss function
-    takes ``(outputs, depth_gt_ms, mask_ms)`` and returns the scalar to minimise first, like ``MVS4net_loss``.
+    Multi-GPU: DistributedDataParallel issues its collectives from autograd hooks and cannot be captured this way; pass
+    ``grad_sync=shard.GradBucket(model.parameters())`` instead (the bare model, not the DDP wrapper): the step then packs
+    the gradients into one 4 MB bucket and issues ONE all-reduce (RCCL, capturable) between backward and the optimizer
+    update, inside the graph -- every rank replays the same captured step (the reference's DDP semantics,
+    train_mvs4.py:389-392: averaged gradients, per-rank BatchNorm statistics).  The optimizer must be built with
+    ``capturable=True`` (torch.optim.Adam / AdamW); the loss function takes ``(outputs, depth_gt_ms, mask_ms)`` and
+    returns the scalar to minimise first, like ``MVS4net_loss``.
     """
 
-    def __init__(self, model, optimizer, loss_fn, imgs, proj_matrices, depth_values, depth_gt_ms, mask_ms, warmup=3):
+    def __init__(self, model, optimizer, loss_fn, imgs, proj_matrices, depth_values, depth_gt_ms, mask_ms, warmup=3,
+                 grad_sync=None):
         if not model.training:
             raise RuntimeError("GraphedTrainStep captures a training step: call model.train() first")
         for group in optimizer.param_groups:
             if not group.get("capturable", False):
                 raise RuntimeError("GraphedTrainStep: build the optimizer with capturable=True")
-        self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
+        if isinstance(model, torch.nn.parallel.DistributedDataParallel):
+            raise RuntimeError("GraphedTrainStep: pass the bare model and grad_sync=shard.GradBucket(model.parameters()) "
+                               "(DistributedDataParallel's hook-driven reducer cannot be captured)")
+        self.model, self.optimizer, self.loss_fn, self.grad_sync = model, optimizer, loss_fn, grad_sync
         self.imgs = [i.clone() for i in imgs]
         self.proj = {k: v.clone() for k, v in proj_matrices.items()}
         self.depth_values = depth_values.clone()
@@ -75,7 +83,9 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # (with a collective in the step, RCCL's watchdog thread touches the device during the capture: relaxed mode)
+        mode = {} if grad_sync is None or grad_sync.world() == 1 else {"capture_error_mode": "thread_local"}
+        with torch.cuda.graph(self.graph, **mode):
             self.loss = self._step()
 
     def _step(self):
@@ -86,6 +96,8 @@ class GraphedTrainStep:
         res = self.loss_fn(out, self.gt, self.mask)
         loss = res[0] if isinstance(res, (tuple, list)) else res
         loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.sync()          # pack -> one all-reduce -> p.grad = slices of the averaged bucket
         self.optimizer.step()
         return loss.detach()
 

@@ -140,15 +140,40 @@ class MVS4net(nn.Module):
         return ops.schedule_range(prev["depth"].detach(), D, self.depth_interals_ratio[stage_idx] * depth_interval, H, W)
 
     def _check_inputs(self, imgs, proj_matrices, depth_values):
-        if not imgs[0].is_cuda:
-            raise RuntimeError("mvster_amd.MVS4net runs on MI355X only: move the model and inputs to the GPU "
-                               "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests)")
-        if imgs[0].dtype != torch.float32:
-            raise RuntimeError("mvster_amd.MVS4net is fp32-only, like the reference path")
-        H, W = imgs[0].shape[-2:]
+        if len(imgs) == 0 or not torch.is_tensor(imgs[0]):
+            raise RuntimeError("imgs: a non-empty list of [B,3,H,W] tensors expected")
+        if imgs[0].dim() != 4 or imgs[0].shape[1] != 3:
+            raise RuntimeError("imgs: a list of [B,3,H,W] tensors expected, got %s" % (tuple(imgs[0].shape),))
+        B, _, H, W = imgs[0].shape
         if H % 64 or W % 64:
             raise RuntimeError("image size %dx%d: H and W must be multiples of 64 (stage-1 is H/8 and reg2d "
                                "halves three more times)" % (H, W))
+        N = len(imgs)
+        for i, im in enumerate(imgs):
+            if tuple(im.shape) != (B, 3, H, W) or im.device != imgs[0].device or im.dtype != torch.float32:
+                raise RuntimeError("imgs[%d]: %s %s on %s, expected [%d,3,%d,%d] float32 (the path is fp32-only, like the "
+                                   "reference's) on %s" % (i, tuple(im.shape), im.dtype, im.device, B, H, W, imgs[0].device))
+        # the raw pointers of these go straight to the kernels: every stage's projection stack and the depth range are
+        # checked here (reference layout: proj_matrices[stage] [B,N,2,4,4] = (extrinsic, intrinsic) per view,
+        # datasets/dtu_yao4.py:176-189; depth_values [B,D>=2], MVS4Net.py:60-63)
+        for s in range(self.num_stage):
+            name = "stage%d" % (s + 1)
+            if name not in proj_matrices:
+                raise RuntimeError("proj_matrices has no %r entry (keys: %s)" % (name, sorted(proj_matrices.keys())))
+            pm = proj_matrices[name]
+            if tuple(pm.shape) != (B, N, 2, 4, 4):
+                raise RuntimeError("proj_matrices[%r]: shape %s, expected [%d,%d,2,4,4] (batch, views = len(imgs))"
+                                   % (name, tuple(pm.shape), B, N))
+            if not pm.dtype.is_floating_point:
+                raise RuntimeError("proj_matrices[%r]: floating-point tensor expected, got %s" % (name, pm.dtype))
+        if N < 2:
+            raise RuntimeError("at least one source view is needed (len(imgs) = %d)" % N)
+        if depth_values.dim() != 2 or depth_values.shape[0] != B or depth_values.shape[1] < 2:
+            raise RuntimeError("depth_values: shape %s, expected [%d, D >= 2] (the range is read from its first and last "
+                               "column)" % (tuple(depth_values.shape), B))
+        if not imgs[0].is_cuda:
+            raise RuntimeError("mvster_amd.MVS4net runs on MI355X only: move the model and inputs to the GPU "
+                               "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests)")
 
     # ------------------------------------------------------------------ eval: all-HIP
     @torch.no_grad()

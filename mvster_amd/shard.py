@@ -6,6 +6,8 @@ source views) is an independent unit, so inference uses one process per GPU, wei
 reference's scan loop does on one GPU (test_mvs4.py:161-164).  Training is the reference's DDP
 (train_mvs4.py:321-326, :389-392): one all-reduce of 4.04 MB of fp32 gradients per step, which
 ``torch.distributed`` backend "nccl" runs on RCCL over xGMI; a single default 25 MB bucket.
+``GradBucket`` is the same reduction without DDP's autograd hooks: one flat bucket, ONE all-reduce issued from the
+training step itself -- which makes the step capturable in a hipGraph on every rank (``graph.GraphedTrainStep``).
 """
 import os
 
@@ -79,3 +81,56 @@ def wrap_ddp(model, local_rank=None):
         lr = torch.cuda.current_device() if local_rank is None else local_rank
         return torch.nn.parallel.DistributedDataParallel(model, device_ids=[lr], output_device=lr)
     return torch.nn.parallel.DistributedDataParallel(model)
+
+
+class GradBucket:
+    """All gradients of a model in ONE flat fp32 bucket (4.04 MB for the shipped network: far below the size where a ring
+    over xGMI would be bandwidth-bound, so one collective per step is the right granularity) and one all-reduce per step.
+
+    ``sync()`` packs the gradients that backward produced (``torch.cat``: a few batched-copy launches), all-reduces the
+    bucket over the process group (RCCL on the GPU, gloo in the CPU tests), averages, and re-points every ``p.grad`` at its
+    slice of the bucket, so the optimizer reads the averaged values without an unpack pass.  No autograd hooks and no host
+    synchronisation: unlike DistributedDataParallel's reducer the sequence is a fixed list of launches and can be captured
+    in a hipGraph together with forward, backward and the optimizer step.  The result equals DDP's (mean over ranks of the
+    per-rank gradients, train_mvs4.py:389-392); BatchNorm statistics stay per rank, as there."""
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise RuntimeError("GradBucket: no parameter requires a gradient")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        for p in self.params:
+            if p.device != dev or p.dtype != dt:
+                raise RuntimeError("GradBucket: parameters must share one device and dtype")
+        self.group = group
+        self.sizes = [p.numel() for p in self.params]
+        self.flat = torch.zeros(sum(self.sizes), device=dev, dtype=dt)
+        self.views, o = [], 0
+        for p, n in zip(self.params, self.sizes):
+            self.views.append(self.flat[o:o + n].view_as(p))
+            o += n
+
+    def world(self):
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(self.group)
+
+    def sync(self):
+        grads = [p.grad for p in self.params]
+        if all(g is not None for g in grads):
+            # (gradients that already live in the bucket -- an eager loop without zero_grad(set_to_none=True) -- are packed
+            #  onto themselves: the copy is skipped for them)
+            if not all(g.data_ptr() == v.data_ptr() for g, v in zip(grads, self.views)):
+                torch.cat([g.reshape(-1) for g in grads], out=self.flat)
+        else:
+            self.flat.zero_()
+            for g, v in zip(grads, self.views):
+                if g is not None and g.data_ptr() != v.data_ptr():
+                    v.copy_(g)
+        w = self.world()
+        if w > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.div_(w)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        return self.flat

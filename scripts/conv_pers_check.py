@@ -74,7 +74,7 @@ def check():
                 break
             want = layer(x, tiles=(1, 1, 0))
             skip = torch.randn_like(want)
-            for wpc in (0, 1, 2, 4):
+            for wpc in (0, 1, 2, 4, 18):
                 got = layer(x, tiles=(2, nt, 5 | (wpc << 8)))
                 gs = layer(x, skip=skip, skip_mode=1, tiles=(2, nt, 5 | (wpc << 8)))
                 ws = layer(x, skip=skip, skip_mode=1, tiles=(1, 1, 0))
@@ -101,15 +101,67 @@ def times():
             row = "%-16s %-18s plan v%d(%d,%d) %6.1f us %5.1f TF/s |" % (name, "x".join(map(str, shape)), var0, mt0, nt0, base,
                                                                        fl / base / 1e6)
             if supported(layer, x, nt):
-                for wpc in (1, 2, 3, 4, 5):
+                for wpc in (1, 2, 3, 4, 18, 19, 20):        # 16 + n: static priority by wave slot (conv_pers.hip)
                     us = min(timeit(lambda: layer(x, tiles=(2, nt, 5 | (wpc << 8))), n=10) for _ in range(2))
-                    row += " w%d %6.1f (%5.1f)" % (wpc, us, fl / us / 1e6)
+                    row += " %s%d %5.1f (%5.1f)" % ("p" if wpc > 15 else "w", wpc & 15, us, fl / us / 1e6)
+                for wpc in (1, 2):
+                    try:
+                        us = min(timeit(lambda: layer(x, tiles=(4, nt, 5 | (wpc << 8))), n=10) for _ in range(2))
+                        ok = torch.equal(layer(x, tiles=(4, nt, 5 | (wpc << 8))), layer(x, tiles=(1, 1, 0)))
+                        row += " mt4w%d %5.1f (%5.1f)%s" % (wpc, us, fl / us / 1e6, "" if ok else " DIFFERENT")
+                    except RuntimeError:
+                        break
             else:
                 row += " (not built)"
             print(row, flush=True)
 
 
+ONE = [  # (name, cin, cout, production input shape, skip)
+    ("64->144 1x1", 64, 144, (5, 1, 128, 160), False),
+    ("64->72 1x1", 64, 72, (5, 1, 128, 160), False),
+    ("64->64 1x1", 64, 64, (5, 1, 64, 80), False),
+    ("32->64 1x1", 32, 64, (5, 1, 128, 160), False),
+    ("64->64 1x1 +skip", 64, 64, (5, 1, 128, 160), True),
+]
+
+
+def one_by_one():
+    """variant 6 (persistent 1x1, weights in LDS) against the direct kernel: values on a ragged shape, time on the
+    production shape."""
+    bad = 0
+    for name, cin, cout, shape, with_skip in ONE:
+        layer = make_layer(cin, cout, (1, 1, 1), (1, 1, 1), relu=not with_skip)
+        xr = torch.randn(2, 1, 37, 53, cin, device=dev)
+        want = layer(xr, tiles=(1, 1, 0))
+        sk = torch.randn_like(want) if with_skip else None
+        if with_skip:
+            want = layer(xr, skip=sk, skip_mode=1, tiles=(1, 1, 0))
+        for mt in (1, 2):
+            got = layer(xr, skip=sk, skip_mode=1 if with_skip else 0, tiles=(mt, 1, 6))
+            torch.cuda.synchronize()
+            ok = torch.equal(got, want)
+            bad += 0 if ok else 1
+            print("%-18s ragged 2x1x37x53 mt%d: %s (max |d| %.3g)" % (name, mt, "bit-identical" if ok else "DIFFERENT",
+                                                                      (got - want).abs().max().item()))
+        x = torch.randn(*shape, cin, device=dev)
+        skp = torch.randn(*shape, cout, device=dev) if with_skip else None
+        sm = 1 if with_skip else 0
+        fl = layer.flops(*shape)
+        _, mt0, nt0, _, var0 = layer._geom(*shape, sm)
+        base = min(timeit(lambda: layer(x, skip=skp, skip_mode=sm), n=10) for _ in range(2))
+        row = "%-18s %-16s plan v%d(%d,%d) %6.1f us %5.1f TF/s |" % (name, "x".join(map(str, shape)), var0, mt0, nt0, base, fl / base / 1e6)
+        for mt in (1, 2):
+            for wpc in (1, 2, 3):
+                us = min(timeit(lambda: layer(x, skip=skp, skip_mode=sm, tiles=(mt, 1, 6 | (wpc << 8))), n=10) for _ in range(2))
+                row += " mt%dw%d %5.1f" % (mt, wpc, us)
+        print(row, flush=True)
+    print("1x1 value check: %s" % ("all bit-identical to the direct kernel" if bad == 0 else "%d MISMATCHES" % bad))
+    return bad
+
+
 if __name__ == "__main__":
+    if "--one" in sys.argv:
+        sys.exit(1 if one_by_one() else 0)
     rc = 0
     if "--time-only" not in sys.argv:
         rc = check()

@@ -32,7 +32,7 @@ cp.ConvLayer.__call__ = rec
 model(imgs, proj, dv)
 cp.ConvLayer.__call__ = orig
 torch.cuda.synchronize()
-names = {0: "direct", 1: "lds", 2: "splitk", 3: "small", 4: "deconv_small"}
+names = {0: "direct", 1: "lds", 2: "splitk", 3: "small", 4: "deconv_small", 5: "persistent", 6: "persistent1x1"}
 total = 0.0
 for i, (layer, xs, ss, sm) in enumerate(calls):
     x = torch.randn(*xs, device=dev)
@@ -45,6 +45,6 @@ for i, (layer, xs, ss, sm) in enumerate(calls):
     fl = layer.flops(B, Di, Hi, Wi)
     total += us
     print("%2d %-46s %-12s mt%d nt%d %8.1f us %7.2f TF/s %7.0f GB/s%s" % (
-        i, cp.layer_signature(layer, B, Di, Hi, Wi, sm), names[var], mt, nt, us, fl / us / 1e6, nbytes / us / 1e3,
+        i, cp.layer_signature(layer, B, Di, Hi, Wi, sm), names[var & 0xff], mt, nt, us, fl / us / 1e6, nbytes / us / 1e3,
         "  +prob" if layer.prob is not None else ""), flush=True)
 print("sum of conv layers: %.1f us" % total)

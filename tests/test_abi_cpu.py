@@ -19,7 +19,7 @@ def lib():
 
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "mvster_hip.h")).read()
-    return sorted(set(re.findall(r"\bint\s+(mvster_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(mvster_\w+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported(lib):
@@ -30,6 +30,11 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, n), n
     # and the Python binding table covers exactly the header
     assert sorted(_lib.SIGNATURES.keys()) == names
+
+
+def test_last_kernel_accessor(lib):
+    from mvster_amd import _lib
+    assert _lib.last_kernel() == ""            # nothing launched in this process (no GPU here)
 
 
 def test_null_and_shape_errors_are_reported_without_a_gpu(lib):
@@ -83,3 +88,26 @@ def test_unsupported_switches_fail_loudly():
         MVS4net(dcn=True)
     with pytest.raises(NotImplementedError):
         MVS4net(asff=True)
+
+
+def test_boundary_rejects_malformed_inputs(shipped_cfg):
+    """MVS4net.forward validates what it hands to the kernels as raw pointers: view count, per-stage projection stacks,
+    the depth range (shape errors come before the device check, so this runs without a GPU)."""
+    from mvster_amd import MVS4net
+    from mvster_amd.synthetic import make_inputs
+    m = MVS4net(**shipped_cfg).eval()
+    imgs, proj, dv = make_inputs(nviews=3, H=64, W=64)
+    with pytest.raises(RuntimeError, match="stage3"):
+        m(imgs, {k: v for k, v in proj.items() if k != "stage3"}, dv)
+    with pytest.raises(RuntimeError, match=r"proj_matrices\['stage2'\]"):
+        m(imgs, dict(proj, stage2=proj["stage2"][:, :2]), dv)                 # one view short
+    with pytest.raises(RuntimeError, match="views = len"):
+        m(imgs[:2], proj, dv)                                                  # list and stacks disagree
+    with pytest.raises(RuntimeError, match="depth_values"):
+        m(imgs, proj, dv[:, :1])
+    with pytest.raises(RuntimeError, match="depth_values"):
+        m(imgs, proj, dv.reshape(-1))
+    with pytest.raises(RuntimeError, match=r"imgs\[1\]"):
+        m([imgs[0], imgs[1][:, :, :32], imgs[2]], proj, dv)
+    with pytest.raises(RuntimeError, match="multiples of 64"):
+        m([i[:, :, :48] for i in imgs], proj, dv)

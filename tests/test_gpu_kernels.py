@@ -296,7 +296,63 @@ def test_conv_bn_relu(name, cfg, shape):
                 err = (got - want).abs().max().item()
                 worst = max(worst, err)
                 assert err <= 2e-5 * want.abs().max().item(), (name, "lds", mt, nt, err)
-    note("conv_" + name, max_abs=worst, ref_absmax=want.abs().max().item(), lds_tested=float(lds_ok))
+    # persistent kernels (conv_pers.hip): LDS-DMA double-buffered patches (variant 5) / 1x1 with resident weights (6);
+    # what a family does not cover reports "unsupported" and is skipped
+    pers_tested = 0
+    for variant, mts in ((5, (2,)), (6, (1, 2))):
+        for mt in mts:
+            for nt in (1, 2, 4):
+                if layer.ntile_total % nt or (variant == 6 and nt > 1):
+                    continue
+                for wpc in (0, 1):
+                    try:
+                        got = layer(cl5(x).to(DEV), tiles=(mt, nt, variant | (wpc << 8))).cpu()
+                    except RuntimeError as e:
+                        assert "unsupported" in str(e), e
+                        continue
+                    pers_tested += 1
+                    err = (got - want).abs().max().item()
+                    worst = max(worst, err)
+                    assert err <= 2e-5 * want.abs().max().item(), (name, "persistent", variant, mt, nt, err)
+    note("conv_" + name, max_abs=worst, ref_absmax=want.abs().max().item(), lds_tested=float(lds_ok), persistent_tested=float(pers_tested))
+
+
+PERS_CASES = [  # (cin, cout, kernel, stride, nt, input [B,D,H,W]): every instance of the persistent family, ragged sizes
+    (16, 16, (1, 3, 3), (1, 1, 1), 1, (2, 1, 70, 100)), (16, 16, (1, 3, 3), (1, 1, 1), 1, (1, 1, 4, 33)),
+    (16, 64, (1, 3, 3), (1, 1, 1), 1, (1, 1, 37, 65)),
+    (32, 32, (1, 3, 3), (1, 1, 1), 2, (3, 1, 64, 64)), (32, 64, (1, 3, 3), (1, 1, 1), 2, (1, 1, 21, 50)),
+    (16, 32, (1, 5, 5), (1, 2, 2), 2, (2, 1, 70, 100)), (16, 32, (1, 5, 5), (1, 2, 2), 2, (1, 1, 8, 34)),
+    (16, 16, (3, 3, 3), (1, 1, 1), 1, (2, 4, 38, 70)), (16, 16, (3, 3, 3), (1, 1, 1), 1, (1, 3, 5, 31)),
+    (16, 32, (1, 3, 3), (1, 2, 2), 2, (2, 4, 70, 100)), (16, 32, (1, 3, 3), (1, 2, 2), 2, (1, 1, 6, 66)),
+    (64, 144, (1, 1, 1), (1, 1, 1), 1, (2, 1, 37, 53)), (64, 72, (1, 1, 1), (1, 1, 1), 1, (2, 1, 37, 53)),
+    (32, 64, (1, 1, 1), (1, 1, 1), 1, (1, 2, 9, 17)), (64, 16, (1, 1, 1), (1, 1, 1), 1, (1, 1, 64, 80)),
+]
+
+
+@pytest.mark.parametrize("cin,cout,kernel,stride,nt,shape", PERS_CASES)
+@pytest.mark.parametrize("with_skip", [False, True])
+def test_persistent_conv_bit_identical_to_direct(cin, cout, kernel, stride, nt, shape, with_skip):
+    """The persistent kernels accumulate in the packed K order (tap-major, channel-minor) like the direct kernel and share
+    its epilogue arithmetic: outputs must be EQUAL, for every workgroups-per-CU setting (the grid changes which workgroup
+    walks which tiles) and with the fused skip / ReLU."""
+    g = torch.Generator().manual_seed(cin * 131 + cout + kernel[0] + shape[2])
+    w = (torch.randn(cout, cin, *kernel, generator=g) * 0.1).to(DEV)
+    layer = cp.ConvLayer(w, False, stride, tuple(k // 2 for k in kernel), relu=not with_skip)
+    layer.scale.copy_(torch.rand(layer.scale.shape, generator=g) + 0.5)
+    layer.shift.copy_(torch.randn(layer.shift.shape, generator=g) * 0.1)
+    x = torch.randn(*shape, cin, generator=g).to(DEV)
+    want = layer(x, tiles=(1, 1, 0))
+    skip = torch.randn(want.shape, generator=g).to(DEV) if with_skip else None
+    sm = cp.SKIP_ADD if with_skip else cp.SKIP_NONE
+    if with_skip:
+        want = layer(x, skip=skip, skip_mode=sm, tiles=(1, 1, 0))
+    variant = 6 if kernel == (1, 1, 1) else 5
+    for mt in ((1, 2) if variant == 6 else (2,)):
+        for wpc in (0, 1, 2, 4):
+            got = layer(x, skip=skip, skip_mode=sm, tiles=(mt, nt, variant | (wpc << 8)))
+            assert torch.equal(got, want), (mt, wpc, (got - want).abs().max().item())
+    from mvster_amd import _lib
+    assert _lib.last_kernel().startswith("conv1x1_pers_kernel<" if variant == 6 else "conv_pers_kernel<")
 
 
 @pytest.mark.parametrize("cin,cout,k,pad,op,s", [(64, 32, (1, 3, 3), (0, 1, 1), (0, 1, 1), (1, 2, 2)),

@@ -287,8 +287,10 @@ def test_train_step_vs_golden(shipped_cfg, checkpoint, golden):
     note("train_step", loss=loss.item(), want_loss=want_loss, stage1_attn_max=a1, worst_grad_rel=worst)
     assert out["photometric_confidence"].dim() == 0
     assert a1 <= 1e-3
-    # the reference's own parameter gradients (7 tensors across the FPN and the U-Nets); measured 0.86 %
-    assert worst <= 2e-2
+    # the reference's own parameter gradients (7 tensors across the FPN and the U-Nets); measured 0.86 % (near-tie argmax
+    # flips against the reference move individual hypotheses; the per-module gradient tests in test_gpu_train.py, <= 4e-6
+    # relative, are what pins the kernels)
+    assert worst <= 1.5e-2
     # later stages can pick other hypotheses on near-ties, so the total loss is compared loosely
     assert abs(ots[0].item() - float(g.np("ot")[0])) <= 2e-3 * abs(float(g.np("ot")[0]))
     assert abs(loss.item() - want_loss) <= 5e-2 * abs(want_loss)
@@ -493,6 +495,6 @@ def test_train_step_full_size_vs_pytorch_rocm(shipped_cfg, checkpoint):
     assert set(g_ref) == set(g_nat)
     assert a1 <= 1e-3 and ot1 <= 2e-3          # measured 2.7e-4 / 1e-7 (the small-size step: 3e-5)
     assert abs(l_ref - l_nat) <= 2e-2 * abs(l_ref)
-    assert worst <= max(2e-2, 2 * noise), (worst_name, worst, noise)
+    assert worst <= max(2e-2, 1.25 * noise), (worst_name, worst, noise)     # measured 13 % at 12 % noise
     for k, v in g_nat.items():
         assert torch.isfinite(v).all(), k

@@ -70,3 +70,88 @@ def test_two_process_gloo():
     for rank, same_grads, same_bn in res:
         assert same_grads            # gradients are averaged across ranks
         assert not same_bn           # BatchNorm running stats are NOT synchronised (reference: plain BatchNorm)
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    shard.init_distributed(backend="gloo")
+    from oracle import mvs4_oracle as O
+
+    def build():
+        torch.manual_seed(0)
+        return O.Reg2d(input_channel=4, base_channel=8)
+    xs = [torch.randn(2, 4, 4, 8, 8, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    # (a) the bucketed all-reduce (what GraphedTrainStep captures): one flat bucket, one collective
+    net = build()
+    net(xs[rank]).square().mean().backward()
+    own = {k: p.grad.clone() for k, p in net.named_parameters()}
+    bucket = shard.GradBucket(net.parameters())
+    flat = bucket.sync()
+    assert flat.numel() == sum(p.numel() for p in net.parameters())
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))      # slices, no unpack pass
+    got = {k: p.grad.clone() for k, p in net.named_parameters()}
+    # (b) DistributedDataParallel on the same data: the reference's reduction
+    ddp_net = build()
+    ddp = shard.wrap_ddp(ddp_net)                   # (keep the wrapper alive through backward: its reducer owns the hooks)
+    ddp(xs[rank]).square().mean().backward()
+    want = {k: p.grad.clone() for k, p in ddp_net.named_parameters()}
+    # (c) by hand: the mean over ranks of the per-rank gradients
+    mean = {}
+    for k, g in own.items():
+        parts = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(parts, g)
+        mean[k] = torch.stack(parts).mean(0)
+    # (relative to the largest gradient of the model: some tensors -- a bias in front of a softmax -- have gradients that
+    #  are rounding noise only)
+    scale = max(v.abs().max().item() for v in want.values())
+    worst_ddp = max((got[k] - want[k]).abs().max().item() for k in got) / scale
+    worst_mean = max((got[k] - mean[k]).abs().max().item() for k in got) / scale
+    # every rank holds the same averaged gradients
+    digest = torch.cat([g.reshape(-1) for g in got.values()])
+    parts = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(parts, digest)
+    # a second step: gradients now live in the bucket; zero_grad(set_to_none=True) + backward + sync again
+    net.zero_grad(set_to_none=True)
+    net(xs[rank]).square().mean().backward()
+    bucket.sync()
+    again = max(((p.grad - got[k]).abs().max()).item() for k, p in net.named_parameters())
+    q.put((rank, worst_ddp, worst_mean, all(torch.equal(parts[0], t) for t in parts), again))
+    dist.destroy_process_group()
+
+
+def test_bucketed_all_reduce_equals_ddp_two_ranks():
+    """shard.GradBucket (one flat bucket + one all-reduce, the capturable form of the gradient exchange) against
+    DistributedDataParallel and against the hand-computed mean, 2 gloo ranks on different samples."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, worst_ddp, worst_mean, same_everywhere, again in res:
+        assert worst_ddp <= 1e-6, (rank, worst_ddp)
+        assert worst_mean <= 1e-6, (rank, worst_mean)
+        assert same_everywhere
+        assert again <= 1e-7
+
+
+def test_grad_bucket_single_process_is_a_pack():
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    lin(torch.randn(5, 4)).sum().backward()
+    want = [p.grad.clone() for p in lin.parameters()]
+    b = shard.GradBucket(lin.parameters())
+    flat = b.sync()
+    assert flat.numel() == 4 * 3 + 3 + 3 * 2 + 2 and b.world() == 1
+    for p, w in zip(lin.parameters(), want):
+        assert torch.equal(p.grad, w)
+    # a parameter that received no gradient contributes zeros
+    lin.zero_grad(set_to_none=True)
+    lin[1](torch.randn(5, 3)).sum().backward()
+    b.sync()
+    assert lin[0].weight.grad.abs().max() == 0 and lin[1].weight.grad.abs().max() > 0
