@@ -15,6 +15,11 @@ torch.distributed.run on 127.0.0.1 with a free port).  ``--stub`` replaces the G
 step on the gloo backend: the launch / barrier / MAX-over-ranks / one-line protocol without a GPU
 (tests/test_bench_cpu.py).
 
+``--mode train`` times BASELINE.json configs[3] instead: one training step (forward, OT loss, backward, Adam) of the
+512x640, 5-view, batch 2 per GPU workload per rank, the whole step captured in one hipGraph; with N > 1 ranks the
+gradients go through ``shard.GradBucket`` (one 4.04 MB fp32 all-reduce over RCCL/xGMI per step, inside the graph: the
+reference's DDP semantics, train_mvs4.py:389-392).  value = samples/s over all ranks.
+
 Extra objects in the line:
   roofline      the dominant kernel instance of the forward, timed with HIP events on the launch
                 stream in an instrumented eager pass inside this script (same inputs, same kernels)
@@ -234,6 +239,19 @@ def stub_main(args):
         raise SystemExit("bench.py --gpus %d: launched with WORLD_SIZE=%d" % (args.gpus, world))
     x = torch.randn(64, 64)
     step = lambda: (x @ x).sum().item()     # noqa: E731
+    if args.mode == "train":
+        # the training protocol on a toy module: backward, ONE bucketed all-reduce (shard.GradBucket), SGD update
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(16, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1))
+        opt = torch.optim.SGD(net.parameters(), lr=1e-2)
+        bucket = shard.GradBucket(net.parameters())
+        xb = torch.randn(8, 16, generator=torch.Generator().manual_seed(rank))
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            net(xb).square().mean().backward()
+            bucket.sync()
+            opt.step()
     for _ in range(args.warmup):
         step()
     shard.barrier()
@@ -243,11 +261,182 @@ def stub_main(args):
     shard.barrier()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0)
     ranks_seen = int(round(shard.sum_over_ranks(1.0)))
+    spread = None
+    if args.mode == "train":
+        # after the same number of averaged updates every rank holds the same parameters (collectives: every rank calls)
+        digest = float(sum(p.detach().double().sum() for p in net.parameters()))
+        spread = shard.max_over_ranks(digest) + shard.max_over_ranks(-digest)
     if rank == 0:
-        print(json.dumps({"metric": "stub steps/s", "value": round(args.steps * world / elapsed, 3), "unit": "steps/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
-                          "scaling": "weak", "ranks_seen": ranks_seen, "stub": True}))
+        line = {"metric": "stub steps/s", "value": round(args.steps * world / elapsed, 3), "unit": "steps/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+                "scaling": "weak", "ranks_seen": ranks_seen, "stub": True, "mode": args.mode}
+        if spread is not None:
+            line["param_digest_spread"] = spread
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+class TrainKernelTimer:
+    """HIP-event timing of the weight-gradient and warp-backward launches of an eager training step."""
+
+    def __init__(self):
+        self.records = []
+
+    def install(self):
+        import mvster_amd.ops as ops
+        from mvster_amd import _lib
+        timer = self
+        self._orig = (ops.conv_wgrad, ops.warp_agg_bwd_cl)
+
+        def wgrad(x_cl, gy_cl, kernel, stride, padding, **kw):
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+            out = timer._orig[0](x_cl, gy_cl, kernel, stride, padding, **kw)
+            e1.record()
+            B, Do, Ho, Wo, CO = gy_cl.shape
+            flops = 2 * B * Do * Ho * Wo * kernel[0] * kernel[1] * kernel[2] * x_cl.shape[-1] * CO
+            # (two launches: the slot kernel, whose name the library reported, and the finish; both inside the pair)
+            timer.records.append((_lib.last_kernel(), e0, e1, flops, 4 * (x_cl.numel() + gy_cl.numel())))
+            return out
+
+        def warp_bwd(ref_cl, src_cl, rt, hypo, out, wsum, grad_out, G, *a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            res = timer._orig[1](ref_cl, src_cl, rt, hypo, out, wsum, grad_out, G, *a, **k)
+            e1.record()
+            # algorithmic bytes: read features, hypotheses, the forward's outputs and the incoming gradient; write both gradients
+            bytes_ = 4 * (2 * ref_cl.numel() + 2 * src_cl.numel() + hypo.numel() + out.numel() + wsum.numel() + grad_out.numel())
+            timer.records.append((_lib.last_kernel(), e0, e1, 0, bytes_))
+            return res
+
+        ops.conv_wgrad, ops.warp_agg_bwd_cl = wgrad, warp_bwd
+
+    def remove(self):
+        import mvster_amd.ops as ops
+        ops.conv_wgrad, ops.warp_agg_bwd_cl = self._orig
+
+
+def train_main(args):
+    """BASELINE.json configs[3]: DDP training, batch 2 per GPU, 512x640, 5 views -- one captured step per rank."""
+    from mvster_amd import MVS4net, MVS4net_loss, shard
+    from mvster_amd.graph import GraphedTrainStep
+    from mvster_amd.synthetic import make_inputs
+
+    rank, local_rank, world = shard.init_distributed()
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d: launched with WORLD_SIZE=%d" % (args.gpus, world))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    B = args.batch if args.batch > 1 else 2            # scripts/train_dtu.sh:20: batch 2 per GPU
+    model = MVS4net(**SHIPPED)
+    model.load_state_dict(load_weights(), strict=True)
+    if args.coherent:
+        with torch.no_grad():
+            for r in model.reg:
+                r.prob.weight.zero_()
+                r.prob.weight.requires_grad_(False)
+    model.to(dev).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    H, W, N = args.height, args.width, args.views
+    imgs, proj, dv = make_inputs(nviews=N, H=H, W=W, seed=100 + rank, device=dev, batch=B)      # every rank its own samples
+    g = torch.Generator().manual_seed(rank)
+    gt, mask = {}, {}
+    for s in range(1, 5):
+        hs, ws = H // 2 ** (4 - s), W // 2 ** (4 - s)
+        gt["stage%d" % s] = (500 + 300 * torch.rand(B, hs, ws, generator=g)).to(dev)
+        mask["stage%d" % s] = (torch.rand(B, hs, ws, generator=g) > 0.2).float().to(dev)
+
+    def loss_fn(o, g_, m_):
+        return MVS4net_loss(o, g_, m_, stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10, ot_eps=1,
+                            ot_continous=False, mono=True)
+
+    bucket = shard.GradBucket(params) if world > 1 or os.environ.get("MVSTER_FORCE_BUCKET") else None
+    opt = torch.optim.Adam(params, lr=1e-4, capturable=not args.no_graph, fused=True)
+    if args.no_graph:
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = loss_fn(model(imgs, proj, dv), gt, mask)[0]
+            loss.backward()
+            if bucket is not None:
+                bucket.sync()
+            opt.step()
+            return loss.detach()
+    else:
+        graphed = GraphedTrainStep(model, opt, loss_fn, imgs, proj, dv, gt, mask, warmup=3, grad_sync=bucket)
+        step = lambda: graphed()               # noqa: E731
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    shard.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    shard.barrier()
+    torch.cuda.synchronize()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0)
+    ranks_seen = int(round(shard.sum_over_ranks(1.0)))
+    last_loss = float(loss.item())
+    # every rank must hold the same parameters after the same averaged updates (collectives: every rank calls)
+    digest = float(sum(p.detach().double().sum() for p in params))
+    spread = shard.max_over_ranks(digest) + shard.max_over_ranks(-digest)
+
+    rooflines = []
+    if rank == 0:
+        timer = TrainKernelTimer()
+        timer.install()
+        try:
+            for i in range(3):
+                if i == 1:
+                    timer.records.clear()
+                torch.cuda._sleep(20_000_000)          # keep the GPU behind the host: event pairs bracket kernel time
+                model.zero_grad(set_to_none=True)
+                loss_fn(model(imgs, proj, dv), gt, mask)[0].backward()
+            torch.cuda.synchronize()
+        finally:
+            timer.remove()
+        agg = {}
+        for name, e0, e1, flops, bytes_ in timer.records:
+            a = agg.setdefault(name, dict(ms=0.0, n=0, flops=0, bytes=0))
+            a["ms"] += e0.elapsed_time(e1)
+            a["n"] += 1
+            a["flops"] += flops
+            a["bytes"] += bytes_
+        for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            if name.startswith("conv_wgrad"):
+                ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+                rooflines.append({"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                  "avg_launch_us": round(a["ms"] / a["n"] * 1e3, 2), "launches_per_step": a["n"] // 2,
+                                  "ms_per_step": round(a["ms"] / 2, 3), "note": "slot kernel + finish kernel per launch"})
+            else:
+                ach = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+                rooflines.append({"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                  "avg_launch_us": round(a["ms"] / a["n"] * 1e3, 2), "launches_per_step": a["n"] // 2,
+                                  "ms_per_step": round(a["ms"] / 2, 3)})
+    if rank == 0:
+        line = {
+            "metric": "training samples/sec (DTU %dx%d, %d-view, batch %d/GPU, DDP gradient all-reduce)" % (H, W, N, B),
+            "value": round(args.steps * world * B / elapsed, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "mode": "train",
+            "config": {"workload": "DTU mid %dx%d, %d views, DDP training batch=%d/GPU, 4-stage cascade 8/8/4/4 hyp, OT loss "
+                                   "(10 Sinkhorn iterations), Adam" % (H, W, N, B),
+                       "launch": "eager" if args.no_graph else "one hipGraph per step (forward + loss + backward + "
+                                                               "gradient all-reduce + Adam)",
+                       "parallelism": "dp%d" % world,
+                       "gradient_sync": ("none (one rank)" if bucket is None else
+                                         "one %.2f MB fp32 bucket, one all-reduce per step (RCCL), averaged" % (bucket.flat.numel() * 4 / 1e6)),
+                       "depth_regime": "smooth (prob heads zeroed)" if args.coherent else "random-weight winners"},
+            "ranks_seen": ranks_seen, "loss_last": round(last_loss, 5), "param_digest_spread_over_ranks": spread,
+            "roofline": rooflines[0] if rooflines else None, "rooflines": rooflines[:8], "cpu_baseline": None,
+        }
+        print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -268,6 +457,16 @@ def main():
                          "separate HIP streams (1 = strictly one after the other)")
     ap.add_argument("--batch", type=int, default=1,
                     help="depth maps per forward call (the B of MVS4net.forward); the reference's eval driver uses 1")
+    ap.add_argument("--no-stream-inputs", action="store_true",
+                    help="skip the second timed loop that feeds the inputs from pinned host memory (value_with_h2d)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the few graph replays of the 1152x1600x5 and 1024x1920x7 workloads (other_configs)")
+    ap.add_argument("--mode", choices=("eval", "train"), default="eval",
+                    help="eval: depth-maps/s of the forward (the headline, BASELINE configs[1]); train: samples/s of the "
+                         "captured training step with the bucketed RCCL gradient all-reduce (BASELINE configs[3])")
+    ap.add_argument("--coherent", action="store_true",
+                    help="train mode: zero the prob heads, i.e. smooth depth maps between stages as in a trained network "
+                         "(the fixture weights are random: neighbouring pixels pick unrelated hypotheses)")
     ap.add_argument("--stub", action="store_true",
                     help="CPU/gloo dry run of the launch + timing protocol (no GPU, no model); used by the CPU tests")
     args = ap.parse_args()
@@ -276,6 +475,8 @@ def main():
         sys.exit(self_launch(args.gpus))       # no launcher around us: start the ranks ourselves
     if args.stub:
         return stub_main(args)
+    if args.mode == "train":
+        return train_main(args)
 
     from mvster_amd import MVS4net, shard
     from mvster_amd.graph import GraphedForward
@@ -345,6 +546,82 @@ def main():
     torch.cuda.synchronize()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0)
     ranks_seen = int(round(shard.sum_over_ranks(1.0)))
+
+    # ---- the same loop with the inputs coming from the host: pinned buffers, one copy stream -----------------------
+    # (the reference's loop moves every sample to the GPU first, test_mvs4.py:202-207).  `value` above keeps the inputs
+    # resident in HBM as the metric is defined; this is the PCIe-inclusive rate measured, not computed.
+    with_h2d = None
+    if not args.no_graph and args.inflight > 1 and not args.no_stream_inputs:
+        copy_stream = torch.cuda.Stream(device=dev)
+        host = []
+        for g, _ in slots:
+            host.append(([i.cpu().pin_memory() for i in g.imgs], {k: v.cpu().pin_memory() for k, v in g.proj.items()},
+                         g.depth_values.cpu().pin_memory()))
+        copied = [torch.cuda.Event() for _ in slots]
+        done = [torch.cuda.Event() for _ in slots]
+        for e in done:
+            e.record()
+        k_h2d = [0]
+
+        def step_h2d():
+            i = k_h2d[0] % len(slots)
+            k_h2d[0] += 1
+            g, st = slots[i]
+            hi, hp, hd = host[i]
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(done[i])            # the slot's previous replay has consumed its inputs
+                for dst, src in zip(g.imgs, hi):
+                    dst.copy_(src, non_blocking=True)
+                for kk in g.proj:
+                    g.proj[kk].copy_(hp[kk], non_blocking=True)
+                g.depth_values.copy_(hd, non_blocking=True)
+                copied[i].record()
+            with torch.cuda.stream(st):
+                st.wait_event(copied[i])
+                g.graph.replay()
+                done[i].record()
+
+        for _ in range(args.warmup):
+            step_h2d()
+        torch.cuda.synchronize()
+        shard.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_h2d()
+        torch.cuda.synchronize()
+        shard.barrier()
+        torch.cuda.synchronize()
+        el2 = shard.max_over_ranks(time.perf_counter() - t1)
+        mb = sum(i.numel() for i in slots[0][0].imgs) * 4 / 1e6
+        with_h2d = {"value": round(args.steps * world * args.batch / el2, 3), "unit": "depth-maps/s",
+                    "ms_per_step": round(1e3 * el2 / args.steps, 4), "h2d_MB_per_depth_map": round(mb / args.batch, 2),
+                    "how": "pinned host buffers, one copy stream, copy of map k+1 under the forward of map k"}
+
+    # ---- the other inference configurations of BASELINE.json (runnable forms of configs[2] and configs[4]) ----------
+    other_configs = []
+    if rank == 0 and not args.no_graph and not args.no_other_configs and (args.height, args.width, args.views) == (512, 640, 5):
+        for (oh, ow, on, label) in ((1152, 1600, 5, "DTU raw as it runs (1152x1600, 5 views)"),
+                                    (1024, 1920, 7, "Tanks&Temples as it runs (1024x1920, 7 views)")):
+            try:
+                im, pr, d = make_inputs(nviews=on, H=oh, W=ow, seed=7, device=dev)
+                go = GraphedForward(model, im, pr, d)
+                for _ in range(2):
+                    go()
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                nrep = 5
+                for _ in range(nrep):
+                    go()
+                torch.cuda.synchronize()
+                ms = 1e3 * (time.perf_counter() - c0) / nrep
+                other_configs.append({"workload": label + ", 4-stage cascade, B=1 eval, one depth map at a time",
+                                      "ms_per_depth_map": round(ms, 3), "depth_maps_per_s": round(1e3 / ms, 2),
+                                      "finite": bool(torch.isfinite(go.outputs["depth"]).all().item())})
+                del go, im, pr, d
+                torch.cuda.empty_cache()
+            except RuntimeError as e:          # (out of memory next to the resident slots: reported, not fatal)
+                other_configs.append({"workload": label, "error": str(e)[:120]})
 
     # ---- instrumented eager pass: per-kernel HIP-event timing (rank 0 only) -------------------
     roofline = None
@@ -451,6 +728,10 @@ def main():
         if sequential is not None:
             line["single_forward_ms"] = round(1e3 * sequential, 4)       # one depth map at a time (latency)
             line["value_one_in_flight"] = round(world * args.batch / sequential, 3)
+        if with_h2d is not None:
+            line["value_with_h2d"] = with_h2d          # never `value`: the metric is defined on HBM-resident inputs
+        if other_configs:
+            line["other_configs"] = other_configs
         if cpu:
             line["vs_cpu_baseline"] = round(line["value"] / cpu["value"], 2)
         print(json.dumps(line))

@@ -84,7 +84,8 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         # (with a collective in the step, RCCL's watchdog thread touches the device during the capture: relaxed mode)
-        mode = {} if grad_sync is None or grad_sync.world() == 1 else {"capture_error_mode": "thread_local"}
+        collective = grad_sync is not None and (grad_sync.world() > 1 or grad_sync.always_reduce)
+        mode = {"capture_error_mode": "thread_local"} if collective else {}
         with torch.cuda.graph(self.graph, **mode):
             self.loss = self._step()
 

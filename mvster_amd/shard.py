@@ -94,7 +94,9 @@ class GradBucket:
     in a hipGraph together with forward, backward and the optimizer step.  The result equals DDP's (mean over ranks of the
     per-rank gradients, train_mvs4.py:389-392); BatchNorm statistics stay per rank, as there."""
 
-    def __init__(self, params, group=None):
+    def __init__(self, params, group=None, always_reduce=False):
+        # always_reduce: issue the collective on a one-rank group too (tests: capturing an RCCL all-reduce on one GPU)
+        self.always_reduce = always_reduce
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise RuntimeError("GradBucket: no parameter requires a gradient")
@@ -128,9 +130,10 @@ class GradBucket:
                 if g is not None and g.data_ptr() != v.data_ptr():
                     v.copy_(g)
         w = self.world()
-        if w > 1:
+        if w > 1 or (self.always_reduce and dist.is_available() and dist.is_initialized()):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.div_(w)
+            if w > 1:
+                self.flat.div_(w)
         for p, v in zip(self.params, self.views):
             p.grad = v
         return self.flat

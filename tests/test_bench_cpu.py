@@ -26,6 +26,15 @@ def test_self_launch_two_ranks():
     assert line["value"] > 0 and line["scaling"] == "weak" and line["higher_is_better"] is True
 
 
+def test_train_mode_protocol_two_ranks():
+    """--mode train: the same launch / barrier / MAX protocol around a step that ends in the bucketed gradient all-reduce
+    (shard.GradBucket); after the timed updates every rank holds the same parameters."""
+    line = _run(["--gpus", "2", "--mode", "train"])
+    assert line["mode"] == "train" and line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert abs(line["param_digest_spread"]) <= 1e-9
+    assert line["value"] > 0
+
+
 def test_single_rank_needs_no_launcher():
     line = _run(["--gpus", "1"])
     assert line["n_gpus"] == 1 and line["ranks_seen"] == 1
