@@ -91,6 +91,14 @@ int mvster_select_depth(const float* logits, const float* feat, const float* pro
                         const float* hypo, float* attn, float* depth, float* conf, float* inv_min, float* inv_max,
                         float* logits_out, int B, int D, int h, int w, float split_itv, void* stream);
 
+/* Backward of mvster_select_depth's differentiable part (training): the 1x1x1 `prob` head + softmax over depth with respect
+ * to the feature volume and the head's parameters, given gattn = d L / d attn [B,D,h,w] (depth, confidence and the
+ * inverse bounds carry no gradient: argmax / detached in the reference, models/mvs4net_utils.py:1068-1088).
+ * dfeat [B,D,h,w,CF] = dlogit * prob_w; partial [B * ceil(h*w/256), CF + 1] = per-workgroup sums of dlogit * feat (d prob_w)
+ * and of dlogit (d prob_b): the caller adds the rows.  CF = 8, D <= 16. */
+int mvster_select_depth_bwd(const float* attn, const float* gattn, const float* feat, const float* prob_w, float* dfeat,
+                            float* partial, int B, int D, int h, int w, int CF, void* stream);
+
 /* in [B,hi,wi] -> out [B,ho,wo], bilinear, align_corners=True.  models/mvs4net_utils.py:1077. */
 int mvster_upsample_bilinear(const float* in, float* out, int B, int hi, int wi, int ho, int wo, void* stream);
 

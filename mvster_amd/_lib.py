@@ -27,6 +27,7 @@ SIGNATURES = {
     "mvster_schedule_inverse_range": [_f, _f, _f, _i, _i, _i, _i, _f],
     "mvster_schedule_range": [_f, _f, _f, _i, _i, _i, _i, _f],
     "mvster_select_depth": [_f, _f, _f, _f, _i, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _f],
+    "mvster_select_depth_bwd": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f],
     "mvster_upsample_bilinear": [_f, _f, _i, _i, _i, _i, _i, _f],
     "mvster_conv_mfma": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f, _i, _i, _i, _i, _f],
     "mvster_conv_small": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f],

@@ -639,6 +639,80 @@ extern "C" int mvster_relative_projection_multi(const float* const* proj_matrice
     return mv_check_launch();
 }
 
+// Backward of (1x1x1 `prob` head) + softmax over depth with respect to the 8-channel feature volume and the head's
+// parameters (training; autograd of models/mvs4net_utils.py:900 and :1068): given d L / d attn,
+//   dlogit[d] = attn[d] * (g[d] - sum_e attn[e] g[e]);  dfeat[d][c] = dlogit[d] * w[c];  dw[c] = sum dlogit feat[c];  db = sum dlogit
+// One thread per pixel walks the D hypotheses; dw / db are reduced per workgroup into partial[block][CF + 1] (summed by
+// the caller in a fixed order: deterministic).  Replaces ~10 tensor-level kernels per stage (two of them passes over the
+// 84 MB feature volume of the full-resolution stage).
+namespace {
+template <int CF>
+__global__ void __launch_bounds__(256) select_depth_bwd_kernel(const float* __restrict__ attn, const float* __restrict__ gattn,
+                                                               const float* __restrict__ feat, const float* __restrict__ prob_w,
+                                                               float* __restrict__ dfeat, float* __restrict__ partial, int D,
+                                                               long hw) {
+    __shared__ float red[4][CF + 1];
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    float dw[CF + 1];
+#pragma unroll
+    for (int c = 0; c <= CF; ++c) dw[c] = 0.0f;
+    if (p < hw) {
+        const long vol = (long)b * D * hw;
+        float a[mv::kSelMaxD], g[mv::kSelMaxD];
+        float dot = 0.0f;
+#pragma unroll
+        for (int d = 0; d < mv::kSelMaxD; ++d) {
+            if (d >= D) break;
+            a[d] = attn[vol + d * hw + p];
+            g[d] = gattn[vol + d * hw + p];
+            dot = fmaf(a[d], g[d], dot);
+        }
+        f32x4 w4[CF / 4];
+#pragma unroll
+        for (int c = 0; c < CF / 4; ++c) w4[c] = ld4(prob_w + 4 * c);
+#pragma unroll
+        for (int d = 0; d < mv::kSelMaxD; ++d) {
+            if (d >= D) break;
+            const float dl = a[d] * (g[d] - dot);
+            const long o = (vol + d * hw + p) * CF;
+#pragma unroll
+            for (int c = 0; c < CF / 4; ++c) {
+                const f32x4 f = ld4(feat + o + 4 * c);
+                st4(dfeat + o + 4 * c, (f32x4){dl * w4[c][0], dl * w4[c][1], dl * w4[c][2], dl * w4[c][3]});
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dw[4 * c + j] = fmaf(dl, f[j], dw[4 * c + j]);
+            }
+            dw[CF] += dl;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c <= CF; ++c) {
+        float v = dw[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x <= CF)
+        partial[((long)blockIdx.y * gridDim.x + blockIdx.x) * (CF + 1) + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+}  // namespace
+
+// attn, gattn [B,D,h,w]; feat, dfeat [B,D,h,w,8]; prob_w [8]; partial [B * ceil(hw/256), 9] (dw[0..7], db): the caller sums
+// its rows.  D <= 16.
+extern "C" int mvster_select_depth_bwd(const float* attn, const float* gattn, const float* feat, const float* prob_w,
+                                       float* dfeat, float* partial, int B, int D, int h, int w, int CF, void* stream) {
+    if (!attn || !gattn || !feat || !prob_w || !dfeat || !partial) return MVSTER_ERR_NULL;
+    if (B <= 0 || D < 1 || D > mv::kSelMaxD || h <= 0 || w <= 0) return MVSTER_ERR_SHAPE;
+    if (CF != 8) return MVSTER_ERR_UNSUPPORTED;
+    const long hw = (long)h * w;
+    hipLaunchKernelGGL(select_depth_bwd_kernel<8>, dim3((unsigned)((hw + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, attn,
+                       gattn, feat, prob_w, dfeat, partial, D, hw);
+    return mv_check_launch();
+}
+
 thread_local const char* mv_last_kernel = "";
 
 // Name (profiler spelling, template arguments included) of the kernel the most recent mvster_conv_mfma / mvster_conv_small /

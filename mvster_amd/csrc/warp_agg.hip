@@ -692,6 +692,248 @@ int launch_fwd_wave(const WarpAggArgs& a, hipStream_t stream) {
     return mv_check_launch();
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-staged source windows (variant 5; C in {8, 16}: the two fine stages, where the time is).
+// The wave-local kernel gathers every tap through the texture path: 4 taps x 32 bytes per (pixel, d, view), 671 MB
+// through L1 per stage-4 launch against 80 MB of HBM traffic, texture-address unit 55 % busy, and inside the forward
+// (features not cache-resident) it waits on many small dependent misses: 48 us against 30 us warm.  Here a workgroup
+// owns a TW x TH tile of reference pixels and walks it in NP passes with the wave kernel's lane mapping; per view it
+//   A. projects all its (pixel, d) pairs and reduces the bounding box of the taps that carry weight (wave butterfly +
+//      four LDS atomics),
+//   B. stages that source window once -- whole texel rows are contiguous in channels-last memory, so this is a handful
+//      of fully coalesced 16-byte loads per thread -- into LDS, one plane per 16-byte channel quad (conflict-free reads),
+//   C. serves the taps with ds_read_b128.  A lane whose weighted taps do not fit the window (capacity WCAP texels:
+//      geometrically incoherent hypotheses) takes the buffer-load path of the wave kernel instead, lane by lane.
+// Arithmetic, lane mapping and summation order are the wave kernel's: bit-identical output (a zero-weight tap may read
+// another in-window texel: 0 * finite = 0 either way).  Pays off when neighbouring pixels carry similar depths (trained
+// networks, stage 1 by construction); on unrelated winner-take-all depths most lanes fall back and the bounding-box
+// pass is pure overhead -- the plan keeps the wave kernel there.
+// ------------------------------------------------------------------------------------------
+#ifndef MV_TILE_WAVES
+#define MV_TILE_WAVES 3      // (measured: 2 -> 66.6 us, 3 -> 57.6 us, 4 -> 77.5 us at stage 4, smooth depths; the wave kernel: 32.3 us)
+#endif
+template <int C, int G, int D, int TW, int TH>
+__global__ void __launch_bounds__(256, MV_TILE_WAVES) warp_agg_fwd_tile_kernel(WarpAggArgs a, int tiles_x, int tiles_y) {
+    constexpr int LPP = C / 8, CG = C / G, GPL = 8 / CG, PPW = 64 / (LPP * D);
+    constexpr int NP = (TW * TH) / (4 * PPW);                     // passes over the tile
+    constexpr int NQ = C / 4;                                     // 16-byte quads per texel = LDS planes
+    constexpr int WCAP = 24 * 1024 / (C * 4);                     // window capacity in texels (24 KB)
+    static_assert(C % 8 == 0 && CG <= 8 && 8 % CG == 0 && PPW * LPP * D == 64 && NP * 4 * PPW == TW * TH, "tile split");
+    __shared__ f32x4 win[NQ * WCAP];
+    __shared__ int box[4];                                        // min x, min y, max x, max y of the weighted taps
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPP, pl = (lane / LPP) % PPW, d = lane / (LPP * PPW);
+    const int b = blockIdx.y;
+    const int hw = a.h * a.w;
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int ty0 = (int)(tile / (unsigned)tiles_x) * TH, tx0 = (int)(tile % (unsigned)tiles_x) * TW;
+    const mv::GridNorm gn = mv::make_grid_norm(a.Hs, a.Ws);
+    const mv::Recip temp = mv::make_recip(a.attn_temp), sqrt_c = mv::make_recip(a.sqrt_c);
+    constexpr int SH = C == 8 ? 5 : 6;                            // log2(bytes per texel)
+    const float xhi = (float)(a.Ws + 4), yhi = (float)(a.Hs + 4);
+    const unsigned src_bytes = (unsigned)a.Hs * (unsigned)a.Ws * (unsigned)(C * 4);
+    const int row_bytes = a.Ws << SH;
+
+    // per pass: pixel, reference features, hypothesis
+    int pix[NP];
+    bool valid[NP];
+    float depth[NP];
+    f32x4 R0[NP], R1[NP];
+    float acc[NP][GPL], wsum[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int q = (k * 4 + wave) * PPW + pl;                  // tile-local pixel index, row-major
+        const int y = ty0 + q / TW, x = tx0 + q % TW;
+        valid[k] = y < a.h && x < a.w;
+        pix[k] = valid[k] ? y * a.w + x : hw - 1;                 // clamped: every lane takes part in the shuffles
+        depth[k] = a.hypo[((long)b * D + d) * hw + pix[k]];
+        const float* rp = a.ref + (long)b * a.ref_bs + (long)pix[k] * C + sub * 8;
+        R0[k] = ld4(rp);
+        R1[k] = ld4(rp + 4);
+#pragma unroll
+        for (int g = 0; g < GPL; ++g) acc[k][g] = 0.0f;
+        wsum[k] = 1e-8f;
+    }
+
+    for (int v = 0; v < a.NV; ++v) {
+        mv::RT m;
+        const float* r = a.rt + ((long)b * a.NV + v) * 12;        // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 9; ++i) m.r[i] = r[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) m.t[i] = r[9 + i];
+        if (threadIdx.x == 0) { box[0] = 1 << 30; box[1] = 1 << 30; box[2] = -1; box[3] = -1; }
+        // ---- A: taps of every pass, bounding box of the ones that carry weight
+        mv::Taps t[NP];
+        int bx0 = 1 << 30, by0 = 1 << 30, bx1 = -1, by1 = -1;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int y = pix[k] / a.w, x = pix[k] - y * a.w;
+            float sx, sy;
+            mv::project(m, (float)x, (float)y, depth[k], gn, sx, sy);
+            const float cx = __builtin_amdgcn_fmed3f(sx, -4.0f, xhi), cy = __builtin_amdgcn_fmed3f(sy, -4.0f, yhi);
+            const float fx = floorf(cx), fy = floorf(cy);
+            t[k].x0 = (int)fx;
+            t[k].y0 = (int)fy;
+            const float wx1 = mv::sub_rn(cx, fx), wy1 = mv::sub_rn(cy, fy);
+            const float wx0 = mv::sub_rn(1.0f, wx1), wy0 = mv::sub_rn(1.0f, wy1);
+            const bool vx0 = (unsigned)t[k].x0 < (unsigned)a.Ws, vx1 = (unsigned)(t[k].x0 + 1) < (unsigned)a.Ws;
+            const bool vy0 = (unsigned)t[k].y0 < (unsigned)a.Hs, vy1 = (unsigned)(t[k].y0 + 1) < (unsigned)a.Hs;
+            t[k].nw = (vy0 && vx0) ? mv::mul_rn(wy0, wx0) : 0.0f;
+            t[k].ne = (vy0 && vx1) ? mv::mul_rn(wy0, wx1) : 0.0f;
+            t[k].sw = (vy1 && vx0) ? mv::mul_rn(wy1, wx0) : 0.0f;
+            t[k].se = (vy1 && vx1) ? mv::mul_rn(wy1, wx1) : 0.0f;
+            if (valid[k] && (vx0 || vx1) && (vy0 || vy1)) {       // some tap lies inside the map
+                bx0 = min(bx0, max(t[k].x0, 0));
+                by0 = min(by0, max(t[k].y0, 0));
+                bx1 = max(bx1, min(t[k].x0 + 1, a.Ws - 1));
+                by1 = max(by1, min(t[k].y0 + 1, a.Hs - 1));
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            bx0 = min(bx0, __shfl_xor(bx0, off));
+            by0 = min(by0, __shfl_xor(by0, off));
+            bx1 = max(bx1, __shfl_xor(bx1, off));
+            by1 = max(by1, __shfl_xor(by1, off));
+        }
+        __syncthreads();                                          // box initialised; previous view's window no longer read
+        if (lane == 0 && bx1 >= 0) {
+            atomicMin(&box[0], bx0);
+            atomicMin(&box[1], by0);
+            atomicMax(&box[2], bx1);
+            atomicMax(&box[3], by1);
+        }
+        __syncthreads();
+        // window = the box, cut to the capacity (anchored at its top-left corner); an empty box -> texel (0, 0)
+        int wx0 = box[0], wy0 = box[1], wx = box[2] - wx0 + 1, wy = box[3] - wy0 + 1;
+        if (box[2] < 0) { wx0 = 0; wy0 = 0; wx = 1; wy = 1; }
+        wx = min(wx, WCAP);
+        wy = min(wy, WCAP / wx);
+        // ---- B: stage the window: thread -> (texel, quad), a window row is one contiguous run of wx * C * 4 bytes
+        const float* sp = a.src + (long)v * a.src_vs + (long)b * a.src_bs;
+        const int nst = wy * wx * NQ;
+        for (int i = threadIdx.x; i < nst; i += 256) {
+            const int qd = i % NQ, tx = (i / NQ) % wx, tyy = i / (NQ * wx);
+            win[qd * WCAP + tyy * wx + tx] = ld4(sp + ((long)(wy0 + tyy) * a.Ws + (wx0 + tx)) * C + qd * 4);
+        }
+        __syncthreads();
+        // ---- C: the wave kernel's arithmetic, taps from LDS where the lane's weighted taps lie inside the window
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sp), (short)0, (int)src_bytes, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const mv::Taps& tk = t[k];
+            // in-window test on the clamped extent of the taps (taps outside the map carry no weight)
+            const int ex0 = max(tk.x0, 0), ey0 = max(tk.y0, 0), ex1 = min(tk.x0 + 1, a.Ws - 1), ey1 = min(tk.y0 + 1, a.Hs - 1);
+            const bool weighted = (ex0 <= ex1) && (ey0 <= ey1);
+            const bool inwin = !weighted || (ex0 >= wx0 && ey0 >= wy0 && ex1 < wx0 + wx && ey1 < wy0 + wy);
+            f32x4 q0, q1, q2, q3, q4, q5, q6, q7;
+            if (inwin) {
+                // (a tap outside the window has zero weight: it may read any staged texel)
+                const int rx0 = min(max(tk.x0 - wx0, 0), wx - 1), rx1 = min(max(tk.x0 + 1 - wx0, 0), wx - 1);
+                const int ry0 = min(max(tk.y0 - wy0, 0), wy - 1), ry1 = min(max(tk.y0 + 1 - wy0, 0), wy - 1);
+                const f32x4* w0 = win + (sub * 2) * WCAP;
+                const f32x4* w1 = w0 + WCAP;
+                q0 = w0[ry0 * wx + rx0]; q1 = w1[ry0 * wx + rx0];
+                q2 = w0[ry0 * wx + rx1]; q3 = w1[ry0 * wx + rx1];
+                q4 = w0[ry1 * wx + rx0]; q5 = w1[ry1 * wx + rx0];
+                q6 = w0[ry1 * wx + rx1]; q7 = w1[ry1 * wx + rx1];
+            } else {
+                const unsigned oa = (((unsigned)__mul24(tk.y0, a.Ws) + (unsigned)tk.x0) << SH) + (unsigned)(sub * 32);
+                const unsigned ob = oa + (unsigned)row_bytes;
+                q0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, oa, 0, 0));
+                q1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, oa + 16, 0, 0));
+                q2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, oa + (4 * C), 0, 0));
+                q3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, oa + (4 * C + 16), 0, 0));
+                q4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ob, 0, 0));
+                q5 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ob + 16, 0, 0));
+                q6 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ob + (4 * C), 0, 0));
+                q7 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ob + (4 * C + 16), 0, 0));
+            }
+            float part[GPL];
+#define MV_PAIR(c, A, B, Cq, Dq, R, j)                                                                         \
+            {                                                                                                  \
+                const mv::f32x2 wv = mv::blend2(tk.nw, tk.ne, tk.sw, tk.se, (mv::f32x2){A[j], A[j + 1]},       \
+                                                (mv::f32x2){B[j], B[j + 1]}, (mv::f32x2){Cq[j], Cq[j + 1]},    \
+                                                (mv::f32x2){Dq[j], Dq[j + 1]});                                \
+                const mv::f32x2 p2 = mv::mul_rn2(wv, (mv::f32x2){R[j], R[j + 1]});                             \
+                part[(c) / CG] = ((c) % CG == 0) ? p2[0] : mv::add_rn(part[(c) / CG], p2[0]);                  \
+                part[((c) + 1) / CG] = (((c) + 1) % CG == 0) ? p2[1] : mv::add_rn(part[((c) + 1) / CG], p2[1]); \
+            }
+            MV_PAIR(0, q0, q2, q4, q6, R0[k], 0)
+            MV_PAIR(2, q0, q2, q4, q6, R0[k], 2)
+            MV_PAIR(4, q1, q3, q5, q7, R1[k], 0)
+            MV_PAIR(6, q1, q3, q5, q7, R1[k], 2)
+#undef MV_PAIR
+            float cg[GPL];
+#pragma unroll
+            for (int g = 0; g < GPL; ++g) cg[g] = mv::div_rn(part[g], (float)CG);   // .mean(2)
+            float score = 0.0f;
+            const int lane0 = lane - sub;
+#pragma unroll
+            for (int j = 0; j < LPP; ++j)
+#pragma unroll
+                for (int g = 0; g < GPL; ++g) {
+                    const float val = LPP == 1 ? cg[g] : __shfl(cg[g], lane0 + j);
+                    score = (j == 0 && g == 0) ? val : mv::add_rn(score, val);
+                }
+            if (a.fuse_d) score = mv::div_rn(score, temp);
+            float mx = score;
+#pragma unroll
+            for (int j = 0; j < D; ++j) mx = fmaxf(mx, __shfl(score, (j * PPW + pl) * LPP + sub));
+            const float e = expf(mv::sub_rn(score, mx));
+            float den = 0.0f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) den = mv::add_rn(den, __shfl(e, (j * PPW + pl) * LPP + sub));
+            const mv::Recip rden = mv::make_recip(den);
+            float wgt;
+            if (a.fuse_d)
+                wgt = mv::div_rn(mv::div_rn(e, rden), sqrt_c);
+            else
+                wgt = mv::div_rn(1.0f, rden);
+            wsum[k] = mv::add_rn(wsum[k], wgt);
+#pragma unroll
+            for (int g = 0; g < GPL; ++g) acc[k][g] = mv::add_rn(acc[k][g], mv::mul_rn(wgt, cg[g]));
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        if (!valid[k]) continue;
+        const long o = (((long)b * D + d) * hw + pix[k]);
+        float* op = a.out + o * G + sub * GPL;
+        const mv::Recip rw = mv::make_recip(wsum[k]);
+        if (GPL == 4) {
+            st4(op, (f32x4){mv::div_rn(acc[k][0], rw), mv::div_rn(acc[k][GPL > 1 ? 1 : 0], rw),
+                            mv::div_rn(acc[k][GPL > 2 ? 2 : 0], rw), mv::div_rn(acc[k][GPL > 3 ? 3 : 0], rw)});
+        } else {
+#pragma unroll
+            for (int g = 0; g < GPL; ++g) op[g] = mv::div_rn(acc[k][g], rw);
+        }
+        if (a.wsum_out && sub == 0) a.wsum_out[o] = wsum[k];
+    }
+}
+
+template <int C, int G, int D>
+int launch_fwd_tile(const WarpAggArgs& a, hipStream_t stream) {
+    constexpr int TW = 32, TH = C == 8 ? 8 : 4;
+    if ((long)a.Hs * a.Ws >= (1L << 23) || (long)a.Hs * a.Ws * C * 4 >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    const int tiles_x = (a.w + TW - 1) / TW, tiles_y = (a.h + TH - 1) / TH;
+    MV_NOTE_KERNEL("warp_agg_fwd_tile_kernel<%d, %d, %d, %d, %d>", C, G, D, TW, TH);
+    hipLaunchKernelGGL((warp_agg_fwd_tile_kernel<C, G, D, TW, TH>), dim3(tiles_x * tiles_y, a.B), dim3(256), 0, stream, a, tiles_x,
+                       tiles_y);
+    return mv_check_launch();
+}
+
+template <int C, int G>
+int dispatch_fwd_tile(const WarpAggArgs& a, hipStream_t stream) {
+    if (a.D == 4) return launch_fwd_tile<C, G, 4>(a, stream);
+    if (a.D == 8) return launch_fwd_tile<C, G, 8>(a, stream);
+    return MVSTER_ERR_UNSUPPORTED;
+}
+
 template <int C, int G>
 int dispatch_fwd_wave(const WarpAggArgs& a, hipStream_t stream) {
     if (a.D == 4) return launch_fwd_wave<C, G, 4>(a, stream);
@@ -1477,6 +1719,13 @@ extern "C" int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat,
         else if (C == 32 && G == 4 && variant == 4) rc = dispatch_fwd_pix<32, 4>(a, s);
         if (rc != MVSTER_ERR_UNSUPPORTED && !(rc == MVSTER_ERR_SHAPE && variant == 0)) return rc;
         // (a map too large for the 24-bit index arithmetic falls through to the wave-local kernel)
+    }
+    if (group_cor && (D == 4 || D == 8) && variant == 5) {      // LDS-staged source windows (the two fine stages)
+        if (C == 8 && G == 4) return dispatch_fwd_tile<8, 4>(a, s);
+        if (C == 8 && G == 8) return dispatch_fwd_tile<8, 8>(a, s);
+        if (C == 16 && G == 4) return dispatch_fwd_tile<16, 4>(a, s);
+        if (C == 16 && G == 8) return dispatch_fwd_tile<16, 8>(a, s);
+        return MVSTER_ERR_UNSUPPORTED;
     }
     if (group_cor && (D == 4 || D == 8) && (variant == 0 || variant == 3)) {
         if (C == 8 && G == 4) return dispatch_fwd_wave<8, 4>(a, s);

@@ -87,8 +87,9 @@ class reg2d(nn.Module):
         """[B,G,D,h,w] -> logits [B,D,h,w] (the reference's signature)."""
         return self.forward_cl(_to_cl5(x))
 
-    def forward_cl(self, x):
-        """[B,D,h,w,G] -> logits [B,D,h,w]."""
+    def forward_cl(self, x, return_features=False):
+        """[B,D,h,w,G] -> logits [B,D,h,w]; ``return_features``: the 8-channel volume in front of the ``prob`` head instead
+        (MVS4net's training forward applies the head inside its fused selection kernel)."""
         c0 = self.conv0.forward_cl(x)
         c2 = self.conv2.forward_cl(self.conv1.forward_cl(c0))
         c4 = self.conv4.forward_cl(self.conv3.forward_cl(c2))
@@ -96,6 +97,8 @@ class reg2d(nn.Module):
         x = _deconv_bn_relu_cl(self.conv7, x, skip=c4)
         x = _deconv_bn_relu_cl(self.conv9, x, skip=c2)
         x = _deconv_bn_relu_cl(self.conv11, x, skip=c0)
+        if return_features:
+            return x
         # 1x1x1 conv 8 -> 1 as multiply + 8-wide reduction (rocBLAS gemv takes 8 ms on this [2.6 M, 8] shape)
         return (x * self.prob.weight.reshape(-1)).sum(-1) + self.prob.bias
 

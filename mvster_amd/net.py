@@ -48,6 +48,30 @@ class _WarpAggCL(torch.autograd.Function):
         return g_ref, g_src, None, None, None, None, None, None
 
 
+class _SelectDepthCL(torch.autograd.Function):
+    """reg2d's 1x1x1 ``prob`` head + softmax over depth + first-max argmax + gather + inverse bounds of one stage in ONE
+    kernel each way (mvs4net_utils.py:900, :1068-1088).  Differentiable output: ``attn_weight`` (w.r.t. the 8-channel
+    feature volume, ``prob.weight`` and ``prob.bias``); depth and the inverse bounds carry no gradient, as in the
+    reference (argmax; the next stage detaches them)."""
+
+    @staticmethod
+    def forward(ctx, feat_cl, prob_w, prob_b, hypo, split_itv, inverse_depth):
+        feat_cl = feat_cl.contiguous()
+        w = prob_w.detach().reshape(-1).contiguous()
+        sel = ops.select_depth(hypo, split_itv, inverse_depth, feat_cl=feat_cl, prob_w=w, prob_b=prob_b.detach().reshape(-1))
+        ctx.save_for_backward(sel["attn_weight"], feat_cl, w)
+        ctx.shapes = (prob_w.shape, prob_b.shape)
+        outs = (sel["attn_weight"], sel["depth"]) + ((sel["inverse_min_depth"], sel["inverse_max_depth"]) if inverse_depth else ())
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, gattn, *unused):
+        attn, feat_cl, w = ctx.saved_tensors
+        dfeat, dw, db = ops.select_depth_bwd(attn, gattn, feat_cl, w)
+        return dfeat, dw.reshape(ctx.shapes[0]), db.reshape(ctx.shapes[1]), None, None, None
+
+
 class MVS4net(nn.Module):
     def __init__(self, arch_mode="fpn", reg_net="reg2d", num_stage=4, fpn_base_channel=8, reg_channel=8,
                  stage_splits=[8, 8, 4, 4], depth_interals_ratio=[0.5, 0.5, 0.5, 1], group_cor=False,
@@ -294,7 +318,17 @@ class MVS4net(nn.Module):
                 hypo = self._hypotheses(s, depth_values, depth_interval, prev, h, w)
             cor = _WarpAggCL.apply(pyr[:B].reshape(B, h, w, C), pyr[B:].reshape(nv - 1, B, h, w, C),
                                    rt, hypo, G, self.group_cor, self.attn_fuse_d, float(self.attn_temp))
-            st = self._stage_outputs(s, self.reg[s].forward_cl(cor), hypo, dev)
+            reg = self.reg[s]
+            if isinstance(reg, reg2d) and self.training and self.stage_splits[s] >= (3 if self.inverse_depth else 1):
+                # prob head + softmax + argmax + gather + inverse bounds: one kernel forward, one backward
+                res = _SelectDepthCL.apply(reg.forward_cl(cor, return_features=True), reg.prob.weight, reg.prob.bias, hypo,
+                                           float(self.depth_interals_ratio[s]), self.inverse_depth)
+                st = {"depth": res[1], "photometric_confidence": torch.zeros((), dtype=torch.float32, device=dev),
+                      "hypo_depth": hypo, "attn_weight": res[0]}
+                if self.inverse_depth:
+                    st["inverse_min_depth"], st["inverse_max_depth"] = res[2], res[3]
+            else:
+                st = self._stage_outputs(s, reg.forward_cl(cor), hypo, dev)
             if self.mono:
                 st["mono_feat"] = pyr[:B].reshape(B, h, w, C).permute(0, 3, 1, 2)      # [B,C,h,w] view
                 ref_feats.append(pyr[:B])

@@ -205,6 +205,25 @@ def select_depth(hypo, split_itv, inverse_depth, logits=None, feat_cl=None, prob
     return out
 
 
+def select_depth_bwd(attn, gattn, feat_cl, prob_w):
+    """Gradients of ``select_depth(..., feat_cl=, prob_w=, prob_b=)`` w.r.t. the feature volume and the head's parameters
+    given d L / d attn_weight: (dfeat [B,D,h,w,8], d prob_w [8], d prob_b [1]).  One kernel + one small row sum."""
+    gattn = gattn.contiguous()
+    for t, n in ((attn, "attn"), (gattn, "gattn"), (feat_cl, "feat"), (prob_w, "prob_w")):
+        _chk(t, "select_depth_bwd:" + n)
+    B, D, h, w = attn.shape
+    CF = feat_cl.shape[-1]
+    if tuple(feat_cl.shape) != (B, D, h, w, CF) or tuple(gattn.shape) != (B, D, h, w) or prob_w.numel() != CF:
+        raise RuntimeError("select_depth_bwd: inconsistent shapes")
+    dfeat = torch.empty_like(feat_cl)
+    partial = torch.empty(B * ((h * w + 255) // 256), CF + 1, device=attn.device, dtype=torch.float32)
+    rc = _lib.load().mvster_select_depth_bwd(_ptr(attn), _ptr(gattn), _ptr(feat_cl), _ptr(prob_w), _ptr(dfeat), _ptr(partial),
+                                             B, D, h, w, CF, _stream())
+    _lib.check(rc, "select_depth_bwd")
+    sums = partial.sum(0)
+    return dfeat, sums[:CF], sums[CF:]
+
+
 def upsample_bilinear(x, scale):
     """[B,h,w] -> [B,h*scale,w*scale], align_corners=True (mvs4net_utils.py:1077)."""
     x = x.contiguous()

@@ -197,6 +197,48 @@ def test_warp_agg_kernel_variants_bit_identical(C, G, D, fuse):
             assert torch.equal(ws, wbase), (C, G, D, h, w, variant)
 
 
+@pytest.mark.parametrize("C,G,D", [(8, 4, 4), (16, 4, 4), (8, 8, 8), (16, 8, 4), (8, 4, 8), (16, 4, 8)])
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("regime", ["smooth", "random", "mixed", "planes"])
+def test_warp_agg_lds_window_variant_bit_identical(C, G, D, fuse, regime):
+    """The LDS-staged source-window form (variant 5) against the one-thread form: equal bits whether every tap comes from
+    the staged window (smooth hypotheses), almost none does (per-pixel random depths: the lane-by-lane buffer-load path),
+    or a mixture -- incl. ragged tiles, views that leave the map, B = 2 and the saved softmax mass."""
+    from mvster_amd.synthetic import make_inputs as mk
+    for (h, w, nv, B) in ((37, 53, 3, 2), (64, 96, 4, 1), (5, 7, 2, 1), (40, 130, 2, 1)):
+        g = torch.Generator().manual_seed(C * 131 + D * 7 + h)
+        _, proj, dv = mk(nviews=nv + 1, H=h * 8, W=w * 8, batch=B, seed=h, rotate=True)
+        pm = proj["stage4"].clone()
+        # stage-4 intrinsics are for the full-resolution map of an (8h x 8w) image: rescale to this h x w map
+        pm[:, :, 1, :2, :] = pm[:, :, 1, :2, :] / 8.0
+        lo, hi = dv[:, :1, None, None], dv[:, -1:, None, None]
+        yy = torch.linspace(0, 1, h).view(1, 1, h, 1)
+        xx = torch.linspace(0, 1, w).view(1, 1, 1, w)
+        plane = lo + (hi - lo) * (0.2 + 0.5 * xx + 0.2 * yy)                   # a slanted plane
+        step = (hi - lo) / 64 * torch.arange(D).view(1, D, 1, 1)
+        if regime == "smooth":
+            hypo = (plane + step).expand(B, D, h, w).clone()
+        elif regime == "random":
+            hypo = lo + (hi - lo) * torch.rand(B, D, h, w, generator=g)
+        elif regime == "mixed":
+            hypo = (plane + step).expand(B, D, h, w).clone()
+            out = torch.rand(B, 1, h, w, generator=g) < 0.1                   # 10 % outlier pixels
+            hypo = torch.where(out, lo + (hi - lo) * torch.rand(B, D, h, w, generator=g), hypo)
+        else:                                                                  # two planes with a depth step in the tile
+            hypo = (plane + step + (hi - lo) * 0.3 * (xx > 0.47).float()).expand(B, D, h, w).clone()
+        ref = torch.randn(B, h, w, C, generator=g)
+        src = torch.randn(nv, B, h, w, C, generator=g)
+        rt = ops.relative_projection(pm.to(DEV))
+        args = (ref.to(DEV), src.to(DEV), rt, hypo.contiguous().to(DEV), G, True, fuse, 2.0)
+        base, wbase = ops.warp_agg_fwd_cl(*args, want_wsum=True, variant=1)
+        assert torch.isfinite(base).all() and base.abs().max() > 0
+        o, ws = ops.warp_agg_fwd_cl(*args, want_wsum=True, variant=5)
+        from mvster_amd import _lib
+        assert _lib.last_kernel().startswith("warp_agg_fwd_tile_kernel<")
+        assert torch.equal(o, base), (C, G, D, h, w, regime, (o - base).abs().max().item())
+        assert torch.equal(ws, wbase), (C, G, D, h, w, regime)
+
+
 @pytest.mark.parametrize("case", ["a", "b", "c", "d", "e"])
 def test_warp_agg_vs_reference_homo_warping(golden, case):
     """The reference's homo_warping outputs (fixture G1) pushed through the rest of the stage arithmetic on the CPU, against

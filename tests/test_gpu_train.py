@@ -675,3 +675,45 @@ def test_graphed_step_with_bucketed_all_reduce_single_rank():
     for p, v in zip(bucket.params, bucket.views):
         assert p.grad.data_ptr() == v.data_ptr()
     assert torch.isfinite(bucket.flat).all() and bucket.flat.abs().max() > 0
+
+
+@pytest.mark.parametrize("D,inverse", [(4, True), (8, True), (5, False), (16, True)])
+def test_fused_stage_selection_vs_autograd(D, inverse):
+    """net._SelectDepthCL (prob head + softmax + argmax + gather + inverse bounds: one kernel forward, one backward)
+    against the tensor-level form of models/mvs4net_utils.py:900, :1068-1088 under fp64 autograd."""
+    from mvster_amd.net import _SelectDepthCL
+    g = torch.Generator().manual_seed(D)
+    B, h, w = 2, 19, 23
+    feat = torch.randn(B, D, h, w, 8, generator=g)
+    pw = torch.randn(1, 8, 1, 1, 1, generator=g)
+    pb = torch.randn(1, generator=g)
+    hypo = (1.0 / (1.0 / 900 + 2e-5 * (torch.arange(D).view(1, D, 1, 1) + 0.1 * torch.rand(B, D, h, w, generator=g)))).float()
+    gout = torch.randn(B, D, h, w, generator=g)
+    ratio = 0.5
+    # reference, fp64
+    f64, w64, b64 = feat.double().requires_grad_(True), pw.double().requires_grad_(True), pb.double().requires_grad_(True)
+    logits = (f64 * w64.reshape(-1)).sum(-1) + b64
+    attn = torch.softmax(logits, 1)
+    (attn * gout.double()).sum().backward()
+    idx = attn.max(1, keepdim=True)[1]
+    depth = torch.gather(hypo.double(), 1, idx).squeeze(1)
+    # fused
+    fd, wd, bd = feat.to(DEV).requires_grad_(True), pw.to(DEV).requires_grad_(True), pb.to(DEV).requires_grad_(True)
+    res = _SelectDepthCL.apply(fd, wd, bd, hypo.to(DEV), ratio, inverse)
+    (res[0] * gout.to(DEV)).sum().backward()
+    assert (res[0].cpu().double() - attn.detach()).abs().max() <= 2e-6
+    top2 = attn.detach().topk(2, dim=1)[0]
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-5
+    assert torch.equal(res[1].cpu()[clear], depth.float()[clear])
+    if inverse:
+        itv = 1.0 / hypo[:, 2].double() - 1.0 / hypo[:, 1].double()
+        assert ((res[2].cpu().double() - (1 / depth + ratio * itv))[clear].abs().max() <= 1e-9)
+        assert ((res[3].cpu().double() - (1 / depth - ratio * itv))[clear].abs().max() <= 1e-9)
+    wscale = w64.grad.norm().item()
+    for got, want, name in ((fd.grad, f64.grad, "feat"), (wd.grad, w64.grad, "prob.weight"), (bd.grad, b64.grad, "prob.bias")):
+        # (d prob.bias = the sum of the softmax Jacobian's rows = 0 up to rounding: measured against the weight gradient's size)
+        den = wscale if name == "prob.bias" else want.norm().item()
+        e = ((got.cpu().double() - want).norm() / den).item()
+        note("fused_selection_D%d_%s" % (D, name), rel_l2=e)
+        assert e <= 2e-6, (name, e)
+    assert not res[1].requires_grad and res[0].requires_grad
