@@ -136,6 +136,16 @@ int mvster_deconv_small(const float* in, const float* w, const float* scale, con
                         const float* prob_w, const float* prob_b, float* out, int NB, int Hi, int Wi, int cin,
                         int cout, int relu, void* stream);
 
+/* reg2d's last layer and the depth selection in one launch (models/mvs4net_utils.py:897-900 and :1068-1088):
+ * mvster_deconv_small (ConvTranspose 16 -> 8 + BatchNorm + ReLU + skip, fused 1x1x1 `prob` head) followed by
+ * mvster_select_depth, bit for bit, without the logits volume going through HBM.  in [B*D,Hi,Wi,16] (slice b*D + d),
+ * skip [B*D,2Hi,2Wi,8] or null, hypo [B,D,2Hi,2Wi] -> attn [B,D,2Hi,2Wi], depth / conf / inv_min / inv_max [B,2Hi,2Wi]
+ * (conf and inv_* optional; inv_* need D >= 3), logits_out [B,D,2Hi,2Wi] optional.  2 <= D <= 16. */
+int mvster_deconv_select(const float* in, const float* w, const float* scale, const float* shift, const float* skip,
+                         const float* prob_w, const float* prob_b, const float* hypo, float* attn, float* depth, float* conf,
+                         float* inv_min, float* inv_max, float* logits_out, int B, int D, int Hi, int Wi, int cin, int relu,
+                         float split_itv, void* stream);
+
 /* FPN4 top-down tail, re-associated: G [NB,H/2,W/2,9*CO] = 1x1 conv of the half-resolution top-down
  * map with the 9 taps of the output conv stacked on the channel axis; vb [9,CO] = the taps applied to the
  * lateral conv's bias; P [NB,H,W,CO] = sum over in-bounds taps of (bilinear x2 align_corners upsample of

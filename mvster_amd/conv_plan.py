@@ -65,6 +65,8 @@ def layer_signature(layer, B, Di, Hi, Wi, skip_mode):
         "T" if layer.transposed else "C", layer.cin, layer.cout, *layer.kernel, *layer.stride, B, Di, Hi, Wi, skip_mode)
 
 
+import os as _os
+FUSE_SELECT = not _os.environ.get("MVSTER_NO_FUSE_SELECT")      # reg2d conv11 + prob + selection in one launch (A/B switch)
 LDS_BUDGET = 12 * 256 * 16      # bytes of staged patch the LDS variant accepts (conv_mfma.hip kMaxStage)
 FORCE_VARIANT = None            # None = choose per layer; 0 / 1 pin the kernel variant (experiments, tests)
 
@@ -447,6 +449,46 @@ class Reg2dPlan:
         t = self.conv7(t, skip=c4, skip_mode=SKIP_ADD)
         t = self.conv9(t, skip=c2, skip_mode=SKIP_ADD)
         return self.conv11(t, skip=c0, skip_mode=SKIP_ADD)
+
+    def select(self, x, hypo, split_itv, inverse_depth, want_logits=False):
+        """x [B,D,h,w,G] -> the stage's selection dict (ops.select_depth's): the U-Net, then conv11 + `prob` + softmax +
+        argmax + gather + bounds in ONE launch (mvster_deconv_select) when conv11 runs on the narrow deconvolution kernel;
+        otherwise logits + ops.select_depth.  Same bits either way."""
+        c0 = self.conv0(x)
+        c2 = self.conv2(self.conv1(c0))
+        c4 = self.conv4(self.conv3(c2))
+        t = self.conv6(self.conv5(c4))
+        t = self.conv7(t, skip=c4, skip_mode=SKIP_ADD)
+        t = self.conv9(t, skip=c2, skip_mode=SKIP_ADD)
+        L = self.conv11
+        B, D, hi, wi, _ = t.shape
+        if (FUSE_SELECT and L.w_deconv is not None and L.prob is not None and L.cin == 16 and FORCE_VARIANT in (None, 4)
+                and 2 <= D <= 16 and t.is_contiguous() and c0.is_contiguous()):
+            dev = t.device
+            hypo = hypo.contiguous()
+            attn = torch.empty(B, D, 2 * hi, 2 * wi, device=dev, dtype=torch.float32)
+            depth = torch.empty(B, 2 * hi, 2 * wi, device=dev, dtype=torch.float32)
+            conf = torch.empty_like(depth)
+            imin = torch.empty_like(depth) if inverse_depth else None
+            imax = torch.empty_like(depth) if inverse_depth else None
+            lo = torch.empty_like(attn) if want_logits else None
+            rc = _lib.load().mvster_deconv_select(
+                t.data_ptr(), L.w_deconv.data_ptr(), L.scale.data_ptr(), L.shift.data_ptr(), c0.data_ptr(),
+                L.prob[0].data_ptr(), L.prob[1].data_ptr(), hypo.data_ptr(), attn.data_ptr(), depth.data_ptr(), conf.data_ptr(),
+                None if imin is None else imin.data_ptr(), None if imax is None else imax.data_ptr(),
+                None if lo is None else lo.data_ptr(), B, D, hi, wi, L.cin, int(L.relu), float(split_itv), ops._stream())
+            _lib.check(rc, "deconv_select")
+            out = {"attn_weight": attn, "depth": depth, "conf": conf}
+            if inverse_depth:
+                out["inverse_min_depth"], out["inverse_max_depth"] = imin, imax
+            if want_logits:
+                out["logits"] = lo
+            return out
+        res = self.conv11(t, skip=c0, skip_mode=SKIP_ADD)
+        if self.fused_prob:
+            return ops.select_depth(hypo, split_itv, inverse_depth, feat_cl=res, prob_w=self.prob_w, prob_b=self.prob_b,
+                                    want_logits=want_logits)
+        return ops.select_depth(hypo, split_itv, inverse_depth, logits=res, want_logits=want_logits)
 
     def flops(self, B, D, h, w):
         tot, shp = 0, None

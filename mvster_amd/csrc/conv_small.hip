@@ -154,12 +154,9 @@ struct DeconvArgs {
     unsigned in_bytes;
 };
 
+// The 2 x 2 outputs (all COUT channels, after scale / shift, ReLU and the skip connection) of input voxel (nb, i, j).
 template <int CIN, int COUT>
-__global__ void __launch_bounds__(256) deconv_small_kernel(DeconvArgs a) {
-    const int pix = xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    const int nb = blockIdx.y;
-    if (pix >= a.Hi * a.Wi) return;
-    const int i = pix / a.Wi, j = pix - i * a.Wi;
+__device__ __forceinline__ void deconv_voxel(const DeconvArgs& a, int nb, int i, int j, float (&v)[4][COUT]) {
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)a.in_bytes, 0x00020000);
     const unsigned base = (unsigned)((nb * a.Hi + i) * a.Wi + j) * CIN * 4u;
@@ -179,12 +176,22 @@ __global__ void __launch_bounds__(256) deconv_small_kernel(DeconvArgs a) {
 
     const f32x2v* w2 = reinterpret_cast<const f32x2v*>(a.w);
     auto wrow = [&](int ky, int kx, int ci) { return w2 + ((ky * 3 + kx) * CIN + ci) * (COUT / 2); };   // wave-uniform
+    // the rolled channel loop is software-pipelined: the four corner loads of trip t + 1 are issued before the FMAs of
+    // trip t (as plain load-then-compute trips every trip sat out a memory latency; fully unrolled, hipcc hoists all 1152
+    // scalar weights at once and spills SGPRs into VGPR lanes)
+    auto load4 = [&](int c4, f32x4v (&x)[4]) {
+        const unsigned c4b = (unsigned)c4 * 4u;
+        x[0] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + c4b, 0, 0));
+        x[1] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o01 == 0xFFFFFFF0u ? o01 : o01 + c4b, 0, 0));
+        x[2] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o10 == 0xFFFFFFF0u ? o10 : o10 + c4b, 0, 0));
+        x[3] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o11 == 0xFFFFFFF0u ? o11 : o11 + c4b, 0, 0));
+    };
+    f32x4v xn[4];
+    load4(0, xn);
 #pragma unroll 1
     for (int c4 = 0; c4 < CIN; c4 += 4) {
-        const f32x4v x00 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + c4 * 4u, 0, 0));
-        const f32x4v x01 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o01 == 0xFFFFFFF0u ? o01 : o01 + c4 * 4u, 0, 0));
-        const f32x4v x10 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o10 == 0xFFFFFFF0u ? o10 : o10 + c4 * 4u, 0, 0));
-        const f32x4v x11 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o11 == 0xFFFFFFF0u ? o11 : o11 + c4 * 4u, 0, 0));
+        const f32x4v x00 = xn[0], x01 = xn[1], x10 = xn[2], x11 = xn[3];
+        load4(c4 + 4 < CIN ? c4 + 4 : c4, xn);            // (unconditional: the last trip re-reads its own quad)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int ci = c4 + k;
@@ -203,36 +210,108 @@ __global__ void __launch_bounds__(256) deconv_small_kernel(DeconvArgs a) {
             }
         }
     }
-
     const int Ho = 2 * a.Hi, Wo = 2 * a.Wi;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int oy = 2 * i + (q >> 1), ox = 2 * j + (q & 1);
         const long opix = ((long)nb * Ho + oy) * Wo + ox;
-        float v[COUT];
 #pragma unroll
         for (int c = 0; c < COUT; ++c) {
-            v[c] = fmaf(acc[q][c >> 1][c & 1], a.scale[c], a.shift[c]);
-            if (a.relu) v[c] = fmaxf(v[c], 0.0f);
+            v[q][c] = fmaf(acc[q][c >> 1][c & 1], a.scale[c], a.shift[c]);
+            if (a.relu) v[q][c] = fmaxf(v[q][c], 0.0f);
         }
         if (a.skip) {
 #pragma unroll
             for (int c = 0; c < COUT; c += 4) {
                 const f32x4v s4 = ld4(a.skip + opix * COUT + c);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[c + k] += s4[k];
+                for (int k = 0; k < 4; ++k) v[q][c + k] += s4[k];
             }
         }
-        if (a.prob_w) {
-            float lo = v[0] * a.prob_w[0], hi = v[4] * a.prob_w[4];
-#pragma unroll
-            for (int k = 1; k < 4; ++k) { lo = fmaf(v[k], a.prob_w[k], lo); hi = fmaf(v[4 + k], a.prob_w[4 + k], hi); }
-            a.out[opix] = (lo + hi) + a.prob_b[0];
-        } else {
-#pragma unroll
-            for (int c = 0; c < COUT; c += 4) st4(a.out + opix * COUT + c, (f32x4v){v[c], v[c + 1], v[c + 2], v[c + 3]});
-        }
     }
+}
+
+// 8-channel dot product of the `prob` head (reference reg2d.prob, mvs4net_utils.py:900), same association as everywhere
+__device__ __forceinline__ float prob_logit(const float (&v)[8], const float* prob_w, const float* prob_b) {
+    float lo = v[0] * prob_w[0], hi = v[4] * prob_w[4];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { lo = fmaf(v[k], prob_w[k], lo); hi = fmaf(v[4 + k], prob_w[4 + k], hi); }
+    return (lo + hi) + prob_b[0];
+}
+
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256) deconv_small_kernel(DeconvArgs a) {
+    const int pix = xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    const int nb = blockIdx.y;
+    if (pix >= a.Hi * a.Wi) return;
+    const int i = pix / a.Wi, j = pix - i * a.Wi;
+    float v[4][COUT];
+    deconv_voxel<CIN, COUT>(a, nb, i, j, v);
+    const int Ho = 2 * a.Hi, Wo = 2 * a.Wi;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int oy = 2 * i + (q >> 1), ox = 2 * j + (q & 1);
+        const long opix = ((long)nb * Ho + oy) * Wo + ox;
+        if constexpr (COUT == 8) {
+            if (a.prob_w) {
+                a.out[opix] = prob_logit(v[q], a.prob_w, a.prob_b);
+                continue;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < COUT; c += 4) st4(a.out + opix * COUT + c, (f32x4v){v[q][c], v[q][c + 1], v[q][c + 2], v[q][c + 3]});
+    }
+}
+
+// reg2d's last layer AND the depth selection in one launch: conv11 (ConvTranspose 16 -> 8, BatchNorm, ReLU, + skip c0),
+// the 1x1x1 `prob` head, softmax over depth, first-max argmax, gather, confidence, inverse bounds
+// (models/mvs4net_utils.py:897-900, :1068-1088).  The logits never leave the chip: workgroup = 64 input pixels x D
+// hypotheses; thread (p, d) computes the 2 x 2 logits of its voxel, they meet in LDS, and thread (p, q) then finishes
+// output pixel q of p's 2 x 2 block with mv::select_from_logits -- the arithmetic of deconv_small_kernel followed by
+// select_depth_kernel, bit for bit.
+struct SelectOut {
+    const float* hypo;     // [B, D, Ho, Wo]
+    float *attn, *depth, *conf, *inv_min, *inv_max, *logits_out;   // conf / inv_* / logits_out optional
+    int D;
+    float split_itv;
+};
+
+template <int CIN>
+__global__ void __launch_bounds__(1024) deconv_select_kernel(DeconvArgs a, SelectOut so) {
+    __shared__ float lg[mv::kSelMaxD][4][64];
+    const int px = threadIdx.x, d = threadIdx.y;
+    const int pix = xcd_remap(blockIdx.x, gridDim.x) * 64 + px;
+    const int b = blockIdx.y;
+    const bool inside = pix < a.Hi * a.Wi;
+    const int pc = inside ? pix : a.Hi * a.Wi - 1;
+    const int i = pc / a.Wi, j = pc - i * a.Wi;
+    {
+        float v[4][8];
+        deconv_voxel<CIN, 8>(a, b * so.D + d, i, j, v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lg[d][q][px] = prob_logit(v[q], a.prob_w, a.prob_b);
+    }
+    __syncthreads();
+    if (!inside) return;
+    const int Ho = 2 * a.Hi, Wo = 2 * a.Wi;
+    const long hw = (long)Ho * Wo;
+    auto finish = [&](int q) {
+        const long p = (long)(2 * i + (q >> 1)) * Wo + (2 * j + (q & 1));
+        float l[mv::kSelMaxD];
+#pragma unroll
+        for (int dd = 0; dd < mv::kSelMaxD; ++dd) {
+            if (dd >= so.D) break;
+            l[dd] = lg[dd][q][px];
+            if (so.logits_out) so.logits_out[((long)b * so.D + dd) * hw + p] = l[dd];
+        }
+        const long vol = (long)b * so.D * hw, img = (long)b * hw;
+        mv::select_from_logits(l, so.hypo + vol, so.attn + vol, so.depth + img, so.conf ? so.conf + img : nullptr,
+                               so.inv_min ? so.inv_min + img : nullptr, so.inv_max ? so.inv_max + img : nullptr, so.D, hw, p,
+                               so.split_itv);
+    };
+    // output pixels q = d and d + D of the 2 x 2 block (D >= 2 covers all four)
+    if (d < 4) finish(d);
+    if (d + so.D < 4) finish(d + so.D);
 }
 
 }  // namespace
@@ -260,5 +339,29 @@ extern "C" int mvster_deconv_small(const float* in, const float* w, const float*
     } else {
         return MVSTER_ERR_UNSUPPORTED;
     }
+    return mv_check_launch();
+}
+
+// mvster_deconv_small (16 -> 8, fused `prob` head) + mvster_select_depth in one launch: in [B*D,Hi,Wi,16] (slices b*D + d),
+// skip [B*D,2Hi,2Wi,8] or null, hypo [B,D,2Hi,2Wi] -> attn [B,D,2Hi,2Wi], depth / conf / inv_min / inv_max [B,2Hi,2Wi]
+// (conf, inv_* optional), logits_out [B,D,2Hi,2Wi] optional.  Bit-identical to the two launches.  D <= 16.
+extern "C" int mvster_deconv_select(const float* in, const float* w, const float* scale, const float* shift, const float* skip,
+                                    const float* prob_w, const float* prob_b, const float* hypo, float* attn, float* depth,
+                                    float* conf, float* inv_min, float* inv_max, float* logits_out, int B, int D, int Hi,
+                                    int Wi, int cin, int relu, float split_itv, void* stream) {
+    if (!in || !w || !scale || !shift || !prob_w || !prob_b || !hypo || !attn || !depth) return MVSTER_ERR_NULL;
+    if ((inv_min == nullptr) != (inv_max == nullptr)) return MVSTER_ERR_NULL;
+    if (B <= 0 || D < 2 || D > mv::kSelMaxD || Hi <= 0 || Wi <= 0 || (inv_min && D < 3)) return MVSTER_ERR_SHAPE;
+    if (cin != 16) return MVSTER_ERR_UNSUPPORTED;
+    const long in_elems = (long)B * D * Hi * Wi * cin;
+    if (in_elems >= (1L << 30) || (long)B * D * Hi * Wi * 4 * 8 >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    DeconvArgs a;
+    a.in = in; a.w = w; a.scale = scale; a.shift = shift; a.skip = skip; a.prob_w = prob_w; a.prob_b = prob_b;
+    a.out = nullptr; a.NB = B * D; a.Hi = Hi; a.Wi = Wi; a.relu = relu; a.in_bytes = (unsigned)(in_elems * 4);
+    SelectOut so;
+    so.hypo = hypo; so.attn = attn; so.depth = depth; so.conf = conf; so.inv_min = inv_min; so.inv_max = inv_max;
+    so.logits_out = logits_out; so.D = D; so.split_itv = split_itv;
+    MV_NOTE_KERNEL("deconv_select_kernel<16>");
+    hipLaunchKernelGGL(deconv_select_kernel<16>, dim3((Hi * Wi + 63) / 64, B), dim3(64, D), 0, (hipStream_t)stream, a, so);
     return mv_check_launch();
 }

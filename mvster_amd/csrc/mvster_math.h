@@ -410,27 +410,14 @@ constexpr int kSelMaxD = 16;
 // prob 1x1x1 (optional) + softmax over D + first-max argmax + gather + inverse bounds
 // (mvs4net_utils.py:900, :1068-1088).  All pointers are one batch item's; plane stride = hw.
 // feat: [D, hw, CF] channels-last or null (then logits [D, hw] is read).
-MV_HD void select_pixel(const float* logits, const float* feat, const float* prob_w, const float* prob_b, int CF,
-                        const float* hypo, float* attn, float* depth, float* conf, float* inv_min, float* inv_max,
-                        float* logits_out, int D, long hw, long p, float split_itv) {
-    float lg[kSelMaxD];  // fully unrolled + guarded so that it stays in registers on the GPU
+// softmax over D + first-max argmax + gather + inverse bounds from the D logits of one pixel (lg is overwritten)
+MV_HD void select_from_logits(float (&lg)[kSelMaxD], const float* hypo, float* attn, float* depth, float* conf,
+                              float* inv_min, float* inv_max, int D, long hw, long p, float split_itv) {
     float mx = -INFINITY;
 #pragma unroll
     for (int d = 0; d < kSelMaxD; ++d) {
         if (d >= D) break;
-        const long o = d * hw + p;
-        float v;
-        if (feat) {
-            const float* f = feat + o * CF;
-            v = 0.0f;
-            for (int c = 0; c < CF; ++c) v = fmaf(f[c], prob_w[c], v);
-            v = add_rn(v, prob_b[0]);
-            if (logits_out) logits_out[o] = v;
-        } else {
-            v = logits[o];
-        }
-        lg[d] = v;
-        mx = fmaxf(mx, v);
+        mx = fmaxf(mx, lg[d]);
     }
     float den = 0.0f;
 #pragma unroll
@@ -460,6 +447,29 @@ MV_HD void select_pixel(const float* logits, const float* feat, const float* pro
         inv_min[p] = add_rn(inv_d, delta);
         inv_max[p] = sub_rn(inv_d, delta);
     }
+}
+
+MV_HD void select_pixel(const float* logits, const float* feat, const float* prob_w, const float* prob_b, int CF,
+                        const float* hypo, float* attn, float* depth, float* conf, float* inv_min, float* inv_max,
+                        float* logits_out, int D, long hw, long p, float split_itv) {
+    float lg[kSelMaxD];  // fully unrolled + guarded so that it stays in registers on the GPU
+#pragma unroll
+    for (int d = 0; d < kSelMaxD; ++d) {
+        if (d >= D) break;
+        const long o = d * hw + p;
+        float v;
+        if (feat) {
+            const float* f = feat + o * CF;
+            v = 0.0f;
+            for (int c = 0; c < CF; ++c) v = fmaf(f[c], prob_w[c], v);
+            v = add_rn(v, prob_b[0]);
+            if (logits_out) logits_out[o] = v;
+        } else {
+            v = logits[o];
+        }
+        lg[d] = v;
+    }
+    select_from_logits(lg, hypo, attn, depth, conf, inv_min, inv_max, D, hw, p, split_itv);
 }
 
 // F.interpolate(bilinear, align_corners=True) of one [hi, wi] map at output pixel p

@@ -174,14 +174,28 @@ __global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* _
     const int r0 = mv::make_lerp(ylo, Hh, H).i0, r1 = mv::make_lerp(yhi, Hh, H).i1;
     const int c0 = mv::make_lerp(xlo, Wh, W).i0, c1 = mv::make_lerp(xhi, Wh, W).i1;
     const int nr = r1 - r0 + 1, nc = c1 - c0 + 1;       // <= PR, <= PC
-    const float* g = G + (long)b * Hh * Wh * CGT + cbase;
-    // (walks the PC-wide patch, compile-time divisors, and skips the unused columns: a runtime `% nc` per element was
-    //  half of this loop's instructions)
-    for (int i = threadIdx.x; i < nr * PC * Q; i += 256) {
+    // Staging: ALL of a thread's loads are issued before the first one is consumed (up to 12 x 16 bytes in flight per
+    // thread; unused slots fall outside the buffer descriptor and cost nothing).  As a load-store loop the 10-odd trips
+    // each waited out a full memory latency, three workgroups per CU could not cover it, and the launch was
+    // latency-bound on its own staging (profiles/r03_i_fpn_gather.txt).  Walks the PC-wide patch with compile-time
+    // divisors and skips the unused columns.
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(G + (long)b * Hh * Wh * CGT + cbase), (short)0, (int)((long)Hh * Wh * CGT * 4 - cbase * 4), 0x00020000);
+    constexpr int NIT = (PR * PC * Q + 255) / 256;
+    f32x4 stg[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + it * 256;
         const int q = i % Q, pix = i / Q;
         const int pc = pix % PC, pr = pix / PC;
-        if (pc < nc)
-            patch[(pr * PC + pc) * Q + q] = ld4(g + ((long)(r0 + pr) * Wh + (c0 + pc)) * CGT + (q >> 1) * COT + (q & 1) * 4);
+        const bool ok = pr < nr && pc < nc;
+        const unsigned off = ok ? (unsigned)(((r0 + pr) * Wh + (c0 + pc)) * CGT + (q >> 1) * COT + (q & 1) * 4) * 4u : 0xFFFFFFF0u;
+        stg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grsrc, off, 0, 0));
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + it * 256;
+        if (i < PR * PC * Q) patch[i] = stg[it];               // (i = (pr * PC + pc) * Q + q)
     }
     if (threadIdx.x < 9 * CO) {
         const int cls = threadIdx.x / CO, c = threadIdx.x % CO;
@@ -566,7 +580,7 @@ extern "C" int mvster_fpn_tail_gather(const float* G, const float* vb, float* P,
         }
         return mv_check_launch();
     }
-    if (H >= 16 && W >= 64) {   // LDS-tiled gather (8 x 32 output tiles, 8 channels per workgroup)
+    if (H >= 16 && W >= 64 && (long)(H / 2) * (W / 2) * 9 * CO * 4 < (1L << 31)) {   // LDS-tiled gather (8 x 32 output tiles, 8 channels per workgroup; 32-bit offsets)
         const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
         if (CO == 8)
             hipLaunchKernelGGL(fpn_tail_gather_lds_kernel<8>, dim3(tiles_x * tiles_y * NB), block, 0, s, G, vb, P, NB, H, W,

@@ -252,7 +252,10 @@ class MVS4net(nn.Module):
                                       float(self.attn_temp), variant=self.warp_variant)
             plan = regs[s]
             want_logits = capture is not None
-            if plan.fused_prob:
+            if isinstance(plan, Reg2dPlan):
+                # (the U-Net's last layer, the prob head and the selection in one launch where the plan allows it)
+                sel = plan.select(cor, hypo, self.depth_interals_ratio[s], self.inverse_depth, want_logits=want_logits)
+            elif plan.fused_prob:
                 sel = ops.select_depth(hypo, self.depth_interals_ratio[s], self.inverse_depth, feat_cl=plan(cor),
                                        prob_w=plan.prob_w, prob_b=plan.prob_b, want_logits=want_logits)
             else:

@@ -197,6 +197,35 @@ def test_warp_agg_kernel_variants_bit_identical(C, G, D, fuse):
             assert torch.equal(ws, wbase), (C, G, D, h, w, variant)
 
 
+@pytest.mark.parametrize("D,inverse,G,shape", [(4, True, 4, (1, 37, 53)), (8, True, 8, (2, 16, 24)), (4, False, 4, (1, 64, 80)),
+                                               (3, True, 4, (1, 9, 70)), (16, True, 8, (1, 10, 12)), (2, False, 4, (1, 6, 6))])
+def test_fused_conv11_selection_bit_identical(D, inverse, G, shape):
+    """Reg2dPlan.select: reg2d's last layer + prob head + softmax / argmax / gather / bounds in one launch
+    (mvster_deconv_select) against the two launches (deconv_small with the fused prob head, then select_depth): every
+    output equal, incl. the optional logits, odd sizes and every D the selection kernel takes."""
+    torch.manual_seed(D * 7 + G)
+    m = M.reg2d(input_channel=G, base_channel=8)
+    m.load_state_dict(randomize_state(m.state_dict(), seed=3, prob_gain=8.0))
+    plan = cp.Reg2dPlan(m.to(DEV).eval())
+    B, h, w = shape
+    h, w = h // 8 * 8 or 8, w // 8 * 8 or 8                                  # the U-Net halves three times
+    x = torch.randn(B, D, h, w, G, device=DEV)
+    hypo = (1.0 / (1.0 / 900 + 2e-5 * (torch.arange(D).view(1, D, 1, 1) + 0.1 * torch.rand(B, D, h, w)))).float().to(DEV)
+    cp.FUSE_SELECT = False
+    try:
+        want = plan.select(x, hypo, 0.5, inverse, want_logits=True)
+    finally:
+        cp.FUSE_SELECT = True
+    got = plan.select(x, hypo, 0.5, inverse, want_logits=True)
+    from mvster_amd import _lib
+    assert _lib.last_kernel() == "deconv_select_kernel<16>"
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), (k, (got[k] - want[k]).abs().max().item())
+    plain = plan.select(x, hypo, 0.5, inverse)
+    assert "logits" not in plain and torch.equal(plain["depth"], want["depth"])
+
+
 @pytest.mark.parametrize("C,G,D", [(8, 4, 4), (16, 4, 4), (8, 8, 8), (16, 8, 4), (8, 4, 8), (16, 4, 8)])
 @pytest.mark.parametrize("fuse", [True, False])
 @pytest.mark.parametrize("regime", ["smooth", "random", "mixed", "planes"])
