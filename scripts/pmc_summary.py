@@ -14,7 +14,7 @@ agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(os.path.join(root, "*", "*counter_collection.csv")):
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            k = r.get("Kernel_Name", "?").replace("(anonymous namespace)::", "").replace("void ", "")
+            k = r.get("Kernel_Name", "?").replace("(anonymous namespace)::", "").replace("void ", "").replace("mvconv::", "")
             k = k.split("(")[0]
             a = agg[k][r.get("Counter_Name")]
             a[0] += float(r.get("Counter_Value", 0) or 0)

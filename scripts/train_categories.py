@@ -13,10 +13,11 @@ for r in rows:
     n = r["Name"]
     t, c = float(r["TotalDurationNs"]) / steps / 1e6, int(r["Calls"]) / steps
     if "wgrad" in n: k = "weight gradients (+finish)"
-    elif "conv_" in n or "deconv" in n: k = "conv forward / input gradient"
+    elif "conv_" in n or "deconv" in n or "conv1x1" in n: k = "conv forward / input gradient"
     elif "bn_" in n[:60]: k = "BatchNorm kernels"
     elif "warp_agg_bwd" in n or "scatter_gather" in n or "absmax" in n: k = "warp backward"
     elif "warp_agg_fwd" in n: k = "warp forward"
+    elif "select_depth" in n: k = "stage selection (fwd + bwd)"
     elif "fpn_" in n: k = "FPN gather / adjoint"
     elif "at::native" in n or "rocclr" in n or "Cijk" in n or "rocblas" in n or "at::" in n: k = "torch (aten) kernels"
     elif "pack_weights" in n: k = "weight re-pack"
