@@ -111,7 +111,7 @@ int mvster_upsample_bilinear(const float* in, float* out, int B, int hi, int wi,
  * variant 0 = direct (operands from L1), 1 = LDS-staged input patch (ordinary convs, cin % 16 == 0,
  * mt in {2,4}: the workgroup tile is 2*mt rows x 32 columns), 2 = direct with the 4 waves of a workgroup
  * splitting K (small deep layers; cin >= 16, mt*nt <= 4), 5 = persistent workgroups with LDS-DMA double-buffered
- * input patches and workgroup-resident weights (ordinary convs, cin in {16, 32}, cout % 16 == 0, kernels
+ * input patches and workgroup-resident weights (ordinary convs, cin in {16, 32, 64}, cout % 16 == 0, kernels
  * (1|3)x3x3 and 1x5x5, in-plane stride 1 or 2, mt = 2; bits 8.. of `variant` = workgroups per CU, 0 = default),
  * 6 = persistent 1x1x1 kernel with all packed weights resident in LDS and the input read once (cin in {32, 64},
  * cout % 4 == 0, optional same-shape skip; nt is ignored: a wave walks all N tiles).

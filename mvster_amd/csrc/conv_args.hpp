@@ -57,6 +57,8 @@ static inline void find_divisor(unsigned d, unsigned& mul, unsigned& shr) {
 
 // conv_pers.hip: persistent LDS-DMA kernel family (variant 5 of mvster_conv_mfma); wpc = workgroups per CU (0 = default)
 int dispatch_pers(const ConvArgs& a, int mt, int nt, int wpc, hipStream_t s);
+// conv_pers.hip: ping-pong form of the persistent kernel, eight waves per workgroup (variant 7)
+int dispatch_pp(const ConvArgs& a, int mt, int nt, hipStream_t s);
 // conv_pers.hip: persistent 1x1 kernel with all weights in LDS (variant 6)
 int dispatch_1x1(const ConvArgs& a, int mt, int wpc, hipStream_t s);
 

@@ -365,6 +365,311 @@ __global__ void __launch_bounds__(256) conv_pers_kernel(ConvArgs a, PersArgs p) 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Ping-pong form of the persistent kernel (variant 7): a workgroup of EIGHT waves, two per SIMD.  The model fitted to
+// conv_pers_kernel's measurements says its steady state is 58-61 % MFMA-busy because a wavefront's
+// address arithmetic, DMA issue, barrier wait and epilogue (~1 700 cycles per tile) are not overlapped with MFMAs -- not
+// by hipcc inside the wave, and not by a second workgroup on the CU either, which runs in phase with the first.  Here
+// the overlap is built into the structure (see the main loop).
+// ------------------------------------------------------------------------------------------------------------------
+template <int MT, int NT, int KW, int SW, int NCH, int KD, bool WREG, int PF, bool SKIP>
+__global__ void __launch_bounds__(512) conv_pp_kernel(ConvArgs a, PersArgs p) {
+    using G = PersGeom<MT, KW, SW, KD>;
+    constexpr int TY = G::TY, KH = G::KH, PW = G::PW, PH = G::PH, PWH = G::PWH, PLANE = G::PLANE, NBLK = G::NBLK;
+    constexpr int NTAP = KD * KH * KW, TAPS2D = KH * KW;
+    constexpr int BUF = NCH * 2 * PLANE;                    // float4 per patch buffer
+    constexpr int NI = NCH * 2 * NBLK;                      // DMA wave-instructions per tile
+    constexpr int NIW = (NI + 3) / 4;
+    constexpr int CIN = NCH * 16;
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave8 >> 2;                             // which half of the workgroup: its own tiles, its own two patch buffers
+    const int wave = wave8 & 3;                             // wave inside the half: M tiles and DMA slots as in conv_pers_kernel
+    f32x4v* const lds = reinterpret_cast<f32x4v*>(lds_raw) + grp * 2 * BUF;
+    f32x4v* const scratch = reinterpret_cast<f32x4v*>(lds_raw) + 4 * BUF;    // 64 float4: target of the surplus DMA slots
+    f32x4v* const wl = scratch + 64;                        // [tap][chunk][nt][lane], shared by both halves (unused with WREG)
+    const int lm = lane & 15, lq = lane >> 4;
+    const int nt0 = blockIdx.y * NT;
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)a.in_bytes, 0x00020000);
+
+    // ---- tile-independent per-lane part of the DMA addresses ------------------------------------------------------
+    // instruction i = wave + 4n -> (chunk c, plane pl, block blk); lane -> slot blk*64 + lane of that plane
+    // slot -> (patch row, px, quad parity).  dbase = byte offset of the lane's 16 bytes relative to the patch origin
+    // (0x80000000 for slots that hold no pixel: stays out of range after adding any tile origin < 2^31);
+    // dpos = px | py << 8 | pz << 16 for the border tiles, whose out-of-image lanes are sent out of range one by one.
+    unsigned dbase[NIW];
+    int dpos[NIW];
+#pragma unroll
+    for (int n = 0; n < NIW; ++n) {
+        const int i = wave + 4 * n;
+        const int c = i / (2 * NBLK), r = i - c * 2 * NBLK, pl = r / NBLK, blk = r - pl * NBLK;
+        const int s = blk * 64 + lane;
+        const int q1 = s & 1;
+        int prow, px;
+        if (SW == 1) {
+            const int pix = s >> 1;
+            prow = pix / PW;
+            px = pix - prow * PW;
+        } else {
+            int t = s >> 1;
+            const int xh = t % PWH;
+            t /= PWH;
+            prow = t >> 1;
+            px = 2 * xh + (t & 1);
+        }
+        const bool valid = i < NI && prow < G::ROWS && px < PW;
+        const int pz = KD == 1 ? 0 : prow / PH, py = prow - pz * PH;
+        dpos[n] = px | (py << 8) | (pz << 16);
+        dbase[n] = valid ? (unsigned)(((pz * a.Hi + py) * a.Wi + px) * (CIN * 4) + (c * 16 + pl * 8 + q1 * 4) * 4) : 0x80000000u;
+    }
+
+    auto decode_tile = [&](unsigned tile) -> TilePos {
+        TilePos t;
+        // (branch-free: a select on the divisor being 1 would split the loop body into several basic blocks)
+        auto div = [&](unsigned n, int k) -> unsigned { return ((__umulhi(n, p.mul[k]) >> p.shr[k]) & ~p.one[k]) | (n & p.one[k]); };
+        unsigned q = div(tile, 0);
+        t.tx0 = (int)(tile - q * p.tiles_x) * 32;
+        unsigned q2 = div(q, 1);
+        t.ty0 = (int)(q - q2 * p.tiles_y) * TY;
+        const unsigned q3 = div(q2, 2);
+        t.zo = (int)(q2 - q3 * (unsigned)a.Do);
+        t.b = (int)q3;
+        return t;
+    };
+
+    // (branch-free: on interior tiles every lane's bounds test passes; `live` = false sends the whole patch out of range --
+    //  used for the DMA slot of a tile that does not exist, so that the loop body stays one basic block)
+    auto dma_tile = [&](const TilePos& t, int buf, bool live) {
+        const int iz0 = t.zo * a.sd - a.pd[0], iy0 = t.ty0 * SW - a.ph[0], ix0 = t.tx0 * SW - a.pw[0];
+        // byte offset of the patch origin (may be negative on border tiles: 32-bit wrap-around arithmetic)
+        const unsigned origin = (unsigned)((((t.b * a.Di + iz0) * a.Hi + iy0) * a.Wi + ix0) * (CIN * 4));
+        const unsigned wi = live ? (unsigned)a.Wi : 0u;
+        f32x4v* const dst0 = lds + buf * BUF;
+#pragma unroll
+        for (int n = 0; n < NIW; ++n) {
+            const int i = wave + 4 * n;
+            {
+                const int ix = ix0 + (dpos[n] & 255), iy = iy0 + ((dpos[n] >> 8) & 255), iz = iz0 + (dpos[n] >> 16);
+                bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < wi;
+                if (KD > 1) ok = ok && (unsigned)iz < (unsigned)a.Di;
+                // (named operands: hipcc 7.2 silently drops the kernel's host stub when this builtin is handed an arithmetic
+                //  expression as its offset)
+                const unsigned off = ok ? dbase[n] + origin : 0x80000000u;
+                // (a wave without an n-th slot still issues it -- into the scratch block, every lane out of range: no
+                //  wave-dependent branch in the loop body)
+                f32x4v* const dst = (NI % 4 == 0 || n + 1 < NIW || i < NI) ? dst0 + (i / NBLK) * PLANE + (i % NBLK) * 64 : scratch;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_void*)dst, 16, off, 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- once per workgroup: weights, scale / shift, A-read bases ------------------------------------------------
+    const unsigned nwg = gridDim.x;
+    const unsigned first = xcd_remap(blockIdx.x, nwg);   // the workgroup's tiles: first, first + nwg, ...; half grp takes every other one
+    const unsigned ntl = first < p.ntiles ? (p.ntiles - first + nwg - 1) / nwg : 0u;       // tiles of this workgroup
+    const int kcount = (int)((ntl + 1u - (unsigned)grp) >> 1);                           // ... of this half
+    auto tile_of = [&](int k) -> unsigned { return first + (unsigned)(2 * k + grp) * nwg; };
+    if (kcount > 0) dma_tile(decode_tile(tile_of(0)), 0, true);
+    if (grp == 0 && kcount > 1) dma_tile(decode_tile(tile_of(1)), 1, true);   // (half 0 computes first: its second patch too)
+    f32x4v wreg[WREG ? NTAP * NCH * NT : 1];
+    const long wstep = (long)a.ntile_total * 256;          // floats per K step of the packed weights
+    if (WREG) {
+#pragma unroll
+        for (int s = 0; s < NTAP * NCH; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                wreg[s * NT + nt] = *reinterpret_cast<const f32x4v*>(a.wpk + s * wstep + ((long)(nt0 + nt) * 64 + lane) * 4);
+    } else {
+        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.wpk), (short)0, (int)(NTAP * NCH * wstep * 4), 0x00020000);
+        for (int i = wave8; i < NTAP * NCH * NT; i += 8) {
+            const int s = i / NT, nt = i - s * NT;
+            const unsigned off = (unsigned)((s * wstep + (long)(nt0 + nt) * 256) * 4) + lane * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(wl + i * 64), 16, off, 0, 0, 0);
+        }
+    }
+    f32x4v scv[NT], shv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n0 = (nt0 + nt) * 16 + lq * 4;
+        scv[nt] = *reinterpret_cast<const f32x4v*>(a.scale + n0);
+        shv[nt] = *reinterpret_cast<const f32x4v*>(a.shift + n0);
+    }
+    // float4 index (inside a chunk's plane pair) of this lane's A operand for tap (0,0,0) of each of its M tiles
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int t = wave * MT + mt;
+        const int row = t >> 1, x = (t & 1) * 16 + lm;
+        const int rs = G::ROWSLOTS;
+        abase[mt] = (SW == 1 ? row * rs + x * 2 : row * 2 * rs + x * 2) + (lq >> 1) * PLANE + (lq & 1);
+    }
+    // output (and skip) byte offset of this lane's 4 channels of each M tile, relative to the tile's first pixel
+    const __amdgpu_buffer_rsrc_t out_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t skip_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(SKIP ? a.skip : a.in), (short)0, SKIP ? (int)p.out_bytes : 0, 0x00020000);
+    unsigned obase[MT];
+    int orc[MT];            // row | col << 8 of the M tile's pixel inside the workgroup tile
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int t = wave * MT + mt;
+        const int row = t >> 1, col = (t & 1) * 16 + lm;
+        orc[mt] = row | (col << 8);
+        obase[mt] = (unsigned)((row * a.Wo + col) * a.cout + nt0 * 16 + lq * 4) * 4u;
+    }
+    auto tap_off = [&](int kz, int ky, int kx) -> int {     // float4 offset of a tap relative to abase (compile-time)
+        const int prow = kz * PH + ky;
+        return SW == 1 ? prow * G::ROWSLOTS + kx * 2 : prow * G::ROWSLOTS + (kx & 1) * PWH * 2 + (kx >> 1) * 2;
+    };
+
+    __syncthreads();        // (waits vmcnt(0): first patch and the weights have landed)
+
+    // The loop body is ONE basic block (2-D kernels): the DMA of tile t+1, the MFMAs of tile t and the epilogue of tile
+    // t-1 are independent instruction streams that the scheduler interleaves -- at one wavefront per SIMD nothing else
+    // could fill the matrix pipe's shadow.  Stores stay below the DMA issues (sched_barrier) so that a counted
+    // vmcnt(stores) before the barrier means "the next patch has landed" without draining the stores.
+    f32x4v pacc[MT][NT], pskv[MT][NT];
+    unsigned pooff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        pooff[mt] = 0x80000000u;                 // nothing to store in the first round
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) pacc[mt][nt] = pskv[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    }
+    auto epilogue = [&](const f32x4v (&accv)[MT][NT], const f32x4v (&skvv)[MT][NT], const unsigned (&off)[MT]) {
+        // the accumulator is D^T (weights in the A slot): 4 consecutive output channels of one voxel per lane
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4v v = accv[mt][nt];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = fmaf(v[j], scv[nt][j], shv[nt][j]);
+                    if (a.relu) v[j] = fmaxf(v[j], 0.0f);
+                    if (SKIP) v[j] += skvv[mt][nt][j];
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, off[mt] + nt * 64, 0, 0);
+            }
+        }
+    };
+
+    // Half-phases: in even ones half 0 runs the MFMAs of its tile k while half 1 "prepares" (epilogue of its previous tile,
+    // output offsets / skip loads of its next one, DMA issue for the one after, counted wait for the patch it is about to
+    // use); in odd ones the roles swap; one barrier of all eight waves per half-phase.  The two wavefronts that share a SIMD
+    // are therefore ALWAYS in anti-phase: one feeds the matrix pipe, the other issues its scalar / vector / memory work in
+    // the pipe's shadow.
+    f32x4v skvN[MT][NT];
+    unsigned ooffN[MT];
+    TilePos here = decode_tile(kcount > 0 ? tile_of(0) : 0u);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) ooffN[mt] = 0x80000000u;
+    const int nhalf = 2 * (int)((ntl + 1u) >> 1) + 1;
+    // (the prepare step of half 0 belongs to odd half-phases, that of half 1 to even ones; both start by preparing tile 0's
+    //  offsets here, outside the loop, because half 0's first MFMA phase comes before its first prepare phase)
+    {
+        const unsigned oorigin = (unsigned)((((here.b * a.Do + here.zo) * a.Ho + here.ty0) * a.Wo + here.tx0) * a.cout) * 4u;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bool ok = grp == 0 && kcount > 0 && here.ty0 + (orc[mt] & 255) < a.Ho && here.tx0 + (orc[mt] >> 8) < a.Wo;
+            ooffN[mt] = ok ? obase[mt] + oorigin : 0x80000000u;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                skvN[mt][nt] = SKIP ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, ooffN[mt] + nt * 64, 0, 0))
+                                    : (f32x4v){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    for (int hp = 0; hp < nhalf; ++hp) {
+        if ((hp & 1) == grp) {
+            // ---------------- MFMA half-phase: tile k of this half --------------------------------------------------
+            const int k = (hp - grp) >> 1;
+            if (k < kcount) {
+                const int cur = k & 1;
+                f32x4v acc[MT][NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+                const f32x4v* patch = lds + cur * BUF;
+                const int kz_lo = KD == 1 ? 0 : max(0, a.pd[0] - here.zo * a.sd), kz_hi = KD == 1 ? 1 : min(KD, a.Di + a.pd[0] - here.zo * a.sd);
+#pragma unroll
+                for (int kz = 0; kz < KD; ++kz) {
+                    if (kz < kz_lo || kz >= kz_hi) continue;
+                    f32x4v A[PF + 1][NCH][MT], Bv[PF + 1][NCH][NT];
+                    auto load_tap = [&](int t2, f32x4v (&Aa)[NCH][MT], f32x4v (&Bb)[NCH][NT]) {
+                        const int ky = t2 / KW, kx = t2 - ky * KW;
+                        const int to = tap_off(kz, ky, kx);
+                        const int tap = kz * TAPS2D + t2;
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) Aa[c][mt] = patch[abase[mt] + c * 2 * PLANE + to];
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                Bb[c][nt] = WREG ? wreg[(tap * NCH + c) * NT + nt] : wl[((tap * NCH + c) * NT + nt) * 64 + lane];
+                        }
+                    };
+#pragma unroll
+                    for (int t2 = 0; t2 < PF && t2 < TAPS2D; ++t2) load_tap(t2, A[t2 % (PF + 1)], Bv[t2 % (PF + 1)]);
+#pragma unroll
+                    for (int t2 = 0; t2 < TAPS2D; ++t2) {
+                        if (t2 + PF < TAPS2D) load_tap(t2 + PF, A[(t2 + PF) % (PF + 1)], Bv[(t2 + PF) % (PF + 1)]);
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                    for (int nt = 0; nt < NT; ++nt)
+                                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bv[t2 % (PF + 1)][c][nt][j], A[t2 % (PF + 1)][c][mt][j],
+                                                                                           acc[mt][nt], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    pooff[mt] = ooffN[mt];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        pacc[mt][nt] = acc[mt][nt];
+                        pskv[mt][nt] = skvN[mt][nt];
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): done reading this patch
+        } else {
+            // ---------------- prepare half-phase (the other half owns the matrix pipe) --------------------------------
+            const int kn = (hp + 1 - grp) >> 1;                          // the tile whose MFMAs come next half-phase
+            epilogue(pacc, pskv, pooff);                                 // tile kn - 1 (out-of-range offsets: nothing stored)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) pooff[mt] = 0x80000000u;
+            __builtin_amdgcn_sched_barrier(0);
+            const bool have = kn < kcount;
+            here = decode_tile(have ? tile_of(kn) : 0u);
+            const unsigned oorigin = (unsigned)((((here.b * a.Do + here.zo) * a.Ho + here.ty0) * a.Wo + here.tx0) * a.cout) * 4u;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bool ok = have && here.ty0 + (orc[mt] & 255) < a.Ho && here.tx0 + (orc[mt] >> 8) < a.Wo;
+                ooffN[mt] = ok ? obase[mt] + oorigin : 0x80000000u;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    skvN[mt][nt] = SKIP ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, ooffN[mt] + nt * 64, 0, 0))
+                                        : (f32x4v){0.f, 0.f, 0.f, 0.f};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const bool more = kn + 1 < kcount;
+            dma_tile(decode_tile(more ? tile_of(kn + 1) : 0u), (kn + 1) & 1, more);
+            // the patch of tile kn (its DMA was issued one prepare phase ago) has landed once only this phase's own
+            // memory operations are outstanding: MT*NT stores, the skip loads, NIW DMA instructions
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * NT * (SKIP ? 2 : 1) + NIW) : "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // 1x1 convolutions with many output channels (variant 6): the 64 -> 144 / 64 -> 72 "tap" convolutions of the
 // re-associated FPN levels (conv_plan.FpnPlan), 64 -> 64 / 32 -> 64 laterals.  The direct kernel walks 3 (5) N tiles per
 // pass over the input, i.e. reads the input 3 (1) times and the weights from L1 for every M tile: 135.6 MB of HBM traffic
@@ -525,6 +830,53 @@ int launch_pers(const ConvArgs& a, int wpc, hipStream_t s) {
     return mv_check_launch();
 }
 
+template <int MT, int NT, int KW, int SW, int NCH, int KD, bool WREG, int PF, bool SKIP>
+int launch_pp(const ConvArgs& a, hipStream_t s) {
+    using G = PersGeom<MT, KW, SW, KD>;
+    constexpr int NTAP = KD * KW * KW;
+    const size_t lds = (size_t)(4 * NCH * 2 * G::PLANE + 64 + (WREG ? 0 : NTAP * NCH * NT * 64)) * 16;
+    if (lds > 160 * 1024) return MVSTER_ERR_UNSUPPORTED;
+    auto kern = conv_pp_kernel<MT, NT, KW, SW, NCH, KD, WREG, PF, SKIP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return MVSTER_ERR_LAUNCH;
+        attr_set = true;
+    }
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MVSTER_ERR_LAUNCH;
+        g_num_cu = prop.multiProcessorCount;
+    }
+    PersArgs p;
+    p.tiles_x = (unsigned)((a.Wo + 31) / 32);
+    p.tiles_y = (unsigned)((a.Ho + G::TY - 1) / G::TY);
+    const long ntiles = (long)p.tiles_x * p.tiles_y * a.Do * a.B;
+    const long out_bytes = (long)a.B * a.DoF * a.HoF * a.WoF * a.cout * 4;
+    if (ntiles >= (1L << 30) || a.in_bytes >= (1u << 31) || out_bytes >= (1L << 31)) return MVSTER_ERR_UNSUPPORTED;
+    p.ntiles = (unsigned)ntiles;
+    p.out_bytes = (unsigned)out_bytes;
+    p.prio = 0;
+    const unsigned divisors[3] = {p.tiles_x, p.tiles_y, (unsigned)a.Do};
+    for (int i = 0; i < 3; ++i) {
+        find_divisor(divisors[i], p.mul[i], p.shr[i]);
+        p.one[i] = divisors[i] == 1 ? ~0u : 0u;
+    }
+    // one workgroup (8 waves) per CU; every workgroup walks the same number of tiles, an even number where possible
+    // (both halves busy in every half-phase)
+    const int ny = a.ntile_total / NT;
+    long gmax = (long)g_num_cu / ny;
+    if (gmax < 1) gmax = 1;
+    long per = (ntiles + gmax - 1) / gmax;
+    if (per > 1 && (per & 1)) ++per;
+    const long gx = (ntiles + per - 1) / per;
+    MV_NOTE_KERNEL("conv_pp_kernel<%d, %d, %d, %d, %d, %d, %s, %d, %s>", MT, NT, KW, SW, NCH, KD, WREG ? "true" : "false", PF,
+                   SKIP ? "true" : "false");
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, ny, 1), dim3(512), lds, s, a, p);
+    return mv_check_launch();
+}
+
 }  // namespace
 
 #ifdef MVSTER_TIMELINE
@@ -581,11 +933,28 @@ int dispatch_1x1(const ConvArgs& a, int mt, int wpc, hipStream_t s) {
     return MVSTER_ERR_UNSUPPORTED;
 }
 
-// Layers the family covers: ordinary (non-transposed) convolutions, cin in {16, 32}, cout % 16 == 0, kernel (1|3) x 3 x 3
+// variant 7: the ping-pong form; the instances whose four patch buffers (+ resident weights) fit 160 KB of LDS
+int dispatch_pp(const ConvArgs& a, int mt, int nt, hipStream_t s) {
+    if (a.nclass != 1 || a.osd != 1 || a.osh != 1 || a.osw != 1 || a.skip_mode > 1 || a.prob_w || a.cout % 16 != 0 ||
+        a.sh != a.sw || a.kh[0] != a.kw[0] || a.ntile_total % nt != 0 || mt != 2 || a.cin % 16 != 0)
+        return MVSTER_ERR_UNSUPPORTED;
+    const int kd = a.kd[0], kw = a.kw[0], sw = a.sw, nch = a.cin / 16;
+#define MV_PP(NT_, KW_, SW_, NCH_, KD_, WREG_, PF_) \
+    if (nt == NT_ && kw == KW_ && sw == SW_ && nch == NCH_ && kd == KD_)                                        \
+        return a.skip_mode == 1 ? launch_pp<2, NT_, KW_, SW_, NCH_, KD_, WREG_, PF_, true>(a, s)                 \
+                                : launch_pp<2, NT_, KW_, SW_, NCH_, KD_, WREG_, PF_, false>(a, s);
+    MV_PP(1, 3, 1, 1, 1, true, 2)      // 16 -> 16 3x3
+    MV_PP(2, 3, 1, 2, 1, false, 1)     // 32 -> 32 3x3
+    MV_PP(2, 3, 2, 1, 1, true, 1)      // 16 -> 32 3x3 stride 2
+#undef MV_PP
+    return MVSTER_ERR_UNSUPPORTED;
+}
+
+// Layers the family covers: ordinary (non-transposed) convolutions, cin in {16, 32, 64}, cout % 16 == 0, kernel (1|3) x 3 x 3
 // or 1 x 5 x 5 with "same" padding geometry handled by the generic bounds checks, stride 1 or 2 in-plane.
 int dispatch_pers(const ConvArgs& a, int mt, int nt, int wpc, hipStream_t s) {
     if (a.nclass != 1 || a.osd != 1 || a.osh != 1 || a.osw != 1 || a.skip_mode > 1 || a.prob_w || a.cout % 16 != 0 ||
-        a.sh != a.sw || a.kh[0] != a.kw[0] || a.ntile_total % nt != 0 || (mt != 2 && mt != 4))
+        a.sh != a.sw || a.kh[0] != a.kw[0] || a.ntile_total % nt != 0 || mt != 2)
         return MVSTER_ERR_UNSUPPORTED;
     const int kd = a.kd[0], kw = a.kw[0], sw = a.sw, nch = a.cin / 16;
     if (a.cin % 16 != 0) return MVSTER_ERR_UNSUPPORTED;
@@ -596,6 +965,8 @@ int dispatch_pers(const ConvArgs& a, int mt, int nt, int wpc, hipStream_t s) {
                                 : launch_pers<MT_, NT_, KW_, SW_, NCH_, KD_, WREG_, PF_, false>(a, wpc, s);
     MV_P(1, 3, 1, 1, 1, true, 2)      // 16 -> 16 3x3           (FPN conv1.1/1.2, composed mid level)
     MV_P(2, 3, 1, 2, 1, false, 1)     // 32 -> 32 3x3           (FPN conv2.1/2.2)
+    MV_P(1, 3, 1, 2, 1, false, 1)     // 32 -> N 3x3, one N tile per workgroup
+    MV_P(1, 3, 1, 4, 1, false, 1)     // 64 -> N 3x3, one N tile per workgroup (36 KB of weights + 2 x 58 KB of patch: one workgroup per CU)
     MV_P(2, 5, 2, 1, 1, false, 1)     // 16 -> 32 5x5 stride 2  (FPN conv2.0)
     MV_P(1, 3, 1, 1, 3, false, 2)     // 16 -> 16 3x3x3         (reg2d conv2)
     MV_P(2, 3, 2, 1, 1, false, 1)     // 16 -> 32 3x3 stride 2  (reg2d conv3)

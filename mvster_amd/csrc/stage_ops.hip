@@ -345,42 +345,50 @@ fpn_lateral_up_kernel(const float* __restrict__ x, const float* __restrict__ A, 
     const f32x4 bv = ld4(bias + chunk * 4);
     const float* qb = q + (long)b * Hh * Wh * CO + chunk * 4;
     const int base = xcd_remap(blockIdx.x, gridDim.x) * (kLateralSlots * kLateralIters);
-    // kLateralPix pixels per trip, all their loads issued first (measured: 1 -> 54 us, 2 -> 59 us, 4 -> 59 us; the
-    // kernel moves 173 MB, i.e. 3.2 TB/s, like the MFMA layers that write a tensor of this size)
-    for (int it = 0; it < kLateralIters; it += kLateralPix) {
-        mv::Lerp ly[kLateralPix], lx[kLateralPix];
-        f32x4 xv[kLateralPix][CI / 4], q00[kLateralPix], q01[kLateralPix], q10[kLateralPix], q11[kLateralPix];
-        int pp[kLateralPix];
+    // Software-pipelined over the workgroup's 16 pixels per slot: the nine loads of pixel it + 1 are in flight under the
+    // arithmetic of pixel it.  (As load -> compute -> store trips each trip waited out a memory latency; issuing the loads
+    // of 2 or 4 pixels together and then computing them was measured no better: 54 / 59 / 59 us.)
+    struct Px {
+        mv::Lerp ly, lx;
+        f32x4 xv[CI / 4], q00, q01, q10, q11;
+        int p;
+    };
+    auto fetch = [&](int it, Px& o) {
+        const int p = base + it * kLateralSlots + slot;
+        o.p = p;
+        const int pc = min(p, H * W - 1);
+        unsigned xu;
+        const int y = (int)fdivmod((unsigned)pc, wdiv, xu);
+        const int xx = (int)xu;
+        o.ly = mv::make_lerp(y, Hh, H);
+        o.lx = mv::make_lerp(xx, Wh, W);
+        const float* xp = x + ((long)b * H * W + pc) * CI;
 #pragma unroll
-        for (int u = 0; u < kLateralPix; ++u) {
-            const int p = base + (it + u) * kLateralSlots + slot;
-            pp[u] = p;
-            const int pc = min(p, H * W - 1);
-            unsigned xu;
-            const int y = (int)fdivmod((unsigned)pc, wdiv, xu);
-            const int xx = (int)xu;
-            ly[u] = mv::make_lerp(y, Hh, H);
-            lx[u] = mv::make_lerp(xx, Wh, W);
-            const float* xp = x + ((long)b * H * W + pc) * CI;
+        for (int c = 0; c < CI / 4; ++c) o.xv[c] = ld4(xp + 4 * c);
+        o.q00 = ld4(qb + ((long)o.ly.i0 * Wh + o.lx.i0) * CO);
+        o.q01 = ld4(qb + ((long)o.ly.i0 * Wh + o.lx.i1) * CO);
+        o.q10 = ld4(qb + ((long)o.ly.i1 * Wh + o.lx.i0) * CO);
+        o.q11 = ld4(qb + ((long)o.ly.i1 * Wh + o.lx.i1) * CO);
+    };
+    auto finish = [&](const Px& o) {
+        f32x4 r;
 #pragma unroll
-            for (int c = 0; c < CI / 4; ++c) xv[u][c] = ld4(xp + 4 * c);
-            q00[u] = ld4(qb + ((long)ly[u].i0 * Wh + lx[u].i0) * CO);
-            q01[u] = ld4(qb + ((long)ly[u].i0 * Wh + lx[u].i1) * CO);
-            q10[u] = ld4(qb + ((long)ly[u].i1 * Wh + lx[u].i0) * CO);
-            q11[u] = ld4(qb + ((long)ly[u].i1 * Wh + lx[u].i1) * CO);
+        for (int j = 0; j < 4; ++j) {
+            float acc = bv[j];
+#pragma unroll
+            for (int c = 0; c < CI; ++c) acc = fmaf(a[j][c], o.xv[c / 4][c % 4], acc);
+            r[j] = mv::bilerp(o.ly, o.lx, o.q00[j], o.q01[j], o.q10[j], o.q11[j]) + acc;
         }
-#pragma unroll
-        for (int u = 0; u < kLateralPix; ++u) {
-            f32x4 r;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float acc = bv[j];
-#pragma unroll
-                for (int c = 0; c < CI; ++c) acc = fmaf(a[j][c], xv[u][c / 4][c % 4], acc);
-                r[j] = mv::bilerp(ly[u], lx[u], q00[u][j], q01[u][j], q10[u][j], q11[u][j]) + acc;
-            }
-            if (pp[u] < H * W) st4(out + ((long)b * H * W + pp[u]) * CO + chunk * 4, r);
-        }
+        if (o.p < H * W) st4(out + ((long)b * H * W + o.p) * CO + chunk * 4, r);
+    };
+    Px cur, nxt;
+    fetch(0, cur);
+#pragma unroll 1
+    for (int it = 0; it < kLateralIters; it += 2) {
+        fetch(it + 1, nxt);
+        finish(cur);
+        fetch(it + 2 < kLateralIters ? it + 2 : it + 1, cur);      // (unconditional: the last trip re-reads its pixel)
+        finish(nxt);
     }
 }
 

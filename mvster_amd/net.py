@@ -142,16 +142,29 @@ class MVS4net(nn.Module):
         self._plans.clear()
         return super()._apply(fn, *args, **kwargs)
 
+    def _state_stamp(self):
+        """Changes whenever a parameter or buffer the eval plans were folded from is written in place through the tensor
+        (``p.mul_()``, ``copy_``, an optimizer step, an EMA swap: ``_version``) or replaced (``p.data = t``: the storage
+        address).  348 Python attribute reads per forward, ~60 us; writes through a detached alias of the storage cannot be
+        seen from here -- call ``invalidate_plans()`` after those."""
+        import itertools
+        acc = 0
+        for t in itertools.chain(self.feature.parameters(), self.feature.buffers(), self.reg.parameters(), self.reg.buffers()):
+            acc = (acc * 1000003 + t._version * 7919 + t.data_ptr()) & 0xFFFFFFFFFFFF
+        return acc
+
     def _get_plans(self):
         # per device: an nn.DataParallel replica on cuda:1 must not run plans whose packed weights live on cuda:0
         dev = next(self.parameters()).device
-        plans = self._plans.get(dev)
-        if plans is None:
+        hit = self._plans.get(dev)
+        # (inside a graph capture the plans of the warm-up runs are the ones to record: no re-build there)
+        stamp = hit[2] if hit is not None and torch.cuda.is_current_stream_capturing() else self._state_stamp()
+        if hit is None or hit[2] != stamp:
             with torch.no_grad():
                 fpn = FpnPlan(self.feature)
                 regs = [Reg2dPlan(m) if isinstance(m, reg2d) else Reg3dPlan(m) for m in self.reg]
-            plans = self._plans[dev] = (fpn, regs)
-        return plans
+            hit = self._plans[dev] = (fpn, regs, stamp)
+        return hit[0], hit[1]
 
     # ------------------------------------------------------------------ pieces
     def _hypotheses(self, stage_idx, depth_values, depth_interval, prev, H, W):

@@ -68,7 +68,7 @@ def candidates(layer, B, Di, Hi, Wi, sm):
             for m in (1, 2):
                 for wpc in (1, 2, 3):
                     out.append(("Q%d w%d" % (m, wpc), (m, 1, 6 | (wpc << 8))))
-        if layer.kernel in ((1, 3, 3), (3, 3, 3), (1, 5, 5)) and layer.cin in (16, 32) and layer.cout % 16 == 0:
+        if layer.kernel in ((1, 3, 3), (3, 3, 3), (1, 5, 5)) and layer.cin in (16, 32, 64) and layer.cout % 16 == 0:
             for n in nts:
                 for wpc in (1, 2, 3):
                     out.append(("P2,%d w%d" % (n, wpc), (2, n, 5 | (wpc << 8))))

@@ -21,8 +21,8 @@ FAMILIES = [
     ("16->32 3x3 s2", 16, 32, (1, 3, 3), (1, 2, 2), 2),
 ]
 EXTRA = [
-    ("64->64 3x3", 64, 64, (1, 3, 3), (1, 1, 1), 4),
-    ("64->32 3x3", 64, 32, (1, 3, 3), (1, 1, 1), 2),
+    ("64->64 3x3", 64, 64, (1, 3, 3), (1, 1, 1), 1),
+    ("64->32 3x3", 64, 32, (1, 3, 3), (1, 1, 1), 1),
     ("32->64 5x5 s2", 32, 64, (1, 5, 5), (1, 2, 2), 4),
     ("32->32 3x3x3", 32, 32, (3, 3, 3), (1, 1, 1), 2),
     ("32->64 3x3 s2", 32, 64, (1, 3, 3), (1, 2, 2), 4),

@@ -392,6 +392,8 @@ PERS_CASES = [  # (cin, cout, kernel, stride, nt, input [B,D,H,W]): every instan
     (16, 16, (1, 3, 3), (1, 1, 1), 1, (2, 1, 70, 100)), (16, 16, (1, 3, 3), (1, 1, 1), 1, (1, 1, 4, 33)),
     (16, 64, (1, 3, 3), (1, 1, 1), 1, (1, 1, 37, 65)),
     (32, 32, (1, 3, 3), (1, 1, 1), 2, (3, 1, 64, 64)), (32, 64, (1, 3, 3), (1, 1, 1), 2, (1, 1, 21, 50)),
+    (64, 64, (1, 3, 3), (1, 1, 1), 1, (2, 1, 37, 50)), (64, 32, (1, 3, 3), (1, 1, 1), 1, (1, 1, 16, 33)),
+    (32, 32, (1, 3, 3), (1, 1, 1), 1, (1, 1, 20, 40)),
     (16, 32, (1, 5, 5), (1, 2, 2), 2, (2, 1, 70, 100)), (16, 32, (1, 5, 5), (1, 2, 2), 2, (1, 1, 8, 34)),
     (16, 16, (3, 3, 3), (1, 1, 1), 1, (2, 4, 38, 70)), (16, 16, (3, 3, 3), (1, 1, 1), 1, (1, 3, 5, 31)),
     (16, 32, (1, 3, 3), (1, 2, 2), 2, (2, 4, 70, 100)), (16, 32, (1, 3, 3), (1, 2, 2), 2, (1, 1, 6, 66)),

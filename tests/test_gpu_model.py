@@ -498,3 +498,28 @@ def test_train_step_full_size_vs_pytorch_rocm(shipped_cfg, checkpoint):
     assert worst <= max(2e-2, 1.25 * noise), (worst_name, worst, noise)     # measured 13 % at 12 % noise
     for k, v in g_nat.items():
         assert torch.isfinite(v).all(), k
+
+
+def test_eval_plans_follow_in_place_parameter_updates(shipped_cfg, checkpoint):
+    """The folded-BatchNorm eval plans are stamped with every parameter's / buffer's version and storage address: an
+    in-place update while the model stays in eval mode (EMA swap, ``copy_``, ``p.data = ...``) is picked up by the next
+    forward instead of being served from stale packed weights."""
+    imgs, proj, dv = to_dev(*make_inputs(nviews=3, H=64, W=128, seed=5))
+    m = MVS4net(**shipped_cfg)
+    m.load_state_dict(checkpoint, strict=True)
+    m.to(DEV).eval()
+    before = m(imgs, proj, dv)["stage4"]["attn_weight"].clone()
+    plans_a = m._get_plans()
+    assert m._get_plans()[0] is plans_a[0]                       # nothing changed: same plans
+    with torch.no_grad():
+        m.reg[3].conv0.conv.weight.mul_(1.5)                     # in place through the tensor
+        m.feature.conv0[0].bn.running_mean.add_(0.05)            # a buffer
+        m.reg[2].prob.weight.data = m.reg[2].prob.weight.data * 0.5          # storage replaced
+    after = m(imgs, proj, dv)["stage4"]["attn_weight"]
+    assert m._get_plans()[0] is not plans_a[0]
+    fresh = MVS4net(**shipped_cfg)
+    fresh.load_state_dict(m.state_dict(), strict=True)
+    fresh.to(DEV).eval()
+    want = fresh(imgs, proj, dv)["stage4"]["attn_weight"]
+    assert torch.equal(after, want)
+    assert not torch.equal(after, before)
