@@ -131,7 +131,7 @@ class ConvLayer:
         self._cin_raw = cin
         self.classes, self.woff = self._class_table()
         self.wpk = None
-        self.w_small = self.w_deconv = None
+        self.w_small = self.w_deconv = self.wpk_wino = None
         self._pack(w)
         self.ntile_total = (cout + 15) // 16
         npad = self.ntile_total * 16
@@ -229,6 +229,25 @@ class ConvLayer:
             if self.cin != cin:
                 ws = torch.nn.functional.pad(ws, (0, 0, 0, self.cin - cin))
             self.w_small = ws.contiguous().to(dev)
+        self._pack_wino(w)
+
+    def wino_eligible(self):
+        """3x3 stride-1 pad-1 single-slice layers the Winograd kernel (variant 8, conv_wino.hip) covers."""
+        return (not self.transposed and self.kernel == (1, 3, 3) and self.stride == (1, 1, 1) and self.padding == (0, 1, 1)
+                and self.cin in (16, 32) and self.cout % 16 == 0)
+
+    def _pack_wino(self, w, swap=False, flip=False):
+        """Transformed weights G g G^T of an eligible layer in the packed fragment order (one launch, reads ``w`` in place)."""
+        if not self.wino_eligible() or not w.is_cuda:
+            self.wpk_wino = None
+            return
+        if self.wpk_wino is None:
+            self.wpk_wino = torch.empty(16 * self.cin * ((self.cout + 15) // 16) * 16, device=w.device, dtype=torch.float32)
+        st = w.stride()
+        s_n, s_c = (st[1], st[0]) if swap else (st[0], st[1])
+        rc = _lib.load().mvster_pack_wino_weights(w.data_ptr(), self.wpk_wino.data_ptr(), self.cout, self._cin_raw, self.cin,
+                                                  s_n, s_c, st[3], st[4], int(flip), ops._stream())
+        _lib.check(rc, "pack_wino_weights")
 
     def repack_on_device(self, weight, swap=False, flip=False):
         """Refresh ``wpk`` of an ordinary (non-transposed) layer with one kernel, reading the parameter tensor in
@@ -248,6 +267,8 @@ class ConvLayer:
                                                   kh, kw, s_n, s_c, st[2], st[3], st[4], int(flip),
                                                   ops._stream())
         _lib.check(rc, "pack_conv_weights")
+        if self.wpk_wino is not None:
+            self._pack_wino(w, swap, flip)
         if self.w_small is not None:
             wv = w.transpose(0, 1) if swap else w
             if flip:
@@ -391,8 +412,13 @@ class ConvLayer:
                 ops._stream())
             _lib.check(rc, "conv_small")
             return out
+        wpk = self.wpk
+        if (variant & 0xff) == 8:
+            if self.wpk_wino is None:
+                raise RuntimeError("conv_wino: layer not eligible")
+            wpk = self.wpk_wino
         rc = _lib.load().mvster_conv_mfma(
-            x.data_ptr(), self.wpk.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+            x.data_ptr(), wpk.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
             None if skip is None else skip.data_ptr(), self.zeros.data_ptr(),
             None if self.prob is None else self.prob[0].data_ptr(), None if self.prob is None else self.prob[1].data_ptr(),
             out.data_ptr(), geom.ctypes.data_as(ctypes.c_void_p), int(geom.size), self.woff.ctypes.data_as(ctypes.c_void_p), self.cin,

@@ -55,10 +55,61 @@ static inline void find_divisor(unsigned d, unsigned& mul, unsigned& shr) {
     shr = (unsigned)(p - 32);
 }
 
+// ---- shared by the persistent LDS-DMA kernels (conv_pers.hip, conv_wino.hip) ------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void;
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+struct PersArgs {
+    unsigned tiles_x, tiles_y, ntiles;       // tiles per (b, z) slice and in total
+    unsigned out_bytes;                      // size of `out` (and of a same-shape skip): < 2^31
+    int prio;                                // 1: waves in odd slots of their SIMD run at raised priority (see kernel)
+    unsigned mul[3], shr[3], one[3];         // multiply-shift division by tiles_x, tiles_y, Do; one = ~0 if the divisor is 1
+};
+
+struct TilePos { int b, zo, ty0, tx0; };
+
+template <int MT, int KW, int SW, int KD>
+struct PersGeom {
+    static constexpr int TY = 2 * MT;
+    static constexpr int KH = KW;
+    static constexpr int PW = 31 * SW + KW;                  // patch width (input pixels)
+    static constexpr int PH = (TY - 1) * SW + KH;            // patch height of one depth slice
+    static constexpr int ROWS = KD * PH;
+    static constexpr int PWH = (PW + 1) / 2;                 // stride 2: columns per parity
+    static constexpr int ROWSLOTS = SW == 1 ? PW * 2 : PWH * 4;           // float4 slots of one patch row in one plane
+    static constexpr int USED = ROWS * ROWSLOTS;                          // slots of one plane that hold pixels
+    static constexpr int NBLK = (USED + 63) / 64;                         // DMA wave-instructions per plane
+    static constexpr int PLANE = ((NBLK * 64 + 7) & ~7) + 4;              // plane pitch (float4), = 4 mod 8
+};
+
+// host side: tile counts, sizes and the multiply-shift divisors of a launch whose workgroup tile is TY x 32 output pixels
+// of one (b, z) slice.  false: a tensor of 2 GB or more (32-bit byte offsets; 0x80000000 + any offset must stay out of range)
+static inline bool fill_pers_args(const ConvArgs& a, int TY, PersArgs& p) {
+    p.tiles_x = (unsigned)((a.Wo + 31) / 32);
+    p.tiles_y = (unsigned)((a.Ho + TY - 1) / TY);
+    const long ntiles = (long)p.tiles_x * p.tiles_y * a.Do * a.B;
+    const long out_bytes = (long)a.B * a.DoF * a.HoF * a.WoF * a.cout * 4;
+    if (ntiles >= (1L << 30) || a.in_bytes >= (1u << 31) || out_bytes >= (1L << 31)) return false;
+    p.ntiles = (unsigned)ntiles;
+    p.out_bytes = (unsigned)out_bytes;
+    p.prio = 0;
+    const unsigned divisors[3] = {p.tiles_x, p.tiles_y, (unsigned)a.Do};
+    for (int i = 0; i < 3; ++i) {
+        find_divisor(divisors[i], p.mul[i], p.shr[i]);
+        p.one[i] = divisors[i] == 1 ? ~0u : 0u;
+    }
+    return true;
+}
+
+// compute units of the current device (0 on error); conv_pers.hip
+int num_cus();
+
 // conv_pers.hip: persistent LDS-DMA kernel family (variant 5 of mvster_conv_mfma); wpc = workgroups per CU (0 = default)
 int dispatch_pers(const ConvArgs& a, int mt, int nt, int wpc, hipStream_t s);
 // conv_pers.hip: ping-pong form of the persistent kernel, eight waves per workgroup (variant 7)
 int dispatch_pp(const ConvArgs& a, int mt, int nt, hipStream_t s);
+// conv_wino.hip: Winograd F(2x2, 3x3) form of the persistent kernel (variant 8; `wpk` = the transformed weights)
+int dispatch_wino(const ConvArgs& a, int nt, int wpc, hipStream_t s);
 // conv_pers.hip: persistent 1x1 kernel with all weights in LDS (variant 6)
 int dispatch_1x1(const ConvArgs& a, int mt, int wpc, hipStream_t s);
 

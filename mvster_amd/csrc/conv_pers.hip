@@ -26,7 +26,6 @@
 namespace mvconv {
 namespace {
 
-typedef __attribute__((address_space(3))) void lds_void;
 
 // Probe build only (make timeline; scripts/conv_pers_timeline.py): per wavefront and tile, s_memtime at the phase
 // boundaries.  Record = 8 x u64 per (workgroup, wave, tile slot < 16): t0 loop top, t1 DMA of the next tile issued,
@@ -42,34 +41,19 @@ __device__ unsigned long long* g_ptl = nullptr;
                                                          : (k) == 6 ? __builtin_amdgcn_s_getreg(63508) : tile;          \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
     } while (0)
+// conv_pp_kernel: per wavefront and half-phase (< 16): [0] top of the half-phase, [1] work done (before the barrier),
+// [2] 1 = MFMA half-phase with a tile, 2 = prepare half-phase, 0 = idle, [3] HW_ID.
+#define MV_PPTL(k, v)                                                                                                   \
+    do {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        if (g_ptl && lane == 0 && hp < 16)                                                                              \
+            g_ptl[(((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave8) * 16 + hp) * 4 + (k)] = (v);           \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
 #else
 #define MV_PTL(k)
+#define MV_PPTL(k, v)
 #endif
-
-typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-
-struct PersArgs {
-    unsigned tiles_x, tiles_y, ntiles;       // tiles per (b, z) slice and in total
-    unsigned out_bytes;                      // size of `out` (and of a same-shape skip): < 2^31
-    int prio;                                // 1: waves in odd slots of their SIMD run at raised priority (see kernel)
-    unsigned mul[3], shr[3], one[3];         // multiply-shift division by tiles_x, tiles_y, Do; one = ~0 if the divisor is 1
-};
-
-struct TilePos { int b, zo, ty0, tx0; };
-
-template <int MT, int KW, int SW, int KD>
-struct PersGeom {
-    static constexpr int TY = 2 * MT;
-    static constexpr int KH = KW;
-    static constexpr int PW = 31 * SW + KW;                  // patch width (input pixels)
-    static constexpr int PH = (TY - 1) * SW + KH;            // patch height of one depth slice
-    static constexpr int ROWS = KD * PH;
-    static constexpr int PWH = (PW + 1) / 2;                 // stride 2: columns per parity
-    static constexpr int ROWSLOTS = SW == 1 ? PW * 2 : PWH * 4;           // float4 slots of one patch row in one plane
-    static constexpr int USED = ROWS * ROWSLOTS;                          // slots of one plane that hold pixels
-    static constexpr int NBLK = (USED + 63) / 64;                         // DMA wave-instructions per plane
-    static constexpr int PLANE = ((NBLK * 64 + 7) & ~7) + 4;              // plane pitch (float4), = 4 mod 8
-};
 
 // MT, NT: register tile (M tiles x N tiles of 16) per wave; KW = KH in {3, 5}; SW = SH in {1, 2}; NCH = cin / 16;
 // KD in {1, 3}; WREG: the layer's weights live in registers (KD*KW*KW*NCH*NT float4 per lane), else in LDS;
@@ -582,6 +566,8 @@ __global__ void __launch_bounds__(512) conv_pp_kernel(ConvArgs a, PersArgs p) {
         }
     }
     for (int hp = 0; hp < nhalf; ++hp) {
+        MV_PPTL(0, __builtin_amdgcn_s_memtime());
+        MV_PPTL(3, __builtin_amdgcn_s_getreg(63492));
         if ((hp & 1) == grp) {
             // ---------------- MFMA half-phase: tile k of this half --------------------------------------------------
             const int k = (hp - grp) >> 1;
@@ -639,6 +625,7 @@ __global__ void __launch_bounds__(512) conv_pp_kernel(ConvArgs a, PersArgs p) {
                 }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): done reading this patch
+            MV_PPTL(2, k < kcount ? 1 : 0);
         } else {
             // ---------------- prepare half-phase (the other half owns the matrix pipe) --------------------------------
             const int kn = (hp + 1 - grp) >> 1;                          // the tile whose MFMAs come next half-phase
@@ -663,8 +650,10 @@ __global__ void __launch_bounds__(512) conv_pp_kernel(ConvArgs a, PersArgs p) {
             dma_tile(decode_tile(more ? tile_of(kn + 1) : 0u), (kn + 1) & 1, more);
             // the patch of tile kn (its DMA was issued one prepare phase ago) has landed once only this phase's own
             // memory operations are outstanding: MT*NT stores, the skip loads, NIW DMA instructions
+            MV_PPTL(2, __builtin_amdgcn_s_memtime());      // (probe build: prepare work issued, before the wait)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * NT * (SKIP ? 2 : 1) + NIW) : "memory");
         }
+        MV_PPTL(1, __builtin_amdgcn_s_memtime());
         __builtin_amdgcn_s_barrier();
     }
 }
@@ -775,7 +764,6 @@ __global__ void __launch_bounds__(256) conv1x1_pers_kernel(ConvArgs a, unsigned 
     }
 }
 
-int g_num_cu = 0;
 
 template <int MT, int NT, int KW, int SW, int NCH, int KD, bool WREG, int PF, bool SKIP>
 int launch_pers(const ConvArgs& a, int wpc, hipStream_t s) {
@@ -791,28 +779,13 @@ int launch_pers(const ConvArgs& a, int wpc, hipStream_t s) {
             return MVSTER_ERR_LAUNCH;
         attr_set = true;
     }
-    if (g_num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MVSTER_ERR_LAUNCH;
-        g_num_cu = prop.multiProcessorCount;
-    }
+    const int g_num_cu = num_cus();
+    if (g_num_cu <= 0) return MVSTER_ERR_LAUNCH;
     PersArgs p;
-    p.tiles_x = (unsigned)((a.Wo + 31) / 32);
-    p.tiles_y = (unsigned)((a.Ho + G::TY - 1) / G::TY);
-    const long ntiles = (long)p.tiles_x * p.tiles_y * a.Do * a.B;
-    // 32-bit byte offsets, and 0x80000000 + any in-tensor offset must stay out of range: both tensors < 2 GB
-    const long out_bytes = (long)a.B * a.DoF * a.HoF * a.WoF * a.cout * 4;
-    if (ntiles >= (1L << 30) || a.in_bytes >= (1u << 31) || out_bytes >= (1L << 31)) return MVSTER_ERR_UNSUPPORTED;
-    p.ntiles = (unsigned)ntiles;
-    p.out_bytes = (unsigned)out_bytes;
+    if (!fill_pers_args(a, G::TY, p)) return MVSTER_ERR_UNSUPPORTED;
+    const long ntiles = p.ntiles;
     p.prio = (wpc >> 4) & 1;
     wpc &= 15;
-    const unsigned divisors[3] = {p.tiles_x, p.tiles_y, (unsigned)a.Do};
-    for (int i = 0; i < 3; ++i) {
-        find_divisor(divisors[i], p.mul[i], p.shr[i]);
-        p.one[i] = divisors[i] == 1 ? ~0u : 0u;
-    }
     // resident workgroups per CU: what LDS allows, at most 4 (registers), unless the caller pins it
     int by_lds = (int)((160 * 1024) / lds);
     int per_cu = wpc > 0 ? wpc : (by_lds > 3 ? 3 : by_lds);
@@ -843,26 +816,11 @@ int launch_pp(const ConvArgs& a, hipStream_t s) {
             return MVSTER_ERR_LAUNCH;
         attr_set = true;
     }
-    if (g_num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MVSTER_ERR_LAUNCH;
-        g_num_cu = prop.multiProcessorCount;
-    }
+    const int g_num_cu = num_cus();
+    if (g_num_cu <= 0) return MVSTER_ERR_LAUNCH;
     PersArgs p;
-    p.tiles_x = (unsigned)((a.Wo + 31) / 32);
-    p.tiles_y = (unsigned)((a.Ho + G::TY - 1) / G::TY);
-    const long ntiles = (long)p.tiles_x * p.tiles_y * a.Do * a.B;
-    const long out_bytes = (long)a.B * a.DoF * a.HoF * a.WoF * a.cout * 4;
-    if (ntiles >= (1L << 30) || a.in_bytes >= (1u << 31) || out_bytes >= (1L << 31)) return MVSTER_ERR_UNSUPPORTED;
-    p.ntiles = (unsigned)ntiles;
-    p.out_bytes = (unsigned)out_bytes;
-    p.prio = 0;
-    const unsigned divisors[3] = {p.tiles_x, p.tiles_y, (unsigned)a.Do};
-    for (int i = 0; i < 3; ++i) {
-        find_divisor(divisors[i], p.mul[i], p.shr[i]);
-        p.one[i] = divisors[i] == 1 ? ~0u : 0u;
-    }
+    if (!fill_pers_args(a, G::TY, p)) return MVSTER_ERR_UNSUPPORTED;
+    const long ntiles = p.ntiles;
     // one workgroup (8 waves) per CU; every workgroup walks the same number of tiles, an even number where possible
     // (both halves busy in every half-phase)
     const int ny = a.ntile_total / NT;
@@ -899,12 +857,8 @@ int launch_1x1(const ConvArgs& a, int wpc, hipStream_t s) {
             return MVSTER_ERR_LAUNCH;
         attr_set = true;
     }
-    if (g_num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MVSTER_ERR_LAUNCH;
-        g_num_cu = prop.multiProcessorCount;
-    }
+    const int g_num_cu = num_cus();
+    if (g_num_cu <= 0) return MVSTER_ERR_LAUNCH;
     const long ngroups = (mtot + 64 * MT - 1) / (64 * MT);
     int by_lds = (int)((160 * 1024) / lds);
     int per_cu = wpc > 0 ? wpc : 2;
@@ -918,6 +872,17 @@ int launch_1x1(const ConvArgs& a, int wpc, hipStream_t s) {
     return mv_check_launch();
 }
 }  // namespace
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        n = prop.multiProcessorCount;
+    }
+    return n;
+}
 
 // 1x1x1 stride-1 convolutions, cin in {32, 64}, any cout % 4 == 0, optional same-shape skip (variant 6).
 int dispatch_1x1(const ConvArgs& a, int mt, int wpc, hipStream_t s) {

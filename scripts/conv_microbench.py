@@ -72,6 +72,11 @@ def candidates(layer, B, Di, Hi, Wi, sm):
             for n in nts:
                 for wpc in (1, 2, 3):
                     out.append(("P2,%d w%d" % (n, wpc), (2, n, 5 | (wpc << 8))))
+        if layer.wino_eligible():
+            # Winograd F(2x2,3x3) on the persistent frame (conv_wino.hip); not bit-identical to the others
+            for n in nts:
+                for wpc in (1, 2):
+                    out.append(("W%d w%d" % (n, wpc), (2, n, 8 | (wpc << 8))))
     return out
 
 

@@ -428,6 +428,88 @@ def test_persistent_conv_bit_identical_to_direct(cin, cout, kernel, stride, nt, 
     assert _lib.last_kernel().startswith("conv1x1_pers_kernel<" if variant == 6 else "conv_pers_kernel<")
 
 
+PP_CASES = [(16, 16, (1, 1, 1), 1, (2, 1, 70, 100)), (16, 16, (1, 1, 1), 1, (1, 1, 4, 33)), (32, 32, (1, 1, 1), 2, (3, 1, 64, 64)),
+            (32, 32, (1, 1, 1), 2, (7, 1, 12, 64)), (16, 32, (1, 2, 2), 2, (2, 4, 70, 100)), (16, 32, (1, 2, 2), 2, (1, 1, 5, 200))]
+
+
+@pytest.mark.parametrize("cin,cout,stride,nt,shape", PP_CASES)
+@pytest.mark.parametrize("with_skip", [False, True])
+def test_pingpong_conv_bit_identical_to_direct(cin, cout, stride, nt, shape, with_skip):
+    """Variant 7 (eight waves, the two halves of a workgroup in anti-phase) walks the same K order: EQUAL to the direct
+    kernel, odd and even tile counts per workgroup, workgroups with no tile at all."""
+    g = torch.Generator().manual_seed(cin * 17 + cout + shape[2])
+    w = (torch.randn(cout, cin, 1, 3, 3, generator=g) * 0.1).to(DEV)
+    layer = cp.ConvLayer(w, False, stride, (0, 1, 1), relu=not with_skip)
+    layer.scale.copy_(torch.rand(layer.scale.shape, generator=g) + 0.5)
+    layer.shift.copy_(torch.randn(layer.shift.shape, generator=g) * 0.1)
+    x = torch.randn(*shape, cin, generator=g).to(DEV)
+    want = layer(x, tiles=(1, 1, 0))
+    skip = torch.randn(want.shape, generator=g).to(DEV) if with_skip else None
+    sm = cp.SKIP_ADD if with_skip else cp.SKIP_NONE
+    if with_skip:
+        want = layer(x, skip=skip, skip_mode=sm, tiles=(1, 1, 0))
+    got = layer(x, skip=skip, skip_mode=sm, tiles=(2, nt, 7))
+    assert torch.equal(got, want), (got - want).abs().max().item()
+    from mvster_amd import _lib
+    assert _lib.last_kernel().startswith("conv_pp_kernel<")
+
+
+WINO_CASES = [  # (cin, cout, nt, input [B,D,H,W]): every instance of the Winograd family, ragged sizes, odd widths / heights
+    (16, 16, 1, (2, 1, 70, 100)), (16, 16, 1, (1, 1, 4, 33)), (16, 16, 1, (7, 1, 13, 63)), (16, 32, 2, (1, 1, 37, 65)),
+    (32, 32, 2, (3, 1, 64, 64)), (32, 32, 2, (1, 4, 38, 70)), (32, 16, 1, (1, 1, 5, 200)), (32, 64, 2, (1, 1, 21, 50)),
+]
+
+
+@pytest.mark.parametrize("cin,cout,nt,shape", WINO_CASES)
+@pytest.mark.parametrize("with_skip", [False, True])
+def test_winograd_conv_against_fp64_and_direct(cin, cout, nt, shape, with_skip):
+    """Variant 8 computes the 3x3 convolution as F(2x2, 3x3) minimal filtering: a different operation order, so the
+    comparison is against an fp64 convolution -- its error must stay within 2e-6 of max |y| (the direct kernel's own error on
+    these inputs is ~4e-7) -- and within 2e-6 of the direct kernel."""
+    g = torch.Generator().manual_seed(cin * 29 + cout + shape[3])
+    w = (torch.randn(cout, cin, 1, 3, 3, generator=g) * 0.1).to(DEV)
+    layer = cp.ConvLayer(w, False, (1, 1, 1), (0, 1, 1), relu=not with_skip)
+    assert layer.wino_eligible() and layer.wpk_wino is not None
+    layer.scale.copy_(torch.rand(layer.scale.shape, generator=g) + 0.5)
+    layer.shift.copy_(torch.randn(layer.shift.shape, generator=g) * 0.1)
+    x = torch.randn(*shape, cin, generator=g).to(DEV)
+    B, D, H, W = shape
+    ref = F.conv2d(x.double().reshape(B * D, H, W, cin).permute(0, 3, 1, 2), w[:, :, 0].double(), padding=1)
+    ref = ref * layer.scale[:cout].double().view(1, -1, 1, 1) + layer.shift[:cout].double().view(1, -1, 1, 1)
+    if not with_skip:
+        ref = ref.clamp_min(0)
+    ref = ref.permute(0, 2, 3, 1).reshape(B, D, H, W, cout)
+    skip = torch.randn(B, D, H, W, cout, generator=g).to(DEV) if with_skip else None
+    sm = cp.SKIP_ADD if with_skip else cp.SKIP_NONE
+    if with_skip:
+        ref = ref + skip.double()
+    direct = layer(x, skip=skip, skip_mode=sm, tiles=(1, 1, 0))
+    scale = ref.abs().max().item()
+    for wpc in (0, 1, 2):
+        got = layer(x, skip=skip, skip_mode=sm, tiles=(2, nt, 8 | (wpc << 8)))
+        assert torch.isfinite(got).all()
+        assert (got.double() - ref).abs().max().item() <= 2e-6 * scale, (wpc, (got.double() - ref).abs().max().item() / scale)
+        assert (got - direct).abs().max().item() <= 2e-6 * scale
+    from mvster_amd import _lib
+    assert _lib.last_kernel().startswith("conv_wino_kernel<")
+    note("conv_winograd_%d_%d_%s" % (cin, cout, "x".join(map(str, shape))), err_over_max=(got.double() - ref).abs().max().item() / scale,
+         direct_err_over_max=(direct.double() - ref).abs().max().item() / scale)
+
+
+def test_winograd_weights_follow_in_place_repack():
+    """The transformed weights are refreshed by the same call that refreshes the packed ones (training: once per step),
+    also in the swapped / mirrored form of an input gradient."""
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(16, 16, 1, 3, 3, generator=g) * 0.1).to(DEV)
+    layer = cp.ConvLayer(w, False, (1, 1, 1), (0, 1, 1))
+    x = torch.randn(1, 1, 9, 21, 16, generator=g).to(DEV)
+    w2 = (torch.randn(16, 16, 1, 3, 3, generator=g) * 0.1).to(DEV)
+    layer.repack_on_device(w2, swap=True, flip=True)
+    want = F.conv2d(x[0].double().permute(0, 3, 1, 2), w2[:, :, 0].double().transpose(0, 1).flip(2, 3), padding=1).permute(0, 2, 3, 1)
+    got = layer(x, tiles=(2, 1, 8))
+    assert (got[0].double() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+
+
 @pytest.mark.parametrize("cin,cout,k,pad,op,s", [(64, 32, (1, 3, 3), (0, 1, 1), (0, 1, 1), (1, 2, 2)),
                                                  (16, 8, (1, 3, 3), (0, 1, 1), (0, 1, 1), (1, 2, 2)),
                                                  (32, 16, (1, 3, 3), (0, 1, 1), (0, 1, 1), (1, 2, 2)),
