@@ -118,7 +118,9 @@ int mvster_upsample_bilinear(const float* in, float* out, int B, int hi, int wi,
  * 7 = variant 5 with eight waves per workgroup in ping-pong (3x3, cin 16 / 32; measured no faster, kept for the record),
  * 8 = Winograd F(2x2, 3x3) on the persistent LDS-DMA frame: 1x3x3 stride 1 pad 1, cin in {16, 32}, cout % 16 == 0,
  * optional same-shape skip; `wpk` must be the array written by mvster_pack_wino_weights (not bit-identical to the other
- * variants: fp32 with a different operation order).
+ * variants: fp32 with a different operation order),
+ * 9 = the same transform for deep layers: (1|3)x3x3 stride 1, cin in {16, 32, 64}; patch slices and transformed weights
+ * stream through LDS rings one depth tap and 16-channel chunk at a time.
  * Conv3d/ConvTranspose3d/BatchNorm3d/ReLU of reg2d/reg3d (models/mvs4net_utils.py:870-965) and
  * Conv2d/BatchNorm2d/ReLU/upsample-add of FPN4 (:419-502). */
 int mvster_conv_mfma(const float* in, const float* wpk, const float* scale, const float* shift, const float* skip,
@@ -179,12 +181,12 @@ int mvster_fpn_lateral_up(const float* x, const float* A, const float* bias, con
 int mvster_pack_conv_weights(const float* w, float* wpk, int cout, int cin, int cin_pad, int kd, int kh, int kw, long s_n,
                              long s_c, long s_z, long s_y, long s_x, int flip, void* stream);
 
-/* Transformed weights of the Winograd F(2x2, 3x3) kernel (variant 8 of mvster_conv_mfma, which takes this array as its
- * `wpk`): U = G g G^T per (cout, cin) pair of w [cout, cin, 3, 3] (element strides; flip = 1 mirrors the taps), stored in
- * the same fragment order with the 16 transform points in place of the taps: 16 * cin_pad/16 K steps x ceil(cout/16) x 256
- * floats.  Stands in for the weight side of nn.Conv2d(3x3) (models/mvs4net_utils.py:116-123). */
-int mvster_pack_wino_weights(const float* w, float* wpk, int cout, int cin, int cin_pad, long s_n, long s_c, long s_y,
-                             long s_x, int flip, void* stream);
+/* Transformed weights of the Winograd F(2x2, 3x3) kernels (variants 8 / 9 of mvster_conv_mfma, which take this array as
+ * their `wpk`): U = G g G^T per (cout, cin, kz) of w [cout, cin, kd, 3, 3], kd in {1, 3} (element strides; flip = 1 mirrors
+ * the taps), stored in the same fragment order with the 16 transform points in place of the in-plane taps:
+ * kd * 16 * cin_pad/16 K steps x ceil(cout/16) x 256 floats.  Stands in for the weight side of nn.Conv2d(3x3) (models/mvs4net_utils.py:116-123). */
+int mvster_pack_wino_weights(const float* w, float* wpk, int cout, int cin, int cin_pad, int kd, long s_n, long s_c, long s_z,
+                             long s_y, long s_x, int flip, void* stream);
 
 /* The same refresh for a transposed layer (output-parity classes): w [cin, cout, kd, kh, kw] contiguous, ktot = kd*kh*kw
  * <= 27; class c packs the taps taps[c*27 .. c*27 + ntaps[c]) (flattened indices, input-offset order) at float offset

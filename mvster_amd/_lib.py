@@ -37,7 +37,7 @@ SIGNATURES = {
     "mvster_fpn_lateral_up": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f],
     "mvster_fpn_tail_gather_bwd": [_f, _f, _i, _i, _i, _i, _i, _f],
     "mvster_pack_conv_weights": [_f, _f] + [_i] * 6 + [_l] * 5 + [_i, _f],
-    "mvster_pack_wino_weights": [_f, _f, _i, _i, _i, _l, _l, _l, _l, _i, _f],
+    "mvster_pack_wino_weights": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _l, _l, _i, _f],
     "mvster_pack_conv_weights_classes": [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f],
     "mvster_conv_wgrad": [_f, _f, _f] + [_i] * 20 + [_f],
     "mvster_bn_relu_fwd": [_f, _f, _f, _f, _f, _l, _i, _i, _i, _f],

@@ -232,9 +232,9 @@ class ConvLayer:
         self._pack_wino(w)
 
     def wino_eligible(self):
-        """3x3 stride-1 pad-1 single-slice layers the Winograd kernel (variant 8, conv_wino.hip) covers."""
-        return (not self.transposed and self.kernel == (1, 3, 3) and self.stride == (1, 1, 1) and self.padding == (0, 1, 1)
-                and self.cin in (16, 32) and self.cout % 16 == 0)
+        """(1|3)x3x3 stride-1 layers the Winograd kernels (variants 8 / 9, conv_wino.hip) cover."""
+        return (not self.transposed and self.kernel in ((1, 3, 3), (3, 3, 3)) and self.stride == (1, 1, 1)
+                and self.padding == (self.kernel[0] // 2, 1, 1) and self.cin in (16, 32, 64) and self.cout % 16 == 0)
 
     def _pack_wino(self, w, swap=False, flip=False):
         """Transformed weights G g G^T of an eligible layer in the packed fragment order (one launch, reads ``w`` in place)."""
@@ -242,11 +242,12 @@ class ConvLayer:
             self.wpk_wino = None
             return
         if self.wpk_wino is None:
-            self.wpk_wino = torch.empty(16 * self.cin * ((self.cout + 15) // 16) * 16, device=w.device, dtype=torch.float32)
+            self.wpk_wino = torch.empty(self.kernel[0] * 16 * self.cin * ((self.cout + 15) // 16) * 16, device=w.device,
+                                        dtype=torch.float32)
         st = w.stride()
         s_n, s_c = (st[1], st[0]) if swap else (st[0], st[1])
         rc = _lib.load().mvster_pack_wino_weights(w.data_ptr(), self.wpk_wino.data_ptr(), self.cout, self._cin_raw, self.cin,
-                                                  s_n, s_c, st[3], st[4], int(flip), ops._stream())
+                                                  self.kernel[0], s_n, s_c, st[2], st[3], st[4], int(flip), ops._stream())
         _lib.check(rc, "pack_wino_weights")
 
     def repack_on_device(self, weight, swap=False, flip=False):
@@ -413,7 +414,7 @@ class ConvLayer:
             _lib.check(rc, "conv_small")
             return out
         wpk = self.wpk
-        if (variant & 0xff) == 8:
+        if (variant & 0xff) in (8, 9):
             if self.wpk_wino is None:
                 raise RuntimeError("conv_wino: layer not eligible")
             wpk = self.wpk_wino

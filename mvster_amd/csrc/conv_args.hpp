@@ -108,8 +108,8 @@ int num_cus();
 int dispatch_pers(const ConvArgs& a, int mt, int nt, int wpc, hipStream_t s);
 // conv_pers.hip: ping-pong form of the persistent kernel, eight waves per workgroup (variant 7)
 int dispatch_pp(const ConvArgs& a, int mt, int nt, hipStream_t s);
-// conv_wino.hip: Winograd F(2x2, 3x3) form of the persistent kernel (variant 8; `wpk` = the transformed weights)
-int dispatch_wino(const ConvArgs& a, int nt, int wpc, hipStream_t s);
+// conv_wino.hip: Winograd F(2x2, 3x3) forms of the persistent kernel (variants 8 and 9 = ring; `wpk` = the transformed weights)
+int dispatch_wino(const ConvArgs& a, int nt, int wpc, bool ring, hipStream_t s);
 // conv_pers.hip: persistent 1x1 kernel with all weights in LDS (variant 6)
 int dispatch_1x1(const ConvArgs& a, int mt, int wpc, hipStream_t s);
 

@@ -300,25 +300,360 @@ int launch_wino(const ConvArgs& a, int wpc, hipStream_t s) {
     return mv_check_launch();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same transform for the deep layers: 3x3x3 kernels (reg2d's conv2/4/6, models/mvs4net_utils.py:885-891) and 64-channel
+// 3x3 layers, whose patches and transformed weights do not fit LDS as a whole.  The K dimension is walked in STEPS of one
+// depth tap and one 16-channel chunk: a step's input is one patch slice (10 x 34 pixels x 16 channels, 22 KB), its weights
+// U[kz][.][chunk] are 16 KB per N tile.  Both stream through LDS rings filled by LDS-DMA:
+//   * patch ring of 4 slices: the slice of step g+3 is requested at the top of step g, so that at the start of step g the
+//     slices of g and g+1 are known to have landed -- the 16 ds_read_b128 of step g+1 are issued BEFORE the MFMAs of step
+//     g and its transform runs after them (one wave per SIMD: nothing else hides that latency);
+//   * weight ring of 2: U of step g+1 is requested at the top of step g (issued before the patch request, so the counted
+//     s_waitcnt at the end of the step covers it), read back in groups of 4 transform points, one group ahead of the MFMAs;
+//   * one barrier per step; the 16*NT accumulators live across the steps of a tile, the output transform and the fused
+//     epilogue run at its last step.  Depth taps that fall into the zero padding are skipped (no step).
+// Patch rows are stored with even and odd columns apart (a lane's 4x4 block starts at column 2*lm: the 16 lanes of a read
+// are then 32 bytes apart -- the 64-byte stride of the plain layout costs a 2-way bank conflict on every read,
+// SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE in profiles/r03_k_wino_pmc.txt).
+// ------------------------------------------------------------------------------------------------------------------
+struct RingGeom {
+    static constexpr int TY = 8, PWH = 17, PH = 10;                     // 34 patch columns as 17 even + 17 odd
+    static constexpr int ROWSLOTS = PWH * 4;                              // float4 slots of one patch row in one plane
+    static constexpr int USED = PH * ROWSLOTS;
+    static constexpr int NBLK = (USED + 63) / 64;                         // DMA wave-instructions per plane
+    static constexpr int PLANE = ((NBLK * 64 + 7) & ~7) + 4;              // plane pitch (float4)
+    static constexpr int SLICE = 2 * PLANE;                               // float4 per ring slot
+};
+
+struct RingStep {          // one step of one tile: everything wave-uniform
+    unsigned tile;
+    int kz, c, kz_hi;
+    TilePos pos;
+    bool live;
+};
+
+template <int NT, int NCH, int KD, bool SKIP>
+__global__ void __launch_bounds__(256) conv_wino_ring_kernel(ConvArgs a, PersArgs p) {
+    using G = RingGeom;
+    constexpr int TY = G::TY, PLANE = G::PLANE, NBLK = G::NBLK, RS = G::ROWSLOTS, SLICE = G::SLICE;
+    constexpr int NI = 2 * NBLK;                            // DMA wave-instructions per slice
+    constexpr int NIW = (NI + 3) / 4;
+    constexpr int NUW = 4 * NT;                             // weight DMA instructions per wave and step (16 * NT in all)
+    constexpr int CIN = NCH * 16;
+    constexpr int UST = 16 * NT * 64;                       // float4 per weight ring slot
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    f32x4v* const ring = reinterpret_cast<f32x4v*>(lds_raw);              // 4 patch slices
+    f32x4v* const uring = ring + 4 * SLICE;                               // 2 weight slots [point][nt][lane]
+    f32x4v* const scratch = uring + 2 * UST;                              // 64 float4: surplus DMA slots
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lm = lane & 15, lq = lane >> 4;
+    const int nt0 = blockIdx.y * NT;
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)a.in_bytes, 0x00020000);
+    const long wstep = (long)a.ntile_total * 256;          // floats per K step (16 channels) of the packed weights
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.wpk), (short)0, (int)(KD * 16 * NCH * wstep * 4), 0x00020000);
+
+    // ---- LDS-DMA address decode of one slice: instruction i = wave + 4n -> (plane, block); lane -> slot -> (row, px, quad)
+    unsigned dbase[NIW];
+    int dpos[NIW];
+#pragma unroll
+    for (int n = 0; n < NIW; ++n) {
+        const int i = wave + 4 * n;
+        const int pl = i / NBLK, blk = i - pl * NBLK;
+        const int s = blk * 64 + lane;
+        const int q1 = s & 1;
+        int t = s >> 1;
+        const int xh = t % G::PWH;
+        t /= G::PWH;
+        const int py = t >> 1, px = 2 * xh + (t & 1);
+        const bool valid = i < NI && py < G::PH;
+        dpos[n] = px | (py << 8);
+        dbase[n] = valid ? (unsigned)((py * a.Wi + px) * (CIN * 4) + (pl * 8 + q1 * 4) * 4) : 0x80000000u;
+    }
+    auto decode_tile = [&](unsigned tile) -> TilePos {
+        TilePos t;
+        auto div = [&](unsigned n, int k) -> unsigned { return ((__umulhi(n, p.mul[k]) >> p.shr[k]) & ~p.one[k]) | (n & p.one[k]); };
+        unsigned q = div(tile, 0);
+        t.tx0 = (int)(tile - q * p.tiles_x) * 32;
+        unsigned q2 = div(q, 1);
+        t.ty0 = (int)(q - q2 * p.tiles_y) * TY;
+        const unsigned q3 = div(q2, 2);
+        t.zo = (int)(q2 - q3 * (unsigned)a.Do);
+        t.b = (int)q3;
+        return t;
+    };
+    const unsigned nwg = gridDim.x;
+    auto first_step = [&](unsigned tile) -> RingStep {
+        RingStep st;
+        st.tile = tile;
+        st.live = tile < p.ntiles;
+        st.pos = decode_tile(st.live ? tile : 0u);
+        st.kz = KD == 1 ? 0 : max(0, a.pd[0] - st.pos.zo);                 // depth taps inside the volume (stride 1)
+        st.kz_hi = KD == 1 ? 1 : min(KD, a.Di + a.pd[0] - st.pos.zo);
+        st.c = 0;
+        return st;
+    };
+    auto is_last = [&](const RingStep& st) -> bool { return st.c == NCH - 1 && st.kz == st.kz_hi - 1; };
+    auto next_step = [&](const RingStep& st) -> RingStep {
+        if (!st.live) return st;
+        if (is_last(st)) return first_step(st.tile + nwg);
+        RingStep n = st;
+        if (++n.c == NCH) {
+            n.c = 0;
+            ++n.kz;
+        }
+        return n;
+    };
+    auto dma_slice = [&](const RingStep& st, int slot) {
+        const int iz = st.pos.zo + st.kz - a.pd[0], iy0 = st.pos.ty0 - a.ph[0], ix0 = st.pos.tx0 - a.pw[0];
+        const unsigned origin = (unsigned)(((((st.pos.b * a.Di + iz) * a.Hi + iy0) * a.Wi + ix0) * CIN + st.c * 16) * 4);
+        const unsigned wi = st.live ? (unsigned)a.Wi : 0u;
+        f32x4v* const dst0 = ring + slot * SLICE;
+#pragma unroll
+        for (int n = 0; n < NIW; ++n) {
+            const int i = wave + 4 * n;
+            const int ix = ix0 + (dpos[n] & 255), iy = iy0 + (dpos[n] >> 8);
+            const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < wi;
+            const unsigned off = ok ? dbase[n] + origin : 0x80000000u;
+            f32x4v* const dst = (NI % 4 == 0 || n + 1 < NIW || i < NI) ? dst0 + (i / NBLK) * PLANE + (i % NBLK) * 64 : scratch;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_void*)dst, 16, off, 0, 0, 0);
+        }
+    };
+    auto dma_weights = [&](const RingStep& st, int slot) {
+        // K steps of this (kz, chunk): (kz*16 + point)*NCH + c; instruction u = wave + 4m -> (point, nt)
+        const unsigned base = (unsigned)(((long)(st.kz * 16 * NCH + st.c) * wstep + (long)nt0 * 256) * 4) + lane * 16;
+        f32x4v* const dst0 = uring + slot * UST;
+#pragma unroll
+        for (int m = 0; m < NUW; ++m) {
+            const int u = wave + 4 * m;
+            const int q = u / NT, nt = u - q * NT;
+            const unsigned off = st.live ? base + (unsigned)(((long)q * NCH * wstep + nt * 256) * 4) : 0x80000000u;
+            f32x4v* const dst = dst0 + u * 64;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)dst, 16, off, 0, 0, 0);
+        }
+    };
+
+    // ---- once per workgroup -------------------------------------------------------------------------------------------
+    f32x4v scv[NT], shv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n0 = (nt0 + nt) * 16 + lq * 4;
+        scv[nt] = *reinterpret_cast<const f32x4v*>(a.scale + n0);
+        shv[nt] = *reinterpret_cast<const f32x4v*>(a.shift + n0);
+    }
+    // float4 index of this lane's 4x4 block origin inside a slice: row 2*wave, column pair lm, its channel quad
+    const int abase = 2 * wave * RS + 2 * lm + (lq >> 1) * PLANE + (lq & 1);
+    const __amdgpu_buffer_rsrc_t out_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t skip_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(SKIP ? a.skip : a.in), (short)0, SKIP ? (int)p.out_bytes : 0, 0x00020000);
+    const unsigned obase = (unsigned)((2 * wave * a.Wo + 2 * lm) * a.cout + nt0 * 16 + lq * 4) * 4u;
+    const unsigned opix = (unsigned)a.cout * 4u, orow = (unsigned)a.Wo * opix;
+    const float floor_v = a.relu ? 0.0f : -__builtin_inff();
+
+    Q4 d[4][4], V[4][4];
+    auto read_block = [&](int slot) {
+        const f32x4v* patch = ring + slot * SLICE + abase;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const f32x4v v = patch[r * RS + (x & 1) * (G::PWH * 2) + (x >> 1) * 2];
+                d[r][x] = {{v[0], v[1]}, {v[2], v[3]}};
+            }
+    };
+    auto transform_block = [&]() {       // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const Q4 t0 = d[0][x] - d[2][x], t1 = d[1][x] + d[2][x], t2 = d[2][x] - d[1][x], t3 = d[1][x] - d[3][x];
+            d[0][x] = t0;
+            d[1][x] = t1;
+            d[2][x] = t2;
+            d[3][x] = t3;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            V[r][0] = d[r][0] - d[r][2];
+            V[r][1] = d[r][1] + d[r][2];
+            V[r][2] = d[r][2] - d[r][1];
+            V[r][3] = d[r][1] - d[r][3];
+        }
+    };
+
+    // steps in flight: s0 = the one computed now, s1 = next (its weights are requested now), s3 = three ahead (its slice is)
+    RingStep s0 = first_step(xcd_remap(blockIdx.x, nwg));
+    RingStep s1 = next_step(s0), s2 = next_step(s1), s3 = next_step(s2);
+    dma_slice(s0, 0);
+    dma_slice(s1, 1);
+    dma_slice(s2, 2);
+    dma_weights(s0, 0);
+    f32x4v acc[16][NT];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[q][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();        // (waits for everything requested so far)
+    read_block(0);
+    transform_block();
+
+    for (int g = 0; s0.live; ++g) {
+        const bool last = is_last(s0);
+        // the tile's output offsets and skip values: only needed behind its last step, requested ahead of the DMA (older in
+        // the memory queue than anything this step waits for)
+        unsigned ooff[2][2];
+        f32x4v skv[2][2][NT];
+        if (last) {
+            const TilePos& here = s0.pos;
+            const unsigned oorigin = (unsigned)((((here.b * a.Do + here.zo) * a.Ho + here.ty0) * a.Wo + here.tx0) * a.cout) * 4u;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bool ok = here.ty0 + 2 * wave + i < a.Ho && here.tx0 + 2 * lm + j < a.Wo;
+                    ooff[i][j] = ok ? obase + oorigin + i * orow + j * opix : 0x80000000u;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        skv[i][j][nt] = SKIP ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, ooff[i][j] + nt * 64, 0, 0))
+                                             : (f32x4v){0.f, 0.f, 0.f, 0.f};
+                }
+        }
+        dma_weights(s1, (g + 1) & 1);
+        dma_slice(s3, (g + 3) & 3);
+        __builtin_amdgcn_sched_barrier(0);
+        read_block((g + 1) & 3);          // next step's pixels: in flight under this step's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const f32x4v* const us = uring + (g & 1) * UST + lane;
+            f32x4v ub[2][4][NT];
+            auto load_u = [&](int grp, f32x4v (&dst)[4][NT]) {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) dst[qq][nt] = us[((grp * 4 + qq) * NT + nt) * 64];
+            };
+            load_u(0, ub[0]);
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                if (grp < 3) load_u(grp + 1, ub[(grp + 1) & 1]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[grp * 4 + qq][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[grp & 1][qq][nt][j], elem(V[grp][qq], j),
+                                                                                         acc[grp * 4 + qq][nt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (the packed additions are inline assembly: MFMA results reach them only behind these wait states, and the
+        //  transform below overwrites MFMA source registers)
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (last) {
+            // Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; fused epilogue on the 2x2 pixels x 4 channels of this lane
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                Q4 m[16], t[2][4];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) m[q] = {{acc[q][nt][0], acc[q][nt][1]}, {acc[q][nt][2], acc[q][nt][3]}};
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    t[0][x] = m[0 + x] + m[4 + x] + m[8 + x];
+                    t[1][x] = m[4 + x] - (m[8 + x] + m[12 + x]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    Q4 y[2];
+                    y[0] = t[i][0] + t[i][1] + t[i][2];
+                    y[1] = t[i][1] - (t[i][2] + t[i][3]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4v v = {y[j].lo[0], y[j].lo[1], y[j].hi[0], y[j].hi[1]};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = fmaxf(fmaf(v[e], scv[nt][e], shv[nt][e]), floor_v);
+                            if (SKIP) v[e] += skv[i][j][nt][e];
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, ooff[i][j] + nt * 64, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[q][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        transform_block();                // d (step g+1) -> V
+        __builtin_amdgcn_sched_barrier(0);
+        // slice g+2 and weights g+1 have landed once only this step's slice request (and the stores behind it) are
+        // outstanding; then everyone is done with slice g and weight slot g & 1
+        if (last) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW + 4 * NT) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        s0 = s1;
+        s1 = s2;
+        s2 = s3;
+        s3 = next_step(s3);
+    }
+}
+
+template <int NT, int NCH, int KD, bool SKIP>
+int launch_wino_ring(const ConvArgs& a, hipStream_t s) {
+    using G = RingGeom;
+    const size_t lds = (size_t)(4 * G::SLICE + 2 * 16 * NT * 64 + 64) * 16;
+    if (lds > 160 * 1024) return MVSTER_ERR_UNSUPPORTED;
+    auto kern = conv_wino_ring_kernel<NT, NCH, KD, SKIP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return MVSTER_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int ncu = num_cus();
+    if (ncu <= 0) return MVSTER_ERR_LAUNCH;
+    PersArgs p;
+    if (!fill_pers_args(a, G::TY, p)) return MVSTER_ERR_UNSUPPORTED;
+    if ((long)KD * 16 * NCH * a.ntile_total * 1024 >= (1L << 31)) return MVSTER_ERR_UNSUPPORTED;
+    const long ntiles = p.ntiles;
+    const int ny = a.ntile_total / NT;
+    long gmax = (long)ncu / ny;                            // one workgroup per CU (LDS)
+    if (gmax < 1) gmax = 1;
+    const long rounds = (ntiles + gmax - 1) / gmax;       // equal shares
+    const long gx = (ntiles + rounds - 1) / rounds;
+    MV_NOTE_KERNEL("conv_wino_ring_kernel<%d, %d, %d, %s>", NT, NCH, KD, SKIP ? "true" : "false");
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, ny, 1), dim3(256), lds, s, a, p);
+    return mv_check_launch();
+}
+
 // G g G^T for one (cout, cin) pair, G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]; one thread per packed element
-__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ wpk, int cout, int cin_raw, int cin, long s_n,
-                                 long s_c, long s_y, long s_x, int flip, int ntile) {
-    const long total = (long)16 * cin * ntile * 16;
+__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ wpk, int cout, int cin_raw, int cin, int kd, long s_n,
+                                 long s_c, long s_z, long s_y, long s_x, int flip, int ntile) {
+    const long total = (long)kd * 16 * cin * ntile * 16;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    // packed fragment order [K step][N tile][lane][j]: K = point * cin + ci, lane = (ci % 16 / 4) * 16 + (n % 16), j = ci % 4
+    // packed fragment order [K step][N tile][lane][j]: K = (kz * 16 + point) * cin + ci, lane = (ci % 16 / 4) * 16 + (n % 16), j = ci % 4
     const int j = (int)(idx & 3), lanei = (int)((idx >> 2) & 63);
     const long rest = idx >> 8;
     const int t = (int)(rest % ntile);
     const int kstep = (int)(rest / ntile);
     const int k = kstep * 16 + (lanei >> 4) * 4 + j;
     const int n = t * 16 + (lanei & 15);
-    const int q = k / cin, ci = k - q * cin;
+    const int qz = k / cin, ci = k - qz * cin;
+    const int kz = qz >> 4, q = qz & 15;
     float u = 0.f;
     if (n < cout && ci < cin_raw) {
         const int xi = q >> 2, nu = q & 3;
         const float Gm[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
-        const float* g = w + n * s_n + ci * s_c;
+        const float* g = w + n * s_n + ci * s_c + (flip ? kd - 1 - kz : kz) * s_z;
         float rowv[3];
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
@@ -337,13 +672,26 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
 
 }  // namespace
 
-// 3x3 stride-1 pad-1 single-slice convolutions, cin in {16, 32}, cout % 16 == 0, optional same-shape skip (variant 8)
-int dispatch_wino(const ConvArgs& a, int nt, int wpc, hipStream_t s) {
+// variant 8: 3x3 stride-1 pad-1 single-slice convolutions, cin in {16, 32}, weights resident per workgroup;
+// variant 9 (ring = true): (1|3)x3x3 stride 1, pad (kd/2, 1, 1), cin in {16, 32, 64}, patch slices and weights streamed.
+// cout % 16 == 0, optional same-shape skip.
+int dispatch_wino(const ConvArgs& a, int nt, int wpc, bool ring, hipStream_t s) {
     if (a.nclass != 1 || a.osd != 1 || a.osh != 1 || a.osw != 1 || a.skip_mode > 1 || a.prob_w || a.cout % 16 != 0 ||
-        a.sh != 1 || a.sw != 1 || a.sd != 1 || a.kd[0] != 1 || a.kh[0] != 3 || a.kw[0] != 3 || a.ph[0] != 1 || a.pw[0] != 1 ||
-        a.pd[0] != 0 || nt < 1 || a.ntile_total % nt != 0 || a.cin % 16 != 0)
+        a.sh != 1 || a.sw != 1 || a.sd != 1 || a.kh[0] != 3 || a.kw[0] != 3 || a.ph[0] != 1 || a.pw[0] != 1 ||
+        nt < 1 || a.ntile_total % nt != 0 || a.cin % 16 != 0)
         return MVSTER_ERR_UNSUPPORTED;
-    const int nch = a.cin / 16;
+    const int nch = a.cin / 16, kd = a.kd[0];
+    if (!(kd == 1 && a.pd[0] == 0) && !(kd == 3 && a.pd[0] == 1)) return MVSTER_ERR_UNSUPPORTED;
+    if (ring) {
+#define MV_R(NT_, NCH_, KD_)                                                                        \
+    if (nt == NT_ && nch == NCH_ && kd == KD_)                                                      \
+        return a.skip_mode == 1 ? launch_wino_ring<NT_, NCH_, KD_, true>(a, s) : launch_wino_ring<NT_, NCH_, KD_, false>(a, s);
+        MV_R(1, 1, 3) MV_R(1, 2, 3) MV_R(2, 2, 3) MV_R(1, 4, 3) MV_R(2, 4, 3)
+        MV_R(1, 4, 1) MV_R(2, 4, 1) MV_R(1, 2, 1) MV_R(2, 2, 1) MV_R(1, 1, 1)
+#undef MV_R
+        return MVSTER_ERR_UNSUPPORTED;
+    }
+    if (kd != 1) return MVSTER_ERR_UNSUPPORTED;
 #define MV_W(NT_, NCH_, WREG_)                                                                      \
     if (nt == NT_ && nch == NCH_)                                                                   \
         return a.skip_mode == 1 ? launch_wino<NT_, NCH_, WREG_, true>(a, wpc, s) : launch_wino<NT_, NCH_, WREG_, false>(a, wpc, s);
@@ -357,15 +705,15 @@ int dispatch_wino(const ConvArgs& a, int nt, int wpc, hipStream_t s) {
 
 }  // namespace mvconv
 
-// Transformed weights for variant 8: w [cout, cin, 3, 3] (element strides given; `flip` mirrors the taps, for the
-// input-gradient form) -> wpk [16 * cin_pad / 16][ceil(cout / 16)][64][4] floats.
-extern "C" int mvster_pack_wino_weights(const float* w, float* wpk, int cout, int cin_raw, int cin_pad, long s_n, long s_c, long s_y,
-                                        long s_x, int flip, void* stream) {
+// Transformed weights for variants 8 / 9: w [cout, cin, kd, 3, 3] (element strides given; `flip` mirrors the taps, for the
+// input-gradient form) -> wpk [kd * 16 * cin_pad / 16][ceil(cout / 16)][64][4] floats.
+extern "C" int mvster_pack_wino_weights(const float* w, float* wpk, int cout, int cin_raw, int cin_pad, int kd, long s_n, long s_c,
+                                        long s_z, long s_y, long s_x, int flip, void* stream) {
     if (!w || !wpk) return MVSTER_ERR_NULL;
-    if (cout < 1 || cin_raw < 1 || cin_pad < cin_raw || cin_pad % 16 != 0) return MVSTER_ERR_SHAPE;
+    if (cout < 1 || cin_raw < 1 || cin_pad < cin_raw || cin_pad % 16 != 0 || (kd != 1 && kd != 3)) return MVSTER_ERR_SHAPE;
     const int ntile = (cout + 15) / 16;
-    const long total = (long)16 * cin_pad * ntile * 16;
+    const long total = (long)kd * 16 * cin_pad * ntile * 16;
     hipLaunchKernelGGL(mvconv::pack_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, wpk, cout,
-                       cin_raw, cin_pad, s_n, s_c, s_y, s_x, flip, ntile);
+                       cin_raw, cin_pad, kd, s_n, s_c, s_z, s_y, s_x, flip, ntile);
     return mv_check_launch();
 }

@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(256) fpn_tail_gather_bwd_kernel(const float* _
 // thrashes the 32 KB L1 (122 us).  Here a thread owns one float4 of output channels (its 4 x CI weights stay in
 // registers) and consecutive threads consecutive channels, so every corner read and every store of a wavefront is a
 // contiguous run of whole cache lines; a workgroup of (CO/4) x 14 threads walks 14 pixels at a time.
-constexpr int kLateralSlots = 14, kLateralIters = 16, kLateralPix = 1;   // 18 x 14 = 252 threads
+constexpr int kLateralSlots = 14, kLateralIters = 16;   // 18 x 14 = 252 threads
 
 template <int CI, int CO>
 __global__ void __launch_bounds__(CO / 4 * kLateralSlots)
