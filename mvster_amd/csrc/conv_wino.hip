@@ -29,6 +29,22 @@ namespace {
 
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
+// Probe build only (make timeline; scripts/conv_wino_timeline.py): s_memtime stamps of conv_wino_ring_kernel, per workgroup,
+// wave and step (< 32): [0] top of the step, [1] MFMAs issued, [2] transform done (before the end-of-step wait), [3] past
+// the barrier.
+#ifdef MVSTER_TIMELINE
+__device__ unsigned long long* g_wtl = nullptr;
+#define MV_WTL(k)                                                                                                       \
+    do {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        if (g_wtl && lane == 0 && g < 32)                                                                               \
+            g_wtl[(((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave8) * 32 + g) * 4 + (k)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
+#else
+#define MV_WTL(k)
+#endif
+
 // Packed fp32 additions: one instruction per TWO lanes-elements (the transforms are additions only; hipcc emits v_pk_add_f32
 // for a + b but four v_sub_f32 for a float4 subtraction -- the negation is an operand modifier of the packed form).
 // The hazard recogniser does not look inside inline assembly: results of MFMAs reach these only behind the explicit
@@ -332,46 +348,73 @@ struct RingStep {          // one step of one tile: everything wave-uniform
     bool live;
 };
 
-template <int NT, int NCH, int KD, bool SKIP>
-__global__ void __launch_bounds__(256) conv_wino_ring_kernel(ConvArgs a, PersArgs p) {
+// Eight waves per workgroup, two per SIMD: waves 0-3 are the four tile rows of one N tile; waves 4-7 either compute the
+// SECOND N tile of the same pixels (SPLITN: the layer has >= 32 output channels; both halves read the same slices, each
+// issues half of the DMA) or only issue the DMA (cout == 16).  Why: an LDS-DMA instruction stalls the issuing wave for
+// 60-180 cycles (MI355X_MICROARCH "LDS-DMA piece issue cost"), ~10 of them per step; with one wave per SIMD the matrix pipe
+// idles through every one of those stalls (first version, 4 waves: 4 000 cycles per 64-MFMA step), with a second wave on the
+// SIMD the pipe has other MFMAs to run.  (VALU work is not hidden that way: fp32 MFMAs and VALU instructions of two waves on
+// one SIMD were never seen to overlap -- conv_pp_kernel in conv_pers.hip is the experiment.)
+template <int NCH, int KD, bool SKIP, bool SPLITN>
+__global__ void __launch_bounds__(512) conv_wino_ring_kernel(ConvArgs a, PersArgs p) {
+    constexpr int NT = 1;                                   // N tiles per compute wave
+    constexpr int NTW = SPLITN ? 2 : 1;                     // N tiles per workgroup
     using G = RingGeom;
     constexpr int TY = G::TY, PLANE = G::PLANE, NBLK = G::NBLK, RS = G::ROWSLOTS, SLICE = G::SLICE;
-    constexpr int NI = 2 * NBLK;                            // DMA wave-instructions per slice
-    constexpr int NIW = (NI + 3) / 4;
-    constexpr int NUW = 4 * NT;                             // weight DMA instructions per wave and step (16 * NT in all)
+    constexpr int NLW = SPLITN ? 8 : 4;                     // waves that issue DMA
+    constexpr int NIW = (NBLK + NLW / 2 - 1) / (NLW / 2);  // slice DMA instructions per loading wave and step (one plane's share)
+    constexpr int NUW = 16 * NTW / NLW;                     // weight DMA instructions per loading wave and step
     constexpr int CIN = NCH * 16;
-    constexpr int UST = 16 * NT * 64;                       // float4 per weight ring slot
+    constexpr int UST = 16 * NTW * 64;                      // float4 per weight ring slot
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     f32x4v* const ring = reinterpret_cast<f32x4v*>(lds_raw);              // 4 patch slices
     f32x4v* const uring = ring + 4 * SLICE;                               // 2 weight slots [point][nt][lane]
     f32x4v* const scratch = uring + 2 * UST;                              // 64 float4: surplus DMA slots
 
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = wave8 >> 2, wave = wave8 & 3;          // wave: tile row pair (compute) 
+    const bool loads = SPLITN || half == 1;
+    const int lw = SPLITN ? wave8 : wave;                   // index among the loading waves
     const int lm = lane & 15, lq = lane >> 4;
-    const int nt0 = blockIdx.y * NT;
-    const __amdgpu_buffer_rsrc_t in_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)a.in_bytes, 0x00020000);
+    const int nt0 = blockIdx.y * NTW;                       // first N tile of the workgroup
+    const int ntw = SPLITN ? half : 0;                      // this wave's N tile inside the workgroup
+    // Consecutive LDS-DMA instructions of a wave that target consecutive kilobytes of LDS share ONE M0 value and differ in
+    // the instruction's immediate offset (0, 1024, 2048, 3072) -- rewriting M0 between two of them makes the second wait
+    // until the first has landed (measured: 270-350 cycles per instruction, profiles/r03_k_wino_timeline.txt).  The
+    // immediate also moves the global address, so instruction k reads through a descriptor whose base is 1024*k lower.
     const long wstep = (long)a.ntile_total * 256;          // floats per K step (16 channels) of the packed weights
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.wpk), (short)0, (int)(KD * 16 * NCH * wstep * 4), 0x00020000);
+    auto in_rsrc = [&](int k) -> __amdgpu_buffer_rsrc_t {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in) - 256 * k, (short)0, (int)(a.in_bytes + 1024u * k), 0x00020000);
+    };
+    auto w_rsrc = [&](int k) -> __amdgpu_buffer_rsrc_t {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpk) - 256 * k, (short)0,
+                                                 (int)(KD * 16 * NCH * wstep * 4 + 1024 * k), 0x00020000);
+    };
 
-    // ---- LDS-DMA address decode of one slice: instruction i = wave + 4n -> (plane, block); lane -> slot -> (row, px, quad)
-    unsigned dbase[NIW];
-    int dpos[NIW];
-#pragma unroll
-    for (int n = 0; n < NIW; ++n) {
-        const int i = wave + 4 * n;
-        const int pl = i / NBLK, blk = i - pl * NBLK;
-        const int s = blk * 64 + lane;
+    // ---- LDS-DMA address decode of one slice: instruction i = lw + NLW*n -> (plane, block); lane -> slot -> (row, px, quad)
+    // dbase = byte offset of the lane's 16 bytes relative to the slice origin (0x80000000: the slot holds no pixel),
+    // dpos = px | row << 8 for the border test.  Kept in registers when every wave loads (3 pieces each); recomputed per
+    // step by the loading waves of the cout == 16 form (6 pieces: 12 registers the compute waves cannot spare).
+    static_assert((NLW / 2) * NIW >= NBLK, "the waves of one plane cover its blocks");
+    const int lpl = lw / (NLW / 2), lblk0 = (lw % (NLW / 2)) * NIW;       // this wave's plane and first block
+    auto decode_piece = [&](int n, int ln, unsigned& db, int& dp) {
+        const int pl = lpl, blk = lblk0 + n;
+        const int s = blk * 64 + ln;
         const int q1 = s & 1;
         int t = s >> 1;
         const int xh = t % G::PWH;
         t /= G::PWH;
         const int py = t >> 1, px = 2 * xh + (t & 1);
-        const bool valid = i < NI && py < G::PH;
-        dpos[n] = px | (py << 8);
-        dbase[n] = valid ? (unsigned)((py * a.Wi + px) * (CIN * 4) + (pl * 8 + q1 * 4) * 4) : 0x80000000u;
+        const bool valid = blk < NBLK && py < G::PH;
+        dp = px | (py << 8);
+        db = valid ? (unsigned)((py * a.Wi + px) * (CIN * 4) + (pl * 8 + q1 * 4) * 4) : 0x80000000u;
+    };
+    unsigned dbase[SPLITN ? NIW : 1];
+    int dpos[SPLITN ? NIW : 1];
+    if (SPLITN) {
+#pragma unroll
+        for (int n = 0; n < NIW; ++n) decode_piece(n, lane, dbase[n], dpos[n]);
     }
     auto decode_tile = [&](unsigned tile) -> TilePos {
         TilePos t;
@@ -407,32 +450,82 @@ __global__ void __launch_bounds__(256) conv_wino_ring_kernel(ConvArgs a, PersArg
         }
         return n;
     };
-    auto dma_slice = [&](const RingStep& st, int slot) {
-        const int iz = st.pos.zo + st.kz - a.pd[0], iy0 = st.pos.ty0 - a.ph[0], ix0 = st.pos.tx0 - a.pw[0];
-        const unsigned origin = (unsigned)(((((st.pos.b * a.Di + iz) * a.Hi + iy0) * a.Wi + ix0) * CIN + st.c * 16) * 4);
-        const unsigned wi = st.live ? (unsigned)a.Wi : 0u;
-        f32x4v* const dst0 = ring + slot * SLICE;
-#pragma unroll
-        for (int n = 0; n < NIW; ++n) {
-            const int i = wave + 4 * n;
-            const int ix = ix0 + (dpos[n] & 255), iy = iy0 + (dpos[n] >> 8);
-            const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < wi;
-            const unsigned off = ok ? dbase[n] + origin : 0x80000000u;
-            f32x4v* const dst = (NI % 4 == 0 || n + 1 < NIW || i < NI) ? dst0 + (i / NBLK) * PLANE + (i % NBLK) * 64 : scratch;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_void*)dst, 16, off, 0, 0, 0);
+    // One slice / weight request = NIW / NUW LDS-DMA instructions of this wave, issued one by one ("pieces") so that the
+    // compute waves can spread them over the MFMA phase: an LDS-DMA instruction holds its wave for 60-180 cycles, which the
+    // other wave of the SIMD fills with its MFMAs only if that wave is not stalled at the same place.
+    // Interior slices (all 10 x 34 pixels inside the image) need no per-lane test: the lane's offset is a constant and
+    // the slice origin goes into the instruction's scalar offset -- no VALU work at all.
+    struct SliceReq {
+        unsigned origin, wi;
+        int iy0, ix0;
+        bool interior;
+        f32x4v* dst0;
+    };
+    auto slice_req = [&](const RingStep& st, int slot) -> SliceReq {
+        SliceReq r;
+        const int iz = st.pos.zo + st.kz - a.pd[0];
+        r.iy0 = st.pos.ty0 - a.ph[0];
+        r.ix0 = st.pos.tx0 - a.pw[0];
+        r.origin = (unsigned)(((((st.pos.b * a.Di + iz) * a.Hi + r.iy0) * a.Wi + r.ix0) * CIN + st.c * 16) * 4);
+        r.wi = st.live ? (unsigned)a.Wi : 0u;
+        r.interior = st.live && r.iy0 >= 0 && r.ix0 >= 0 && r.iy0 + G::PH <= a.Hi && r.ix0 + 2 * G::PWH <= a.Wi;
+        r.dst0 = ring + slot * SLICE;
+        return r;
+    };
+    auto slice_piece = [&](const SliceReq& r, int n, unsigned db, int dp) {
+        // pieces 4k .. 4k+3 of this wave: M0 = the wave's first block + 4 KB * k, immediate 1024 * (n % 4); the piece past
+        // the plane's last block (one wave per plane has it) goes to the scratch block, every lane out of range
+        constexpr int IMM[4] = {0, 1024, 2048, 3072};
+        const bool real = lblk0 + n < NBLK;
+        f32x4v* const dst = (NIW * (NLW / 2) == NBLK || n + 1 < NIW || real) ? r.dst0 + lpl * PLANE + (lblk0 + (n & ~3)) * 64
+                                                                             : scratch - (n & 3) * 64;
+        // (named operands: hipcc 7.2 silently drops the kernel's host stub when this builtin is handed an arithmetic
+        //  expression as its offset)
+        const __amdgpu_buffer_rsrc_t rs = in_rsrc(n & 3);
+        if (r.interior) {
+            const unsigned so = r.origin;
+            switch (n & 3) {
+                case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, db, so, IMM[0], 0); break;
+                case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, db, so, IMM[1], 0); break;
+                case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, db, so, IMM[2], 0); break;
+                default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, db, so, IMM[3], 0); break;
+            }
+        } else {
+            const int ix = r.ix0 + (dp & 255), iy = r.iy0 + (dp >> 8);
+            const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < r.wi;
+            const unsigned off = ok ? db + r.origin : 0x80000000u;
+            switch (n & 3) {
+                case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, off, 0, IMM[0], 0); break;
+                case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, off, 0, IMM[1], 0); break;
+                case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, off, 0, IMM[2], 0); break;
+                default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, off, 0, IMM[3], 0); break;
+            }
         }
     };
-    auto dma_weights = [&](const RingStep& st, int slot) {
-        // K steps of this (kz, chunk): (kz*16 + point)*NCH + c; instruction u = wave + 4m -> (point, nt)
-        const unsigned base = (unsigned)(((long)(st.kz * 16 * NCH + st.c) * wstep + (long)nt0 * 256) * 4) + lane * 16;
-        f32x4v* const dst0 = uring + slot * UST;
-#pragma unroll
-        for (int m = 0; m < NUW; ++m) {
-            const int u = wave + 4 * m;
-            const int q = u / NT, nt = u - q * NT;
-            const unsigned off = st.live ? base + (unsigned)(((long)q * NCH * wstep + nt * 256) * 4) : 0x80000000u;
-            f32x4v* const dst = dst0 + u * 64;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)dst, 16, off, 0, 0, 0);
+    struct WeightReq {
+        unsigned base;
+        f32x4v* dst0;
+    };
+    auto weight_req = [&](const RingStep& st, int slot) -> WeightReq {
+        // K steps of this (kz, chunk): (kz*16 + point)*NCH + c; a dead step asks beyond the array (nothing is fetched)
+        WeightReq r;
+        r.base = st.live ? (unsigned)(((long)(st.kz * 16 * NCH + st.c) * wstep + (long)nt0 * 256) * 4) : 0x80000000u;
+        r.dst0 = uring + slot * UST;
+        return r;
+    };
+    const unsigned wlane = lane * 16;
+    static_assert(NUW <= 4, "one M0 value per weight request");
+    auto weight_piece = [&](const WeightReq& r, int m) {
+        const int u = lw * NUW + m;                         // -> (point, nt); this wave's NUW kilobytes are consecutive
+        const int q = u / NTW, nt = u - q * NTW;
+        const unsigned so = r.base + (unsigned)(((long)q * NCH * wstep + nt * 256) * 4);
+        f32x4v* const dst = r.dst0 + lw * NUW * 64;
+        const __amdgpu_buffer_rsrc_t rs = w_rsrc(m);
+        switch (m) {
+            case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, wlane, so, 0, 0); break;
+            case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, wlane, so, 1024, 0); break;
+            case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, wlane, so, 2048, 0); break;
+            default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, wlane, so, 3072, 0); break;
         }
     };
 
@@ -440,7 +533,7 @@ __global__ void __launch_bounds__(256) conv_wino_ring_kernel(ConvArgs a, PersArg
     f32x4v scv[NT], shv[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int n0 = (nt0 + nt) * 16 + lq * 4;
+        const int n0 = (nt0 + ntw + nt) * 16 + lq * 4;
         scv[nt] = *reinterpret_cast<const f32x4v*>(a.scale + n0);
         shv[nt] = *reinterpret_cast<const f32x4v*>(a.shift + n0);
     }
@@ -450,7 +543,7 @@ __global__ void __launch_bounds__(256) conv_wino_ring_kernel(ConvArgs a, PersArg
         __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (int)p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t skip_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(SKIP ? a.skip : a.in), (short)0, SKIP ? (int)p.out_bytes : 0, 0x00020000);
-    const unsigned obase = (unsigned)((2 * wave * a.Wo + 2 * lm) * a.cout + nt0 * 16 + lq * 4) * 4u;
+    const unsigned obase = (unsigned)((2 * wave * a.Wo + 2 * lm) * a.cout + (nt0 + ntw) * 16 + lq * 4) * 4u;
     const unsigned opix = (unsigned)a.cout * 4u, orow = (unsigned)a.Wo * opix;
     const float floor_v = a.relu ? 0.0f : -__builtin_inff();
 
@@ -486,119 +579,186 @@ __global__ void __launch_bounds__(256) conv_wino_ring_kernel(ConvArgs a, PersArg
     // steps in flight: s0 = the one computed now, s1 = next (its weights are requested now), s3 = three ahead (its slice is)
     RingStep s0 = first_step(xcd_remap(blockIdx.x, nwg));
     RingStep s1 = next_step(s0), s2 = next_step(s1), s3 = next_step(s2);
-    dma_slice(s0, 0);
-    dma_slice(s1, 1);
-    dma_slice(s2, 2);
-    dma_weights(s0, 0);
+    if (loads) {
+        // (the loading waves of the cout == 16 form keep their own copy of the decode: it is live only on their path)
+        unsigned db0[NIW];
+        int dp0[NIW];
+#pragma unroll
+        for (int n = 0; n < NIW; ++n) decode_piece(n, lane, db0[n], dp0[n]);
+        const RingStep* const first[3] = {&s0, &s1, &s2};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const SliceReq r = slice_req(*first[k], k);
+#pragma unroll
+            for (int n = 0; n < NIW; ++n) slice_piece(r, n, db0[n], dp0[n]);
+        }
+        const WeightReq w0 = weight_req(s0, 0);
+#pragma unroll
+        for (int m = 0; m < NUW; ++m) weight_piece(w0, m);
+    }
+    __syncthreads();        // (waits for everything requested so far)
+    if (!SPLITN && half == 1) {
+        // ---- loading waves (cout == 16 form): a loop of their own -- same barrier count, none of the compute registers.
+        // Per step: this step's requests, then wait until slice g+2 and weights g+1 have landed.
+        unsigned dbl[NIW];
+        int dpl[NIW];
+#pragma unroll
+        for (int n = 0; n < NIW; ++n) decode_piece(n, lane, dbl[n], dpl[n]);
+        for (int g = 0; s0.live; ++g) {
+            MV_WTL(0);
+            const WeightReq wr = weight_req(s1, (g + 1) & 1);
+#pragma unroll
+            for (int m = 0; m < NUW; ++m) weight_piece(wr, m);
+            const SliceReq sr = slice_req(s3, (g + 3) & 3);
+#pragma unroll
+            for (int n = 0; n < NIW; ++n) slice_piece(sr, n, dbl[n], dpl[n]);
+            MV_WTL(1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+            MV_WTL(2);
+            __builtin_amdgcn_s_barrier();
+            MV_WTL(3);
+            s0 = s1;
+            s1 = s2;
+            s2 = s3;
+            s3 = next_step(s3);
+        }
+        return;
+    }
     f32x4v acc[16][NT];
 #pragma unroll
     for (int q = 0; q < 16; ++q)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[q][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-    __syncthreads();        // (waits for everything requested so far)
     read_block(0);
     transform_block();
 
     for (int g = 0; s0.live; ++g) {
         const bool last = is_last(s0);
-        // the tile's output offsets and skip values: only needed behind its last step, requested ahead of the DMA (older in
-        // the memory queue than anything this step waits for)
-        unsigned ooff[2][2];
-        f32x4v skv[2][2][NT];
-        if (last) {
-            const TilePos& here = s0.pos;
-            const unsigned oorigin = (unsigned)((((here.b * a.Do + here.zo) * a.Ho + here.ty0) * a.Wo + here.tx0) * a.cout) * 4u;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const bool ok = here.ty0 + 2 * wave + i < a.Ho && here.tx0 + 2 * lm + j < a.Wo;
-                    ooff[i][j] = ok ? obase + oorigin + i * orow + j * opix : 0x80000000u;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        skv[i][j][nt] = SKIP ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, ooff[i][j] + nt * 64, 0, 0))
-                                             : (f32x4v){0.f, 0.f, 0.f, 0.f};
-                }
-        }
-        dma_weights(s1, (g + 1) & 1);
-        dma_slice(s3, (g + 3) & 3);
-        __builtin_amdgcn_sched_barrier(0);
-        read_block((g + 1) & 3);          // next step's pixels: in flight under this step's MFMAs
-        __builtin_amdgcn_sched_barrier(0);
+        MV_WTL(0);
         {
-            const f32x4v* const us = uring + (g & 1) * UST + lane;
-            f32x4v ub[2][4][NT];
-            auto load_u = [&](int grp, f32x4v (&dst)[4][NT]) {
+            // the tile's output offsets and skip values: only needed behind its last step, requested ahead of the DMA
+            // (older in the memory queue than anything this step waits for)
+            unsigned ooff[2][2];
+            f32x4v skv[2][2][NT];
+            if (last) {
+                const TilePos& here = s0.pos;
+                const unsigned oorigin = (unsigned)((((here.b * a.Do + here.zo) * a.Ho + here.ty0) * a.Wo + here.tx0) * a.cout) * 4u;
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) dst[qq][nt] = us[((grp * 4 + qq) * NT + nt) * 64];
-            };
-            load_u(0, ub[0]);
+                    for (int j = 0; j < 2; ++j) {
+                        const bool ok = here.ty0 + 2 * wave + i < a.Ho && here.tx0 + 2 * lm + j < a.Wo;
+                        ooff[i][j] = ok ? obase + oorigin + i * orow + j * opix : 0x80000000u;
 #pragma unroll
-            for (int grp = 0; grp < 4; ++grp) {
-                if (grp < 3) load_u(grp + 1, ub[(grp + 1) & 1]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
+                        for (int nt = 0; nt < NT; ++nt)
+                            skv[i][j][nt] = SKIP ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, ooff[i][j] + nt * 64, 0, 0))
+                                                 : (f32x4v){0.f, 0.f, 0.f, 0.f};
+                    }
+            }
+            // This step's requests (weights of step g+1, then the slice of step g+3) and the 16 reads of the next step's
+            // pixels are spread over the four MFMA groups: their issue stalls fall between this wave's MFMAs, where the
+            // other wave of the SIMD has MFMAs to run, instead of at a place where both wait.
+            const WeightReq wr = weight_req(s1, (g + 1) & 1);
+            const SliceReq sr = slice_req(s3, (g + 3) & 3);
+            const f32x4v* const nextp = ring + ((g + 1) & 3) * SLICE + abase;
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const f32x4v* const us = uring + (g & 1) * UST + ntw * 64 + lane;
+                f32x4v ub[2][4][NT];
+                auto load_u = [&](int grp, f32x4v (&dst)[4][NT]) {
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[grp * 4 + qq][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[grp & 1][qq][nt][j], elem(V[grp][qq], j),
-                                                                                         acc[grp * 4 + qq][nt], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // (the packed additions are inline assembly: MFMA results reach them only behind these wait states, and the
-        //  transform below overwrites MFMA source registers)
-        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (last) {
-            // Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; fused epilogue on the 2x2 pixels x 4 channels of this lane
+                        for (int nt = 0; nt < NT; ++nt) dst[qq][nt] = us[((grp * 4 + qq) * NTW + nt) * 64];
+                };
+                constexpr int NP = SPLITN ? NUW + NIW : 0;          // DMA pieces of a compute wave per step
+                load_u(0, ub[0]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                Q4 m[16], t[2][4];
+                for (int grp = 0; grp < 4; ++grp) {
+                    if (grp < 3) load_u(grp + 1, ub[(grp + 1) & 1]);
 #pragma unroll
-                for (int q = 0; q < 16; ++q) m[q] = {{acc[q][nt][0], acc[q][nt][1]}, {acc[q][nt][2], acc[q][nt][3]}};
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    t[0][x] = m[0 + x] + m[4 + x] + m[8 + x];
-                    t[1][x] = m[4 + x] - (m[8 + x] + m[12 + x]);
-                }
+                        for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    Q4 y[2];
-                    y[0] = t[i][0] + t[i][1] + t[i][2];
-                    y[1] = t[i][1] - (t[i][2] + t[i][3]);
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[grp * 4 + qq][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[grp & 1][qq][nt][j], elem(V[grp][qq], j),
+                                                                                             acc[grp * 4 + qq][nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        f32x4v v = {y[j].lo[0], y[j].lo[1], y[j].hi[0], y[j].hi[1]};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = fmaxf(fmaf(v[e], scv[nt][e], shv[nt][e]), floor_v);
-                            if (SKIP) v[e] += skv[i][j][nt][e];
+                    for (int k = grp * 2; k < grp * 2 + 2 && k < NP; ++k) {
+                        if (k < NUW) {
+                            weight_piece(wr, k);
+                        } else {
+                            slice_piece(sr, k - NUW, dbase[k - NUW], dpos[k - NUW]);
                         }
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, ooff[i][j] + nt * 64, 0, 0);
+                    }
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {               // row grp of the next step's 4x4 block
+                        const f32x4v v = nextp[grp * RS + (x & 1) * (G::PWH * 2) + (x >> 1) * 2];
+                        d[grp][x] = {{v[0], v[1]}, {v[2], v[3]}};
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            MV_WTL(1);
+            __builtin_amdgcn_sched_barrier(0);
+            // (the packed additions are inline assembly: MFMA results reach them only behind these wait states, and the
+            //  transform below overwrites MFMA source registers)
+            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (last) {
+                // Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; fused epilogue on the 2x2 pixels x 4 channels of this lane
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    Q4 m[16], t[2][4];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) m[q] = {{acc[q][nt][0], acc[q][nt][1]}, {acc[q][nt][2], acc[q][nt][3]}};
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        t[0][x] = m[0 + x] + m[4 + x] + m[8 + x];
+                        t[1][x] = m[4 + x] - (m[8 + x] + m[12 + x]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        Q4 y[2];
+                        y[0] = t[i][0] + t[i][1] + t[i][2];
+                        y[1] = t[i][1] - (t[i][2] + t[i][3]);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            f32x4v v = {y[j].lo[0], y[j].lo[1], y[j].hi[0], y[j].hi[1]};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[e] = fmaxf(fmaf(v[e], scv[nt][e], shv[nt][e]), floor_v);
+                                if (SKIP) v[e] += skv[i][j][nt][e];
+                            }
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, ooff[i][j] + nt * 64, 0, 0);
+                        }
                     }
                 }
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[q][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
             }
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[q][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_sched_barrier(0);
+            transform_block();                // d (step g+1) -> V
+            MV_WTL(2);
+            __builtin_amdgcn_sched_barrier(0);
+            // slice g+2 and weights g+1 have landed once only this step's slice request (and the stores behind it) are
+            // outstanding
+            if (SPLITN) {
+                if (last) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW + 4 * NT) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+                }
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        transform_block();                // d (step g+1) -> V
-        __builtin_amdgcn_sched_barrier(0);
-        // slice g+2 and weights g+1 have landed once only this step's slice request (and the stores behind it) are
-        // outstanding; then everyone is done with slice g and weight slot g & 1
-        if (last) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW + 4 * NT) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
-        }
+        // everyone is done with slice g and weight slot g & 1
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
+        MV_WTL(3);
         s0 = s1;
         s1 = s2;
         s2 = s3;
@@ -606,12 +766,13 @@ __global__ void __launch_bounds__(256) conv_wino_ring_kernel(ConvArgs a, PersArg
     }
 }
 
-template <int NT, int NCH, int KD, bool SKIP>
+template <int NCH, int KD, bool SKIP, bool SPLITN>
 int launch_wino_ring(const ConvArgs& a, hipStream_t s) {
     using G = RingGeom;
+    constexpr int NT = SPLITN ? 2 : 1;                     // N tiles per workgroup
     const size_t lds = (size_t)(4 * G::SLICE + 2 * 16 * NT * 64 + 64) * 16;
     if (lds > 160 * 1024) return MVSTER_ERR_UNSUPPORTED;
-    auto kern = conv_wino_ring_kernel<NT, NCH, KD, SKIP>;
+    auto kern = conv_wino_ring_kernel<NCH, KD, SKIP, SPLITN>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -629,8 +790,8 @@ int launch_wino_ring(const ConvArgs& a, hipStream_t s) {
     if (gmax < 1) gmax = 1;
     const long rounds = (ntiles + gmax - 1) / gmax;       // equal shares
     const long gx = (ntiles + rounds - 1) / rounds;
-    MV_NOTE_KERNEL("conv_wino_ring_kernel<%d, %d, %d, %s>", NT, NCH, KD, SKIP ? "true" : "false");
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, ny, 1), dim3(256), lds, s, a, p);
+    MV_NOTE_KERNEL("conv_wino_ring_kernel<%d, %d, %s, %s>", NCH, KD, SKIP ? "true" : "false", SPLITN ? "true" : "false");
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, ny, 1), dim3(512), lds, s, a, p);
     return mv_check_launch();
 }
 
@@ -683,9 +844,10 @@ int dispatch_wino(const ConvArgs& a, int nt, int wpc, bool ring, hipStream_t s) 
     const int nch = a.cin / 16, kd = a.kd[0];
     if (!(kd == 1 && a.pd[0] == 0) && !(kd == 3 && a.pd[0] == 1)) return MVSTER_ERR_UNSUPPORTED;
     if (ring) {
+        // nt = 2: the two halves of the workgroup compute two N tiles; nt = 1: waves 4-7 only issue the DMA
 #define MV_R(NT_, NCH_, KD_)                                                                        \
     if (nt == NT_ && nch == NCH_ && kd == KD_)                                                      \
-        return a.skip_mode == 1 ? launch_wino_ring<NT_, NCH_, KD_, true>(a, s) : launch_wino_ring<NT_, NCH_, KD_, false>(a, s);
+        return a.skip_mode == 1 ? launch_wino_ring<NCH_, KD_, true, NT_ == 2>(a, s) : launch_wino_ring<NCH_, KD_, false, NT_ == 2>(a, s);
         MV_R(1, 1, 3) MV_R(1, 2, 3) MV_R(2, 2, 3) MV_R(1, 4, 3) MV_R(2, 4, 3)
         MV_R(1, 4, 1) MV_R(2, 4, 1) MV_R(1, 2, 1) MV_R(2, 2, 1) MV_R(1, 1, 1)
 #undef MV_R
@@ -704,6 +866,12 @@ int dispatch_wino(const ConvArgs& a, int nt, int wpc, bool ring, hipStream_t s) 
 }
 
 }  // namespace mvconv
+
+#ifdef MVSTER_TIMELINE
+extern "C" int mvster_debug_wino_timeline(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(mvconv::g_wtl), &buf, sizeof(buf)) == hipSuccess ? MVSTER_OK : MVSTER_ERR_LAUNCH;
+}
+#endif
 
 // Transformed weights for variants 8 / 9: w [cout, cin, kd, 3, 3] (element strides given; `flip` mirrors the taps, for the
 // input-gradient form) -> wpk [kd * 16 * cin_pad / 16][ceil(cout / 16)][64][4] floats.

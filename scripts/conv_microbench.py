@@ -74,9 +74,13 @@ def candidates(layer, B, Di, Hi, Wi, sm):
                     out.append(("P2,%d w%d" % (n, wpc), (2, n, 5 | (wpc << 8))))
         if layer.wino_eligible():
             # Winograd F(2x2,3x3) on the persistent frame (conv_wino.hip); not bit-identical to the others
-            for n in nts:
-                for wpc in (1, 2):
-                    out.append(("W%d w%d" % (n, wpc), (2, n, 8 | (wpc << 8))))
+            if layer.kernel[0] == 1 and layer.cin in (16, 32):
+                for n in nts:
+                    for wpc in (1, 2):
+                        out.append(("W%d w%d" % (n, wpc), (2, n, 8 | (wpc << 8))))
+            for n in (1, 2):                  # ring form: 1 = waves 4-7 only load, 2 = they compute a second N tile
+                if n in nts:
+                    out.append(("R%d" % n, (2, n, 9)))
     return out
 
 

@@ -454,45 +454,51 @@ def test_pingpong_conv_bit_identical_to_direct(cin, cout, stride, nt, shape, wit
     assert _lib.last_kernel().startswith("conv_pp_kernel<")
 
 
-WINO_CASES = [  # (cin, cout, nt, input [B,D,H,W]): every instance of the Winograd family, ragged sizes, odd widths / heights
-    (16, 16, 1, (2, 1, 70, 100)), (16, 16, 1, (1, 1, 4, 33)), (16, 16, 1, (7, 1, 13, 63)), (16, 32, 2, (1, 1, 37, 65)),
-    (32, 32, 2, (3, 1, 64, 64)), (32, 32, 2, (1, 4, 38, 70)), (32, 16, 1, (1, 1, 5, 200)), (32, 64, 2, (1, 1, 21, 50)),
+WINO_CASES = [  # (cin, cout, kd, nt, variant, input [B,D,H,W]): every instance of the Winograd families, ragged sizes
+    (16, 16, 1, 1, 8, (2, 1, 70, 100)), (16, 16, 1, 1, 8, (1, 1, 4, 33)), (16, 16, 1, 1, 8, (7, 1, 13, 63)),
+    (16, 32, 1, 2, 8, (1, 1, 37, 65)), (32, 32, 1, 2, 8, (3, 1, 64, 64)), (32, 32, 1, 2, 8, (1, 4, 38, 70)),
+    (32, 16, 1, 1, 8, (1, 1, 5, 200)), (32, 64, 1, 2, 8, (1, 1, 21, 50)),
+    # ring form: depth taps (with the padded ones skipped), 64 channels, both roles of waves 4-7, dead steps at the end
+    (16, 16, 3, 1, 9, (2, 4, 38, 70)), (16, 16, 3, 1, 9, (1, 1, 5, 31)), (16, 16, 3, 1, 9, (1, 2, 8, 32)),
+    (32, 32, 3, 2, 9, (1, 8, 16, 20)), (32, 32, 3, 1, 9, (2, 3, 9, 40)), (64, 64, 3, 2, 9, (1, 4, 13, 63)),
+    (64, 64, 3, 1, 9, (1, 8, 8, 10)), (64, 64, 1, 2, 9, (5, 1, 20, 40)), (64, 32, 1, 1, 9, (2, 1, 37, 50)),
+    (64, 32, 1, 2, 9, (1, 1, 16, 33)), (16, 16, 1, 1, 9, (1, 1, 4, 33)), (32, 32, 1, 2, 9, (3, 1, 64, 64)),
 ]
 
 
-@pytest.mark.parametrize("cin,cout,nt,shape", WINO_CASES)
+@pytest.mark.parametrize("cin,cout,kd,nt,variant,shape", WINO_CASES)
 @pytest.mark.parametrize("with_skip", [False, True])
-def test_winograd_conv_against_fp64_and_direct(cin, cout, nt, shape, with_skip):
-    """Variant 8 computes the 3x3 convolution as F(2x2, 3x3) minimal filtering: a different operation order, so the
-    comparison is against an fp64 convolution -- its error must stay within 2e-6 of max |y| (the direct kernel's own error on
+def test_winograd_conv_against_fp64_and_direct(cin, cout, kd, nt, variant, shape, with_skip):
+    """Variants 8 / 9 compute the 3x3 in-plane taps as F(2x2, 3x3) minimal filtering: a different operation order, so the
+    comparison is against an fp64 convolution -- the error must stay within 2e-6 of max |y| (the direct kernel's own error on
     these inputs is ~4e-7) -- and within 2e-6 of the direct kernel."""
-    g = torch.Generator().manual_seed(cin * 29 + cout + shape[3])
-    w = (torch.randn(cout, cin, 1, 3, 3, generator=g) * 0.1).to(DEV)
-    layer = cp.ConvLayer(w, False, (1, 1, 1), (0, 1, 1), relu=not with_skip)
+    g = torch.Generator().manual_seed(cin * 29 + cout + shape[3] + kd)
+    w = (torch.randn(cout, cin, kd, 3, 3, generator=g) * 0.1).to(DEV)
+    layer = cp.ConvLayer(w, False, (1, 1, 1), (kd // 2, 1, 1), relu=not with_skip)
     assert layer.wino_eligible() and layer.wpk_wino is not None
     layer.scale.copy_(torch.rand(layer.scale.shape, generator=g) + 0.5)
     layer.shift.copy_(torch.randn(layer.shift.shape, generator=g) * 0.1)
     x = torch.randn(*shape, cin, generator=g).to(DEV)
     B, D, H, W = shape
-    ref = F.conv2d(x.double().reshape(B * D, H, W, cin).permute(0, 3, 1, 2), w[:, :, 0].double(), padding=1)
-    ref = ref * layer.scale[:cout].double().view(1, -1, 1, 1) + layer.shift[:cout].double().view(1, -1, 1, 1)
+    ref = F.conv3d(x.double().permute(0, 4, 1, 2, 3), w.double(), padding=(kd // 2, 1, 1))
+    ref = ref * layer.scale[:cout].double().view(1, -1, 1, 1, 1) + layer.shift[:cout].double().view(1, -1, 1, 1, 1)
     if not with_skip:
         ref = ref.clamp_min(0)
-    ref = ref.permute(0, 2, 3, 1).reshape(B, D, H, W, cout)
+    ref = ref.permute(0, 2, 3, 4, 1)
     skip = torch.randn(B, D, H, W, cout, generator=g).to(DEV) if with_skip else None
     sm = cp.SKIP_ADD if with_skip else cp.SKIP_NONE
     if with_skip:
         ref = ref + skip.double()
     direct = layer(x, skip=skip, skip_mode=sm, tiles=(1, 1, 0))
     scale = ref.abs().max().item()
-    for wpc in (0, 1, 2):
-        got = layer(x, skip=skip, skip_mode=sm, tiles=(2, nt, 8 | (wpc << 8)))
+    for wpc in ((0, 1, 2) if variant == 8 else (0,)):
+        got = layer(x, skip=skip, skip_mode=sm, tiles=(2, nt, variant | (wpc << 8)))
         assert torch.isfinite(got).all()
         assert (got.double() - ref).abs().max().item() <= 2e-6 * scale, (wpc, (got.double() - ref).abs().max().item() / scale)
         assert (got - direct).abs().max().item() <= 2e-6 * scale
     from mvster_amd import _lib
-    assert _lib.last_kernel().startswith("conv_wino_kernel<")
-    note("conv_winograd_%d_%d_%s" % (cin, cout, "x".join(map(str, shape))), err_over_max=(got.double() - ref).abs().max().item() / scale,
+    assert _lib.last_kernel().startswith("conv_wino_kernel<" if variant == 8 else "conv_wino_ring_kernel<")
+    note("conv_winograd%d_%d_%d_k%d_nt%d_%s" % (variant, cin, cout, kd, nt, "x".join(map(str, shape))), err_over_max=(got.double() - ref).abs().max().item() / scale,
          direct_err_over_max=(direct.double() - ref).abs().max().item() / scale)
 
 
