@@ -366,10 +366,12 @@ __global__ void __launch_bounds__(512) conv_wino_ring_kernel(ConvArgs a, PersArg
     constexpr int NUW = 16 * NTW / NLW;                     // weight DMA instructions per loading wave and step
     constexpr int CIN = NCH * 16;
     constexpr int UST = 16 * NTW * 64;                      // float4 per weight ring slot
+    constexpr bool URES = KD * NCH * NTW <= 4;              // all transformed weights of the workgroup fit 64 KB: fetched once
+    constexpr int USLOTS = URES ? KD * NCH : 2;
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     f32x4v* const ring = reinterpret_cast<f32x4v*>(lds_raw);              // 4 patch slices
     f32x4v* const uring = ring + 4 * SLICE;                               // 2 weight slots [point][nt][lane]
-    f32x4v* const scratch = uring + 2 * UST;                              // 64 float4: surplus DMA slots
+    f32x4v* const scratch = uring + USLOTS * UST;                         // 64 float4: surplus DMA slots
 
     const int lane = threadIdx.x & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -592,9 +594,27 @@ __global__ void __launch_bounds__(512) conv_wino_ring_kernel(ConvArgs a, PersArg
 #pragma unroll
             for (int n = 0; n < NIW; ++n) slice_piece(r, n, db0[n], dp0[n]);
         }
-        const WeightReq w0 = weight_req(s0, 0);
+        if (URES) {
+            // resident weights: slot kz * NCH + c, once per workgroup (a step's 16 KB per N tile would otherwise be
+            // re-fetched at every step: with them the CU asks for 38 KB per 64-MFMA step, more than it gets from L2 / MALL
+            // in that time -- scripts/probes/lds_dma_bw.hip, profiles/r03_k_lds_dma_bw.txt)
 #pragma unroll
-        for (int m = 0; m < NUW; ++m) weight_piece(w0, m);
+            for (int kz = 0; kz < KD; ++kz)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    RingStep st = s0;
+                    st.live = true;
+                    st.kz = kz;
+                    st.c = c;
+                    const WeightReq wq = weight_req(st, kz * NCH + c);
+#pragma unroll
+                    for (int m = 0; m < NUW; ++m) weight_piece(wq, m);
+                }
+        } else {
+            const WeightReq w0 = weight_req(s0, 0);
+#pragma unroll
+            for (int m = 0; m < NUW; ++m) weight_piece(w0, m);
+        }
     }
     __syncthreads();        // (waits for everything requested so far)
     if (!SPLITN && half == 1) {
@@ -606,9 +626,11 @@ __global__ void __launch_bounds__(512) conv_wino_ring_kernel(ConvArgs a, PersArg
         for (int n = 0; n < NIW; ++n) decode_piece(n, lane, dbl[n], dpl[n]);
         for (int g = 0; s0.live; ++g) {
             MV_WTL(0);
-            const WeightReq wr = weight_req(s1, (g + 1) & 1);
+            if (!URES) {
+                const WeightReq wr = weight_req(s1, (g + 1) & 1);
 #pragma unroll
-            for (int m = 0; m < NUW; ++m) weight_piece(wr, m);
+                for (int m = 0; m < NUW; ++m) weight_piece(wr, m);
+            }
             const SliceReq sr = slice_req(s3, (g + 3) & 3);
 #pragma unroll
             for (int n = 0; n < NIW; ++n) slice_piece(sr, n, dbl[n], dpl[n]);
@@ -663,7 +685,7 @@ __global__ void __launch_bounds__(512) conv_wino_ring_kernel(ConvArgs a, PersArg
             const f32x4v* const nextp = ring + ((g + 1) & 3) * SLICE + abase;
             __builtin_amdgcn_sched_barrier(0);
             {
-                const f32x4v* const us = uring + (g & 1) * UST + ntw * 64 + lane;
+                const f32x4v* const us = uring + (URES ? s0.kz * NCH + s0.c : g & 1) * UST + ntw * 64 + lane;
                 f32x4v ub[2][4][NT];
                 auto load_u = [&](int grp, f32x4v (&dst)[4][NT]) {
 #pragma unroll
@@ -671,7 +693,8 @@ __global__ void __launch_bounds__(512) conv_wino_ring_kernel(ConvArgs a, PersArg
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) dst[qq][nt] = us[((grp * 4 + qq) * NTW + nt) * 64];
                 };
-                constexpr int NP = SPLITN ? NUW + NIW : 0;          // DMA pieces of a compute wave per step
+                constexpr int NUL = URES ? 0 : NUW;                 // weight pieces per step
+                constexpr int NP = SPLITN ? NUL + NIW : 0;          // DMA pieces of a compute wave per step
                 load_u(0, ub[0]);
 #pragma unroll
                 for (int grp = 0; grp < 4; ++grp) {
@@ -687,10 +710,10 @@ __global__ void __launch_bounds__(512) conv_wino_ring_kernel(ConvArgs a, PersArg
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int k = grp * 2; k < grp * 2 + 2 && k < NP; ++k) {
-                        if (k < NUW) {
+                        if (k < NUL) {
                             weight_piece(wr, k);
                         } else {
-                            slice_piece(sr, k - NUW, dbase[k - NUW], dpos[k - NUW]);
+                            slice_piece(sr, k - NUL, dbase[k - NUL], dpos[k - NUL]);
                         }
                     }
 #pragma unroll
@@ -770,7 +793,8 @@ template <int NCH, int KD, bool SKIP, bool SPLITN>
 int launch_wino_ring(const ConvArgs& a, hipStream_t s) {
     using G = RingGeom;
     constexpr int NT = SPLITN ? 2 : 1;                     // N tiles per workgroup
-    const size_t lds = (size_t)(4 * G::SLICE + 2 * 16 * NT * 64 + 64) * 16;
+    constexpr int USLOTS = KD * NCH * NT <= 4 ? KD * NCH : 2;      // resident weights, else a ring of two steps
+    const size_t lds = (size_t)(4 * G::SLICE + USLOTS * 16 * NT * 64 + 64) * 16;
     if (lds > 160 * 1024) return MVSTER_ERR_UNSUPPORTED;
     auto kern = conv_wino_ring_kernel<NCH, KD, SKIP, SPLITN>;
     static bool attr_set = false;
