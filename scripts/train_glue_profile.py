@@ -40,9 +40,27 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+stacks = "--stacks" in sys.argv
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=stacks) as prof:
     step()
     torch.cuda.synchronize()
+if stacks:
+    # --stacks: who asks for the small kernels -- (aten op, innermost frame inside this package or the autograd engine)
+    src = collections.defaultdict(lambda: [0, 0.0])
+    for ev in prof.events():
+        if not ev.name.startswith("aten::") or ev.self_device_time_total <= 0:
+            continue
+        frame = "(autograd engine / no python frame)"
+        for fr in (ev.stack or []):
+            if "mvster_amd/" in fr or "bench.py" in fr or "scripts/" in fr:
+                frame = fr.split("mvster_amd/")[-1] if "mvster_amd/" in fr else fr.split("/")[-1]
+                break
+        a = src[(ev.name, frame[:100])]
+        a[0] += 1
+        a[1] += ev.self_device_time_total
+    for (name, frame), (n, t) in sorted(src.items(), key=lambda kv: -kv[1][0])[:70]:
+        print("%5d x %8.1f us  %-24s %s" % (n, t, name, frame))
+    sys.exit(0)
 agg = collections.defaultdict(lambda: [0, 0.0])
 for ev in prof.events():
     if not ev.name.startswith("aten::") or ev.self_device_time_total <= 0:
