@@ -89,6 +89,22 @@ def _lds_plan(B, Do, Ho, Wo, kernel, stride, ntile_total):
     return None
 
 
+def _wino_plan(layer, B, Do, Ho, Wo):
+    """(variant, mt, nt) of the Winograd kernel for an eligible layer, or None when the map is too small to fill the chip
+    with 8 x 32 tiles (the split-K / direct kernels are faster there: scripts/conv_wino_check.py)."""
+    tiles = B * Do * -(-Ho // 8) * -(-Wo // 32)
+    kd = layer.kernel[0]
+    if kd == 1 and layer.cin in (16, 32):
+        nt = 2 if layer.ntile_total % 2 == 0 else 1
+        if tiles * (layer.ntile_total // nt) >= 192:
+            return 8 | (1 << 8), 2, nt
+        return None
+    nt = 2 if (layer.ntile_total % 2 == 0 and tiles * (layer.ntile_total // 2) >= 224) else 1
+    if tiles * (layer.ntile_total // nt) >= 160:
+        return 9, 2, nt
+    return None
+
+
 def _tiles(M, ntile_total, nclass):
     """(MT, NT): biggest register tile that still fills the chip (>= 2048 waves), else the most waves."""
     best = None
@@ -358,6 +374,13 @@ class ConvLayer:
                         if self.ntile_total % cand == 0 and tiles16 * (self.ntile_total // cand) * len(self.classes) >= 512:
                             nt = cand
                             break
+            if (FORCE_VARIANT is None and self.wpk_wino is not None and self.prob is None
+                    and skip_mode in (SKIP_NONE, SKIP_ADD)):
+                # shapes the measured table does not know: the Winograd kernels win wherever there is a work unit
+                # (8 x 32 output pixels x one pair of N tiles) for most CUs -- the pattern of the table's 61 entries
+                wv = _wino_plan(self, B, Do, Ho, Wo)
+                if wv is not None:
+                    variant, mt, nt = wv
             tuned = _tuning().get(layer_signature(self, B, Di, Hi, Wi, skip_mode)) if FORCE_VARIANT is None else None
             if tuned:
                 variant, mt, nt = tuned

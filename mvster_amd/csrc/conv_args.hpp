@@ -104,6 +104,17 @@ static inline bool fill_pers_args(const ConvArgs& a, int TY, PersArgs& p) {
 // compute units of the current device (0 on error); conv_pers.hip
 int num_cus();
 
+// Dynamic LDS above 64 KB has to be allowed per kernel AND per device (a process may drive several GPUs: nn.DataParallel
+// replicas, one thread per device): one bit per device ordinal in the caller's static mask.
+static inline bool allow_big_lds(const void* kern, unsigned long& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev >= 0 && dev < 64 && ((done >> dev) & 1ul)) return true;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    if (dev >= 0 && dev < 64) done |= 1ul << dev;
+    return true;
+}
+
 // conv_pers.hip: persistent LDS-DMA kernel family (variant 5 of mvster_conv_mfma); wpc = workgroups per CU (0 = default)
 int dispatch_pers(const ConvArgs& a, int mt, int nt, int wpc, hipStream_t s);
 // conv_pers.hip: ping-pong form of the persistent kernel, eight waves per workgroup (variant 7)

@@ -772,13 +772,8 @@ int launch_pers(const ConvArgs& a, int wpc, hipStream_t s) {
     const size_t lds = (size_t)(2 * NCH * 2 * G::PLANE + 64 + (WREG ? 0 : NTAP * NCH * NT * 64)) * 16;
     if (lds > 160 * 1024) return MVSTER_ERR_UNSUPPORTED;
     auto kern = conv_pers_kernel<MT, NT, KW, SW, NCH, KD, WREG, PF, SKIP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (lds > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return MVSTER_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static unsigned long attr_done = 0;
+    if (lds > 64 * 1024 && !allow_big_lds(reinterpret_cast<const void*>(kern), attr_done)) return MVSTER_ERR_LAUNCH;
     const int g_num_cu = num_cus();
     if (g_num_cu <= 0) return MVSTER_ERR_LAUNCH;
     PersArgs p;
@@ -810,12 +805,8 @@ int launch_pp(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (size_t)(4 * NCH * 2 * G::PLANE + 64 + (WREG ? 0 : NTAP * NCH * NT * 64)) * 16;
     if (lds > 160 * 1024) return MVSTER_ERR_UNSUPPORTED;
     auto kern = conv_pp_kernel<MT, NT, KW, SW, NCH, KD, WREG, PF, SKIP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return MVSTER_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static unsigned long attr_done = 0;
+    if (!allow_big_lds(reinterpret_cast<const void*>(kern), attr_done)) return MVSTER_ERR_LAUNCH;
     const int g_num_cu = num_cus();
     if (g_num_cu <= 0) return MVSTER_ERR_LAUNCH;
     PersArgs p;
@@ -851,12 +842,8 @@ int launch_1x1(const ConvArgs& a, int wpc, hipStream_t s) {
     const long out_bytes = mtot * a.cout * 4;
     if (lds > 160 * 1024 || a.in_bytes >= (1u << 31) || out_bytes >= (1L << 31) || a.cout % 4 != 0) return MVSTER_ERR_UNSUPPORTED;
     auto kern = conv1x1_pers_kernel<NCH, MT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return MVSTER_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static unsigned long attr_done = 0;
+    if (!allow_big_lds(reinterpret_cast<const void*>(kern), attr_done)) return MVSTER_ERR_LAUNCH;
     const int g_num_cu = num_cus();
     if (g_num_cu <= 0) return MVSTER_ERR_LAUNCH;
     const long ngroups = (mtot + 64 * MT - 1) / (64 * MT);

@@ -290,13 +290,8 @@ int launch_wino(const ConvArgs& a, int wpc, hipStream_t s) {
     const size_t lds = (size_t)(2 * NCH * 2 * G::PLANE + 64 + (WREG ? 0 : 16 * NCH * NT * 64)) * 16;
     if (lds > 160 * 1024) return MVSTER_ERR_UNSUPPORTED;
     auto kern = conv_wino_kernel<NT, NCH, WREG, SKIP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (lds > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return MVSTER_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static unsigned long attr_done = 0;
+    if (lds > 64 * 1024 && !allow_big_lds(reinterpret_cast<const void*>(kern), attr_done)) return MVSTER_ERR_LAUNCH;
     const int ncu = num_cus();
     if (ncu <= 0) return MVSTER_ERR_LAUNCH;
     PersArgs p;
@@ -797,12 +792,8 @@ int launch_wino_ring(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (size_t)(4 * G::SLICE + USLOTS * 16 * NT * 64 + 64) * 16;
     if (lds > 160 * 1024) return MVSTER_ERR_UNSUPPORTED;
     auto kern = conv_wino_ring_kernel<NCH, KD, SKIP, SPLITN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return MVSTER_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static unsigned long attr_done = 0;
+    if (!allow_big_lds(reinterpret_cast<const void*>(kern), attr_done)) return MVSTER_ERR_LAUNCH;
     const int ncu = num_cus();
     if (ncu <= 0) return MVSTER_ERR_LAUNCH;
     PersArgs p;

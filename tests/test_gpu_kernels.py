@@ -502,6 +502,31 @@ def test_winograd_conv_against_fp64_and_direct(cin, cout, kd, nt, variant, shape
          direct_err_over_max=(direct.double() - ref).abs().max().item() / scale)
 
 
+def test_untuned_shapes_pick_winograd_when_the_map_is_large_enough():
+    """A shape the measured table has never seen: the plan's rule sends eligible layers with enough 8 x 32 tiles to the
+    Winograd kernels and leaves small maps on the direct / split-K kernels; either way the result is the direct kernel's
+    within the Winograd bound."""
+    from mvster_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    for cin, cout, kd, shape, want in ((16, 16, 1, (7, 1, 72, 104), "conv_wino_kernel<"), (64, 64, 3, (1, 5, 72, 104), "conv_wino_ring_kernel<"),
+                                       (32, 32, 3, (1, 3, 24, 40), None), (16, 16, 1, (1, 1, 24, 40), None)):
+        w = (torch.randn(cout, cin, kd, 3, 3, generator=g) * 0.1).to(DEV)
+        layer = cp.ConvLayer(w, False, (1, 1, 1), (kd // 2, 1, 1), relu=True)
+        x = torch.randn(*shape, cin, generator=g).to(DEV)
+        assert cp.layer_signature(layer, *shape, 0) not in cp._tuning()
+        got = layer(x)
+        name = _lib.last_kernel()
+        if want is not None:
+            assert name.startswith(want), name
+        else:
+            assert not name.startswith("conv_wino"), name
+        ref = layer(x, tiles=(1, 1, 0))
+        # (two fp32 results of a K = 144 ... 1728 reduction in different orders: each is within ~1e-6 of max |y| of the exact
+        #  value on maps of this size, see test_winograd_conv_against_fp64_and_direct)
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= 4e-6, (cin, cout, kd, shape, name, err)
+
+
 def test_winograd_weights_follow_in_place_repack():
     """The transformed weights are refreshed by the same call that refreshes the packed ones (training: once per step),
     also in the swapped / mirrored form of an input gradient."""
