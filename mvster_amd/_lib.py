@@ -40,6 +40,7 @@ SIGNATURES = {
     "mvster_pack_wino_weights": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _l, _l, _i, _f],
     "mvster_pack_conv_weights_classes": [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f],
     "mvster_conv_wgrad": [_f, _f, _f] + [_i] * 20 + [_f],
+    "mvster_conv_wgrad_slots": [_i] * 12,
     "mvster_bn_relu_fwd": [_f, _f, _f, _f, _f, _l, _i, _i, _i, _f],
     "mvster_conv_wgrad_finish": [_f, _f] + [_i] * 10 + [_f],
     "mvster_bn_slots": [_l, _i, _i],

@@ -15,20 +15,12 @@
 // [nblk][taps][COT*16][CIT*16]; the host sums the slots (deterministic, no atomics).
 #include <stdlib.h>
 
-#include "common.hpp"
+#include "conv_wgrad.hpp"
 
 namespace {
 
+using mvwgrad::WgradArgs;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-
-struct WgradArgs {
-    const float* x;     // [B, Di, Hi, Wi, CI]
-    const float* gy;    // [B, Do, Ho, Wo, CO]
-    float* partial;     // [nblk, taps, COT*16, CIT*16]
-    int B, Di, Hi, Wi, CI;
-    int Do, Ho, Wo, CO;
-    int kd, kh, kw, sd, sh, sw, pd, ph, pw;
-};
 
 template <int COT, int CIT>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
@@ -520,6 +512,10 @@ extern "C" int mvster_conv_wgrad(const float* x, const float* gy, float* partial
     const int ntaps = kd * kh * kw;
     hipStream_t s = (hipStream_t)stream;
     if (packed && CI > 8) return MVSTER_ERR_UNSUPPORTED;
+    if (!packed) {
+        const int rc = mvwgrad::try_wgrad_pers(a, nblk, cot, cit, s);
+        if (rc != MVSTER_ERR_UNSUPPORTED) return rc;
+    }
     {
         const int rc = try_wgrad_lds(a, nblk, cot, cit, packed, s);
         if (rc != MVSTER_ERR_UNSUPPORTED) return rc;
@@ -535,6 +531,17 @@ extern "C" int mvster_conv_wgrad(const float* x, const float* gy, float* partial
     MV_W(1, 1) MV_W(1, 2) MV_W(1, 4) MV_W(2, 1) MV_W(2, 2) MV_W(2, 4) MV_W(4, 1) MV_W(4, 2) MV_W(4, 4) MV_W(5, 4)
 #undef MV_W
     return MVSTER_ERR_UNSUPPORTED;
+}
+
+// Slot count the caller should give `partial` for this layer: the persistent kernel's workgroup count where it applies
+// (more slots would only be zero-filled and re-read by the finish), else 0 = the caller's own rule.
+extern "C" int mvster_conv_wgrad_slots(int CI, int CO, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
+                                       int packed) {
+    if (packed || CI <= 0 || CO <= 0) return 0;
+    WgradArgs a{};
+    a.CI = CI; a.CO = CO; a.kd = kd; a.kh = kh; a.kw = kw; a.sd = sd; a.sh = sh; a.sw = sw; a.pd = pd; a.ph = ph; a.pw = pw;
+    const int cot = (CO + 15) / 16 == 3 ? 4 : (CO + 15) / 16, cit = (CI + 15) / 16 == 3 ? 4 : (CI + 15) / 16;
+    return mvwgrad::wgrad_pers_slots(a, cot, cit);
 }
 
 // partial [nblk][ngrp][cop][width] as written by mvster_conv_wgrad -> dw in parameter layout (see the kernel): ntaps =

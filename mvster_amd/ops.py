@@ -319,8 +319,11 @@ def conv_wgrad(x_cl, gy_cl, kernel, stride, padding, co_keep=None, ci_keep=None,
     import os
     cap = int(os.environ.get("MVSTER_WGRAD_NBLK", "1024"))
     nblk = max(1, min((rows + 3) // 4, (32 << 20) // slot_bytes, cap))
-    partial = torch.empty(nblk, ngrp, cop, width, device=x_cl.device, dtype=torch.float32)
     lib = _lib.load()
+    pers = _wgrad_pers_slots(lib, CI, CO, kernel, stride, padding, packed)
+    if pers > 0:
+        nblk = min(nblk, pers)            # the persistent kernel fills one slot per workgroup (conv_wgrad_pers.hip)
+    partial = torch.empty(nblk, ngrp, cop, width, device=x_cl.device, dtype=torch.float32)
     rc = lib.mvster_conv_wgrad(_ptr(x_cl), _ptr(gy_cl), _ptr(partial), nblk, B, Di, Hi, Wi, CI, Do, Ho, Wo, CO,
                                kd, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
                                int(packed), _stream())
@@ -335,6 +338,17 @@ def conv_wgrad(x_cl, gy_cl, kernel, stride, padding, co_keep=None, ci_keep=None,
                                       co_keep, ci_keep, int(mirrored), int(mirrored), _stream())
     _lib.check(rc, "conv_wgrad_finish")
     return dw
+
+
+_WGRAD_SLOTS = {}
+
+
+def _wgrad_pers_slots(lib, CI, CO, kernel, stride, padding, packed):
+    key = (CI, CO, kernel, stride, padding, packed)
+    n = _WGRAD_SLOTS.get(key)
+    if n is None:
+        n = _WGRAD_SLOTS[key] = lib.mvster_conv_wgrad_slots(CI, CO, *kernel, *stride, *padding, int(packed))
+    return n
 
 
 _BN_SLOTS = {}
