@@ -350,10 +350,15 @@ struct RingStep {          // one step of one tile: everything wave-uniform
 // idles through every one of those stalls (first version, 4 waves: 4 000 cycles per 64-MFMA step), with a second wave on the
 // SIMD the pipe has other MFMAs to run.  (VALU work is not hidden that way: fp32 MFMAs and VALU instructions of two waves on
 // one SIMD were never seen to overlap -- conv_pp_kernel in conv_pers.hip is the experiment.)
-template <int NCH, int KD, bool SKIP, bool SPLITN>
+// MODE 0: one N tile, waves 4-7 load.  MODE 1 (SPLITN): waves 4-7 compute the second N tile, every wave loads.  MODE 2: the
+// compute waves hold BOTH N tiles (one input transform for 128 MFMAs instead of 64; no read-ahead of the next step's pixels:
+// the registers are gone) and waves 4-7 load.
+template <int NCH, int KD, bool SKIP, int MODE>
 __global__ void __launch_bounds__(512) conv_wino_ring_kernel(ConvArgs a, PersArgs p) {
-    constexpr int NT = 1;                                   // N tiles per compute wave
-    constexpr int NTW = SPLITN ? 2 : 1;                     // N tiles per workgroup
+    constexpr bool SPLITN = MODE == 1;
+    constexpr int NT = MODE == 2 ? 2 : 1;                   // N tiles per compute wave
+    constexpr int NTW = MODE == 0 ? 1 : 2;                  // N tiles per workgroup
+    constexpr bool AHEAD = NT == 1;                         // next step's pixels are read under this step's MFMAs
     using G = RingGeom;
     constexpr int TY = G::TY, PLANE = G::PLANE, NBLK = G::NBLK, RS = G::ROWSLOTS, SLICE = G::SLICE;
     constexpr int NLW = SPLITN ? 8 : 4;                     // waves that issue DMA
@@ -511,14 +516,14 @@ __global__ void __launch_bounds__(512) conv_wino_ring_kernel(ConvArgs a, PersArg
         return r;
     };
     const unsigned wlane = lane * 16;
-    static_assert(NUW <= 4, "one M0 value per weight request");
+    static_assert(NUW <= 8, "two M0 values per weight request");
     auto weight_piece = [&](const WeightReq& r, int m) {
         const int u = lw * NUW + m;                         // -> (point, nt); this wave's NUW kilobytes are consecutive
         const int q = u / NTW, nt = u - q * NTW;
         const unsigned so = r.base + (unsigned)(((long)q * NCH * wstep + nt * 256) * 4);
-        f32x4v* const dst = r.dst0 + lw * NUW * 64;
-        const __amdgpu_buffer_rsrc_t rs = w_rsrc(m);
-        switch (m) {
+        f32x4v* const dst = r.dst0 + (lw * NUW + (m & ~3)) * 64;
+        const __amdgpu_buffer_rsrc_t rs = w_rsrc(m & 3);
+        switch (m & 3) {
             case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, wlane, so, 0, 0); break;
             case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, wlane, so, 1024, 0); break;
             case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, wlane, so, 2048, 0); break;
@@ -668,8 +673,8 @@ __global__ void __launch_bounds__(512) conv_wino_ring_kernel(ConvArgs a, PersArg
                         ooff[i][j] = ok ? obase + oorigin + i * orow + j * opix : 0x80000000u;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            skv[i][j][nt] = SKIP ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, ooff[i][j] + nt * 64, 0, 0))
-                                                 : (f32x4v){0.f, 0.f, 0.f, 0.f};
+                            skv[i][j][nt] = (SKIP && AHEAD) ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, ooff[i][j] + nt * 64, 0, 0))
+                                                            : (f32x4v){0.f, 0.f, 0.f, 0.f};
                     }
             }
             // This step's requests (weights of step g+1, then the slice of step g+3) and the 16 reads of the next step's
@@ -711,10 +716,12 @@ __global__ void __launch_bounds__(512) conv_wino_ring_kernel(ConvArgs a, PersArg
                             slice_piece(sr, k - NUL, dbase[k - NUL], dpos[k - NUL]);
                         }
                     }
+                    if (AHEAD) {
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) {               // row grp of the next step's 4x4 block
-                        const f32x4v v = nextp[grp * RS + (x & 1) * (G::PWH * 2) + (x >> 1) * 2];
-                        d[grp][x] = {{v[0], v[1]}, {v[2], v[3]}};
+                        for (int x = 0; x < 4; ++x) {           // row grp of the next step's 4x4 block
+                            const f32x4v v = nextp[grp * RS + (x & 1) * (G::PWH * 2) + (x >> 1) * 2];
+                            d[grp][x] = {{v[0], v[1]}, {v[2], v[3]}};
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -726,6 +733,17 @@ __global__ void __launch_bounds__(512) conv_wino_ring_kernel(ConvArgs a, PersArg
             asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             if (last) {
+                if (SKIP && !AHEAD) {
+                    // (two N tiles per wave: no registers to hold the skip values through the step -- requested here, the
+                    //  output transform below covers most of their latency)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                skv[i][j][nt] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, ooff[i][j] + nt * 64, 0, 0));
+                }
                 // Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; fused epilogue on the 2x2 pixels x 4 channels of this lane
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -760,6 +778,7 @@ __global__ void __launch_bounds__(512) conv_wino_ring_kernel(ConvArgs a, PersArg
                     for (int nt = 0; nt < NT; ++nt) acc[q][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (!AHEAD) read_block((g + 1) & 3);
             transform_block();                // d (step g+1) -> V
             MV_WTL(2);
             __builtin_amdgcn_sched_barrier(0);
@@ -784,14 +803,14 @@ __global__ void __launch_bounds__(512) conv_wino_ring_kernel(ConvArgs a, PersArg
     }
 }
 
-template <int NCH, int KD, bool SKIP, bool SPLITN>
+template <int NCH, int KD, bool SKIP, int MODE>
 int launch_wino_ring(const ConvArgs& a, hipStream_t s) {
     using G = RingGeom;
-    constexpr int NT = SPLITN ? 2 : 1;                     // N tiles per workgroup
+    constexpr int NT = MODE == 0 ? 1 : 2;                  // N tiles per workgroup
     constexpr int USLOTS = KD * NCH * NT <= 4 ? KD * NCH : 2;      // resident weights, else a ring of two steps
     const size_t lds = (size_t)(4 * G::SLICE + USLOTS * 16 * NT * 64 + 64) * 16;
     if (lds > 160 * 1024) return MVSTER_ERR_UNSUPPORTED;
-    auto kern = conv_wino_ring_kernel<NCH, KD, SKIP, SPLITN>;
+    auto kern = conv_wino_ring_kernel<NCH, KD, SKIP, MODE>;
     static unsigned long attr_done = 0;
     if (!allow_big_lds(reinterpret_cast<const void*>(kern), attr_done)) return MVSTER_ERR_LAUNCH;
     const int ncu = num_cus();
@@ -805,7 +824,7 @@ int launch_wino_ring(const ConvArgs& a, hipStream_t s) {
     if (gmax < 1) gmax = 1;
     const long rounds = (ntiles + gmax - 1) / gmax;       // equal shares
     const long gx = (ntiles + rounds - 1) / rounds;
-    MV_NOTE_KERNEL("conv_wino_ring_kernel<%d, %d, %s, %s>", NCH, KD, SKIP ? "true" : "false", SPLITN ? "true" : "false");
+    MV_NOTE_KERNEL("conv_wino_ring_kernel<%d, %d, %s, %d>", NCH, KD, SKIP ? "true" : "false", MODE);
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, ny, 1), dim3(512), lds, s, a, p);
     return mv_check_launch();
 }
@@ -859,12 +878,14 @@ int dispatch_wino(const ConvArgs& a, int nt, int wpc, bool ring, hipStream_t s) 
     const int nch = a.cin / 16, kd = a.kd[0];
     if (!(kd == 1 && a.pd[0] == 0) && !(kd == 3 && a.pd[0] == 1)) return MVSTER_ERR_UNSUPPORTED;
     if (ring) {
-        // nt = 2: the two halves of the workgroup compute two N tiles; nt = 1: waves 4-7 only issue the DMA
-#define MV_R(NT_, NCH_, KD_)                                                                        \
-    if (nt == NT_ && nch == NCH_ && kd == KD_)                                                      \
-        return a.skip_mode == 1 ? launch_wino_ring<NCH_, KD_, true, NT_ == 2>(a, s) : launch_wino_ring<NCH_, KD_, false, NT_ == 2>(a, s);
-        MV_R(1, 1, 3) MV_R(1, 2, 3) MV_R(2, 2, 3) MV_R(1, 4, 3) MV_R(2, 4, 3)
-        MV_R(1, 4, 1) MV_R(2, 4, 1) MV_R(1, 2, 1) MV_R(2, 2, 1) MV_R(1, 1, 1)
+        // nt = 1: waves 4-7 only issue the DMA (mode 0); nt = 2: the two halves of the workgroup compute one N tile each
+        // (mode 1), or with wpc = 1 the compute waves hold both and waves 4-7 load (mode 2)
+        const int mode = nt == 1 ? 0 : (wpc == 1 ? 2 : 1);
+#define MV_R(MODE_, NCH_, KD_)                                                                      \
+    if (mode == MODE_ && nch == NCH_ && kd == KD_)                                                  \
+        return a.skip_mode == 1 ? launch_wino_ring<NCH_, KD_, true, MODE_>(a, s) : launch_wino_ring<NCH_, KD_, false, MODE_>(a, s);
+        MV_R(0, 1, 3) MV_R(0, 2, 3) MV_R(1, 2, 3) MV_R(2, 2, 3) MV_R(0, 4, 3) MV_R(1, 4, 3) MV_R(2, 4, 3)
+        MV_R(0, 4, 1) MV_R(1, 4, 1) MV_R(2, 4, 1) MV_R(0, 2, 1) MV_R(1, 2, 1) MV_R(2, 2, 1) MV_R(0, 1, 1) MV_R(2, 1, 1)
 #undef MV_R
         return MVSTER_ERR_UNSUPPORTED;
     }

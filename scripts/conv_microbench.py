@@ -81,6 +81,8 @@ def candidates(layer, B, Di, Hi, Wi, sm):
             for n in (1, 2):                  # ring form: 1 = waves 4-7 only load, 2 = they compute a second N tile
                 if n in nts:
                     out.append(("R%d" % n, (2, n, 9)))
+            if 2 in nts:                      # ... or the compute waves hold both N tiles and waves 4-7 load
+                out.append(("R2L", (2, 2, 9 | (1 << 8))))
     return out
 
 

@@ -19,7 +19,10 @@ FAMILIES = [("16->16 3x3", 16, 16, 1, 1, 8), ("16->32 3x3", 16, 32, 1, 2, 8), ("
             ("16->16 3x3 ring", 16, 16, 1, 1, 9), ("32->32 3x3 ring", 32, 32, 1, 2, 9), ("64->64 3x3 ring", 64, 64, 1, 2, 9),
             ("64->64 3x3 ring1", 64, 64, 1, 1, 9), ("64->32 3x3 ring", 64, 32, 1, 2, 9), ("64->32 3x3 ring1", 64, 32, 1, 1, 9),
             ("16->16 3x3x3", 16, 16, 3, 1, 9), ("32->32 3x3x3", 32, 32, 3, 2, 9), ("32->32 3x3x3 nt1", 32, 32, 3, 1, 9),
-            ("64->64 3x3x3", 64, 64, 3, 2, 9), ("64->64 3x3x3 nt1", 64, 64, 3, 1, 9)]
+            ("64->64 3x3x3", 64, 64, 3, 2, 9), ("64->64 3x3x3 nt1", 64, 64, 3, 1, 9),
+            # mode 2 of the ring kernel (variant word 9 | 1 << 8): both N tiles in the compute waves, waves 4-7 load
+            ("32->32 3x3 m2", 32, 32, 1, 2, 265), ("64->64 3x3 m2", 64, 64, 1, 2, 265), ("64->32 3x3 m2", 64, 32, 1, 2, 265),
+            ("16->32 3x3 m2", 16, 32, 1, 2, 265), ("32->32 3x3x3 m2", 32, 32, 3, 2, 265), ("64->64 3x3x3 m2", 64, 64, 3, 2, 265)]
 CHECK_SHAPES = [(2, 1, 70, 100), (1, 1, 4, 33), (3, 1, 64, 64), (1, 1, 8, 32), (1, 1, 5, 200), (7, 1, 13, 63), (1, 4, 38, 70),
                 (2, 3, 9, 40), (1, 8, 16, 20)]
 PROD = {"16->16 3x3": [(5, 1, 256, 320)], "32->32 3x3": [(5, 1, 128, 160)], "16->32 3x3": [(5, 1, 256, 320)],
@@ -30,7 +33,10 @@ PROD = {"16->16 3x3": [(5, 1, 256, 320)], "32->32 3x3": [(5, 1, 128, 160)], "16-
         "32->32 3x3x3": [(1, 4, 128, 160), (1, 4, 64, 80), (1, 8, 32, 40), (1, 8, 16, 20)],
         "32->32 3x3x3 nt1": [(1, 4, 128, 160), (1, 4, 64, 80), (1, 8, 32, 40), (1, 8, 16, 20)],
         "64->64 3x3x3": [(1, 4, 64, 80), (1, 4, 32, 40), (1, 8, 16, 20), (1, 8, 8, 10)],
-        "64->64 3x3x3 nt1": [(1, 4, 64, 80), (1, 4, 32, 40), (1, 8, 16, 20), (1, 8, 8, 10)]}
+        "64->64 3x3x3 nt1": [(1, 4, 64, 80), (1, 4, 32, 40), (1, 8, 16, 20), (1, 8, 8, 10)],
+        "32->32 3x3 m2": [(5, 1, 128, 160)], "64->64 3x3 m2": [(5, 1, 64, 80)], "64->32 3x3 m2": [(5, 1, 128, 160)],
+        "16->32 3x3 m2": [(5, 1, 256, 320)], "32->32 3x3x3 m2": [(1, 4, 128, 160), (1, 4, 64, 80)],
+        "64->64 3x3x3 m2": [(1, 4, 64, 80), (1, 4, 32, 40)]}
 
 
 def make_layer(cin, cout, kd=1, relu=True):
@@ -64,7 +70,7 @@ def check():
                 ref = exact(layer, w, x, sk)
                 direct = layer(x, skip=sk, skip_mode=sm, tiles=(1, 1, 0))
                 for wpc in ((1, 2) if var == 8 else (0,)):
-                    got = layer(x, skip=sk, skip_mode=sm, tiles=(2, nt, var | (wpc << 8)))
+                    got = layer(x, skip=sk, skip_mode=sm, tiles=(2, nt, var | (wpc << 8)))        # (var may carry its own mode bits)
                     torch.cuda.synchronize()
                     scale = ref.abs().max().item()
                     e_w = (got.double() - ref).abs().max().item() / scale

@@ -463,6 +463,9 @@ WINO_CASES = [  # (cin, cout, kd, nt, variant, input [B,D,H,W]): every instance 
     (32, 32, 3, 2, 9, (1, 8, 16, 20)), (32, 32, 3, 1, 9, (2, 3, 9, 40)), (64, 64, 3, 2, 9, (1, 4, 13, 63)),
     (64, 64, 3, 1, 9, (1, 8, 8, 10)), (64, 64, 1, 2, 9, (5, 1, 20, 40)), (64, 32, 1, 1, 9, (2, 1, 37, 50)),
     (64, 32, 1, 2, 9, (1, 1, 16, 33)), (16, 16, 1, 1, 9, (1, 1, 4, 33)), (32, 32, 1, 2, 9, (3, 1, 64, 64)),
+    # ... mode 2 (variant word 9 | 1 << 8): two N tiles per compute wave, loading waves
+    (32, 32, 1, 2, 265, (3, 1, 64, 64)), (64, 64, 3, 2, 265, (1, 4, 13, 63)), (64, 32, 1, 2, 265, (2, 1, 37, 50)),
+    (16, 32, 1, 2, 265, (1, 1, 37, 65)), (32, 64, 3, 2, 265, (1, 8, 16, 20)), (64, 64, 1, 2, 265, (1, 1, 8, 32)),
 ]
 
 
@@ -492,12 +495,14 @@ def test_winograd_conv_against_fp64_and_direct(cin, cout, kd, nt, variant, shape
     direct = layer(x, skip=skip, skip_mode=sm, tiles=(1, 1, 0))
     scale = ref.abs().max().item()
     for wpc in ((0, 1, 2) if variant == 8 else (0,)):
-        got = layer(x, skip=skip, skip_mode=sm, tiles=(2, nt, variant | (wpc << 8)))
+        got = layer(x, skip=skip, skip_mode=sm, tiles=(2, nt, variant | (wpc << 8)))      # (265 = 9 with its mode bit set)
         assert torch.isfinite(got).all()
         assert (got.double() - ref).abs().max().item() <= 2e-6 * scale, (wpc, (got.double() - ref).abs().max().item() / scale)
         assert (got - direct).abs().max().item() <= 2e-6 * scale
     from mvster_amd import _lib
     assert _lib.last_kernel().startswith("conv_wino_kernel<" if variant == 8 else "conv_wino_ring_kernel<")
+    if variant == 265:
+        assert _lib.last_kernel().endswith(", 2>")
     note("conv_winograd%d_%d_%d_k%d_nt%d_%s" % (variant, cin, cout, kd, nt, "x".join(map(str, shape))), err_over_max=(got.double() - ref).abs().max().item() / scale,
          direct_err_over_max=(direct.double() - ref).abs().max().item() / scale)
 
