@@ -58,8 +58,10 @@ __device__ unsigned long long* g_ptl = nullptr;
 // MT, NT: register tile (M tiles x N tiles of 16) per wave; KW = KH in {3, 5}; SW = SH in {1, 2}; NCH = cin / 16;
 // KD in {1, 3}; WREG: the layer's weights live in registers (KD*KW*KW*NCH*NT float4 per lane), else in LDS;
 // PF = prefetch distance of the tap pipeline (taps); SKIP: a same-shape tensor is added in the epilogue.
-template <int MT, int NT, int KW, int SW, int NCH, int KD, bool WREG, int PF, bool SKIP>
-__global__ void __launch_bounds__(256) conv_pers_kernel(ConvArgs a, PersArgs p) {
+// LD: waves 4-7 of a 512-thread workgroup issue the LDS-DMA (a loop of their own, same barriers), waves 0-3 compute -- a wave
+// that requests data at the rate HBM delivers it stalls ~300 cycles per kilobyte at issue (conv_wgrad_pers.hip measured it).
+template <int MT, int NT, int KW, int SW, int NCH, int KD, bool WREG, int PF, bool SKIP, bool LD>
+__global__ void __launch_bounds__(LD ? 512 : 256) conv_pers_kernel(ConvArgs a, PersArgs p) {
     using G = PersGeom<MT, KW, SW, KD>;
     constexpr int TY = G::TY, KH = G::KH, PW = G::PW, PH = G::PH, PWH = G::PWH, PLANE = G::PLANE, NBLK = G::NBLK;
     constexpr int NTAP = KD * KH * KW, TAPS2D = KH * KW;
@@ -73,7 +75,9 @@ __global__ void __launch_bounds__(256) conv_pers_kernel(ConvArgs a, PersArgs p) 
     f32x4v* const wl = scratch + 64;                        // [tap][chunk][nt][lane]  (unused with WREG)
 
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wave8 & 3;
+    const bool loader = LD && wave8 >= 4, loads = !LD || loader;
     const int lm = lane & 15, lq = lane >> 4;
     const int nt0 = blockIdx.y * NT;
     // Two workgroups sharing a CU start together and, left alone, stay IN phase: both in their MFMA phase (sharing the
@@ -164,7 +168,7 @@ __global__ void __launch_bounds__(256) conv_pers_kernel(ConvArgs a, PersArgs p) 
     const unsigned nwg = gridDim.x;
     unsigned tile = xcd_remap(blockIdx.x, nwg);          // this workgroup's tiles: tile, tile + nwg, ...  (see host side)
     TilePos pos = decode_tile(tile < p.ntiles ? tile : 0);
-    if (tile < p.ntiles) dma_tile(pos, 0, true);
+    if (tile < p.ntiles && loads) dma_tile(pos, 0, true);
     f32x4v wreg[WREG ? NTAP * NCH * NT : 1];
     const long wstep = (long)a.ntile_total * 256;          // floats per K step of the packed weights
     if (WREG) {
@@ -176,7 +180,7 @@ __global__ void __launch_bounds__(256) conv_pers_kernel(ConvArgs a, PersArgs p) 
     } else {
         const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.wpk), (short)0, (int)(NTAP * NCH * wstep * 4), 0x00020000);
-        for (int i = wave; i < NTAP * NCH * NT; i += 4) {
+        for (int i = loads ? wave : NTAP * NCH * NT; i < NTAP * NCH * NT; i += 4) {
             const int s = i / NT, nt = i - s * NT;
             const unsigned off = (unsigned)((s * wstep + (long)(nt0 + nt) * 256) * 4) + lane * 16;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(wl + i * 64), 16, off, 0, 0, 0);
@@ -218,6 +222,17 @@ __global__ void __launch_bounds__(256) conv_pers_kernel(ConvArgs a, PersArgs p) 
     };
 
     __syncthreads();        // (waits vmcnt(0): first patch and the weights have landed)
+    if (loader) {
+        // the loading waves: request tile t+1 while the compute waves work on tile t, wait until it has landed, meet them
+        for (int it = 0; tile < p.ntiles; tile += nwg, ++it) {
+            const bool has_next = tile + nwg < p.ntiles;
+            pos = decode_tile(has_next ? tile + nwg : tile);
+            dma_tile(pos, (it & 1) ^ 1, has_next);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
 
     // The loop body is ONE basic block (2-D kernels): the DMA of tile t+1, the MFMAs of tile t and the epilogue of tile
     // t-1 are independent instruction streams that the scheduler interleaves -- at one wavefront per SIMD nothing else
@@ -271,7 +286,7 @@ __global__ void __launch_bounds__(256) conv_pers_kernel(ConvArgs a, PersArgs p) 
         }
         const bool has_next = tile + nwg < p.ntiles;
         pos = decode_tile(has_next ? tile + nwg : tile);
-        dma_tile(pos, cur ^ 1, has_next);
+        if (!LD) dma_tile(pos, cur ^ 1, has_next);
         MV_PTL(1);
         // VMEM may not cross: the DMA issues stay above, the stores of the deferred epilogue below
         __builtin_amdgcn_sched_barrier(0x78F);
@@ -326,10 +341,12 @@ __global__ void __launch_bounds__(256) conv_pers_kernel(ConvArgs a, PersArgs p) 
         MV_PTL(2);
         // the next tile's patch has landed once at most the stores issued after it are outstanding; then everyone is
         // done reading this tile's patch
-        if (KD == 1) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * NT) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!LD) {
+            if (KD == 1) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * NT) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): (the barrier builtin alone does not wait for the LDS reads)
         __builtin_amdgcn_s_barrier();
@@ -765,13 +782,13 @@ __global__ void __launch_bounds__(256) conv1x1_pers_kernel(ConvArgs a, unsigned 
 }
 
 
-template <int MT, int NT, int KW, int SW, int NCH, int KD, bool WREG, int PF, bool SKIP>
+template <int MT, int NT, int KW, int SW, int NCH, int KD, bool WREG, int PF, bool SKIP, bool LD>
 int launch_pers(const ConvArgs& a, int wpc, hipStream_t s) {
     using G = PersGeom<MT, KW, SW, KD>;
     constexpr int NTAP = KD * KW * KW;
     const size_t lds = (size_t)(2 * NCH * 2 * G::PLANE + 64 + (WREG ? 0 : NTAP * NCH * NT * 64)) * 16;
     if (lds > 160 * 1024) return MVSTER_ERR_UNSUPPORTED;
-    auto kern = conv_pers_kernel<MT, NT, KW, SW, NCH, KD, WREG, PF, SKIP>;
+    auto kern = conv_pers_kernel<MT, NT, KW, SW, NCH, KD, WREG, PF, SKIP, LD>;
     static unsigned long attr_done = 0;
     if (lds > 64 * 1024 && !allow_big_lds(reinterpret_cast<const void*>(kern), attr_done)) return MVSTER_ERR_LAUNCH;
     const int g_num_cu = num_cus();
@@ -792,9 +809,9 @@ int launch_pers(const ConvArgs& a, int wpc, hipStream_t s) {
     // equal shares: every workgroup walks the same number of tiles (no straggler round)
     const long rounds = (ntiles + gmax - 1) / gmax;
     const long gx = (ntiles + rounds - 1) / rounds;
-    MV_NOTE_KERNEL("conv_pers_kernel<%d, %d, %d, %d, %d, %d, %s, %d, %s>", MT, NT, KW, SW, NCH, KD, WREG ? "true" : "false", PF,
-                   SKIP ? "true" : "false");
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, ny, 1), dim3(256), lds, s, a, p);
+    MV_NOTE_KERNEL("conv_pers_kernel<%d, %d, %d, %d, %d, %d, %s, %d, %s, %s>", MT, NT, KW, SW, NCH, KD, WREG ? "true" : "false", PF,
+                   SKIP ? "true" : "false", LD ? "true" : "false");
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, ny, 1), dim3(LD ? 512 : 256), lds, s, a, p);
     return mv_check_launch();
 }
 
@@ -911,10 +928,19 @@ int dispatch_pers(const ConvArgs& a, int mt, int nt, int wpc, hipStream_t s) {
     const int kd = a.kd[0], kw = a.kw[0], sw = a.sw, nch = a.cin / 16;
     if (a.cin % 16 != 0) return MVSTER_ERR_UNSUPPORTED;
 #define MV_P(NT_, KW_, SW_, NCH_, KD_, WREG_, PF_) MV_Q(2, NT_, KW_, SW_, NCH_, KD_, WREG_, PF_)
+    const bool ld = (wpc & 32) != 0;          // bit 5 of the workgroups-per-CU field: waves 4-7 issue the DMA
 #define MV_Q(MT_, NT_, KW_, SW_, NCH_, KD_, WREG_, PF_) \
-    if (mt == MT_ && nt == NT_ && kw == KW_ && sw == SW_ && nch == NCH_ && kd == KD_)                              \
-        return a.skip_mode == 1 ? launch_pers<MT_, NT_, KW_, SW_, NCH_, KD_, WREG_, PF_, true>(a, wpc, s)          \
-                                : launch_pers<MT_, NT_, KW_, SW_, NCH_, KD_, WREG_, PF_, false>(a, wpc, s);
+    if (mt == MT_ && nt == NT_ && kw == KW_ && sw == SW_ && nch == NCH_ && kd == KD_) {                            \
+        if (ld) {                                                                                                  \
+            /* (built for the stride-2 families only: on the stride-1 ones the Winograd kernels are ahead anyway) */  \
+            if constexpr (SW_ == 2)                                                                                \
+                return a.skip_mode == 1 ? launch_pers<MT_, NT_, KW_, SW_, NCH_, KD_, WREG_, PF_, true, true>(a, wpc, s)   \
+                                        : launch_pers<MT_, NT_, KW_, SW_, NCH_, KD_, WREG_, PF_, false, true>(a, wpc, s); \
+            return MVSTER_ERR_UNSUPPORTED;                                                                         \
+        }                                                                                                          \
+        return a.skip_mode == 1 ? launch_pers<MT_, NT_, KW_, SW_, NCH_, KD_, WREG_, PF_, true, false>(a, wpc, s)   \
+                                : launch_pers<MT_, NT_, KW_, SW_, NCH_, KD_, WREG_, PF_, false, false>(a, wpc, s);  \
+    }
     MV_P(1, 3, 1, 1, 1, true, 2)      // 16 -> 16 3x3           (FPN conv1.1/1.2, composed mid level)
     MV_P(2, 3, 1, 2, 1, false, 1)     // 32 -> 32 3x3           (FPN conv2.1/2.2)
     MV_P(1, 3, 1, 2, 1, false, 1)     // 32 -> N 3x3, one N tile per workgroup

@@ -72,6 +72,9 @@ def candidates(layer, B, Di, Hi, Wi, sm):
             for n in nts:
                 for wpc in (1, 2, 3):
                     out.append(("P2,%d w%d" % (n, wpc), (2, n, 5 | (wpc << 8))))
+                if layer.stride[2] == 2:      # waves 4-7 issue the DMA (built for the stride-2 families)
+                    for wpc in (33, 34):
+                        out.append(("P2,%d L%d" % (n, wpc & 15), (2, n, 5 | (wpc << 8))))
         if layer.wino_eligible():
             # Winograd F(2x2,3x3) on the persistent frame (conv_wino.hip); not bit-identical to the others
             if layer.kernel[0] == 1 and layer.cin in (16, 32):

@@ -101,9 +101,10 @@ def times():
             row = "%-16s %-18s plan v%d(%d,%d) %6.1f us %5.1f TF/s |" % (name, "x".join(map(str, shape)), var0, mt0, nt0, base,
                                                                        fl / base / 1e6)
             if supported(layer, x, nt):
-                for wpc in (1, 2, 3, 4, 18, 19, 20):        # 16 + n: static priority by wave slot (conv_pers.hip)
+                for wpc in (1, 2, 3, 33, 34):               # 32 + n: waves 4-7 issue the DMA (conv_pers.hip)
                     us = min(timeit(lambda: layer(x, tiles=(2, nt, 5 | (wpc << 8))), n=10) for _ in range(2))
-                    row += " %s%d %5.1f (%5.1f)" % ("p" if wpc > 15 else "w", wpc & 15, us, fl / us / 1e6)
+                    ok = torch.equal(layer(x, tiles=(2, nt, 5 | (wpc << 8))), layer(x, tiles=(1, 1, 0)))
+                    row += " %s%d %5.1f (%5.1f)%s" % ("L" if wpc > 31 else "w", wpc & 15, us, fl / us / 1e6, "" if ok else " DIFFERENT")
                 for wpc in (1, 2):
                     try:
                         us = min(timeit(lambda: layer(x, tiles=(4, nt, 5 | (wpc << 8))), n=10) for _ in range(2))
