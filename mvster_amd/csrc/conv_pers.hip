@@ -366,6 +366,171 @@ __global__ void __launch_bounds__(LD ? 512 : 256) conv_pers_kernel(ConvArgs a, P
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// 8 -> 16 channels, stride 2 (FPN conv1.0: 5x5 on the full-resolution maps; reg2d conv1: 3x3): the persistent frame for
+// EIGHT input channels.  A 16-wide K step of the packed weights is two kernel taps x 8 channels, so lane (lm, lq) reads
+// tap 2s + (lq >> 1), channel quad lq & 1: one plane of [pixel][2 quads] per patch, the tap pair's two LDS offsets picked per
+// lane once.  All 13 (5) weight fragments in registers; four compute waves (2 M tiles each: 4 x 32 output pixels per tile),
+// waves 4-7 issue the LDS-DMA (the input is the largest tensor of the forward and comes from HBM).  The direct kernel these
+// layers ran on feeds every K step from L1 (2 KB per 4 MFMAs and wave = the TCP's 64 B/clk): 0.30 of the MFMA peak.
+// Same K order and epilogue arithmetic as the direct kernel: bit-identical.
+// ------------------------------------------------------------------------------------------------------------------
+template <int KW, bool SKIP>
+__global__ void __launch_bounds__(512) conv_pers8_kernel(ConvArgs a, PersArgs p) {
+    constexpr int MT = 2, SW = 2;
+    using G = PersGeom<MT, KW, SW, 1>;
+    constexpr int TY = G::TY, PW = G::PW, PWH = G::PWH, PLANE = G::PLANE, NBLK = G::NBLK;
+    constexpr int NTAP = KW * KW, NKS = (NTAP * 8 + 15) / 16;             // K steps of 16 = tap pairs
+    constexpr int NIW = (NBLK + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    f32x4v* const lds = reinterpret_cast<f32x4v*>(lds_raw);              // two patches of one plane each
+    f32x4v* const scratch = lds + 2 * PLANE;
+
+    const int lane = threadIdx.x & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wave8 & 3;
+    const bool loader = wave8 >= 4;
+    const int lm = lane & 15, lq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)a.in_bytes, 0x00020000);
+
+    auto decode_tile = [&](unsigned tile) -> TilePos {
+        TilePos t;
+        auto div = [&](unsigned n, int k) -> unsigned { return ((__umulhi(n, p.mul[k]) >> p.shr[k]) & ~p.one[k]) | (n & p.one[k]); };
+        unsigned q = div(tile, 0);
+        t.tx0 = (int)(tile - q * p.tiles_x) * 32;
+        unsigned q2 = div(q, 1);
+        t.ty0 = (int)(q - q2 * p.tiles_y) * TY;
+        const unsigned q3 = div(q2, 2);
+        t.zo = (int)(q2 - q3 * (unsigned)a.Do);
+        t.b = (int)q3;
+        return t;
+    };
+    const unsigned nwg = gridDim.x;
+    unsigned tile = xcd_remap(blockIdx.x, nwg);
+
+    if (loader) {
+        // instruction i = wave + 4n -> block of 64 slots; slot -> (row, column parity, column pair index, quad)
+        unsigned dbase[NIW];
+        int dpos[NIW];
+#pragma unroll
+        for (int n = 0; n < NIW; ++n) {
+            const int i = wave + 4 * n;
+            const int s = i * 64 + lane;
+            const int q1 = s & 1;
+            int t = s >> 1;
+            const int xh = t % PWH;
+            t /= PWH;
+            const int prow = t >> 1, px = 2 * xh + (t & 1);
+            const bool valid = i < NBLK && prow < G::ROWS && px < PW;
+            dpos[n] = px | (prow << 8);
+            dbase[n] = valid ? (unsigned)((prow * a.Wi + px) * 32 + q1 * 16) : 0x80000000u;
+        }
+        auto dma_tile = [&](const TilePos& t, int buf, bool live) {
+            const int iy0 = t.ty0 * SW - a.ph[0], ix0 = t.tx0 * SW - a.pw[0];
+            const unsigned origin = (unsigned)((((t.b * a.Di + t.zo) * a.Hi + iy0) * a.Wi + ix0) * 32);
+            const unsigned wi = live ? (unsigned)a.Wi : 0u;
+            f32x4v* const dst0 = lds + buf * PLANE;
+#pragma unroll
+            for (int n = 0; n < NIW; ++n) {
+                const int i = wave + 4 * n;
+                const int ix = ix0 + (dpos[n] & 255), iy = iy0 + (dpos[n] >> 8);
+                const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < wi;
+                const unsigned off = ok ? dbase[n] + origin : 0x80000000u;
+                f32x4v* const dst = (NBLK % 4 == 0 || n + 1 < NIW || i < NBLK) ? dst0 + i * 64 : scratch;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_void*)dst, 16, off, 0, 0, 0);
+            }
+        };
+        if (tile < p.ntiles) dma_tile(decode_tile(tile), 0, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int it = 0; tile < p.ntiles; tile += nwg, ++it) {
+            const bool has_next = tile + nwg < p.ntiles;
+            dma_tile(decode_tile(has_next ? tile + nwg : tile), (it & 1) ^ 1, has_next);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+
+    // ---- compute waves ---------------------------------------------------------------------------------------------------
+    f32x4v wreg[NKS];
+#pragma unroll
+    for (int s2 = 0; s2 < NKS; ++s2) wreg[s2] = *reinterpret_cast<const f32x4v*>(a.wpk + (long)s2 * a.ntile_total * 256 + lane * 4);
+    const f32x4v scv = *reinterpret_cast<const f32x4v*>(a.scale + lq * 4), shv = *reinterpret_cast<const f32x4v*>(a.shift + lq * 4);
+    // float4 offset of this lane's tap of every tap pair, relative to its pixel's slot for tap (0, 0)
+    int toff[NKS];
+#pragma unroll
+    for (int s2 = 0; s2 < NKS; ++s2) {
+        int tap = 2 * s2 + (lq >> 1);
+        tap = tap < NTAP ? tap : NTAP - 1;                  // (the padded half of the last K step: zero weights, any patch slot)
+        const int ky = tap / KW, kx = tap - ky * KW;
+        toff[s2] = ky * G::ROWSLOTS + (kx & 1) * PWH * 2 + (kx >> 1) * 2 + (lq & 1);
+    }
+    int abase[MT];
+    unsigned obase[MT];
+    int orc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int t = wave * MT + mt;
+        const int row = t >> 1, col = (t & 1) * 16 + lm;
+        abase[mt] = row * 2 * G::ROWSLOTS + col * 2;
+        orc[mt] = row | (col << 8);
+        obase[mt] = (unsigned)((row * a.Wo + col) * a.cout + lq * 4) * 4u;
+    }
+    const __amdgpu_buffer_rsrc_t out_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t skip_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(SKIP ? a.skip : a.in), (short)0, SKIP ? (int)p.out_bytes : 0, 0x00020000);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                           // (the loaders' first patch has landed)
+    for (int it = 0; tile < p.ntiles; tile += nwg, ++it) {
+        const TilePos here = decode_tile(tile);
+        const unsigned oorigin = (unsigned)((((here.b * a.Do + here.zo) * a.Ho + here.ty0) * a.Wo + here.tx0) * a.cout) * 4u;
+        unsigned ooff[MT];
+        f32x4v skv[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bool ok = here.ty0 + (orc[mt] & 255) < a.Ho && here.tx0 + (orc[mt] >> 8) < a.Wo;
+            ooff[mt] = ok ? obase[mt] + oorigin : 0x80000000u;
+            skv[mt] = SKIP ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, ooff[mt], 0, 0)) : (f32x4v){0.f, 0.f, 0.f, 0.f};
+        }
+        const f32x4v* patch = lds + (it & 1) * PLANE;
+        f32x4v acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        // K order = the packed order (tap-major, channel-minor), operands one K step ahead
+        f32x4v A[2][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) A[0][mt] = patch[abase[mt] + toff[0]];
+#pragma unroll
+        for (int s2 = 0; s2 < NKS; ++s2) {
+            if (s2 + 1 < NKS) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) A[(s2 + 1) & 1][mt] = patch[abase[mt] + toff[s2 + 1]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s2][j], A[s2 & 1][mt][j], acc[mt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4v v = acc[mt];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = fmaf(v[j], scv[j], shv[j]);
+                if (a.relu) v[j] = fmaxf(v[j], 0.0f);
+                if (SKIP) v[j] += skv[mt][j];
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, ooff[mt], 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // done reading this patch
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Ping-pong form of the persistent kernel (variant 7): a workgroup of EIGHT waves, two per SIMD.  The model fitted to
 // conv_pers_kernel's measurements says its steady state is 58-61 % MFMA-busy because a wavefront's
 // address arithmetic, DMA issue, barrier wait and epilogue (~1 700 cycles per tile) are not overlapped with MFMAs -- not
@@ -815,6 +980,31 @@ int launch_pers(const ConvArgs& a, int wpc, hipStream_t s) {
     return mv_check_launch();
 }
 
+template <int KW, bool SKIP>
+int launch_pers8(const ConvArgs& a, int wpc, hipStream_t s) {
+    using G = PersGeom<2, KW, 2, 1>;
+    const size_t lds = (size_t)(2 * G::PLANE + 64) * 16;
+    auto kern = conv_pers8_kernel<KW, SKIP>;
+    static unsigned long attr_done = 0;
+    if (lds > 64 * 1024 && !allow_big_lds(reinterpret_cast<const void*>(kern), attr_done)) return MVSTER_ERR_LAUNCH;
+    const int ncu = num_cus();
+    if (ncu <= 0) return MVSTER_ERR_LAUNCH;
+    PersArgs p;
+    if (!fill_pers_args(a, G::TY, p)) return MVSTER_ERR_UNSUPPORTED;
+    const long ntiles = p.ntiles;
+    wpc &= 15;
+    const int by_lds = (int)((160 * 1024) / lds);
+    int per_cu = wpc > 0 ? wpc : 2;
+    if (per_cu > by_lds) per_cu = by_lds;
+    if (per_cu > 3) per_cu = 3;
+    const long gmax = (long)ncu * per_cu;
+    const long rounds = (ntiles + gmax - 1) / gmax;       // equal shares
+    const long gx = (ntiles + rounds - 1) / rounds;
+    MV_NOTE_KERNEL("conv_pers8_kernel<%d, %s>", KW, SKIP ? "true" : "false");
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, 1, 1), dim3(512), lds, s, a, p);
+    return mv_check_launch();
+}
+
 template <int MT, int NT, int KW, int SW, int NCH, int KD, bool WREG, int PF, bool SKIP>
 int launch_pp(const ConvArgs& a, hipStream_t s) {
     using G = PersGeom<MT, KW, SW, KD>;
@@ -926,6 +1116,12 @@ int dispatch_pers(const ConvArgs& a, int mt, int nt, int wpc, hipStream_t s) {
         a.sh != a.sw || a.kh[0] != a.kw[0] || a.ntile_total % nt != 0 || mt != 2)
         return MVSTER_ERR_UNSUPPORTED;
     const int kd = a.kd[0], kw = a.kw[0], sw = a.sw, nch = a.cin / 16;
+    if (a.cin == 8 && a.cout == 16 && sw == 2 && kd == 1 && a.sd == 1 && nt == 1 && (kw == 3 || kw == 5) && a.ph[0] == kw / 2 &&
+        a.pw[0] == kw / 2) {
+        // 8 -> 16 channels, stride 2: conv_pers8_kernel
+        if (kw == 5) return a.skip_mode == 1 ? launch_pers8<5, true>(a, wpc, s) : launch_pers8<5, false>(a, wpc, s);
+        return a.skip_mode == 1 ? launch_pers8<3, true>(a, wpc, s) : launch_pers8<3, false>(a, wpc, s);
+    }
     if (a.cin % 16 != 0) return MVSTER_ERR_UNSUPPORTED;
 #define MV_P(NT_, KW_, SW_, NCH_, KD_, WREG_, PF_) MV_Q(2, NT_, KW_, SW_, NCH_, KD_, WREG_, PF_)
     const bool ld = (wpc & 32) != 0;          // bit 5 of the workgroups-per-CU field: waves 4-7 issue the DMA

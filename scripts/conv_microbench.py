@@ -68,6 +68,9 @@ def candidates(layer, B, Di, Hi, Wi, sm):
             for m in (1, 2):
                 for wpc in (1, 2, 3):
                     out.append(("Q%d w%d" % (m, wpc), (m, 1, 6 | (wpc << 8))))
+        if layer.cin == 8 and layer.cout == 16 and layer.kernel in ((1, 3, 3), (1, 5, 5)) and layer.stride == (1, 2, 2):
+            for wpc in (1, 2, 3):             # conv_pers8_kernel
+                out.append(("P8 w%d" % wpc, (2, 1, 5 | (wpc << 8))))
         if layer.kernel in ((1, 3, 3), (3, 3, 3), (1, 5, 5)) and layer.cin in (16, 32, 64) and layer.cout % 16 == 0:
             for n in nts:
                 for wpc in (1, 2, 3):

@@ -19,6 +19,8 @@ FAMILIES = [
     ("16->32 5x5 s2", 16, 32, (1, 5, 5), (1, 2, 2), 2),
     ("16->16 3x3x3", 16, 16, (3, 3, 3), (1, 1, 1), 1),
     ("16->32 3x3 s2", 16, 32, (1, 3, 3), (1, 2, 2), 2),
+    ("8->16 5x5 s2", 8, 16, (1, 5, 5), (1, 2, 2), 1),
+    ("8->16 3x3 s2", 8, 16, (1, 3, 3), (1, 2, 2), 1),
 ]
 EXTRA = [
     ("64->64 3x3", 64, 64, (1, 3, 3), (1, 1, 1), 1),
@@ -35,6 +37,8 @@ PROD = {  # production shapes of the 512x640x5 forward (input B, D, H, W) per fa
     "16->32 5x5 s2": [(5, 1, 256, 320)],
     "16->16 3x3x3": [(1, 4, 256, 320), (1, 4, 128, 160), (1, 8, 64, 80), (1, 8, 32, 40)],
     "16->32 3x3 s2": [(1, 4, 256, 320), (1, 4, 128, 160), (1, 8, 64, 80)],
+    "8->16 5x5 s2": [(5, 1, 512, 640)],
+    "8->16 3x3 s2": [(1, 4, 512, 640), (1, 4, 256, 320), (1, 8, 128, 160), (1, 8, 64, 80)],
     "64->64 3x3": [(5, 1, 64, 80)],
     "64->32 3x3": [(5, 1, 128, 160)],
     "32->64 5x5 s2": [(5, 1, 128, 160)],
@@ -101,8 +105,11 @@ def times():
             row = "%-16s %-18s plan v%d(%d,%d) %6.1f us %5.1f TF/s |" % (name, "x".join(map(str, shape)), var0, mt0, nt0, base,
                                                                        fl / base / 1e6)
             if supported(layer, x, nt):
-                for wpc in (1, 2, 3, 33, 34):               # 32 + n: waves 4-7 issue the DMA (conv_pers.hip)
-                    us = min(timeit(lambda: layer(x, tiles=(2, nt, 5 | (wpc << 8))), n=10) for _ in range(2))
+                for wpc in (1, 2, 3, 33, 34):               # 32 + n: waves 4-7 issue the DMA (stride-2 families)
+                    try:
+                        us = min(timeit(lambda: layer(x, tiles=(2, nt, 5 | (wpc << 8))), n=10) for _ in range(2))
+                    except RuntimeError:
+                        continue
                     ok = torch.equal(layer(x, tiles=(2, nt, 5 | (wpc << 8))), layer(x, tiles=(1, 1, 0)))
                     row += " %s%d %5.1f (%5.1f)%s" % ("L" if wpc > 31 else "w", wpc & 15, us, fl / us / 1e6, "" if ok else " DIFFERENT")
                 for wpc in (1, 2):

@@ -397,6 +397,9 @@ PERS_CASES = [  # (cin, cout, kernel, stride, nt, input [B,D,H,W]): every instan
     (16, 32, (1, 5, 5), (1, 2, 2), 2, (2, 1, 70, 100)), (16, 32, (1, 5, 5), (1, 2, 2), 2, (1, 1, 8, 34)),
     (16, 16, (3, 3, 3), (1, 1, 1), 1, (2, 4, 38, 70)), (16, 16, (3, 3, 3), (1, 1, 1), 1, (1, 3, 5, 31)),
     (16, 32, (1, 3, 3), (1, 2, 2), 2, (2, 4, 70, 100)), (16, 32, (1, 3, 3), (1, 2, 2), 2, (1, 1, 6, 66)),
+    # 8 -> 16 channels, stride 2 (conv_pers8_kernel): two taps per 16-wide K step, odd sizes, a map smaller than a tile
+    (8, 16, (1, 5, 5), (1, 2, 2), 1, (2, 1, 70, 100)), (8, 16, (1, 5, 5), (1, 2, 2), 1, (1, 1, 7, 33)),
+    (8, 16, (1, 3, 3), (1, 2, 2), 1, (1, 4, 38, 70)), (8, 16, (1, 3, 3), (1, 2, 2), 1, (3, 1, 4, 6)),
     (64, 144, (1, 1, 1), (1, 1, 1), 1, (2, 1, 37, 53)), (64, 72, (1, 1, 1), (1, 1, 1), 1, (2, 1, 37, 53)),
     (32, 64, (1, 1, 1), (1, 1, 1), 1, (1, 2, 9, 17)), (64, 16, (1, 1, 1), (1, 1, 1), 1, (1, 1, 64, 80)),
 ]
@@ -426,7 +429,7 @@ def test_persistent_conv_bit_identical_to_direct(cin, cout, kernel, stride, nt, 
             got = layer(x, skip=skip, skip_mode=sm, tiles=(mt, nt, variant | (wpc << 8)))
             assert torch.equal(got, want), (mt, wpc, (got - want).abs().max().item())
     from mvster_amd import _lib
-    assert _lib.last_kernel().startswith("conv1x1_pers_kernel<" if variant == 6 else "conv_pers_kernel<")
+    assert _lib.last_kernel().startswith("conv1x1_pers_kernel<" if variant == 6 else "conv_pers8_kernel<" if cin == 8 else "conv_pers_kernel<")
 
 
 PP_CASES = [(16, 16, (1, 1, 1), 1, (2, 1, 70, 100)), (16, 16, (1, 1, 1), 1, (1, 1, 4, 33)), (32, 32, (1, 1, 1), 2, (3, 1, 64, 64)),
