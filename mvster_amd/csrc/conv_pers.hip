@@ -531,6 +531,187 @@ __global__ void __launch_bounds__(512) conv_pers8_kernel(ConvArgs a, PersArgs p)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Transposed 1x3x3 stride (1,2,2) convolutions (reg2d's conv7 / conv9: 64 -> 32, 32 -> 16, with the U-Net skip added at the
+// output resolution).  The direct kernel runs them as four output-parity classes, each a 1-, 2-, 2- or 4-tap stride-1
+// convolution over the input lattice in its own set of workgroups: 2 to 8 K steps per workgroup tile -- all prologue, no
+// steady state (16-25 us at stage 4 against 4-8 us of HBM / MFMA time).  Here a persistent workgroup stages a 4 x 32 input
+// tile (+ one halo row and column: the taps reach i and i + 1) once and computes ALL FOUR classes from it, 18 K steps per
+// chunk set; the classes' packed weights (their own K order: bit-identical to the direct kernel) stay in LDS; four compute
+// waves (2 M tiles each), four loading waves.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NCH, bool SKIP>
+__global__ void __launch_bounds__(512) conv_tpers_kernel(ConvArgs a, PersArgs p) {
+    constexpr int MT = 2;                                   // (one N tile per workgroup: blockIdx.y)
+    using G = PersGeom<MT, 2, 1, 1>;                        // 5 x 33 input pixels per tile
+    constexpr int TY = G::TY, PW = G::PW, PLANE = G::PLANE, NBLK = G::NBLK, RS = G::ROWSLOTS;
+    constexpr int BUF = NCH * 2 * PLANE;
+    constexpr int NI = NCH * 2 * NBLK, NIW = (NI + 3) / 4;
+    constexpr int CIN = NCH * 16;
+    // (K steps of all four classes: (1 + 2 + 2 + 4) taps x NCH chunks = 9 * NCH kilobytes of weights per N tile)
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    f32x4v* const lds = reinterpret_cast<f32x4v*>(lds_raw);
+    f32x4v* const scratch = lds + 2 * BUF;
+    f32x4v* const wl = scratch + 64;                        // [class steps][lane]
+
+    const int lane = threadIdx.x & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wave8 & 3;
+    const bool loader = wave8 >= 4;
+    const int lm = lane & 15, lq = lane >> 4;
+    const int nt0 = blockIdx.y;
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)a.in_bytes, 0x00020000);
+    auto decode_tile = [&](unsigned tile) -> TilePos {
+        TilePos t;
+        auto div = [&](unsigned n, int k) -> unsigned { return ((__umulhi(n, p.mul[k]) >> p.shr[k]) & ~p.one[k]) | (n & p.one[k]); };
+        unsigned q = div(tile, 0);
+        t.tx0 = (int)(tile - q * p.tiles_x) * 32;
+        unsigned q2 = div(q, 1);
+        t.ty0 = (int)(q - q2 * p.tiles_y) * TY;
+        const unsigned q3 = div(q2, 2);
+        t.zo = (int)(q2 - q3 * (unsigned)a.Do);
+        t.b = (int)q3;
+        return t;
+    };
+    const unsigned nwg = gridDim.x;
+    unsigned tile = xcd_remap(blockIdx.x, nwg);
+
+    if (loader) {
+        unsigned dbase[NIW];
+        int dpos[NIW];
+#pragma unroll
+        for (int n = 0; n < NIW; ++n) {
+            const int i = wave + 4 * n;
+            const int c = i / (2 * NBLK), r = i - c * 2 * NBLK, pl = r / NBLK, blk = r - pl * NBLK;
+            const int s = blk * 64 + lane;
+            const int q1 = s & 1, pix = s >> 1;
+            const int prow = pix / PW, px = pix - prow * PW;
+            const bool valid = i < NI && prow < G::ROWS;
+            dpos[n] = px | (prow << 8);
+            dbase[n] = valid ? (unsigned)((prow * a.Wi + px) * (CIN * 4) + (c * 16 + pl * 8 + q1 * 4) * 4) : 0x80000000u;
+        }
+        auto dma_tile = [&](const TilePos& t, int buf, bool live) {
+            const unsigned origin = (unsigned)((((t.b * a.Di + t.zo) * a.Hi + t.ty0) * a.Wi + t.tx0) * (CIN * 4));
+            const unsigned wi = live ? (unsigned)a.Wi : 0u;
+            f32x4v* const dst0 = lds + buf * BUF;
+#pragma unroll
+            for (int n = 0; n < NIW; ++n) {
+                const int i = wave + 4 * n;
+                const int ix = t.tx0 + (dpos[n] & 255), iy = t.ty0 + (dpos[n] >> 8);
+                const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < wi;
+                const unsigned off = ok ? dbase[n] + origin : 0x80000000u;
+                f32x4v* const dst = (NI % 4 == 0 || n + 1 < NIW || i < NI) ? dst0 + (i / NBLK) * PLANE + (i % NBLK) * 64 : scratch;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_void*)dst, 16, off, 0, 0, 0);
+            }
+        };
+        // the four classes' packed weights: class c starts at woff[c], nsteps[c] K steps of ntile_total x 256 floats
+        {
+            const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a.wpk), (short)0, (int)((a.woff[3] + (long)a.nsteps[3] * a.ntile_total * 256) * 4), 0x00020000);
+            int base = 0;
+            for (int c = 0; c < 4; ++c) {
+                for (int sidx = wave; sidx < a.nsteps[c]; sidx += 4) {
+                    const unsigned off = (unsigned)((a.woff[c] + ((long)sidx * a.ntile_total + nt0) * 256) * 4) + lane * 16;
+                    f32x4v* const dst = wl + (base + sidx) * 64;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)dst, 16, off, 0, 0, 0);
+                }
+                base += a.nsteps[c];
+            }
+        }
+        if (tile < p.ntiles) dma_tile(decode_tile(tile), 0, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int it = 0; tile < p.ntiles; tile += nwg, ++it) {
+            const bool has_next = tile + nwg < p.ntiles;
+            dma_tile(decode_tile(has_next ? tile + nwg : tile), (it & 1) ^ 1, has_next);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+
+    // ---- compute waves ---------------------------------------------------------------------------------------------------
+    const f32x4v scv = *reinterpret_cast<const f32x4v*>(a.scale + nt0 * 16 + lq * 4), shv = *reinterpret_cast<const f32x4v*>(a.shift + nt0 * 16 + lq * 4);
+    int abase[MT], orc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int t = wave * MT + mt;
+        const int row = t >> 1, col = (t & 1) * 16 + lm;
+        abase[mt] = row * RS + col * 2 + (lq >> 1) * PLANE + (lq & 1);
+        orc[mt] = row | (col << 8);
+    }
+    const __amdgpu_buffer_rsrc_t out_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t skip_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(SKIP ? a.skip : a.in), (short)0, SKIP ? (int)p.out_bytes : 0, 0x00020000);
+    const unsigned opix = (unsigned)a.cout * 4u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                           // (weights and the first patch have landed)
+    for (int it = 0; tile < p.ntiles; tile += nwg, ++it) {
+        const TilePos here = decode_tile(tile);
+        const f32x4v* patch = lds + (it & 1) * BUF;
+        // output pixel (2y, 2x) of this lane's M tiles; class (py, px) adds (py, px)
+        unsigned obase[MT];
+        bool oval[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int y = here.ty0 + (orc[mt] & 255), x = here.tx0 + (orc[mt] >> 8);
+            oval[mt] = y < a.Ho && x < a.Wo;
+            obase[mt] = (unsigned)(((((here.b * a.DoF + here.zo) * a.HoF + 2 * y) * a.WoF + 2 * x) * a.cout + nt0 * 16 + lq * 4)) * 4u;
+        }
+        int wbase = 0;
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {
+            const int py = cls >> 1, px = cls & 1;
+            const int kh = py + 1, kw = px + 1;               // taps of the class: input offsets 0..kh-1, 0..kw-1
+            f32x4v acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+            f32x4v skv[MT];
+            unsigned ooff[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                ooff[mt] = oval[mt] ? obase[mt] + (unsigned)(py * a.WoF + px) * opix : 0x80000000u;
+                skv[mt] = SKIP ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, ooff[mt], 0, 0)) : (f32x4v){0.f, 0.f, 0.f, 0.f};
+            }
+            // K order of the class's packed block: tap-major (dy, then dx), channel-minor
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    if (dy >= kh || dx >= kw) continue;
+                    const int tap = dy * kw + dx;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const f32x4v w = wl[(wbase + tap * NCH + c) * 64 + lane];
+                        f32x4v A[MT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) A[mt] = patch[abase[mt] + c * 2 * PLANE + dy * RS + dx * 2];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], A[mt][j], acc[mt], 0, 0, 0);
+                    }
+                }
+            wbase += kh * kw * NCH;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4v v = acc[mt];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = fmaf(v[j], scv[j], shv[j]);
+                    if (a.relu) v[j] = fmaxf(v[j], 0.0f);
+                    if (SKIP) v[j] += skv[mt][j];
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, ooff[mt], 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // done reading this patch
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Ping-pong form of the persistent kernel (variant 7): a workgroup of EIGHT waves, two per SIMD.  The model fitted to
 // conv_pers_kernel's measurements says its steady state is 58-61 % MFMA-busy because a wavefront's
 // address arithmetic, DMA issue, barrier wait and epilogue (~1 700 cycles per tile) are not overlapped with MFMAs -- not
@@ -980,6 +1161,33 @@ int launch_pers(const ConvArgs& a, int wpc, hipStream_t s) {
     return mv_check_launch();
 }
 
+template <int NCH, bool SKIP>
+int launch_tpers(const ConvArgs& a, int wpc, hipStream_t s) {
+    using G = PersGeom<2, 2, 1, 1>;
+    const size_t lds = (size_t)(2 * NCH * 2 * G::PLANE + 64 + 9 * NCH * 64) * 16;
+    if (lds > 160 * 1024) return MVSTER_ERR_UNSUPPORTED;
+    auto kern = conv_tpers_kernel<NCH, SKIP>;
+    static unsigned long attr_done = 0;
+    if (lds > 64 * 1024 && !allow_big_lds(reinterpret_cast<const void*>(kern), attr_done)) return MVSTER_ERR_LAUNCH;
+    const int ncu = num_cus();
+    if (ncu <= 0) return MVSTER_ERR_LAUNCH;
+    PersArgs p;
+    if (!fill_pers_args(a, G::TY, p)) return MVSTER_ERR_UNSUPPORTED;          // (tiles over the INPUT lattice: a.Ho, a.Wo, a.Do)
+    const long ntiles = p.ntiles;
+    wpc &= 15;
+    const int by_lds = (int)((160 * 1024) / lds);
+    int per_cu = wpc > 0 ? wpc : 2;
+    if (per_cu > by_lds) per_cu = by_lds;
+    if (per_cu > 2) per_cu = 2;
+    long gmax = (long)ncu * per_cu / a.ntile_total;
+    if (gmax < 1) gmax = 1;
+    const long rounds = (ntiles + gmax - 1) / gmax;
+    const long gx = (ntiles + rounds - 1) / rounds;
+    MV_NOTE_KERNEL("conv_tpers_kernel<%d, %s>", NCH, SKIP ? "true" : "false");
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, a.ntile_total, 1), dim3(512), lds, s, a, p);
+    return mv_check_launch();
+}
+
 template <int KW, bool SKIP>
 int launch_pers8(const ConvArgs& a, int wpc, hipStream_t s) {
     using G = PersGeom<2, KW, 2, 1>;
@@ -1112,6 +1320,16 @@ int dispatch_pp(const ConvArgs& a, int mt, int nt, hipStream_t s) {
 // Layers the family covers: ordinary (non-transposed) convolutions, cin in {16, 32, 64}, cout % 16 == 0, kernel (1|3) x 3 x 3
 // or 1 x 5 x 5 with "same" padding geometry handled by the generic bounds checks, stride 1 or 2 in-plane.
 int dispatch_pers(const ConvArgs& a, int mt, int nt, int wpc, hipStream_t s) {
+    if (a.nclass == 4 && a.osd == 1 && a.osh == 2 && a.osw == 2 && a.sd == 1 && a.sh == 1 && a.sw == 1 && a.skip_mode <= 1 &&
+        !a.prob_w && a.cout % 16 == 0 && (a.cin == 32 || a.cin == 64) && mt == 2 && nt == 1) {
+        // transposed 1x3x3 stride (1,2,2): the classes must be the 1 / 2 / 2 / 4-tap ones in (py, px) order, unpadded
+        for (int c = 0; c < 4; ++c)
+            if (a.kd[c] != 1 || a.kh[c] != (c >> 1) + 1 || a.kw[c] != (c & 1) + 1 || a.pd[c] || a.ph[c] || a.pw[c] || a.od[c] ||
+                a.oh[c] != (c >> 1) || a.ow[c] != (c & 1) || a.nsteps[c] != a.kh[c] * a.kw[c] * (a.cin / 16))
+                return MVSTER_ERR_UNSUPPORTED;
+        if (a.cin == 32) return a.skip_mode == 1 ? launch_tpers<2, true>(a, wpc, s) : launch_tpers<2, false>(a, wpc, s);
+        return a.skip_mode == 1 ? launch_tpers<4, true>(a, wpc, s) : launch_tpers<4, false>(a, wpc, s);
+    }
     if (a.nclass != 1 || a.osd != 1 || a.osh != 1 || a.osw != 1 || a.skip_mode > 1 || a.prob_w || a.cout % 16 != 0 ||
         a.sh != a.sw || a.kh[0] != a.kw[0] || a.ntile_total % nt != 0 || mt != 2)
         return MVSTER_ERR_UNSUPPORTED;

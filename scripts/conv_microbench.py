@@ -78,6 +78,11 @@ def candidates(layer, B, Di, Hi, Wi, sm):
                 if layer.stride[2] == 2:      # waves 4-7 issue the DMA (built for the stride-2 families)
                     for wpc in (33, 34):
                         out.append(("P2,%d L%d" % (n, wpc & 15), (2, n, 5 | (wpc << 8))))
+    if (layer.transposed and layer.prob is None and sm in (0, 1) and layer.kernel == (1, 3, 3) and layer.stride == (1, 2, 2)
+            and layer.cin in (32, 64) and layer.cout % 16 == 0):
+        for wpc in (1, 2):                    # conv_tpers_kernel: all four output-parity classes from one staged tile
+            out.append(("TP w%d" % wpc, (2, 1, 5 | (wpc << 8))))
+    if not layer.transposed and layer.prob is None and sm in (0, 1):
         if layer.wino_eligible():
             # Winograd F(2x2,3x3) on the persistent frame (conv_wino.hip); not bit-identical to the others
             if layer.kernel[0] == 1 and layer.cin in (16, 32):

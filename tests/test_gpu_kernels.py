@@ -432,6 +432,31 @@ def test_persistent_conv_bit_identical_to_direct(cin, cout, kernel, stride, nt, 
     assert _lib.last_kernel().startswith("conv1x1_pers_kernel<" if variant == 6 else "conv_pers8_kernel<" if cin == 8 else "conv_pers_kernel<")
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(64, 32, (2, 3, 9, 21)), (32, 16, (1, 1, 4, 33)), (32, 16, (1, 4, 16, 40)),
+                                            (64, 64, (3, 1, 5, 64)), (32, 32, (1, 2, 7, 31))])
+@pytest.mark.parametrize("with_skip", [False, True])
+def test_persistent_transposed_conv_bit_identical_to_direct(cin, cout, shape, with_skip):
+    """conv_tpers_kernel computes the four output-parity classes of a transposed 1x3x3 stride-(1,2,2) layer from one staged
+    input tile, each in its packed K order: EQUAL to the direct kernel (one launch group per class), ragged sizes, with the
+    U-Net skip added at the output resolution."""
+    g = torch.Generator().manual_seed(cin + cout + shape[3])
+    w = (torch.randn(cin, cout, 1, 3, 3, generator=g) * 0.1).to(DEV)
+    layer = cp.ConvLayer(w, True, (1, 2, 2), (0, 1, 1), relu=True)
+    layer.scale.copy_(torch.rand(layer.scale.shape, generator=g) + 0.5)
+    layer.shift.copy_(torch.randn(layer.shift.shape, generator=g) * 0.1)
+    x = torch.randn(*shape, cin, generator=g).to(DEV)
+    want = layer(x, tiles=(1, 1, 0))
+    skip = torch.randn(want.shape, generator=g).to(DEV) if with_skip else None
+    sm = cp.SKIP_ADD if with_skip else cp.SKIP_NONE
+    if with_skip:
+        want = layer(x, skip=skip, skip_mode=sm, tiles=(1, 1, 0))
+    for wpc in (0, 1, 2):
+        got = layer(x, skip=skip, skip_mode=sm, tiles=(2, 1, 5 | (wpc << 8)))
+        assert torch.equal(got, want), (wpc, (got - want).abs().max().item())
+    from mvster_amd import _lib
+    assert _lib.last_kernel().startswith("conv_tpers_kernel<")
+
+
 PP_CASES = [(16, 16, (1, 1, 1), 1, (2, 1, 70, 100)), (16, 16, (1, 1, 1), 1, (1, 1, 4, 33)), (32, 32, (1, 1, 1), 2, (3, 1, 64, 64)),
             (32, 32, (1, 1, 1), 2, (7, 1, 12, 64)), (16, 32, (1, 2, 2), 2, (2, 4, 70, 100)), (16, 32, (1, 2, 2), 2, (1, 1, 5, 200))]
 
