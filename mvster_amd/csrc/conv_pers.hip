@@ -1043,8 +1043,10 @@ __global__ void __launch_bounds__(256) conv1x1_pers_kernel(ConvArgs a, unsigned 
     const __amdgpu_buffer_rsrc_t in_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (int)out_bytes, 0x00020000);
+    // skip_mode 1: same-shape tensor; 2: [B, 1, Ho/2, Wo/2, cout] map, added through a bilinear x2 (align_corners) up-sampling
     const __amdgpu_buffer_rsrc_t skip_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.skip_mode == 1 ? a.skip : a.in), (short)0, a.skip_mode == 1 ? (int)out_bytes : 0, 0x00020000);
+        const_cast<float*>(a.skip_mode ? a.skip : a.in), (short)0,
+        a.skip_mode == 1 ? (int)out_bytes : a.skip_mode == 2 ? (int)(out_bytes / 4) : 0, 0x00020000);
     {
         const __amdgpu_buffer_rsrc_t w_rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpk), (short)0, NCH * ntile * 1024, 0x00020000);
@@ -1072,6 +1074,10 @@ __global__ void __launch_bounds__(256) conv1x1_pers_kernel(ConvArgs a, unsigned 
     };
     f32x4v A[MT][NCH], An[MT][NCH];
     unsigned vox[MT], voxn[MT];
+    struct Up {                 // skip_mode 2: the four half-resolution texels (byte offsets) and weights of an output voxel
+        unsigned o00, o01, o10, o11;
+        mv::Lerp ly, lx;
+    } up[MT];
     unsigned g = blockIdx.x;
     if (g < ngroups) load_group(g, A, vox);
     __syncthreads();            // weights (LDS-DMA: vmcnt(0)) and scale / shift in LDS
@@ -1079,6 +1085,24 @@ __global__ void __launch_bounds__(256) conv1x1_pers_kernel(ConvArgs a, unsigned 
     for (; g < ngroups; g += gridDim.x) {
         const unsigned gn = g + gridDim.x < ngroups ? g + gridDim.x : g;
         load_group(gn, An, voxn);                                     // next group's operands fly under this group's math
+        if (a.skip_mode == 2) {
+            const int hh = a.HoF / 2, wh = a.WoF / 2;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned m = vox[mt] < mtot ? vox[mt] : 0u;
+                const unsigned t = fast_div(m, (unsigned)a.Wo, a.div_mul[0], a.div_shr[0]);
+                const int ox = (int)(m - t * (unsigned)a.Wo);
+                const unsigned b = fast_div(t, (unsigned)a.Ho, a.div_mul[1], a.div_shr[1]);
+                const int oy = (int)(t - b * (unsigned)a.Ho);
+                up[mt].ly = mv::make_lerp(oy, hh, a.HoF);
+                up[mt].lx = mv::make_lerp(ox, wh, a.WoF);
+                const unsigned base = b * (unsigned)(hh * wh);
+                up[mt].o00 = (base + up[mt].ly.i0 * wh + up[mt].lx.i0) * cout4;
+                up[mt].o01 = (base + up[mt].ly.i0 * wh + up[mt].lx.i1) * cout4;
+                up[mt].o10 = (base + up[mt].ly.i1 * wh + up[mt].lx.i0) * cout4;
+                up[mt].o11 = (base + up[mt].ly.i1 * wh + up[mt].lx.i1) * cout4;
+            }
+        }
         f32x4v Bv[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) Bv[c] = wl[(c * ntile) * 64 + lane];
@@ -1112,6 +1136,17 @@ __global__ void __launch_bounds__(256) conv1x1_pers_kernel(ConvArgs a, unsigned 
                     const f32x4v k = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, off, 0, 0));
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] += k[j];
+                } else if (a.skip_mode == 2) {
+                    // F.interpolate(prev, x2, bilinear, align_corners) + inner(conv) (mvs4net_utils.py:482-488), the direct
+                    // kernel's arithmetic (epilogue_store in conv_mfma.hip)
+                    const bool ok = n0 < (unsigned)a.cout && vox[mt] < mtot;
+                    const unsigned c4 = n0 * 4u;
+                    const f32x4v k00 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, ok ? up[mt].o00 + c4 : 0x80000000u, 0, 0));
+                    const f32x4v k01 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, ok ? up[mt].o01 + c4 : 0x80000000u, 0, 0));
+                    const f32x4v k10 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, ok ? up[mt].o10 + c4 : 0x80000000u, 0, 0));
+                    const f32x4v k11 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, ok ? up[mt].o11 + c4 : 0x80000000u, 0, 0));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = mv::bilerp(up[mt].ly, up[mt].lx, k00[j], k01[j], k10[j], k11[j]) + v[j];
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, off, 0, 0);
             }
@@ -1289,14 +1324,17 @@ int num_cus() {
 // 1x1x1 stride-1 convolutions, cin in {32, 64}, any cout % 4 == 0, optional same-shape skip (variant 6).
 int dispatch_1x1(const ConvArgs& a, int mt, int wpc, hipStream_t s) {
     if (a.nclass != 1 || a.kd[0] != 1 || a.kh[0] != 1 || a.kw[0] != 1 || a.sd != 1 || a.sh != 1 || a.sw != 1 || a.osd != 1 ||
-        a.osh != 1 || a.osw != 1 || a.pd[0] != 0 || a.ph[0] != 0 || a.pw[0] != 0 || a.skip_mode > 1 || a.prob_w)
+        a.osh != 1 || a.osw != 1 || a.pd[0] != 0 || a.ph[0] != 0 || a.pw[0] != 0 || a.skip_mode > 2 || a.prob_w)
         return MVSTER_ERR_UNSUPPORTED;
+    if (a.skip_mode == 2 && (a.Do != 1 || (a.HoF & 1) || (a.WoF & 1))) return MVSTER_ERR_UNSUPPORTED;      // (2-D, even sizes)
     wpc &= 15;
     if (a.cin == 64 && mt == 1) return launch_1x1<4, 1>(a, wpc, s);
     if (a.cin == 64 && mt == 2) return launch_1x1<4, 2>(a, wpc, s);
     if (a.cin == 32 && mt == 1) return launch_1x1<2, 1>(a, wpc, s);
     if (a.cin == 32 && mt == 2) return launch_1x1<2, 2>(a, wpc, s);
     if (a.cin == 32 && mt == 4) return launch_1x1<2, 4>(a, wpc, s);
+    if (a.cin == 16 && mt == 2) return launch_1x1<1, 2>(a, wpc, s);
+    if (a.cin == 16 && mt == 4) return launch_1x1<1, 4>(a, wpc, s);
     return MVSTER_ERR_UNSUPPORTED;
 }
 

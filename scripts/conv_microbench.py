@@ -61,11 +61,16 @@ def candidates(layer, B, Di, Hi, Wi, sm):
         for m, n in ((1, 1), (1, 2), (1, 4), (2, 1), (2, 2)):
             if n in nts:
                 out.append(("S%d,%d" % (m, n), (m, n, 2)))
+    if (not layer.transposed and layer.prob is None and sm == 2 and layer.kernel == (1, 1, 1) and layer.stride == (1, 1, 1)
+            and layer.cin in (16, 32, 64)):
+        for m in (1, 2, 4):                   # persistent 1x1 with the bilinear up-sampling add in its epilogue
+            for wpc in (1, 2, 3):
+                out.append(("Q%d w%d" % (m, wpc), (m, 1, 6 | (wpc << 8))))
     if not layer.transposed and layer.prob is None and sm in (0, 1):
         # persistent kernels (conv_pers.hip); workgroups per CU in bits 8.. of the variant.  What a family does not
         # cover raises and is skipped by the caller.
-        if layer.kernel == (1, 1, 1) and layer.stride == (1, 1, 1) and layer.cin in (32, 64):
-            for m in (1, 2):
+        if layer.kernel == (1, 1, 1) and layer.stride == (1, 1, 1) and layer.cin in (16, 32, 64):
+            for m in (1, 2, 4):
                 for wpc in (1, 2, 3):
                     out.append(("Q%d w%d" % (m, wpc), (m, 1, 6 | (wpc << 8))))
         if layer.cin == 8 and layer.cout == 16 and layer.kernel in ((1, 3, 3), (1, 5, 5)) and layer.stride == (1, 2, 2):

@@ -457,6 +457,27 @@ def test_persistent_transposed_conv_bit_identical_to_direct(cin, cout, shape, wi
     assert _lib.last_kernel().startswith("conv_tpers_kernel<")
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(32, 64, (2, 1, 18, 34)), (64, 64, (1, 1, 8, 66)), (32, 16, (3, 1, 4, 6)),
+                                            (16, 64, (2, 1, 10, 38))])
+def test_persistent_1x1_with_upsample_add_bit_identical_to_direct(cin, cout, shape):
+    """FPN's lateral step -- inner(conv) + bilinear x2 (align_corners) up-sampling of the coarser level -- in the epilogue of
+    the persistent 1x1 kernel: the direct kernel's arithmetic, so EQUAL."""
+    g = torch.Generator().manual_seed(cin + cout)
+    w = (torch.randn(cout, cin, 1, 1, 1, generator=g) * 0.1).to(DEV)
+    layer = cp.ConvLayer(w, False, (1, 1, 1), (0, 0, 0), relu=False)
+    layer.shift.copy_(torch.randn(layer.shift.shape, generator=g) * 0.1)
+    x = torch.randn(*shape, cin, generator=g).to(DEV)
+    B, D, H, W = shape
+    prev = torch.randn(B, 1, H // 2, W // 2, cout, generator=g).to(DEV)
+    want = layer(x, skip=prev, skip_mode=cp.SKIP_UPSAMPLE_ADD, tiles=(1, 1, 0))
+    for mt in ((2, 4) if cin == 16 else (1, 2)):
+        for wpc in (0, 1, 3):
+            got = layer(x, skip=prev, skip_mode=cp.SKIP_UPSAMPLE_ADD, tiles=(mt, 1, 6 | (wpc << 8)))
+            assert torch.equal(got, want), (mt, wpc, (got - want).abs().max().item())
+    from mvster_amd import _lib
+    assert _lib.last_kernel().startswith("conv1x1_pers_kernel<")
+
+
 PP_CASES = [(16, 16, (1, 1, 1), 1, (2, 1, 70, 100)), (16, 16, (1, 1, 1), 1, (1, 1, 4, 33)), (32, 32, (1, 1, 1), 2, (3, 1, 64, 64)),
             (32, 32, (1, 1, 1), 2, (7, 1, 12, 64)), (16, 32, (1, 2, 2), 2, (2, 4, 70, 100)), (16, 32, (1, 2, 2), 2, (1, 1, 5, 200))]
 
