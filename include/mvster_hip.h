@@ -280,6 +280,12 @@ int mvster_geo_filter(const float* depth_ref, const float* depth_src, const doub
                       int* mask_sum, float* depth_sum, unsigned char* view_mask, float* view_depth, float* x_src,
                       float* y_src, int NS, int H, int W, float pix_thres, float rel_thres, void* stream);
 
+/* Batched gather, one launch: for every record r of the DEVICE table `descs` (32-byte records {const float* src; float* dst;
+ * const int* idx; int n; int first_block}), dst[i] = idx[i] > 0 ? src[idx[i] - 1] : 0, i < n (n % 4 == 0); first_block =
+ * prefix sum of ceil(n / 1024), total_blocks their sum.  Refreshes all packed / permuted weight forms of the training step
+ * from their parameters after an optimizer update (host-side plumbing: the reference's layers read the parameters directly). */
+int mvster_gather_batch(const void* descs, int ndesc, int total_blocks, void* stream);
+
 /* Name of the kernel the most recent mvster_conv_mfma / mvster_conv_small / mvster_deconv_small / mvster_conv_wgrad /
  * mvster_warp_agg_fwd / mvster_warp_agg_bwd (first pass) call on the calling host thread launched, in the profiler's spelling with template arguments (e.g. "conv_lds_kernel<2, 1, 3, 1, 3>");
  * "" before the first call.  The pointer stays valid for the life of the library.  (bench.py attributes HIP-event timings

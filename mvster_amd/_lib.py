@@ -54,6 +54,7 @@ SIGNATURES = {
     "mvster_sinkhorn_continuous": [_f, _f, _f, _f, _f, _f, _i, _i, _l, _i, _fl, _f],
     "mvster_geo_filter": [_f] * 10 + [_i, _i, _i, _fl, _fl, _f],
     "mvster_mfma_probe": [_f, _f, _f, _f],
+    "mvster_gather_batch": [_f, _i, _i, _f],
     "mvster_last_kernel": [],
 }
 RESTYPES = {"mvster_last_kernel": ctypes.c_char_p}     # everything else returns an int status

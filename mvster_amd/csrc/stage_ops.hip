@@ -740,3 +740,51 @@ thread_local const char* mv_last_kernel = "";
 // Name (profiler spelling, template arguments included) of the kernel the most recent mvster_conv_mfma / mvster_conv_small /
 // mvster_deconv_small / mvster_warp_agg_fwd call on this thread launched; "" before the first one.
 extern "C" const char* mvster_last_kernel() { return mv_last_kernel; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Batched gather: dst[i] = idx[i] > 0 ? src[idx[i] - 1] : 0 for a table of (src, dst, idx, n) records, ONE launch.
+// The training step refreshes ~130 packed / permuted weight arrays after every optimizer update (forward and
+// input-gradient forms of every layer): as one launch per array that is ~0.5 ms of 3-us kernels inside the captured step.
+// Every such array is a fixed permutation (+ zero padding) of its parameter, so the host records the permutation once
+// (mvster_amd/train_ops.py: the existing pack routines run on a tensor of its own indices) and a step replays this kernel.
+// Replaces nothing in the reference (its layers read nn.Parameter tensors directly); host-side plumbing of the packed forms.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct GatherDesc {
+    const float* src;
+    float* dst;
+    const int* idx;
+    int n;              // elements (a multiple of 4)
+    int first_block;    // prefix sum of ceil(n / 1024) over the records before this one
+};
+
+__global__ void __launch_bounds__(256) gather_batch_kernel(const GatherDesc* __restrict__ descs, int ndesc) {
+    // the record this block belongs to: largest r with first_block[r] <= blockIdx.x
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const GatherDesc d = descs[lo];
+    const int i = ((int)blockIdx.x - d.first_block) * 1024 + threadIdx.x * 4;
+    if (i >= d.n) return;
+    const int4 ix = *reinterpret_cast<const int4*>(d.idx + i);
+    f32x4 v;
+    v[0] = ix.x > 0 ? d.src[ix.x - 1] : 0.0f;
+    v[1] = ix.y > 0 ? d.src[ix.y - 1] : 0.0f;
+    v[2] = ix.z > 0 ? d.src[ix.z - 1] : 0.0f;
+    v[3] = ix.w > 0 ? d.src[ix.w - 1] : 0.0f;
+    st4(d.dst + i, v);
+}
+}  // namespace
+
+// descs: DEVICE array of ndesc records {const float* src; float* dst; const int* idx; int n; int first_block} (32 bytes each,
+// n % 4 == 0, dst and idx 16-byte aligned); total_blocks = sum of ceil(n / 1024).
+extern "C" int mvster_gather_batch(const void* descs, int ndesc, int total_blocks, void* stream) {
+    if (!descs) return MVSTER_ERR_NULL;
+    if (ndesc <= 0 || total_blocks <= 0) return MVSTER_ERR_SHAPE;
+    hipLaunchKernelGGL(gather_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const GatherDesc*>(descs), ndesc);
+    return mv_check_launch();
+}
+

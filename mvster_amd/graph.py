@@ -82,6 +82,10 @@ class GraphedTrainStep:
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # the ~130 per-layer weight refreshes a captured step would record become one launch (train_ops._LayerCache)
+        from . import train_ops
+        self._cache = train_ops.CACHE
+        self._batch = self._cache.build_batch(list(model.parameters()))      # (kept alive here: the graph reads its tables)
         self.graph = torch.cuda.CUDAGraph()
         # (with a collective in the step, RCCL's watchdog thread touches the device during the capture: relaxed mode)
         collective = grad_sync is not None and (grad_sync.world() > 1 or grad_sync.always_reduce)
@@ -93,10 +97,17 @@ class GraphedTrainStep:
         # grads are re-created by every backward: inside the capture they come from the graph's private pool, so a replay
         # writes them in place and no zero-fill / accumulate kernels are recorded
         self.optimizer.zero_grad(set_to_none=True)
-        out = self.model(self.imgs, self.proj, self.depth_values)
-        res = self.loss_fn(out, self.gt, self.mask)
-        loss = res[0] if isinstance(res, (tuple, list)) else res
-        loss.backward()
+        batched = getattr(self, "_batch", None) is not None
+        if batched:
+            self._cache.run_batch(self._batch)
+        try:
+            out = self.model(self.imgs, self.proj, self.depth_values)
+            res = self.loss_fn(out, self.gt, self.mask)
+            loss = res[0] if isinstance(res, (tuple, list)) else res
+            loss.backward()
+        finally:
+            if batched:
+                self._cache.end_batch()
         if self.grad_sync is not None:
             self.grad_sync.sync()          # pack -> one all-reduce -> p.grad = slices of the averaged bucket
         self.optimizer.step()

@@ -55,11 +55,14 @@ class _LayerCache:
     def __init__(self):
         self._d = {}
         self.always_repack = False
+        self._batch = None             # see build_batch()
+        self._batch_active = False
 
-    def get(self, weight, role, build, refresh, owner=None):
+    def get(self, weight, role, build, refresh, owner=None, rargs=None):
         """``build()`` makes the layer; ``refresh(layer)`` re-packs it from the updated parameter.  ``owner``: the
         parameter a derived weight (a product of parameters, a new tensor every step) is cached under; such layers are
-        re-packed on every call."""
+        re-packed on every call.  ``rargs`` = the (swap, flip) that ``refresh`` hands to ``ConvLayer.repack_on_device``
+        (None: the refresh is not of that form and the layer stays out of the batched refresh)."""
         derived = owner is not None
         if derived:
             weight = owner
@@ -67,16 +70,85 @@ class _LayerCache:
         hit = self._d.get(key)
         stamp = (weight._version, weight.data_ptr())
         if hit is not None and hit[0] is weight and hit[2].wpk.device == weight.device:
+            if self._batch_active and key in self._batch["keys"]:
+                return hit[2]                  # refreshed by run_batch() at the top of this step
             if derived or hit[1] != stamp or self.always_repack or torch.cuda.is_current_stream_capturing():
                 refresh(hit[2])
-                self._d[key] = (weight, stamp, hit[2])
+                self._d[key] = (weight, stamp, hit[2], hit[3])
             return hit[2]
         layer = build()
-        self._d[key] = (weight, stamp, layer)
+        self._d[key] = (weight, stamp, layer, None if derived else rargs)
         return layer
 
     def clear(self):
         self._d.clear()
+        self._batch, self._batch_active = None, False
+
+    # ---- batched refresh (captured training steps) ------------------------------------------------------------------------
+    # Inside a hipGraph every cached layer is re-packed at every use (the parameters have moved, and the capture must
+    # record the refresh): ~130 launches of ~3 us per step.  Every packed / permuted form is a fixed permutation (+ zero
+    # padding) of its parameter, so it is recorded ONCE -- by running the layer's own refresh on a tensor that holds its
+    # own indices -- and a step replays all of them in one launch of mvster_gather_batch (the Winograd-transformed
+    # weights, which are arithmetic, keep their own small kernel).
+    def build_batch(self, params=None):
+        """Record the permutations of every cached layer that is refreshed through ``ConvLayer.repack_on_device`` from a
+        contiguous parameter (of ``params``, if given) and return them as one object for ``run_batch`` -- owned by the
+        caller: a captured graph replays a launch that reads its tables.  Call after a step has populated the cache
+        (GraphedTrainStep does, after its warm-up).  None if there is nothing to batch."""
+        import numpy as np
+        from . import _lib
+        only = None if params is None else {id(p) for p in params}
+        recs, keep, keys, wino = [], [], set(), []
+        for key, (weight, _stamp, layer, rargs) in self._d.items():
+            if rargs is None or not weight.is_cuda or not weight.is_contiguous() or weight.dtype != torch.float32:
+                continue
+            if only is not None and id(weight) not in only:
+                continue
+            if weight.numel() >= (1 << 24):
+                continue                       # (indices travel through fp32)
+            swap, flip = rargs
+            bufs = [b for b in (layer.wpk, layer.w_small, layer.w_deconv) if b is not None]
+            if any(b.numel() % 4 or not b.is_contiguous() for b in bufs):
+                continue
+            iota = torch.arange(1, weight.numel() + 1, device=weight.device, dtype=torch.float32).view(weight.shape)
+            had_wino, layer.wpk_wino = layer.wpk_wino, None          # (arithmetic, not a permutation: not on the iota pass)
+            layer.repack_on_device(iota, swap=swap, flip=flip)
+            idx = [b.round().to(torch.int32).clone() for b in bufs]
+            layer.wpk_wino = had_wino
+            layer.repack_on_device(weight, swap=swap, flip=flip)     # back to the real weights
+            for b, ix in zip(bufs, idx):
+                recs.append((weight.data_ptr(), b.data_ptr(), ix.data_ptr(), b.numel()))
+                keep.append(ix)
+            if layer.wpk_wino is not None:
+                wino.append((layer, weight, swap, flip))
+            keys.add(key)
+        if not recs:
+            return None
+        dev = keep[0].device
+        table = np.zeros(len(recs), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("idx", "<u8"), ("n", "<i4"), ("fb", "<i4")]))
+        fb = 0
+        for i, (s_, d_, x_, n_) in enumerate(recs):
+            table[i] = (s_, d_, x_, n_, fb)
+            fb += (n_ + 1023) // 1024
+        descs = torch.from_numpy(table.view(np.uint8).copy()).to(dev)
+        return {"keys": keys, "descs": descs, "n": len(recs), "blocks": fb, "idx": keep, "wino": wino, "lib": _lib}
+
+    def run_batch(self, b):
+        """Refresh every form recorded in ``b`` from its parameter (one launch + the Winograd transforms) and let ``get``
+        skip the per-layer refresh of those layers until ``end_batch``."""
+        if b is None:
+            return
+        self._batch = b
+        rc = b["lib"].load().mvster_gather_batch(b["descs"].data_ptr(), b["n"], b["blocks"], ops._stream())
+        b["lib"].check(rc, "gather_batch")
+        for layer, weight, swap, flip in b["wino"]:
+            w = weight if weight.dim() == 5 else weight.unsqueeze(2)
+            layer._pack_wino(w, swap, flip)
+        self._batch_active = True
+
+    def end_batch(self):
+        self._batch_active = False
+        self._batch = None
 
 
 CACHE = _LayerCache()
@@ -93,7 +165,7 @@ class _ConvCL(torch.autograd.Function):
         cin_p = _cin_for(cin)
         xp = _pad_last(x, cin_p).contiguous()
         layer = CACHE.get(weight, "fwd" + tag, lambda: ConvLayer(w5, transposed, stride, padding, cin_pad=cin_p),
-                          lambda L: L.repack_on_device(weight), owner=own)
+                          lambda L: L.repack_on_device(weight), owner=own, rargs=(False, False))
         if bias is not None:
             layer.shift[:layer.cout] = bias.detach()
         if skip is not None:
@@ -127,17 +199,17 @@ class _ConvCL(torch.autograd.Function):
             if transposed:
                 # y = convT(x; W[cin,cout]) : dx = conv(gy; W read as [out=cin, in=cout], same stride / padding)
                 layer = CACHE.get(weight, "dgrad" + tag, lambda: ConvLayer(w5, False, stride, padding, cin_pad=co_p),
-                                  lambda L: L.repack_on_device(weight), owner=own)
+                                  lambda L: L.repack_on_device(weight), owner=own, rargs=(False, False))
             elif stride == (1, 1, 1):
                 def flipped():
                     return w5.detach().flip(2, 3, 4).transpose(0, 1).contiguous()
                 pad = tuple(k - 1 - p for k, p in zip(kernel, padding))
                 layer = CACHE.get(weight, "dgrad" + tag, lambda: ConvLayer(flipped(), False, stride, pad, cin_pad=co_p),
-                                  lambda L: L.repack_on_device(weight, swap=True, flip=True), owner=own)
+                                  lambda L: L.repack_on_device(weight, swap=True, flip=True), owner=own, rargs=(True, True))
             else:
                 # stride 2: the adjoint is the transposed conv with the same weights (parity classes)
                 layer = CACHE.get(weight, "dgrad" + tag, lambda: ConvLayer(w5, True, stride, padding, cin_pad=co_p),
-                                  lambda L: L.repack_on_device(weight), owner=own)
+                                  lambda L: L.repack_on_device(weight), owner=own, rargs=(False, False))
             gx = layer(gyp)
             if tuple(gx.shape[:4]) != tuple(xp.shape[:4]):
                 raise RuntimeError("conv_cl: input gradient of a strided layer needs even input sizes (%s -> %s)"
