@@ -58,11 +58,12 @@ class _LayerCache:
         self._batch = None             # see build_batch()
         self._batch_active = False
 
-    def get(self, weight, role, build, refresh, owner=None, rargs=None):
+    def get(self, weight, role, build, refresh, owner=None, rargs=None, bias=None):
         """``build()`` makes the layer; ``refresh(layer)`` re-packs it from the updated parameter.  ``owner``: the
         parameter a derived weight (a product of parameters, a new tensor every step) is cached under; such layers are
         re-packed on every call.  ``rargs`` = the (swap, flip) that ``refresh`` hands to ``ConvLayer.repack_on_device``
-        (None: the refresh is not of that form and the layer stays out of the batched refresh)."""
+        (None: the refresh is not of that form and the layer stays out of the batched refresh).  ``bias``: the layer's bias
+        parameter, copied into the epilogue's shift vector at every call (or by the batched refresh)."""
         derived = owner is not None
         if derived:
             weight = owner
@@ -71,13 +72,17 @@ class _LayerCache:
         stamp = (weight._version, weight.data_ptr())
         if hit is not None and hit[0] is weight and hit[2].wpk.device == weight.device:
             if self._batch_active and key in self._batch["keys"]:
-                return hit[2]                  # refreshed by run_batch() at the top of this step
+                return hit[2]                  # refreshed (bias included) by run_batch() at the top of this step
             if derived or hit[1] != stamp or self.always_repack or torch.cuda.is_current_stream_capturing():
                 refresh(hit[2])
-                self._d[key] = (weight, stamp, hit[2], hit[3])
+                self._d[key] = (weight, stamp, hit[2], hit[3], bias)
+            if bias is not None:
+                hit[2].shift[:hit[2].cout] = bias.detach()
             return hit[2]
         layer = build()
-        self._d[key] = (weight, stamp, layer, None if derived else rargs)
+        if bias is not None:
+            layer.shift[:layer.cout] = bias.detach()
+        self._d[key] = (weight, stamp, layer, None if derived else rargs, bias)
         return layer
 
     def clear(self):
@@ -99,7 +104,7 @@ class _LayerCache:
         from . import _lib
         only = None if params is None else {id(p) for p in params}
         recs, keep, keys, wino = [], [], set(), []
-        for key, (weight, _stamp, layer, rargs) in self._d.items():
+        for key, (weight, _stamp, layer, rargs, bias) in self._d.items():
             if rargs is None or not weight.is_cuda or not weight.is_contiguous() or weight.dtype != torch.float32:
                 continue
             if only is not None and id(weight) not in only:
@@ -110,6 +115,8 @@ class _LayerCache:
             bufs = [b for b in (layer.wpk, layer.w_small, layer.w_deconv) if b is not None]
             if any(b.numel() % 4 or not b.is_contiguous() for b in bufs):
                 continue
+            if bias is not None and not (bias.is_contiguous() and bias.dtype == torch.float32 and layer.shift.numel() % 4 == 0):
+                continue                   # (this layer keeps its per-call refresh)
             iota = torch.arange(1, weight.numel() + 1, device=weight.device, dtype=torch.float32).view(weight.shape)
             had_wino, layer.wpk_wino = layer.wpk_wino, None          # (arithmetic, not a permutation: not on the iota pass)
             layer.repack_on_device(iota, swap=swap, flip=flip)
@@ -118,6 +125,11 @@ class _LayerCache:
             layer.repack_on_device(weight, swap=swap, flip=flip)     # back to the real weights
             for b, ix in zip(bufs, idx):
                 recs.append((weight.data_ptr(), b.data_ptr(), ix.data_ptr(), b.numel()))
+                keep.append(ix)
+            if bias is not None:
+                ix = torch.zeros(layer.shift.numel(), device=weight.device, dtype=torch.int32)
+                ix[:layer.cout] = torch.arange(1, layer.cout + 1, device=weight.device, dtype=torch.int32)
+                recs.append((bias.data_ptr(), layer.shift.data_ptr(), ix.data_ptr(), ix.numel()))
                 keep.append(ix)
             if layer.wpk_wino is not None:
                 wino.append((layer, weight, swap, flip))
@@ -165,9 +177,7 @@ class _ConvCL(torch.autograd.Function):
         cin_p = _cin_for(cin)
         xp = _pad_last(x, cin_p).contiguous()
         layer = CACHE.get(weight, "fwd" + tag, lambda: ConvLayer(w5, transposed, stride, padding, cin_pad=cin_p),
-                          lambda L: L.repack_on_device(weight), owner=own, rargs=(False, False))
-        if bias is not None:
-            layer.shift[:layer.cout] = bias.detach()
+                          lambda L: L.repack_on_device(weight), owner=own, rargs=(False, False), bias=bias)
         if skip is not None:
             # y = conv(x) + skip, or + the bilinear x2 (align_corners) of a half-resolution skip, in the kernel's epilogue:
             # the FPN's top-down sums (mvs4net_utils.py:488-496) without materialising the up-sampled 64-channel map
