@@ -46,11 +46,11 @@ def sinkhorn_loss(gt_depth, hypo_depth, attn_weight, mask, iters, eps=1, continu
     return _SinkhornLoss.apply(attn_weight, hypo_depth, gt_depth, mask, int(iters), float(eps), bool(continuous))
 
 
-def _masked_mean(values, mask):
-    """``values[mask].mean()`` without the boolean-index gather: that gather needs the number of selected elements
-    on the host, i.e. a device synchronisation in the middle of every training step."""
-    m = mask.to(values.dtype)
-    return (values * m).sum() / m.sum()
+def _masked_mean(values, m, n=None):
+    """``values[mask].mean()`` without the boolean-index gather (that gather needs the number of selected elements on the
+    host, i.e. a device synchronisation in the middle of every training step); ``m`` = the mask as floats, ``n`` = its sum
+    if the caller already has it."""
+    return (values * m).sum() / (m.sum() if n is None else n)
 
 
 def _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):
@@ -65,18 +65,25 @@ def _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):
         hypo, attn = st["hypo_depth"], st["attn_weight"]
         mask = mask_ms[key] > 0.5
         gt = depth_gt_ms[key]
+        # (one float mask and one pixel count per stage, one reciprocal of the hypotheses: the same values as the
+        #  reference's expressions, a third of the small launches)
+        m = mask.to(torch.float32)
+        n = m.sum()
         if mono and stage_idx != 0:
-            l1 = _masked_mean((st["mono_depth"] - gt).abs(), mask)         # F.l1_loss(mono_depth[mask], gt[mask])
+            l1 = _masked_mean((st["mono_depth"] - gt).abs(), m, n)         # F.l1_loss(mono_depth[mask], gt[mask])
         else:
             l1 = torch.zeros((), dtype=torch.float32, device=dev)
-        if inverse:
-            itv = (1 / hypo[:, 2] - 1 / hypo[:, 1]).abs()
-            outside = ((1 / hypo - 1 / gt.unsqueeze(1)).abs() <= itv.unsqueeze(1)).sum(1) == 0
-        else:
-            itv = (hypo[:, 2] - hypo[:, 1]).abs()
-            outside = ((hypo - gt.unsqueeze(1)).abs() <= itv.unsqueeze(1)).sum(1) == 0
+        with torch.no_grad():                                               # (a diagnostic: no gradient flows through it)
+            if inverse:
+                inv = 1 / hypo
+                itv = (inv[:, 2] - inv[:, 1]).abs()
+                inside = ((inv - (1 / gt).unsqueeze(1)).abs() <= itv.unsqueeze(1)).any(1)
+            else:
+                itv = (hypo[:, 2] - hypo[:, 1]).abs()
+                inside = ((hypo - gt.unsqueeze(1)).abs() <= itv.unsqueeze(1)).any(1)
+            outside_ratio = _masked_mean((~inside).to(torch.float32), m, n)
         ot = sinkhorn_loss(gt, hypo, attn, mask, iters=ot_iter, eps=ot_eps, continuous=ot_continous)
-        yield stage_idx, key, l1, ot, _masked_mean(outside.float(), mask), mask
+        yield stage_idx, key, l1, ot, outside_ratio, mask
 
 
 def MVS4net_loss(inputs, depth_gt_ms, mask_ms, **kwargs):
