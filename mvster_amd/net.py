@@ -28,24 +28,37 @@ from .conv_plan import FpnPlan, Reg2dPlan, Reg3dPlan
 from .modules import FPN4, mono_depth_decoder, reg2d, reg3d
 
 
-class _WarpAggCL(torch.autograd.Function):
-    """cor_feats [B,D,h,w,G] from channels-last features (ref [B,h,w,C], src [NV,B,Hs,Ws,C]); HIP forward + backward."""
+class _WarpAggPyr(torch.autograd.Function):
+    """cor_feats [B,D,h,w,G] from one level of the view-major channels-last pyramid [N*B,1,h,w,C] (the first B maps are the
+    reference view's); HIP forward + backward.  Takes the level whole and returns ONE gradient for it, the kernel writing
+    the two parts in place: slicing outside would have autograd zero-fill, copy and add a full-size buffer per slice on the
+    way back."""
 
     @staticmethod
-    def forward(ctx, ref_cl, src_cl, rt, hypo, G, group_cor, attn_fuse_d, attn_temp):
-        ref_cl, src_cl = ref_cl.contiguous(), src_cl.contiguous()
+    def forward(ctx, pyr, B, rt, hypo, G, group_cor, attn_fuse_d, attn_temp):
+        pyr = pyr.contiguous()
+        ref_cl, src_cl = _WarpAggPyr._parts(pyr, B)
         out, wsum = ops.warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, group_cor, attn_fuse_d, attn_temp, want_wsum=True)
-        ctx.save_for_backward(ref_cl, src_cl, rt, hypo, out, wsum)
-        ctx.cfg = (G, group_cor, attn_fuse_d, attn_temp)
+        ctx.save_for_backward(pyr, rt, hypo, out, wsum)
+        ctx.cfg = (B, G, group_cor, attn_fuse_d, attn_temp)
         return out
 
     @staticmethod
+    def _parts(pyr, B):
+        n, _, h, w, C = pyr.shape
+        return pyr[:B].view(B, h, w, C), pyr[B:].view(n // B - 1, B, h, w, C)
+
+    @staticmethod
     def backward(ctx, grad):
-        ref_cl, src_cl, rt, hypo, out, wsum = ctx.saved_tensors
-        G, group_cor, attn_fuse_d, attn_temp = ctx.cfg
-        g_ref, g_src = ops.warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad.contiguous(), G, group_cor,
-                                           attn_fuse_d, attn_temp)
-        return g_ref, g_src, None, None, None, None, None, None
+        pyr, rt, hypo, out, wsum = ctx.saved_tensors
+        B, G, group_cor, attn_fuse_d, attn_temp = ctx.cfg
+        g_pyr = torch.empty_like(pyr)
+        g_ref, g_src = _WarpAggPyr._parts(g_pyr, B)
+        g_src.zero_()                                                # the source gradient is scattered with atomics
+        ref_cl, src_cl = _WarpAggPyr._parts(pyr, B)
+        ops.warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad.contiguous(), G, group_cor, attn_fuse_d, attn_temp,
+                            into=(g_ref, g_src))
+        return g_pyr, None, None, None, None, None, None, None
 
 
 class _SelectDepthCL(torch.autograd.Function):
@@ -332,8 +345,7 @@ class MVS4net(nn.Module):
             with torch.no_grad():
                 rt = ops.relative_projection(proj_matrices[name].to(dev, torch.float32))
                 hypo = self._hypotheses(s, depth_values, depth_interval, prev, h, w)
-            cor = _WarpAggCL.apply(pyr[:B].reshape(B, h, w, C), pyr[B:].reshape(nv - 1, B, h, w, C),
-                                   rt, hypo, G, self.group_cor, self.attn_fuse_d, float(self.attn_temp))
+            cor = _WarpAggPyr.apply(pyr, B, rt, hypo, G, self.group_cor, self.attn_fuse_d, float(self.attn_temp))
             reg = self.reg[s]
             if isinstance(reg, reg2d) and self.training and self.stage_splits[s] >= (3 if self.inverse_depth else 1):
                 # prob head + softmax + argmax + gather + inverse bounds: one kernel forward, one backward

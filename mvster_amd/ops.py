@@ -97,13 +97,14 @@ def warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, group_cor=True, attn_fuse_d=Tru
 
 
 def warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad_out, G, group_cor=True, attn_fuse_d=True, attn_temp=2.0,
-                    deterministic=None):
+                    deterministic=None, into=None):
     """Gradients of warp_agg_fwd_cl w.r.t. ref_cl and src_cl.  Inside a workgroup the gradients accumulate in 64-bit
     fixed-point LDS counters (integer atomics: 30x cheaper than ds_add_f32 on gfx950, and associative).
     ``deterministic`` (default: off, unless the environment sets MVSTER_BWD_DETERMINISTIC): the workgroups' scatter
     windows are stored densely and summed by a gather pass in fixed order instead of being flushed with global fp32
     atomics, which makes the source gradient bit-reproducible for every tap that falls inside a window (about 20 %
-    slower on smooth depth maps, several times slower when neighbouring pixels' hypotheses are unrelated)."""
+    slower on smooth depth maps, several times slower when neighbouring pixels' hypotheses are unrelated).
+    ``into`` = (g_ref, g_src): write into these contiguous buffers instead of allocating; g_src must come zeroed."""
     import ctypes
     import os
     grad_out = grad_out.contiguous()
@@ -114,8 +115,15 @@ def warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad_out, G, group_cor=
     NV, _, Hs, Ws, _ = src_cl.shape
     D = hypo.shape[1]
     lib = _lib.load()
-    g_ref = torch.empty_like(ref_cl)
-    g_src = torch.zeros_like(src_cl)
+    if into is None:
+        g_ref = torch.empty_like(ref_cl)
+        g_src = torch.zeros_like(src_cl)
+    else:
+        g_ref, g_src = into
+        if g_ref.shape != ref_cl.shape or g_src.shape != src_cl.shape:
+            raise ValueError("warp_agg_bwd: `into` buffers must have the shapes of ref_cl and src_cl")
+        _chk(g_ref, "warp_agg_bwd:into[0]")
+        _chk(g_src, "warp_agg_bwd:into[1]")
     if deterministic is None:
         deterministic = bool(os.environ.get("MVSTER_BWD_DETERMINISTIC"))
     nf, ni = ctypes.c_long(0), ctypes.c_long(0)
