@@ -470,8 +470,22 @@ __global__ void __launch_bounds__(1024) conv_wgrad_finish_kernel(FinishArgs a) {
     const long E = (long)a.ngrp * a.cop * a.width;
     const long e = (long)blockIdx.x * 64 + el;
     float s = 0.0f;
-    if (e < E)
-        for (int n = lane; n < a.nblk; n += 16) s += a.partial[(long)n * E + e];
+    if (e < E) {
+        // eight slots in flight per thread (the loads are issued clamped and masked afterwards: one dependent load after
+        // the other made this kernel a chain of L2 latencies, 7 us per launch and 64 launches per training step)
+        const float* __restrict__ p = a.partial + e;
+        for (int n0 = lane; n0 < a.nblk; n0 += 128) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = n0 + 16 * j;
+                v[j] = p[(long)(n < a.nblk ? n : n0) * E];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = n0 + 16 * j < a.nblk ? v[j] : 0.0f;
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+    }
     red[lane][el] = s;
     __syncthreads();
     if (lane != 0 || e >= E) return;

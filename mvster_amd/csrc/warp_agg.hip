@@ -22,6 +22,7 @@
 //
 // Roofline: HBM-bound.  Algorithmic bytes per launch = 4*[(NV+1)*C*hw + D*hw + G*D*hw]*B.
 #include <stdlib.h>
+#include <algorithm>
 
 #include "common.hpp"
 
@@ -1016,12 +1017,28 @@ __device__ __forceinline__ FixScale make_fix_scale(const float* maxima, int G, i
 __device__ __forceinline__ void fix_add(u64* p, float v, float s) { atomicAdd(p, (u64)__float2ll_rn(v * s)); }
 __device__ __forceinline__ float fix_get(u64 v, float inv) { return (float)(long long)v * inv; }
 
-// max |x| over n floats into *out (a non-negative float orders like its bit pattern); *out must start at 0
-__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, long n, float* out) {
+// max |x| of up to three arrays in one launch: workgroups [first[k], first[k+1]) reduce x[k] (n[k] floats, 16-byte aligned)
+// into out[k] (a non-negative float orders like its bit pattern); out[] must start at 0.  ONE atomic per workgroup and at
+// most ~1.5k workgroups per launch: atomics on one address retire ~13 ns apart on gfx950, and with one per wave and a launch
+// per array (47 k atomics per training step) the twelve launches took 590 us for 262 MB.
+struct AbsMaxArgs {
+    const float* x[3];
+    long n[3];
+    int first[4];
+};
+constexpr int kAbsMaxBlocks = 1536;
+
+__global__ void __launch_bounds__(256) absmax_kernel(AbsMaxArgs a, float* __restrict__ out) {
+    __shared__ float wave_max[4];
+    __shared__ int wave_bad[4];
+    const int b = blockIdx.x;
+    const int k = (b >= a.first[1] ? 1 : 0) + (b >= a.first[2] ? 1 : 0);
+    const float* __restrict__ x = a.x[k];
+    const long n = a.n[k];
     float m = 0.0f;
     bool bad = false;           // fmaxf drops NaN: non-finite elements are tracked separately and reported as NaN
     const long n4 = n >> 2;
-    const long stride = (long)gridDim.x * 256;
+    const long stride = (long)(a.first[k + 1] - a.first[k]) * 256;
     auto take = [&](const f32x4& v) {
         const float a0 = fabsf(v[0]), a1 = fabsf(v[1]), a2 = fabsf(v[2]), a3 = fabsf(v[3]);
         const float mv = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
@@ -1029,9 +1046,9 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
         // (fmaxf drops a NaN operand: the sum below is NaN / Inf exactly if one of the four is)
         bad = bad || !((a0 + a1) + (a2 + a3) < INFINITY);
     };
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    // four independent 16-byte loads in flight per thread: with one, 16 waves per CU keep 16 KB in flight and the 42 MB
-    // gradient volume of stage 4 took 37 us (1.1 TB/s)
+    const long t0 = (long)(b - a.first[k]) * 256 + threadIdx.x;
+    long i = t0;
+    // four independent 16-byte loads in flight per thread
     for (; i + 3 * stride < n4; i += 4 * stride) {
         const f32x4 v0 = ld4(x + i * 4), v1 = ld4(x + (i + stride) * 4), v2 = ld4(x + (i + 2 * stride) * 4),
                     v3 = ld4(x + (i + 3 * stride) * 4);
@@ -1041,15 +1058,42 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
         take(v3);
     }
     for (; i < n4; i += stride) take(ld4(x + i * 4));
-    for (long j = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) {
+    for (long j = (n4 << 2) + t0; j < n; j += stride) {
         m = fmaxf(m, fabsf(x[j]));
         bad = bad || !(fabsf(x[j]) < INFINITY);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
     const bool any_bad = __any(bad);
-    // (as integers, positive floats order like their values and the quiet-NaN pattern lies above +Inf)
-    if ((threadIdx.x & 63) == 0 && (m > 0.0f || any_bad)) atomicMax(reinterpret_cast<int*>(out), any_bad ? 0x7fc00000 : __float_as_int(m));
+    if ((threadIdx.x & 63) == 0) { wave_max[threadIdx.x >> 6] = m; wave_bad[threadIdx.x >> 6] = any_bad ? 1 : 0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+        const bool wg_bad = (wave_bad[0] | wave_bad[1] | wave_bad[2] | wave_bad[3]) != 0;
+        // (as integers, positive floats order like their values and the quiet-NaN pattern lies above +Inf)
+        if (m > 0.0f || wg_bad) atomicMax(reinterpret_cast<int*>(out + k), wg_bad ? 0x7fc00000 : __float_as_int(m));
+    }
+}
+
+// workgroups in proportion to the arrays' sizes (they finish together), each array at least one
+void launch_absmax(const float* const* x, const long* n, int count, float* out, hipStream_t s) {
+    AbsMaxArgs a;
+    long total = 0;
+    for (int k = 0; k < count; ++k) total += n[k];
+    a.first[0] = 0;
+    for (int k = 0; k < 3; ++k) {
+        a.x[k] = k < count ? x[k] : nullptr;
+        a.n[k] = k < count ? n[k] : 0;
+        long nb = 0;
+        if (k < count) {
+            nb = total > 0 ? (long)kAbsMaxBlocks * n[k] / total : 1;
+            nb = std::min(nb, n[k] / 4096 + 1);
+            nb = std::max(nb, 1L);
+        }
+        a.first[k + 1] = a.first[k] + (int)nb;
+    }
+    // (unused entries own no workgroups: first[k] == first[k+1] == gridDim.x, never selected)
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)a.first[3]), dim3(256), 0, s, a, out);
 }
 
 struct WarpAggBwdArgs {
@@ -1815,17 +1859,23 @@ extern "C" int mvster_warp_agg_bwd(const float* ref_feat, const float* src_feat,
         float* mx = reinterpret_cast<float*>(win_org + (ni - 4));
         if (hipMemsetAsync(mx, 0, 16, s) != hipSuccess) return MVSTER_ERR_LAUNCH;
         const long n_go = (long)B * D * h * w * G, n_ref = (long)h * w * C, n_src = (long)Hs * Ws * C;
-        auto launch_max = [&](const float* p, long n, float* out) {
-            hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)min(2048L, n / 4096 + 1)), dim3(256), 0, s, p, n, out);
-        };
-        launch_max(grad_out, n_go, mx);
-        if (ref_batch_stride == n_ref) launch_max(ref_feat, n_ref * B, mx + 1);
-        else for (int bb = 0; bb < B; ++bb) launch_max(ref_feat + (long)bb * ref_batch_stride, n_ref, mx + 1);
-        if (src_batch_stride == n_src && src_view_stride == n_src * B) launch_max(src_feat, n_src * B * NV, mx + 2);
-        else
+        if (ref_batch_stride == n_ref && src_batch_stride == n_src && src_view_stride == n_src * B) {
+            const float* xs[3] = {grad_out, ref_feat, src_feat};
+            const long ns[3] = {n_go, n_ref * B, n_src * B * NV};
+            launch_absmax(xs, ns, 3, mx, s);
+        } else {
+            // strided batches: one launch per contiguous piece (each reduces into its operand's slot)
+            launch_absmax(&grad_out, &n_go, 1, mx, s);
+            for (int bb = 0; bb < B; ++bb) {
+                const float* p = ref_feat + (long)bb * ref_batch_stride;
+                launch_absmax(&p, &n_ref, 1, mx + 1, s);
+            }
             for (int v = 0; v < NV; ++v)
-                for (int bb = 0; bb < B; ++bb)
-                    launch_max(src_feat + (long)v * src_view_stride + (long)bb * src_batch_stride, n_src, mx + 2);
+                for (int bb = 0; bb < B; ++bb) {
+                    const float* p = src_feat + (long)v * src_view_stride + (long)bb * src_batch_stride;
+                    launch_absmax(&p, &n_src, 1, mx + 2, s);
+                }
+        }
         ba.maxima = mx;
     }
 #define MV_CASE(CC, GG, GR) \

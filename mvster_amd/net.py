@@ -41,7 +41,10 @@ class _WarpAggPyr(torch.autograd.Function):
         out, wsum = ops.warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, group_cor, attn_fuse_d, attn_temp, want_wsum=True)
         ctx.save_for_backward(pyr, rt, hypo, out, wsum)
         ctx.cfg = (B, G, group_cor, attn_fuse_d, attn_temp)
-        return out
+        ctx.set_materialize_grads(False)
+        # second output: the reference view's maps [B,1,h,w,C] for other consumers (the monocular head) -- their gradient
+        # comes back here and is added to the B maps it belongs to, instead of a zero-filled full-size buffer per use
+        return out, pyr[:B]
 
     @staticmethod
     def _parts(pyr, B):
@@ -49,15 +52,20 @@ class _WarpAggPyr(torch.autograd.Function):
         return pyr[:B].view(B, h, w, C), pyr[B:].view(n // B - 1, B, h, w, C)
 
     @staticmethod
-    def backward(ctx, grad):
+    def backward(ctx, grad, grad_ref_maps):
         pyr, rt, hypo, out, wsum = ctx.saved_tensors
         B, G, group_cor, attn_fuse_d, attn_temp = ctx.cfg
-        g_pyr = torch.empty_like(pyr)
-        g_ref, g_src = _WarpAggPyr._parts(g_pyr, B)
-        g_src.zero_()                                                # the source gradient is scattered with atomics
-        ref_cl, src_cl = _WarpAggPyr._parts(pyr, B)
-        ops.warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad.contiguous(), G, group_cor, attn_fuse_d, attn_temp,
-                            into=(g_ref, g_src))
+        if grad is None:
+            g_pyr = torch.zeros_like(pyr)
+        else:
+            g_pyr = torch.empty_like(pyr)
+            g_ref, g_src = _WarpAggPyr._parts(g_pyr, B)
+            g_src.zero_()                                            # the source gradient is scattered with atomics
+            ref_cl, src_cl = _WarpAggPyr._parts(pyr, B)
+            ops.warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad.contiguous(), G, group_cor, attn_fuse_d,
+                                attn_temp, into=(g_ref, g_src))
+        if grad_ref_maps is not None:
+            g_pyr[:B] += grad_ref_maps
         return g_pyr, None, None, None, None, None, None, None
 
 
@@ -345,7 +353,7 @@ class MVS4net(nn.Module):
             with torch.no_grad():
                 rt = ops.relative_projection(proj_matrices[name].to(dev, torch.float32))
                 hypo = self._hypotheses(s, depth_values, depth_interval, prev, h, w)
-            cor = _WarpAggPyr.apply(pyr, B, rt, hypo, G, self.group_cor, self.attn_fuse_d, float(self.attn_temp))
+            cor, ref_maps = _WarpAggPyr.apply(pyr, B, rt, hypo, G, self.group_cor, self.attn_fuse_d, float(self.attn_temp))
             reg = self.reg[s]
             if isinstance(reg, reg2d) and self.training and self.stage_splits[s] >= (3 if self.inverse_depth else 1):
                 # prob head + softmax + argmax + gather + inverse bounds: one kernel forward, one backward
@@ -358,8 +366,8 @@ class MVS4net(nn.Module):
             else:
                 st = self._stage_outputs(s, reg.forward_cl(cor), hypo, dev)
             if self.mono:
-                st["mono_feat"] = pyr[:B].reshape(B, h, w, C).permute(0, 3, 1, 2)      # [B,C,h,w] view
-                ref_feats.append(pyr[:B])
+                st["mono_feat"] = ref_maps.reshape(B, h, w, C).permute(0, 3, 1, 2)     # [B,C,h,w] view
+                ref_feats.append(ref_maps)
             prev = st
             outputs[name] = st
             outputs.update(st)

@@ -134,6 +134,39 @@ def test_batch_norm_cl_matches_torch(C, relu):
     assert int(bn_b.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("shape,groups", [((2, 4, 96, 160, 8), 1), ((6, 1, 100, 128, 16), 3)])
+def test_batch_norm_cl_many_slots(shape, groups):
+    """Enough rows for 960 (one group) / 400 (three groups) workgroup slots: the finishing kernels' column sums take two
+    passes of their 4 x 128 lanes / one ragged pass.  Checked against fp64 on the CPU."""
+    C = shape[-1]
+    g = torch.Generator().manual_seed(shape[2] + groups)
+    x = torch.randn(*shape, generator=g) * 1.7 - 0.4
+    gy = torch.randn(*shape, generator=g)
+    bn = torch.nn.BatchNorm3d(C)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=g)
+        bn.bias.uniform_(-0.5, 0.5, generator=g)
+    ref = torch.nn.BatchNorm3d(C).double()
+    ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    per = shape[0] // groups
+    xa = x.double().permute(0, 4, 1, 2, 3).contiguous().requires_grad_(True)
+    ya = torch.cat([torch.relu(ref(xa[v * per:(v + 1) * per])) for v in range(groups)], 0)
+    ya.backward(gy.double().permute(0, 4, 1, 2, 3))
+    bn.to(DEV)
+    xb = x.to(DEV).requires_grad_(True)
+    yb = T.batch_norm_cl(xb, bn, relu=True, groups=groups)
+    yb.backward(gy.to(DEV))
+    assert (yb.detach().cpu().double() - ya.detach().permute(0, 2, 3, 4, 1)).abs().max() <= 2e-5
+    assert (xb.grad.cpu().double() - xa.grad.permute(0, 2, 3, 4, 1)).abs().max() <= 2e-5
+    for name in ("weight", "bias"):
+        want = getattr(ref, name).grad
+        got = getattr(bn, name).grad.cpu().double()
+        assert ((got - want).abs().max() / want.abs().max()).item() <= 2e-5, name
+    assert (bn.running_mean.cpu().double() - ref.running_mean).abs().max() <= 1e-6
+    assert (bn.running_var.cpu().double() - ref.running_var).abs().max() <= 1e-6
+    assert int(bn.num_batches_tracked) == groups
+
+
 @pytest.mark.parametrize("reg_net", ["reg2d", "reg3d"])
 def test_train_step_native_vs_pytorch_rocm(reg_net):
     """One training step (forward, OT loss, backward) with the native convolution passes against the same step with
@@ -450,7 +483,7 @@ def test_upsample2x_nearest_cl_forward_and_adjoint(B, h, w, C):
     assert (xb.grad.cpu()[:, 0] - xa.grad.permute(0, 2, 3, 1)).abs().max() <= 1e-6
 
 
-@pytest.mark.parametrize("C,groups", [(8, 1), (32, 5), (64, 3)])
+@pytest.mark.parametrize("C,groups", [(8, 1), (32, 5), (64, 3), (16, 11)])      # (11 groups: more than one finishing pass)
 def test_batch_norm_cl_groups_skip_and_frozen(C, groups):
     """What the first BatchNorm test leaves out: statistics per view group (parameter gradients summed over the groups,
     running statistics updated group after group, the counter advanced by the number of groups), the skip tensor added
