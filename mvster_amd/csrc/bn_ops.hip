@@ -82,73 +82,27 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__
     }
 }
 
-// The finishing kernels: workgroup b owns channels 4b..4b+3 (8 columns: both slot rows), 128 threads per column strided
-// over the slots, fp64.  The columns of up to kFinishChunk groups are summed between two barriers: every thread first
-// issues all its loads (4 slots x kFinishChunk groups -- the kernel is a chain of L2 latencies, 7-19 us per launch and
-// 108 launches per step when the slots were read one dependent load after the other), the eight lanes of a column that
-// share a wave meet by shuffles, the sixteen waves through LDS.  Whatever depends on the groups' order -- the running
-// averages, the sums over the groups -- is then formed in registers by the column's first thread.
+// The finishing kernels: workgroup b owns channels 4b..4b+3 (8 columns: both slot rows), 128 threads per column
+// strided over the slots, fp64, LDS tree; the groups are walked one after the other so that whatever depends on their
+// order -- the running averages, the sums over the groups -- is formed in registers by the column's first thread.
+// (7 / 6 us per launch, 108 launches per training step.  Two rewrites -- 64 lanes per column meeting by shuffles and one
+// LDS pass for all groups; then every slot load of 8 groups issued up front, 32 per thread -- measured 8.5 / 7.6 and
+// 9.0 / 7.9 us: the slot loads are not what these launches wait for.)
 constexpr int kFinishLanes = 128;
-constexpr int kFinishChunk = 8;
 
-struct FinishLds {
-    double part[kFinishChunk][kFinishLanes / 8][8];       // [group][wave][column]
-    double tot[kFinishChunk][8];                          // [group][column]
-};
-
-__device__ __forceinline__ void column_sums(const float* __restrict__ partial, int g0, int ng, int nblk, int C, FinishLds& l) {
-    const int col = threadIdx.x & 7, lane = threadIdx.x >> 3, wave = threadIdx.x >> 6;
+__device__ __forceinline__ double column_sum(const float* __restrict__ pg, int nblk, int C, double* red) {
+    const int col = threadIdx.x & 7, lane = threadIdx.x >> 3;
     const int off = (col >> 2) * C + blockIdx.x * 4 + (col & 3);
-    double s[kFinishChunk];
-#pragma unroll
-    for (int g = 0; g < kFinishChunk; ++g) s[g] = 0.0;
-    // (uniform group bases + 32-bit lane offsets: with 64-bit addresses per load the 32 loads do not fit 128 registers)
-    const unsigned pitch = 2u * (unsigned)C;
-    for (int n0 = lane; n0 < nblk; n0 += 4 * kFinishLanes) {
-        float v[kFinishChunk][4];
-        // every load is issued (clamped to a valid slot / group) and masked afterwards: a predicated load compiles to a
-        // branch with a wait behind it
-        unsigned idx[4];
-        bool ok[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + j * kFinishLanes;
-            ok[j] = n < nblk;
-            idx[j] = (unsigned)off + (unsigned)(ok[j] ? n : n0) * pitch;
-        }
-#pragma unroll
-        for (int g = 0; g < kFinishChunk; ++g) {
-            const float* __restrict__ pg = partial + (long)(g0 + (g < ng ? g : 0)) * nblk * 2 * C;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[g][j] = pg[idx[j]];
-        }
-#pragma unroll
-        for (int g = 0; g < kFinishChunk; ++g)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[g][j] = (g < ng && ok[j]) ? v[g][j] : 0.0f;
-#pragma unroll
-        for (int g = 0; g < kFinishChunk; ++g)
-            s[g] += ((double)v[g][0] + (double)v[g][1]) + ((double)v[g][2] + (double)v[g][3]);
-    }
-#pragma unroll
-    for (int g = 0; g < kFinishChunk; ++g) {
-        if (g < ng) {                                      // (uniform)
-            double t = s[g];
-            t += __shfl_xor(t, 8);
-            t += __shfl_xor(t, 16);
-            t += __shfl_xor(t, 32);
-            if ((threadIdx.x & 63) < 8) l.part[g][wave][col] = t;
-        }
-    }
+    double s = 0.0;
+    for (int n = lane; n < nblk; n += kFinishLanes) s += (double)pg[(long)n * 2 * C + off];
+    __syncthreads();                       // (red is reused from group to group)
+    red[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x < ng * 8) {
-        const int g = threadIdx.x >> 3;
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < kFinishLanes / 8; ++w) t += l.part[g][w][col];
-        l.tot[g][col] = t;
+    for (int w = kFinishLanes / 2; w > 0; w >>= 1) {
+        if (lane < w) red[threadIdx.x] += red[threadIdx.x + w * 8];
+        __syncthreads();
     }
-    __syncthreads();
+    return red[col];                       // every thread gets its column's total
 }
 
 // Statistics: out [5][groups][C] = mean, biased variance, rstd, scale, shift; then the running-average updates of the
@@ -161,29 +115,29 @@ struct BnFinalizeArgs {
 };
 
 __global__ void __launch_bounds__(kFinishLanes * 8) bn_finalize_kernel(BnFinalizeArgs a) {
-    __shared__ FinishLds lds;
+    __shared__ double red[kFinishLanes * 8];
+    __shared__ double tot[8];
     const int C = a.C, c = blockIdx.x * 4 + (threadIdx.x & 3);
     const bool owner = threadIdx.x < 4, running = a.running_mean != nullptr;
     const float unbias = (float)a.rows / (float)(a.rows > 1 ? a.rows - 1 : 1);
     float rm = 0.0f, rv = 0.0f;
     if (owner && running) { rm = a.running_mean[c]; rv = a.running_var[c]; }
-    for (int g0 = 0; g0 < a.groups; g0 += kFinishChunk) {
-        const int ng = min(kFinishChunk, a.groups - g0);
-        column_sums(a.partial, g0, ng, a.nblk, C, lds);
+    for (int g = 0; g < a.groups; ++g) {
+        const double t = column_sum(a.partial + (long)g * a.nblk * 2 * C, a.nblk, C, red);
+        if (threadIdx.x < 8) tot[threadIdx.x] = t;
+        __syncthreads();
         if (owner) {
-            for (int g = 0; g < ng; ++g) {
-                const double m1 = lds.tot[g][threadIdx.x] / (double)a.rows, m2 = lds.tot[g][4 + threadIdx.x] / (double)a.rows;
-                const float mean = a.x[(long)(g0 + g) * a.rows * C + c] + (float)m1;
-                float var = (float)(m2 - m1 * m1);
-                var = var > 0.0f ? var : 0.0f;
-                const float rstd = 1.0f / sqrtf(var + a.eps);
-                const float scale = a.weight[c] * rstd;
-                float* o = a.out + (long)(g0 + g) * C + c;
-                const long gs = (long)a.groups * C;
-                o[0] = mean; o[gs] = var; o[2 * gs] = rstd; o[3 * gs] = scale; o[4 * gs] = a.bias[c] - mean * scale;
-                rm = (1.0f - a.momentum) * rm + a.momentum * mean;
-                rv = (1.0f - a.momentum) * rv + a.momentum * (var * unbias);
-            }
+            const double m1 = tot[threadIdx.x] / (double)a.rows, m2 = tot[4 + threadIdx.x] / (double)a.rows;
+            const float mean = a.x[(long)g * a.rows * C + c] + (float)m1;
+            float var = (float)(m2 - m1 * m1);
+            var = var > 0.0f ? var : 0.0f;
+            const float rstd = 1.0f / sqrtf(var + a.eps);
+            const float scale = a.weight[c] * rstd;
+            float* o = a.out + (long)g * C + c;
+            const long gs = (long)a.groups * C;
+            o[0] = mean; o[gs] = var; o[2 * gs] = rstd; o[3 * gs] = scale; o[4 * gs] = a.bias[c] - mean * scale;
+            rm = (1.0f - a.momentum) * rm + a.momentum * mean;
+            rv = (1.0f - a.momentum) * rv + a.momentum * (var * unbias);
         }
     }
     if (owner && running) { a.running_mean[c] = rm; a.running_var[c] = rv; }
@@ -195,19 +149,13 @@ __global__ void __launch_bounds__(kFinishLanes * 8) bn_finalize_kernel(BnFinaliz
 __global__ void __launch_bounds__(kFinishLanes * 8) bn_bwd_finish_kernel(const float* __restrict__ partial,
                                                                          float* __restrict__ sums, float* __restrict__ dgamma,
                                                                          float* __restrict__ dbeta, int C, int groups, int nblk) {
-    __shared__ FinishLds lds;
+    __shared__ double red[kFinishLanes * 8];
     const int col = threadIdx.x & 7, c = blockIdx.x * 4 + (col & 3);
     double total = 0.0;
-    for (int g0 = 0; g0 < groups; g0 += kFinishChunk) {
-        const int ng = min(kFinishChunk, groups - g0);
-        column_sums(partial, g0, ng, nblk, C, lds);
-        if (threadIdx.x < 8) {
-            for (int g = 0; g < ng; ++g) {
-                const double t = lds.tot[g][col];
-                sums[((long)(g0 + g) * 2 + (col >> 2)) * C + c] = (float)t;
-                total += t;
-            }
-        }
+    for (int g = 0; g < groups; ++g) {
+        const double t = column_sum(partial + (long)g * nblk * 2 * C, nblk, C, red);
+        if (threadIdx.x < 8) sums[((long)g * 2 + (col >> 2)) * C + c] = (float)t;
+        total += t;
     }
     if (threadIdx.x < 4) dbeta[c] = (float)total;
     else if (threadIdx.x < 8) dgamma[c] = (float)total;

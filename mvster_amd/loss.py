@@ -24,13 +24,13 @@ class _SinkhornLoss(torch.autograd.Function):
         ctx.save_for_backward(jac, m, n)
         # masked mean without a boolean-index gather (which would synchronise); where() keeps a non-finite loss of a
         # masked-out pixel (ground-truth depth 0) out of the sum
-        return torch.where(m > 0.5, loss_pix, torch.zeros_like(loss_pix)).sum() / n
+        return torch.where(m > 0.5, loss_pix, 0.0).sum() / n
 
     @staticmethod
     def backward(ctx, g):
         jac, m, n = ctx.saved_tensors
         w = (m * (g / n)).unsqueeze(1)
-        return torch.where(w != 0, jac * w, torch.zeros_like(jac)), None, None, None, None, None, None
+        return torch.where(w != 0, jac * w, 0.0), None, None, None, None, None, None
 
 
 def sinkhorn_loss(gt_depth, hypo_depth, attn_weight, mask, iters, eps=1, continuous=False):

@@ -136,8 +136,8 @@ def test_batch_norm_cl_matches_torch(C, relu):
 
 @pytest.mark.parametrize("shape,groups", [((2, 4, 96, 160, 8), 1), ((6, 1, 100, 128, 16), 3)])
 def test_batch_norm_cl_many_slots(shape, groups):
-    """Enough rows for 960 (one group) / 400 (three groups) workgroup slots: the finishing kernels' column sums take two
-    passes of their 4 x 128 lanes / one ragged pass.  Checked against fp64 on the CPU."""
+    """Enough rows for 960 (one group) / 400 (three groups) workgroup slots: several strided passes of the finishing
+    kernels' 128 lanes per column, the last one ragged.  Checked against fp64 on the CPU."""
     C = shape[-1]
     g = torch.Generator().manual_seed(shape[2] + groups)
     x = torch.randn(*shape, generator=g) * 1.7 - 0.4
@@ -483,7 +483,7 @@ def test_upsample2x_nearest_cl_forward_and_adjoint(B, h, w, C):
     assert (xb.grad.cpu()[:, 0] - xa.grad.permute(0, 2, 3, 1)).abs().max() <= 1e-6
 
 
-@pytest.mark.parametrize("C,groups", [(8, 1), (32, 5), (64, 3), (16, 11)])      # (11 groups: more than one finishing pass)
+@pytest.mark.parametrize("C,groups", [(8, 1), (32, 5), (64, 3), (16, 11)])
 def test_batch_norm_cl_groups_skip_and_frozen(C, groups):
     """What the first BatchNorm test leaves out: statistics per view group (parameter gradients summed over the groups,
     running statistics updated group after group, the counter advanced by the number of groups), the skip tensor added
