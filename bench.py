@@ -586,6 +586,10 @@ def main():
     with_h2d = None
     if not args.no_graph and args.inflight > 1 and not args.no_stream_inputs:
         copy_stream = torch.cuda.Stream(device=dev)
+        # (with `inflight` slots a slot's copy waits for its previous replay, so a forward is preceded by its own 0.5 ms
+        #  copy: 19.66 MB per depth map as five images at 38.5 GB/s, profiles/r03_q_h2d_rate.txt.  Two more input slots,
+        #  so that copies always run under other maps' forwards, measured SLOWER -- 779 instead of 834 depth-maps/s,
+        #  profiles/r03_q_bench_4slots.json: copies under the forwards cost more than they hide; cause not established)
         host = []
         for g, _ in slots:
             host.append(([i.cpu().pin_memory() for i in g.imgs], {k: v.cpu().pin_memory() for k, v in g.proj.items()},
@@ -629,7 +633,8 @@ def main():
         mb = sum(i.numel() for i in slots[0][0].imgs) * 4 / 1e6
         with_h2d = {"value": round(args.steps * world * args.batch / el2, 3), "unit": "depth-maps/s",
                     "ms_per_step": round(1e3 * el2 / args.steps, 4), "h2d_MB_per_depth_map": round(mb / args.batch, 2),
-                    "how": "pinned host buffers, one copy stream, copy of map k+1 under the forward of map k"}
+                    "how": "pinned host buffers, one copy stream, copy of map k+1 under the forward of map k",
+                    "h2d_GBps": round(mb / args.batch * args.steps * args.batch / el2 / 1e3, 2)}
 
     # ---- the other inference configurations of BASELINE.json (runnable forms of configs[2] and configs[4]) ----------
     other_configs = []

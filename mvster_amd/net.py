@@ -340,7 +340,10 @@ class MVS4net(nn.Module):
         depth_interval = (depth_values[:, -1] - depth_values[:, 0]) / depth_values.size(1)
         nv, B = len(imgs), imgs[0].shape[0]
         # all views through the FPN at once, view-major; BatchNorm statistics stay per view (groups = views)
-        x = torch.cat([img.permute(0, 2, 3, 1).unsqueeze(1) for img in imgs], 0)
+        if any(img.requires_grad for img in imgs):
+            x = torch.cat([img.permute(0, 2, 3, 1).unsqueeze(1) for img in imgs], 0)
+        else:
+            x = ops.pack_images([img.to(dev, torch.float32) for img in imgs])        # [N*B,1,H,W,4] RGB0, one launch
         pyramid = self.feature.forward_cl(x, groups=nv)
         outputs = {}
         prev = None

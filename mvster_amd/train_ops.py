@@ -172,9 +172,11 @@ class _ConvCL(torch.autograd.Function):
         w5 = weight if weight.dim() == 5 else weight.unsqueeze(2)
         own, tag = owner if owner is not None else (None, "")
         cin = w5.shape[0] if transposed else w5.shape[1]
-        if x.shape[-1] != cin:
-            raise RuntimeError("conv_cl: input has %d channels, weight expects %d" % (x.shape[-1], cin))
         cin_p = _cin_for(cin)
+        # (an input that already carries the kernels' channel count is taken as it is -- the RGB0 batch of
+        #  ops.pack_images for the 3-channel first layer; its extra channels meet zero weights)
+        if x.shape[-1] not in (cin, cin_p):
+            raise RuntimeError("conv_cl: input has %d channels, weight expects %d" % (x.shape[-1], cin))
         xp = _pad_last(x, cin_p).contiguous()
         layer = CACHE.get(weight, "fwd" + tag, lambda: ConvLayer(w5, transposed, stride, padding, cin_pad=cin_p),
                           lambda L: L.repack_on_device(weight), owner=own, rargs=(False, False), bias=bias)
@@ -187,14 +189,14 @@ class _ConvCL(torch.autograd.Function):
             y = layer(xp)
         ctx.has_skip = (skip is not None, skip_upsample)
         ctx.save_for_backward(xp, weight, bias)
-        ctx.cfg = (stride, padding, transposed, cin)
+        ctx.cfg = (stride, padding, transposed, cin, x.shape[-1])
         ctx.owner = (own, tag)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         xp, weight, bias = ctx.saved_tensors
-        stride, padding, transposed, cin = ctx.cfg
+        stride, padding, transposed, cin, x_channels = ctx.cfg
         own, tag = ctx.owner
         w5 = weight if weight.dim() == 5 else weight.unsqueeze(2)
         kernel = tuple(w5.shape[2:])
@@ -224,7 +226,7 @@ class _ConvCL(torch.autograd.Function):
             if tuple(gx.shape[:4]) != tuple(xp.shape[:4]):
                 raise RuntimeError("conv_cl: input gradient of a strided layer needs even input sizes (%s -> %s)"
                                    % (tuple(xp.shape), tuple(gx.shape)))
-            gx = gx[..., :cin]
+            gx = gx[..., :x_channels]
         if ctx.needs_input_grad[1]:
             if transposed:
                 gw = ops.conv_wgrad(gyp, xp, kernel, stride, padding, co_keep=cin, ci_keep=co)   # [cin, cout, k]
