@@ -269,6 +269,15 @@ int mvster_sinkhorn(const float* attn, const float* hypo, const float* gt, float
 int mvster_sinkhorn_continuous(const float* attn, const float* hypo, const float* gt, const float* mask, float* loss_pix,
                                float* jac, int B, int D, long HW, int iters, float eps, void* stream);
 
+/* The per-pixel terms of one stage of the training loss around the OT term, one pass (MVS4net_loss,
+ * models/MVS4Net.py:131-151: the mask compare, F.l1_loss(mono_depth[mask], depth_gt[mask]) :136-137, mask_out_of_range
+ * :141-147 and the masked mean of the OT loss).  hypo [B,D,HW] (D >= 3), gt, mask (float, > 0.5 = valid), loss_pix
+ * [B,HW] (from mvster_sinkhorn*), mono [B,HW] or NULL -> terms [5][B*HW]: valid, valid*|mono-gt|, valid*(no hypothesis
+ * within |t(hypo_2)-t(hypo_1)| of gt; t = 1/x when inverse_depth), valid*loss_pix, valid*sign(mono-gt).  The caller
+ * sums the planes: l1 = S1/S0, range ratio = S2/S0, ot = S3/S0. */
+int mvster_stage_loss_terms(const float* hypo, const float* gt, const float* mask, const float* loss_pix,
+                            const float* mono, float* terms, int B, int D, long HW, int inverse_depth, void* stream);
+
 /* Geometric-consistency filter of one reference view against NS source views, fused (test_mvs4.py:273-328 per
  * view pair + the sums of filter_depth :362-385).  depth_ref [H,W], depth_src [NS,H,W]; ref_mats = inv(K_ref)[9],
  * K_ref[9]; view_mats [NS][42] = (E_src inv(E_ref))[3x4], K_src[3x3], inv(K_src)[3x3], (E_ref inv(E_src))[3x4], all

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mvster_upsample2x_nearest_cl": [_f, _f, _i, _i, _i, _i, _i, _f],
     "mvster_sinkhorn": [_f, _f, _f, _f, _f, _i, _i, _l, _i, _fl, _f],
     "mvster_sinkhorn_continuous": [_f, _f, _f, _f, _f, _f, _i, _i, _l, _i, _fl, _f],
+    "mvster_stage_loss_terms": [_f, _f, _f, _f, _f, _f, _i, _i, _l, _i, _f],
     "mvster_geo_filter": [_f] * 10 + [_i, _i, _i, _fl, _fl, _f],
     "mvster_mfma_probe": [_f, _f, _f, _f],
     "mvster_gather_batch": [_f, _i, _i, _f],

@@ -158,6 +158,51 @@ int launch_sinkhorn(const float* attn, const float* hypo, const float* gt, const
     return MVSTER_ERR_UNSUPPORTED;
 }
 
+// The per-pixel terms of one stage of MVS4net_loss (models/MVS4Net.py:131-151) around the OT term, in one pass: the
+// reference forms them with ~25 tensor ops per stage (mask compare, boolean gathers, reciprocals, |.|, <=, sum over D,
+// ...), each a launch of a few microseconds in a training step.  terms [5][B*HW], valid = mask > 0.5:
+//   0: valid ? 1 : 0                                   (sum = number of valid pixels)
+//   1: valid ? |mono - gt| : 0                         (F.l1_loss(mono_depth[mask], depth_gt[mask]), :136-137)
+//   2: valid ? (no hypothesis within one interval of gt) : 0       (mask_out_of_range, :141-147)
+//   3: valid ? loss_pix : 0                            (the masked mean of the per-pixel OT loss)
+//   4: valid ? sign(mono - gt) : 0                     (d |mono - gt| / d mono, for the backward pass)
+// The interval is |t(hypo_2) - t(hypo_1)| with t = 1/x for inverse-depth ranges, x otherwise; a pixel is in range if
+// |t(hypo_d) - t(gt)| <= interval for some d (comparisons with NaN are false, as in the reference).  mono may be null
+// (planes 1 and 4 are then zero).  The caller reduces the planes with one sum.
+__global__ void __launch_bounds__(256) stage_loss_terms_kernel(const float* __restrict__ hypo, const float* __restrict__ gt,
+                                                               const float* __restrict__ mask,
+                                                               const float* __restrict__ loss_pix,
+                                                               const float* __restrict__ mono, float* __restrict__ terms,
+                                                               int B, int D, long HW, int inverse) {
+    const long n = (long)B * HW;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const long b = p / HW, q = p - b * HW;
+    const float* hp = hypo + b * D * HW + q;
+    const bool valid = mask[p] > 0.5f;
+    const float g = gt[p];
+    const float tg = inverse ? 1.0f / g : g;
+    const float t1 = inverse ? 1.0f / hp[HW] : hp[HW], t2 = inverse ? 1.0f / hp[2 * HW] : hp[2 * HW];
+    const float itv = fabsf(t2 - t1);
+    bool inside = false;
+    for (int d = 0; d < D; ++d) {
+        const float h = hp[d * HW];
+        const float t = inverse ? 1.0f / h : h;
+        inside = inside || (fabsf(t - tg) <= itv);
+    }
+    float l1 = 0.0f, sg = 0.0f;
+    if (mono) {
+        const float diff = mono[p] - g;
+        l1 = fabsf(diff);
+        sg = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
+    }
+    terms[p] = valid ? 1.0f : 0.0f;
+    terms[n + p] = valid ? l1 : 0.0f;
+    terms[2 * n + p] = (valid && !inside) ? 1.0f : 0.0f;
+    terms[3 * n + p] = valid ? loss_pix[p] : 0.0f;
+    terms[4 * n + p] = valid ? sg : 0.0f;
+}
+
 }  // namespace
 
 // attn, hypo [B,D,HW]; gt [B,HW] -> loss_pix [B,HW], jac [B,D,HW] = d loss_pix / d attn.  D in {2,...,16}, iters <= 16.
@@ -177,4 +222,17 @@ extern "C" int mvster_sinkhorn_continuous(const float* attn, const float* hypo, 
     if (B <= 0 || HW <= 0 || iters < 0 || !(eps > 0.0f)) return MVSTER_ERR_SHAPE;
     if (iters > kMaxIters) return MVSTER_ERR_UNSUPPORTED;
     return launch_sinkhorn<true>(attn, hypo, gt, mask, loss_pix, jac, B, D, HW, iters, eps, (hipStream_t)stream);
+}
+
+// hypo [B,D,HW] (D >= 3), gt, mask, loss_pix [B,HW], mono [B,HW] or null -> terms [5][B*HW] (see the kernel).
+extern "C" int mvster_stage_loss_terms(const float* hypo, const float* gt, const float* mask, const float* loss_pix,
+                                       const float* mono, float* terms, int B, int D, long HW, int inverse_depth,
+                                       void* stream) {
+    if (!hypo || !gt || !mask || !loss_pix || !terms) return MVSTER_ERR_NULL;
+    if (B <= 0 || HW <= 0 || D < 3) return MVSTER_ERR_SHAPE;
+    const long n = (long)B * HW;
+    if ((n + 255) / 256 >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    hipLaunchKernelGGL(stage_loss_terms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, hypo, gt,
+                       mask, loss_pix, mono, terms, B, D, HW, inverse_depth ? 1 : 0);
+    return mv_check_launch();
 }

@@ -1,5 +1,7 @@
 """Training losses with the reference's signatures.  The Sinkhorn term of ``MVS4net_loss`` / ``Blend_loss`` runs as
-one fused kernel (``mvster_sinkhorn``: per-pixel loss + its gradient, no [B,HW,D,D] intermediates).
+one fused kernel (``mvster_sinkhorn``: per-pixel loss + its gradient, no [B,HW,D,D] intermediates); the terms around it
+(valid mask, monocular L1, out-of-range flag, masked means) as a second one plus a single reduction
+(``mvster_stage_loss_terms``, ``stage_losses``).
 
 ``MVS4net_loss`` / ``Blend_loss`` follow models/MVS4Net.py:113-206; the OT term is the loss value of the reference's
 ``sinkhorn`` (models/mvs4net_utils.py:1096-1142): an entropy-regularised optimal-transport distance between the one-hot
@@ -46,11 +48,57 @@ def sinkhorn_loss(gt_depth, hypo_depth, attn_weight, mask, iters, eps=1, continu
     return _SinkhornLoss.apply(attn_weight, hypo_depth, gt_depth, mask, int(iters), float(eps), bool(continuous))
 
 
-def _masked_mean(values, m, n=None):
-    """``values[mask].mean()`` without the boolean-index gather (that gather needs the number of selected elements on the
-    host, i.e. a device synchronisation in the middle of every training step); ``m`` = the mask as floats, ``n`` = its sum
-    if the caller already has it."""
-    return (values * m).sum() / (m.sum() if n is None else n)
+class _StageLoss(torch.autograd.Function):
+    """One stage of MVS4net_loss (models/MVS4Net.py:131-151) in three launches: the fused Sinkhorn kernel (per-pixel OT
+    loss and its gradient), ``mvster_stage_loss_terms`` (the valid mask, |mono - gt|, the out-of-range flag and the masked
+    OT loss per pixel) and one sum over the planes.  Returns (l1, ot, out_of_range_ratio): the masked means
+    ``F.l1_loss(mono[mask], gt[mask])``, ``sinkhorn(...)[1]`` and ``mask_out_of_range[mask].float().mean()``.  Gradients
+    flow to ``attn`` and ``mono``; the ratio is a diagnostic.  As tensor expressions these were ~30 launches per stage."""
+
+    @staticmethod
+    def forward(ctx, attn, mono, hypo, gt, mask, iters, eps, continuous, inverse):
+        from . import ops
+        m = mask.to(torch.float32).contiguous()
+        attn, hypo, gt = attn.contiguous(), hypo.contiguous(), gt.contiguous()
+        loss_pix, jac = ops.sinkhorn_pixels(attn, hypo, gt, iters, eps, mask=m, continuous=continuous)
+        terms = ops.stage_loss_terms(hypo, gt, m, loss_pix, None if mono is None else mono.contiguous(), inverse)
+        sums = terms[:4].sum(1)                          # valid pixels, sum |mono - gt|, out of range, sum OT loss
+        means = sums[1:] / sums[0]
+        ctx.save_for_backward(jac, terms, sums)
+        ctx.has_mono = mono is not None
+        ctx.set_materialize_grads(False)
+        l1, ratio, ot = means.unbind(0)
+        ctx.mark_non_differentiable(ratio)
+        return l1, ot, ratio
+
+    @staticmethod
+    def backward(ctx, g_l1, g_ot, _g_ratio):
+        jac, terms, sums = ctx.saved_tensors
+        B, _, H, W = jac.shape
+        g_attn = g_mono = None
+        if g_ot is not None and ctx.needs_input_grad[0]:
+            w = (terms[0] * (g_ot / sums[0])).view(B, 1, H, W)
+            g_attn = torch.where(w != 0, jac * w, 0.0)   # (where(): a non-finite Jacobian of a masked-out pixel stays out)
+        if g_l1 is not None and ctx.has_mono and ctx.needs_input_grad[1]:
+            g_mono = (terms[4] * (g_l1 / sums[0])).view(B, H, W)
+        return g_attn, g_mono, None, None, None, None, None, None, None
+
+
+def stage_losses(gt_depth, hypo_depth, attn_weight, mask, mono_depth=None, iters=3, eps=1, continuous=False, inverse=False):
+    """(l1, ot, out_of_range_ratio) of one stage, as MVS4net_loss forms them (models/MVS4Net.py:131-151), on the fused
+    gfx950 kernels; ``l1`` is 0 when ``mono_depth`` is None.  GPU tensors, 3 <= D <= 16 hypotheses, iters <= 16: there is no
+    tensor-level fallback, other inputs raise."""
+    D = attn_weight.shape[1]
+    if not attn_weight.is_cuda:
+        raise RuntimeError("mvster_amd.loss.stage_losses runs on MI355X only (there is no CPU fallback)")
+    if not (3 <= D <= 16 and 0 <= iters <= 16):
+        raise NotImplementedError("stage_losses: D=%d hypotheses / %d iterations (the fused kernels take 3 <= D <= 16, "
+                                  "iters <= 16)" % (D, iters))
+    l1, ot, ratio = _StageLoss.apply(attn_weight, mono_depth, hypo_depth, gt_depth, mask, int(iters), float(eps),
+                                     bool(continuous), bool(inverse))
+    if mono_depth is None:
+        l1 = torch.zeros((), dtype=torch.float32, device=attn_weight.device)
+    return l1, ot, ratio
 
 
 def _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):
@@ -59,31 +107,12 @@ def _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):
     ot_eps = kwargs.get("ot_eps", 1)
     ot_continous = kwargs.get("ot_continous", False)
     mono = kwargs.get("mono", False)
-    dev = mask_ms["stage1"].device
     for stage_idx, key in enumerate([k for k in inputs.keys() if "stage" in k]):
         st = inputs[key]
-        hypo, attn = st["hypo_depth"], st["attn_weight"]
-        mask = mask_ms[key] > 0.5
-        gt = depth_gt_ms[key]
-        # (one float mask and one pixel count per stage, one reciprocal of the hypotheses: the same values as the
-        #  reference's expressions, a third of the small launches)
-        m = mask.to(torch.float32)
-        n = m.sum()
-        if mono and stage_idx != 0:
-            l1 = _masked_mean((st["mono_depth"] - gt).abs(), m, n)         # F.l1_loss(mono_depth[mask], gt[mask])
-        else:
-            l1 = torch.zeros((), dtype=torch.float32, device=dev)
-        with torch.no_grad():                                               # (a diagnostic: no gradient flows through it)
-            if inverse:
-                inv = 1 / hypo
-                itv = (inv[:, 2] - inv[:, 1]).abs()
-                inside = ((inv - (1 / gt).unsqueeze(1)).abs() <= itv.unsqueeze(1)).any(1)
-            else:
-                itv = (hypo[:, 2] - hypo[:, 1]).abs()
-                inside = ((hypo - gt.unsqueeze(1)).abs() <= itv.unsqueeze(1)).any(1)
-            outside_ratio = _masked_mean((~inside).to(torch.float32), m, n)
-        ot = sinkhorn_loss(gt, hypo, attn, mask, iters=ot_iter, eps=ot_eps, continuous=ot_continous)
-        yield stage_idx, key, l1, ot, outside_ratio, mask
+        l1, ot, outside_ratio = stage_losses(depth_gt_ms[key], st["hypo_depth"], st["attn_weight"], mask_ms[key],
+                                             st["mono_depth"] if mono and stage_idx != 0 else None, iters=ot_iter,
+                                             eps=ot_eps, continuous=ot_continous, inverse=inverse)
+        yield stage_idx, key, l1, ot, outside_ratio
 
 
 def MVS4net_loss(inputs, depth_gt_ms, mask_ms, **kwargs):
@@ -91,7 +120,7 @@ def MVS4net_loss(inputs, depth_gt_ms, mask_ms, **kwargs):
     l1ot_lw = kwargs.get("l1ot_lw", [0, 1])
     total = torch.zeros((), dtype=torch.float32, device=mask_ms["stage1"].device)
     l1s, ots, ranges = [], [], []
-    for si, _, l1, ot, rng, _ in _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):
+    for si, _, l1, ot, rng in _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):
         l1s.append(l1)
         ots.append(ot)
         ranges.append(rng)
@@ -107,13 +136,14 @@ def Blend_loss(inputs, depth_gt_ms, mask_ms, **kwargs):
     total = torch.zeros((), dtype=torch.float32, device=mask_ms["stage1"].device)
     l1s, ots, ranges = [], [], []
     last = None
-    for si, key, l1, ot, rng, mask in _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):
+    for si, key, l1, ot, rng in _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):
         l1s.append(l1)
         ots.append(ot)
         ranges.append(rng)
         total = total + stage_lw[si] * (l1ot_lw[0] * l1 + l1ot_lw[1] * ot)
-        last = (key, mask)
-    key, mask = last
+        last = key
+    key = last
+    mask = mask_ms[key] > 0.5
     scale = 128 / (depth_max - depth_min)[:, None, None]
     err = torch.abs(inputs[key]["depth"] * scale - depth_gt_ms[key] * scale)[mask]
     return total, l1s, ots, ranges, err.mean(), (err <= 3).float().mean() * 100, (err <= 1).float().mean() * 100

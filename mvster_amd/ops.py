@@ -458,6 +458,25 @@ def sinkhorn_pixels(attn, hypo, gt, iters, eps, mask=None, continuous=False):
     return loss_pix, jac
 
 
+def stage_loss_terms(hypo, gt, mask, loss_pix, mono=None, inverse_depth=False):
+    """The per-pixel terms of one stage of MVS4net_loss around the OT term (models/MVS4Net.py:131-151), one launch:
+    hypo [B,D,H,W], gt / mask (float, > 0.5 = valid) / loss_pix [B,H,W], mono [B,H,W] or None -> terms [5, B*H*W] =
+    valid, valid*|mono-gt|, valid*out_of_range, valid*loss_pix, valid*sign(mono-gt)."""
+    for t, n in ((hypo, "hypo"), (gt, "gt"), (mask, "mask"), (loss_pix, "loss_pix"), (mono, "mono")):
+        _chk(t, "stage_loss_terms:" + n)
+    B, D, H, W = hypo.shape
+    for t in (gt, mask, loss_pix) + (() if mono is None else (mono,)):
+        if tuple(t.shape) != (B, H, W):
+            raise RuntimeError("stage_loss_terms: inconsistent shapes")
+    if D < 3:
+        raise RuntimeError("stage_loss_terms: the range interval needs at least 3 hypotheses")
+    terms = torch.empty(5, B * H * W, device=hypo.device, dtype=torch.float32)
+    rc = _lib.load().mvster_stage_loss_terms(_ptr(hypo), _ptr(gt), _ptr(mask), _ptr(loss_pix), _ptr(mono), _ptr(terms), B, D,
+                                             H * W, int(bool(inverse_depth)), _stream())
+    _lib.check(rc, "stage_loss_terms")
+    return terms
+
+
 def upsample2x_cl(x, backward=False, mode="bilinear"):
     """x2 up-sampling of a channels-last map [B,h,w,C] -> [B,2h,2w,C], ``mode`` "bilinear" (align_corners=True) or
     "nearest"; ``backward=True`` is the adjoint [B,2h,2w,C] -> [B,h,w,C]."""

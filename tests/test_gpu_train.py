@@ -362,6 +362,81 @@ def test_fused_sinkhorn_vs_reference_values(golden):
                       g.t("mask", DEV), 10, 1.0, continuous=True)
 
 
+@pytest.mark.parametrize("inverse,with_mono,D", [(True, True, 8), (False, True, 4), (True, False, 5), (False, False, 3)])
+def test_fused_stage_terms_vs_tensor_form(inverse, with_mono, D):
+    """mvster_stage_loss_terms + the masked means of one stage (loss.stage_losses) against the reference's tensor
+    expressions (models/MVS4Net.py:131-151: boolean-index gathers, F.l1_loss, the out-of-range count) under autograd:
+    values, the gradients of attn_weight and mono_depth, with invalid ground truth (0) and a NaN outside the mask."""
+    from mvster_amd.loss import stage_losses
+    g = torch.Generator().manual_seed(D + 2 * inverse + with_mono)
+    B, H, W = 2, 19, 23
+    attn = torch.softmax(3 * torch.randn(B, D, H, W, generator=g), 1)
+    inv = 1.0 / 900 + 2e-5 * (torch.arange(D).view(1, D, 1, 1) + 0.1 * torch.rand(B, D, H, W, generator=g))
+    hypo = (1.0 / inv).float()
+    # ground truth from well inside the range to three intervals outside it: both range classes occur
+    gt = (1.0 / (1.0 / 900 + 2e-5 * (-3.0 + (D + 5) * torch.rand(B, H, W, generator=g)))).float()
+    mask = torch.rand(B, H, W, generator=g) > 0.3
+    gt[~mask] = 0.0
+    mono = (gt + 5 * torch.randn(B, H, W, generator=g)).float() if with_mono else None
+    if with_mono:
+        mono[~mask] = float("nan")                                       # never read into the loss
+        mono[0, 3, 4] = gt[0, 3, 4]                                      # |x| at 0: gradient 0 (torch's sgn)
+    ad = attn.clone().requires_grad_(True)
+    md = mono.clone().requires_grad_(True) if with_mono else None
+    l1_w = F.l1_loss(md[mask], gt[mask], reduction="mean") if with_mono else torch.zeros(())
+    t = (lambda x: 1 / x) if inverse else (lambda x: x)
+    itv = (t(hypo[:, 2]) - t(hypo[:, 1])).abs()
+    oor = ((t(hypo) - t(gt).unsqueeze(1)).abs() <= itv.unsqueeze(1)).sum(1) == 0
+    ratio_w = oor[mask].float().mean()
+    ot_w = O.sinkhorn(gt, hypo, ad, mask, 10, 1.0, continuous=False)[1]
+    (0.7 * ot_w + 1.3 * l1_w).backward() if with_mono else ot_w.backward()
+    assert 0.05 < ratio_w.item() < 0.95
+    ag = attn.to(DEV).requires_grad_(True)
+    mg = mono.to(DEV).requires_grad_(True) if with_mono else None
+    l1, ot, ratio = stage_losses(gt.to(DEV), hypo.to(DEV), ag, mask.float().to(DEV), mg, iters=10, eps=1.0, inverse=inverse)
+    (0.7 * ot + 1.3 * l1).backward() if with_mono else ot.backward()
+    assert abs(ratio.item() - ratio_w.item()) <= 1e-6, (ratio.item(), ratio_w.item())
+    assert abs(ot.item() - ot_w.item()) <= 2e-5 * abs(ot_w.item())
+    assert not ratio.requires_grad
+    e_g = ((ag.grad.cpu() - ad.grad).norm() / ad.grad.norm()).item()
+    assert e_g <= 2e-4, e_g
+    if with_mono:
+        assert abs(l1.item() - l1_w.item()) <= 1e-5 * abs(l1_w.item())
+        want = md.grad
+        assert torch.isfinite(mg.grad).all()
+        assert (mg.grad.cpu() - want).abs().max().item() <= 1e-6 * want.abs().max().item()
+        assert mg.grad[0, 3, 4].item() == 0.0
+    else:
+        assert l1.item() == 0.0
+
+
+@pytest.mark.parametrize("name", ["inv", "lin_l1", "cont"])
+def test_losses_vs_reference_values_on_device(golden, name):
+    """MVS4net_loss and Blend_loss (models/MVS4Net.py:113-206) with every per-stage term on the fused kernels, on the
+    reference's own stage outputs: totals, per-stage l1 / OT terms, out-of-range ratios, end-point error figures
+    (fixture G9: values returned by the reference's functions)."""
+    from mvster_amd import Blend_loss, MVS4net_loss
+    from tests.test_oracle_golden import G9_CASES, _g6_train_stage_dicts
+    g = golden("g9_losses")
+    inputs, gt, mask = _g6_train_stage_dicts(golden)
+    inputs = {k: {kk: vv.to(DEV) for kk, vv in v.items()} for k, v in inputs.items()}
+    gt, mask = {k: v.to(DEV) for k, v in gt.items()}, {k: v.to(DEV) for k, v in mask.items()}
+    kw = G9_CASES[name]
+    stack = lambda xs: torch.stack([x.detach().cpu() for x in xs])     # noqa: E731
+    total, l1s, ots, rng = MVS4net_loss(inputs, gt, mask, **kw)
+    want = float(g.np("mvs4_%s_total" % name))
+    assert abs(total.item() - want) <= 2e-5 * abs(want)
+    assert torch.allclose(stack(l1s), g.t("mvs4_%s_l1" % name), rtol=1e-5)
+    assert torch.allclose(stack(ots), g.t("mvs4_%s_ot" % name), rtol=2e-5)
+    assert torch.allclose(stack(rng), g.t("mvs4_%s_range" % name), rtol=1e-6, atol=0)
+    r = Blend_loss(inputs, gt, mask, depth_max=g.t("depth_max", DEV), depth_min=g.t("depth_min", DEV), **kw)
+    assert len(r) == 7
+    want = float(g.np("blend_%s_total" % name))
+    assert abs(r[0].item() - want) <= 2e-5 * abs(want)
+    assert torch.allclose(stack(r[3]), g.t("blend_%s_range" % name), rtol=1e-6, atol=0)
+    assert torch.allclose(stack(list(r[4:])), g.t("blend_%s_epe_err3_err1" % name), rtol=1e-5)
+
+
 def test_native_train_step_under_ddp_single_rank():
     """The reference wraps the model in DistributedDataParallel (train_mvs4.py:389): the native training path (custom
     autograd Functions, cached packed weights) must produce the same gradients through DDP's reducer (RCCL backend,

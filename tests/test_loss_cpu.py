@@ -1,7 +1,8 @@
-"""mvster_amd.loss host logic (masks, range ratios, stage weighting, Blend_loss's error figures) against the
-reference's golden vectors.  The product's OT term is the fused HIP kernel and refuses CPU tensors; here it is replaced
-by the oracle's tensor-level ``sinkhorn`` (pinned by G8 / G8b in test_oracle_golden.py) so that the surrounding logic
-can be checked without a GPU."""
+"""mvster_amd.loss host logic (stage weighting, the terms' bookkeeping, Blend_loss's error figures) against the
+reference's golden vectors.  The product's per-stage terms are fused HIP kernels and refuse CPU tensors; here they are
+replaced by a tensor-level restatement of models/MVS4Net.py:131-151 built on the oracle's ``sinkhorn`` (pinned by
+G8 / G8b in test_oracle_golden.py) so that the surrounding logic can be checked without a GPU.  The kernels themselves
+meet the same golden values in tests/test_gpu_train.py::test_losses_vs_reference_values_on_device."""
 import pytest
 import torch
 
@@ -11,16 +12,33 @@ from oracle.mvs4_oracle import sinkhorn
 from tests.test_oracle_golden import G9_CASES, _g6_train_stage_dicts
 
 
+def oracle_stage_losses(gt, hypo, attn, mask, mono_depth=None, iters=3, eps=1, continuous=False, inverse=False):
+    """(l1, ot, out_of_range_ratio) of one stage as tensor expressions (models/MVS4Net.py:131-151)."""
+    m = mask > 0.5
+    if mono_depth is not None:
+        l1 = torch.nn.functional.l1_loss(mono_depth[m], gt[m], reduction="mean")
+    else:
+        l1 = torch.zeros((), dtype=torch.float32, device=gt.device)
+    t = (lambda x: 1 / x) if inverse else (lambda x: x)
+    itv = (t(hypo[:, 2]) - t(hypo[:, 1])).abs()
+    oor = ((t(hypo) - t(gt).unsqueeze(1)).abs() <= itv.unsqueeze(1)).sum(1) == 0
+    return l1, sinkhorn(gt, hypo, attn, m, iters, eps, continuous)[1], oor[m].float().mean()
+
+
 @pytest.fixture
 def tensor_level_ot(monkeypatch):
-    monkeypatch.setattr(L, "sinkhorn_loss", lambda gt, hypo, attn, mask, iters, eps=1, continuous=False:
-                        sinkhorn(gt, hypo, attn, mask, iters, eps, continuous)[1])
+    monkeypatch.setattr(L, "stage_losses", oracle_stage_losses)
 
 
 def test_ot_term_has_no_cpu_fallback(golden):
     g = golden("g8_sinkhorn")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         L.sinkhorn_loss(g.t("gt"), g.t("hypo"), g.t("attn"), g.t("mask"), 10)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        L.stage_losses(g.t("gt"), g.t("hypo"), g.t("attn"), g.t("mask"), iters=10)
+    inputs, gt, mask = _g6_train_stage_dicts(golden)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        MVS4net_loss(inputs, gt, mask, inverse_depth=True, ot_iter=10, mono=True)
 
 
 @pytest.mark.parametrize("name", sorted(G9_CASES))
