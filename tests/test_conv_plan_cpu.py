@@ -125,6 +125,64 @@ def test_tile_heuristic_and_flops():
     assert cp.Reg2dPlan(m8).flops(1, 8, 64, 64) == 14992 * 8 * 64 * 64
 
 
+def test_tuning_table_is_well_formed():
+    """mvster_amd/tuning_gfx950.json (signature -> [variant word, mt, nt], scripts/conv_microbench.py --emit): every key is
+    a layer signature, every variant word names a kernel family that covers that layer (conv_mfma.hip routes on the low
+    byte, the families read their mode from the bits above), and the tile counts are ones the launchers instantiate.  An
+    entry outside these sets would turn into MVSTER_ERR_UNSUPPORTED on the first forward of that shape."""
+    import json
+    import os
+    import re
+    with open(os.path.join(os.path.dirname(cp.__file__), "tuning_gfx950.json")) as f:
+        table = json.load(f)
+    assert len(table) > 300
+    key = re.compile(r"^([CT])(\d+)-(\d+)_k(\d)x(\d)x(\d)_s(\d)x(\d)x(\d)_(\d+)x(\d+)x(\d+)x(\d+)_sk([012])$")
+    modes = {0: {0}, 1: {0}, 2: {0}, 5: {1, 2, 3, 33, 34}, 6: {2, 3}, 7: {0, 1, 2}, 8: {1, 2}, 9: {0, 1}}
+    for sig, val in table.items():
+        m = key.match(sig)
+        assert m, sig
+        assert isinstance(val, list) and len(val) == 3 and all(isinstance(v, int) for v in val), sig
+        variant, mt, nt = val
+        fam, mode = variant & 0xff, variant >> 8
+        assert fam in modes and mode in modes[fam], (sig, val)
+        assert mt in (1, 2, 4) and nt in (1, 2, 3, 4, 5), (sig, val)
+        transposed, cin, cout = m.group(1) == "T", int(m.group(2)), int(m.group(3))
+        kernel = tuple(int(m.group(i)) for i in (4, 5, 6))
+        stride = tuple(int(m.group(i)) for i in (7, 8, 9))
+        skip = int(m.group(14))
+        assert cin in (4, 8, 16, 32, 64, 80) and cout <= 144, sig         # (80: the padded 72-channel gradient of the FPN gather)
+        if fam in (8, 9):       # Winograd F(2x2, 3x3): ConvLayer.wino_eligible(), no up-sampling skip
+            assert not transposed and kernel in ((1, 3, 3), (3, 3, 3)) and stride == (1, 1, 1), sig
+            assert cin in (16, 32, 64) and cout % 16 == 0 and skip in (0, 1), sig
+            if fam == 9:        # ring kernel: two N tiles per workgroup in modes 1 and 2 (word 9 | 1 << 8), one in mode 0
+                assert nt == (2 if mode == 1 else 1), (sig, val)
+        if fam == 6:            # persistent 1x1
+            assert kernel == (1, 1, 1) and stride == (1, 1, 1) and not transposed, sig
+        if fam == 5:            # persistent LDS-DMA frame: stride-1 16 -> 16, the stride-2 families, the transposed 3x3 layers
+            assert kernel[1] == kernel[2] and kernel[1] in (3, 5), sig
+            assert (mode & 32) == 0 or stride == (1, 2, 2), sig        # loading waves exist for the stride-2 instances only
+        if skip == 2:           # bilinear x2 up-sampling add in the epilogue: the direct / split-K / persistent 1x1 kernels
+            assert fam in (0, 1, 2, 6) and kernel == (1, 1, 1), sig
+
+
+def test_winograd_plan_for_untuned_shapes():
+    """_wino_plan: the heuristic behind shapes the table does not know -- a Winograd kernel wherever the map gives most CUs
+    a work unit, nothing otherwise (the caller keeps the direct / split-K choice)."""
+    class L:
+        kernel = (1, 3, 3)
+        cin = 16
+        ntile_total = 1
+    assert cp._wino_plan(L, 10, 1, 256, 320) == (8 | (1 << 8), 2, 1)
+    assert cp._wino_plan(L, 1, 1, 64, 80) is None                       # 20 tiles
+    L.cin, L.ntile_total = 64, 4
+    v = cp._wino_plan(L, 5, 1, 128, 160)
+    assert v == (9, 2, 2)                                               # 400 tiles x 2 pairs of N tiles
+    assert cp._wino_plan(L, 1, 1, 16, 32) is None
+    L.kernel, L.cin, L.ntile_total = (3, 3, 3), 16, 1
+    assert cp._wino_plan(L, 1, 4, 128, 160) == (9, 2, 1)                # 4 x 16 x 5 = 320 tiles
+    assert cp._wino_plan(L, 1, 4, 32, 40) is None
+
+
 @pytest.mark.parametrize("cin,cout,k,s,p", [(16, 8, (1, 5, 5), (1, 2, 2), (0, 2, 2)), (32, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
                                             (16, 4, 3, 2, 1)])
 def test_transposed_layer_is_the_input_gradient_of_a_strided_conv(cin, cout, k, s, p):
