@@ -1,58 +1,58 @@
 """On-disk formats either side of the path: PFM depth / confidence maps, MVSNet-style
-``*_cam.txt`` and ``pair.txt``, and the multi-scale ``proj_matrices`` dict the forward pass takes.
+``*_cam.txt`` and ``pair.txt``, the evaluation sample (view list, images, multi-scale ``proj_matrices`` dict,
+``depth_values``) the forward pass takes.
 
 Behaviour follows the reference's readers and writers -- ``datasets/data_io.py:6-71`` (``read_pfm`` / ``save_pfm``),
-``datasets/general_eval4.py:59-79`` (``read_cam_file``) and ``:173-188`` (stage matrices), ``test_mvs4.py:94-103``
-(``read_camera_parameters``), ``:126-136`` (``read_pair_file``), ``:138-155`` (``write_cam``).  Those modules import
-cv2 at load time and cannot be imported in this image, so these are restatements checked by round trips and
-hand-built files (tests/test_formats_cpu.py), not by reference-generated goldens.
+``datasets/general_eval4.py:24-57`` (view list), ``:59-79`` (``read_cam_file``), ``:81-86`` (``read_img``), ``:92-108``
+(admissible image size), ``:111-188`` (sample), ``test_mvs4.py:94-103`` (``read_camera_parameters``), ``:126-136``
+(``read_pair_file``), ``:138-155`` (``write_cam``).  **Pinned** by ``tests/golden/g10_formats.npz``: the bytes / text /
+arrays the reference's own functions write and read for the same inputs (``oracle/make_golden.py g10``), compared
+byte for byte and element for element in ``tests/test_formats_cpu.py``.
 """
+import os
 import re
 import sys
 
 import numpy as np
 
+_PFM_DIMS = re.compile(r"^(\d+)\s(\d+)\s$")       # "<width> <height>\n": exactly what the reference accepts
+
+
+def _pfm_header(f):
+    """-> (channels, width, height, scale, numpy byte-order character) of an open PFM file."""
+    magic = f.readline().decode("utf-8").rstrip()
+    if magic not in ("PF", "Pf"):
+        raise Exception("Not a PFM file.")
+    dims = _PFM_DIMS.match(f.readline().decode("utf-8"))
+    if dims is None:
+        raise Exception("Malformed PFM header.")
+    scale = float(f.readline().rstrip())
+    # the sign of the scale line is the byte-order flag: negative = little-endian samples
+    return (3 if magic == "PF" else 1), int(dims.group(1)), int(dims.group(2)), abs(scale), ("<" if scale < 0 else ">")
+
 
 def read_pfm(filename):
-    """-> (data [H,W] or [H,W,3] float32 in top-to-bottom row order, scale)."""
+    """-> (data [H,W] or [H,W,3] in top-to-bottom row order, dtype as stored, scale)."""
     with open(filename, "rb") as f:
-        header = f.readline().decode("utf-8").rstrip()
-        if header == "PF":
-            color = True
-        elif header == "Pf":
-            color = False
-        else:
-            raise Exception("Not a PFM file.")
-        dims = re.match(r"^(\d+)\s(\d+)\s$", f.readline().decode("utf-8"))
-        if not dims:
-            raise Exception("Malformed PFM header.")
-        width, height = map(int, dims.groups())
-        scale = float(f.readline().rstrip())
-        endian = "<" if scale < 0 else ">"           # a negative scale marks little-endian data
-        scale = abs(scale)
-        data = np.fromfile(f, endian + "f")
-    shape = (height, width, 3) if color else (height, width)
-    return np.flipud(np.reshape(data, shape)), scale    # PFM stores rows bottom-to-top
+        channels, width, height, scale, order = _pfm_header(f)
+        samples = np.fromfile(f, order + "f")
+    shape = (height, width, 3) if channels == 3 else (height, width)
+    return samples.reshape(shape)[::-1], scale       # rows are stored bottom-to-top
 
 
 def save_pfm(filename, image, scale=1):
-    image = np.flipud(image)
+    """float32 [H,W], [H,W,1] (both 'Pf') or [H,W,3] ('PF'); samples go out in the array's own byte order."""
     if image.dtype.name != "float32":
         raise Exception("Image dtype must be float32.")
-    if len(image.shape) == 3 and image.shape[2] == 3:
-        color = True
-    elif len(image.shape) == 2 or (len(image.shape) == 3 and image.shape[2] == 1):
-        color = False
-    else:
+    grey = image.ndim == 2 or (image.ndim == 3 and image.shape[2] == 1)
+    if not grey and not (image.ndim == 3 and image.shape[2] == 3):
         raise Exception("Image must have H x W x 3, H x W x 1 or H x W dimensions.")
-    endian = image.dtype.byteorder
-    if endian == "<" or (endian == "=" and sys.byteorder == "little"):
-        scale = -scale
+    order = image.dtype.byteorder
+    little = order == "<" or (order == "=" and sys.byteorder == "little")
+    header = "%s\n%d %d\n%f\n" % ("Pf" if grey else "PF", image.shape[1], image.shape[0], -scale if little else scale)
     with open(filename, "wb") as f:
-        f.write(("PF\n" if color else "Pf\n").encode("utf-8"))
-        f.write("{} {}\n".format(image.shape[1], image.shape[0]).encode("utf-8"))
-        f.write(("%f\n" % scale).encode("utf-8"))
-        image.tofile(f)
+        f.write(header.encode("utf-8"))
+        image[::-1].tofile(f)
 
 
 def _cam_lines(filename):
@@ -124,3 +124,64 @@ def stage_proj_matrices(intrinsics, extrinsics):
 def depth_value_range(depth_min, depth_interval, ndepths=192):
     """The ``depth_values`` vector of a sample (general_eval4.py:168-170)."""
     return np.arange(depth_min, depth_interval * (ndepths - 0.5) + depth_min, depth_interval, dtype=np.float32)
+
+
+def read_img(filename):
+    """8-bit image file -> float32 [H,W,3] in 0..1 (general_eval4.py:81-86)."""
+    from PIL import Image
+    return np.array(Image.open(filename), dtype=np.float32) / 255.0
+
+
+def eval_view_list(datapath, scans, nviews):
+    """[(scan, ref_view, src_views), ...] over the scans' ``pair.txt`` (general_eval4.py:24-57): reference views
+    without sources are dropped, a source list shorter than ``nviews`` is filled up with its first entry."""
+    metas = []
+    for scan in scans:
+        for ref_view, src_views in read_pair_file(os.path.join(datapath, scan, "pair.txt")):
+            if len(src_views) < nviews:
+                src_views = src_views + [src_views[0]] * (nviews - len(src_views))
+            metas.append((scan, ref_view, src_views))
+    return metas
+
+
+def _admissible_size(h, w, max_h, max_w, base=64):
+    """The size the reference's loader brings an image to (general_eval4.py:92-100): shrunk to fit max_h x max_w,
+    then rounded down to multiples of ``base`` (float arithmetic as there)."""
+    if h > max_h or w > max_w:
+        scale = 1.0 * max_h / h
+        if scale * w > max_w:
+            scale = 1.0 * max_w / w
+        return scale * w // base * base, scale * h // base * base
+    return 1.0 * w // base * base, 1.0 * h // base * base
+
+
+def load_eval_sample(datapath, scan, ref_view, src_views, nviews, interval_scale=1.06, ndepths=192,
+                     max_h=None, max_w=None):
+    """One evaluation sample as ``general_eval4.MVSDataset.__getitem__`` (:111-188) hands it to the forward pass:
+    ``imgs`` list of [3,H,W] float32, ``proj_matrices`` dict stage1..4 of [N,2,4,4], ``depth_values`` [ndepths],
+    ``filename`` pattern.  Images must already have an admissible size (H, W multiples of 64 within max_h x max_w):
+    image resampling is outside the path and raises."""
+    imgs, intr, extr, depth_values = [], [], [], None
+    first_hw = None
+    for i, vid in enumerate([ref_view] + list(src_views[:nviews - 1])):
+        img_file = os.path.join(datapath, "{}/images_post/{:0>8}.jpg".format(scan, vid))
+        if not os.path.exists(img_file):
+            img_file = os.path.join(datapath, "{}/images/{:0>8}.jpg".format(scan, vid))
+        img = read_img(img_file)
+        K, E, depth_min, depth_interval = read_cam_file(
+            os.path.join(datapath, "{}/cams/{:0>8}_cam.txt".format(scan, vid)), interval_scale, ndepths)
+        h, w = img.shape[:2]
+        new_w, new_h = _admissible_size(h, w, h if max_h is None else max_h, w if max_w is None else max_w)
+        if (new_h, new_w) != (h, w) or (first_hw is not None and (h, w) != first_hw):
+            raise NotImplementedError("image %s is %dx%d and would be resampled to %dx%d: resize the images first"
+                                      % (img_file, h, w, *(first_hw or (new_h, new_w))))
+        K[0, :] *= 1.0 * new_w / w
+        K[1, :] *= 1.0 * new_h / h
+        first_hw = first_hw or (h, w)
+        imgs.append(img.transpose(2, 0, 1))
+        intr.append(K)
+        extr.append(E)
+        if i == 0:
+            depth_values = depth_value_range(depth_min, depth_interval, ndepths)
+    return {"imgs": imgs, "proj_matrices": stage_proj_matrices(intr, extr), "depth_values": depth_values,
+            "filename": scan + "/{}/" + "{:0>8}".format(ref_view) + "{}"}

@@ -351,6 +351,165 @@ def g9_losses(M):
     npz("g9_losses", **out)
 
 
+def _reference_functions(path, names, env):
+    """Compile, at fixture-generation time, the named top-level functions / class methods of a reference script that
+    cannot be imported whole here (test_mvs4.py parses the command line and imports cv2 / plyfile at load time).  The
+    source is read from the read-only tree, compiled and executed in memory; nothing of it is written anywhere."""
+    import ast
+    tree = ast.parse(open(path).read(), path)
+    found = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in names and node.name not in found:
+            mod = ast.Module(body=[node], type_ignores=[])
+            ns = dict(env)
+            exec(compile(mod, path, "exec"), ns)
+            found[node.name] = ns[node.name]
+    missing = set(names) - set(found)
+    assert not missing, missing
+    return found
+
+
+def g10_formats():
+    """On-disk formats either side of the path, from the reference's own readers / writers:
+    datasets/data_io.py (imported under an empty stand-in ``cv2`` module: read_pfm / save_pfm never touch it),
+    test_mvs4.py:94-155 (read_camera_parameters, read_pair_file, write_cam: extracted with ast, the script itself parses
+    argv on import) and datasets/general_eval4.py (MVSDataset run end to end on a synthetic scan directory whose images
+    already have an admissible size, so its only cv2 call, ``cv2.resize(img, same size)``, is the identity)."""
+    import io
+    import tempfile
+    import types
+    from PIL import Image
+    cv2 = types.ModuleType("cv2")
+
+    def _resize_same_size_only(img, size):
+        assert (img.shape[1], img.shape[0]) == tuple(size), "fixture must not need a real resize"
+        return img
+    cv2.resize = _resize_same_size_only
+    had = sys.modules.get("cv2")
+    sys.modules["cv2"] = cv2
+    sys.path.insert(0, REF)
+    try:
+        import datasets.data_io as DIO
+        import datasets.general_eval4 as GE
+    finally:
+        sys.path.remove(REF)
+        if had is None:
+            del sys.modules["cv2"]
+    T = _reference_functions(os.path.join(REF, "test_mvs4.py"),
+                             ("read_camera_parameters", "read_pair_file", "write_cam"), {"np": np})
+    rs = np.random.RandomState(10)
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="g10_")
+
+    def raw(path):
+        return np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+
+    # --- PFM: grey, H x W x 1, colour, big-endian data, a non-unit scale; the bytes the reference writes and what it reads
+    pfm_cases = {
+        "grey": (rs.rand(5, 7).astype(np.float32) * 900, 1),
+        "grey1": (rs.randn(4, 6, 1).astype(np.float32), 1),
+        "color": (rs.rand(4, 6, 3).astype(np.float32), 2.5),
+        "big": (rs.randn(3, 5).astype(np.float32).astype(">f4"), 1),
+        "special": (np.array([[0.0, -0.0, np.inf], [-np.inf, np.nan, 1e-45]], dtype=np.float32), 1),
+    }
+    for name, (img, scale) in pfm_cases.items():
+        path = os.path.join(tmp, name + ".pfm")
+        DIO.save_pfm(path, img, scale)
+        back, sc = DIO.read_pfm(path)
+        out["pfm_%s_image" % name] = img.astype(np.float32)
+        out["pfm_%s_image_big_endian" % name] = np.array(img.dtype.byteorder == ">")
+        out["pfm_%s_scale_in" % name] = np.array(scale, dtype=np.float64)
+        out["pfm_%s_bytes" % name] = raw(path)
+        out["pfm_%s_read" % name] = np.ascontiguousarray(back).astype(np.float32)
+        out["pfm_%s_read_shape" % name] = np.array(back.shape)
+        out["pfm_%s_scale_out" % name] = np.array(sc, dtype=np.float64)
+    # a hand-built big-endian file with a "1.0" scale line (what other MVSNet tools write), read by the reference
+    vals = np.array([[1.5, -2.0], [3.25, 4.0], [5.0, 6.5]], dtype=">f4")
+    path = os.path.join(tmp, "hand.pfm")
+    open(path, "wb").write(b"Pf\n2 3\n1.0\n" + vals.tobytes())
+    back, sc = DIO.read_pfm(path)
+    out["pfm_hand_bytes"] = raw(path)
+    out["pfm_hand_read"] = np.ascontiguousarray(back).astype(np.float32)
+    out["pfm_hand_scale_out"] = np.array(sc, dtype=np.float64)
+    for bad, blob in (("magic", b"P6\n2 2\n1.0\n"), ("dims", b"Pf\n2x2\n1.0\n")):
+        path = os.path.join(tmp, bad + ".pfm")
+        open(path, "wb").write(blob)
+        try:
+            DIO.read_pfm(path)
+            msg = ""
+        except Exception as e:          # noqa: BLE001
+            msg = str(e)
+        out["pfm_bad_%s_bytes" % bad] = raw(path)
+        out["pfm_bad_%s_message" % bad] = np.array(msg)
+    for bad, img in (("dtype", np.zeros((2, 2), np.float64)), ("shape", np.zeros((2, 2, 2), np.float32))):
+        try:
+            DIO.save_pfm(os.path.join(tmp, "x.pfm"), img)
+            msg = ""
+        except Exception as e:          # noqa: BLE001
+            msg = str(e)
+        out["pfm_bad_%s_message" % bad] = np.array(msg)
+
+    # --- a synthetic scan: five views of 64 x 128, DTU-like cameras; cam files written by the reference's write_cam
+    scan = "scan_g10"
+    os.makedirs(os.path.join(tmp, scan, "cams"))
+    os.makedirs(os.path.join(tmp, scan, "images"))
+    H, W, nv = 64, 128, 5
+    for v in range(nv):
+        cam = np.zeros((2, 4, 4), dtype=np.float32)
+        ang = 0.05 * v
+        cam[0] = np.eye(4)
+        cam[0, :3, :3] = [[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]]
+        cam[0, :3, 3] = [-60.0 * v + 0.123456789, 3.5 * v, 0.25 * v]
+        cam[1, :3, :3] = [[2892.33 * W / 1600 * 4, 0, W / 2 * 4 + 0.7], [0, 2883.18 * H / 1200 * 4, H / 2 * 4 - 0.3], [0, 0, 1]]
+        cam[1, 3] = [425.0 + v, 2.5, 192, 425.0 + v + 2.5 * 192] if v != 2 else [425.0, 1.25, 0, 0]
+        path = os.path.join(tmp, scan, "cams", "%08d_cam.txt" % v)
+        T["write_cam"](path, cam)
+        out["cam%d_array" % v] = cam
+        out["cam%d_text" % v] = raw(path)
+        K, E = T["read_camera_parameters"](path)
+        out["cam%d_intrinsics" % v] = K
+        out["cam%d_extrinsics" % v] = E
+        yy, xx = np.mgrid[0:H, 0:W]
+        img = np.stack([(xx * 2 + 17 * v) % 256, (yy * 3 + xx) % 256, (yy * xx // 7 + 40 * v) % 256], -1).astype(np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, format="JPEG", quality=95)
+        open(os.path.join(tmp, scan, "images", "%08d.jpg" % v), "wb").write(buf.getvalue())
+        out["img%d_jpeg" % v] = np.frombuffer(buf.getvalue(), dtype=np.uint8)
+    # the two-field depth line (no plane count) some T&T cam files carry
+    path2 = os.path.join(tmp, "two_field_cam.txt")
+    txt = open(os.path.join(tmp, scan, "cams", "00000001_cam.txt")).read().rstrip("\n").rsplit("\n", 1)[0] + "\n0.5 0.0125\n"
+    open(path2, "w").write(txt)
+    out["cam_two_field_text"] = raw(path2)
+    pair_txt = "5\n0\n3 1 0.9 2 0.8 3 0.1\n1\n2 0 1.5 2 0.25\n2\n0\n3\n1 0 1.0\n4\n10 3 2.0 2 1.9 1 1.8 0 1.7 3 1.6 3 1.5 3 1.4 3 1.3 3 1.2 3 1.1\n"
+    open(os.path.join(tmp, scan, "pair.txt"), "w").write(pair_txt)
+    out["pair_text"] = np.frombuffer(pair_txt.encode(), dtype=np.uint8)
+    pairs = T["read_pair_file"](os.path.join(tmp, scan, "pair.txt"))
+    out["pair_refs"] = np.array([r for r, _ in pairs])
+    out["pair_src_counts"] = np.array([len(s) for _, s in pairs])
+    out["pair_srcs_flat"] = np.array([x for _, s in pairs for x in s])
+
+    # --- the reference's evaluation dataset on that scan (general_eval4.py:8-188): metas, per-sample tensors
+    for tag, nviews, interval_scale in (("n3", 3, 1.06), ("n5", 5, {scan: 0.8})):
+        ds = GE.MVSDataset(tmp, [scan], "test", nviews, interval_scale=interval_scale, max_h=H, max_w=W, fix_res=False)
+        out["ds_%s_len" % tag] = np.array(len(ds))
+        out["ds_%s_meta_ref" % tag] = np.array([m[1] for m in ds.metas])
+        out["ds_%s_meta_src_counts" % tag] = np.array([len(m[2]) for m in ds.metas])
+        out["ds_%s_meta_srcs_flat" % tag] = np.array([x for m in ds.metas for x in m[2]])
+        for i in range(len(ds)):
+            smp = ds[i]
+            if i == 0:
+                out["ds_%s_%d_imgs" % (tag, i)] = np.stack(smp["imgs"])
+            for st in ("stage1", "stage2", "stage3", "stage4"):
+                out["ds_%s_%d_%s" % (tag, i, st)] = smp["proj_matrices"][st]
+            out["ds_%s_%d_depth_values" % (tag, i)] = smp["depth_values"]
+            out["ds_%s_%d_filename" % (tag, i)] = np.array(smp["filename"])
+    K4, E4, dmin, itv = ds.read_cam_file(path2, 1.06)
+    out["cam_two_field_read"] = np.array([dmin, itv], dtype=np.float64)
+    out["cam_two_field_intrinsics"] = K4
+    out["ds_dims"] = np.array([H, W, nv])
+    npz("g10_formats", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -377,6 +536,8 @@ def main():
         g8b_loss_continuous(U)
     if want("g9"):
         g9_losses(M)
+    if want("g10"):
+        g10_formats()
 
 
 if __name__ == "__main__":
