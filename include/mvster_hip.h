@@ -134,6 +134,13 @@ int mvster_conv_mfma(const float* in, const float* wpk, const float* scale, cons
 int mvster_conv_small(const float* in, const float* w, const float* scale, const float* shift, const float* skip,
                       float* out, int NB, int H, int W, int cin, int relu, void* stream);
 
+/* The same layers (same arguments, same result up to fp32 summation order) on the fp32 matrix cores: the empty half of
+ * the 16-wide N tile holds the NEXT pixel's outputs (weights shifted by one tap column over a four-column K axis: 24
+ * instead of 36 MFMAs per 32 pixels), persistent workgroups, inputs and the skip tile streamed through an LDS-DMA ring
+ * three tiles ahead (csrc/conv_narrow.hip).  mt: tile rows / 4 (2, 4; 0 = by size); wpc: workgroups per CU (0 = default). */
+int mvster_conv_narrow(const float* in, const float* w, const float* scale, const float* shift, const float* skip,
+                       float* out, int NB, int H, int W, int cin, int relu, int mt, int wpc, void* stream);
+
 /* ConvTranspose3d (1,3,3), stride (1,2,2), padding (0,1,1), output_padding (0,1,1) + BatchNorm scale/shift +
  * ReLU + skip add for (cin, cout) in {(16,8), (32,16)} on the VALU (the layers are HBM-bound).  in [NB,Hi,Wi,cin],
  * w [3,3,cin,cout], skip optional [NB,2Hi,2Wi,cout]; prob_w/prob_b optional (cout == 8): fuse the 1x1x1 head,

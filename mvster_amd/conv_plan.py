@@ -69,6 +69,7 @@ import os as _os
 FUSE_SELECT = not _os.environ.get("MVSTER_NO_FUSE_SELECT")      # reg2d conv11 + prob + selection in one launch (A/B switch)
 LDS_BUDGET = 12 * 256 * 16      # bytes of staged patch the LDS variant accepts (conv_mfma.hip kMaxStage)
 FORCE_VARIANT = None            # None = choose per layer; 0 / 1 pin the kernel variant (experiments, tests)
+NARROW_MIN_VOXELS = 64 * 256    # untuned narrow layers take the MFMA kernel from this many output voxels (one 8 x 32 tile per CU)
 
 
 def _lds_plan(B, Do, Ho, Wo, kernel, stride, ntile_total):
@@ -384,8 +385,18 @@ class ConvLayer:
             tuned = _tuning().get(layer_signature(self, B, Di, Hi, Wi, skip_mode)) if FORCE_VARIANT is None else None
             if tuned:
                 variant, mt, nt = tuned
-            if self.w_small is not None and skip_mode in (SKIP_NONE, SKIP_ADD) and FORCE_VARIANT in (None, 3):
-                variant = 3
+            if self.w_small is not None and skip_mode in (SKIP_NONE, SKIP_ADD) and FORCE_VARIANT in (None, 3, 10):
+                # narrow layers: shift-packed MFMA tiles on the persistent LDS-DMA ring (variant 10, conv_narrow.hip; mt = tile
+                # rows / 4, nt = workgroups per CU, 0 = the kernel's defaults) or the VALU kernel (3) for maps too small to
+                # give every CU a tile
+                if FORCE_VARIANT is not None:
+                    variant, mt, nt = FORCE_VARIANT, 0, 0
+                elif tuned and tuned[0] in (3, 10):
+                    variant, mt, nt = tuned
+                else:
+                    variant, mt, nt = (10, 0, 0) if B * Do * Ho * Wo >= NARROW_MIN_VOXELS else (3, 0, 0)
+                if variant == 10 and not hasattr(_lib.load(), "mvster_conv_narrow"):
+                    variant = 3                     # (an older library loaded through MVSTER_LIB for an A/B run)
             if self.w_deconv is not None and skip_mode in (SKIP_NONE, SKIP_ADD) and FORCE_VARIANT in (None, 4):
                 variant = 4
             g = (np.asarray(arr, dtype=np.int32), mt, nt, (B, DoF, HoF, WoF), variant)
@@ -417,7 +428,7 @@ class ConvLayer:
                 out.data_ptr(), B * Di, Hi, Wi, self.cin, self.cout, int(self.relu), ops._stream())
             _lib.check(rc, "deconv_small")
             return out
-        if self.prob is not None and variant in (1, 3):
+        if self.prob is not None and variant in (1, 3, 10):
             variant = 0
             mt, nt = _tiles(B * geom[4] * geom[5] * geom[6], self.ntile_total, len(self.classes))
         out = torch.empty(oshape + ((self.cout,) if self.prob is None else ()), device=x.device, dtype=torch.float32)
@@ -427,6 +438,15 @@ class ConvLayer:
             want = (oshape + (self.cout,)) if skip_mode == SKIP_ADD else (B, 1, oshape[2] // 2, oshape[3] // 2, self.cout)
             if tuple(skip.shape) != tuple(want):
                 raise RuntimeError("conv_mfma: skip shape %s, expected %s" % (tuple(skip.shape), tuple(want)))
+        if variant == 10:
+            if self.w_small is None or skip_mode == SKIP_UPSAMPLE_ADD:
+                raise RuntimeError("conv_narrow: layer not eligible")
+            rc = _lib.load().mvster_conv_narrow(
+                x.data_ptr(), self.w_small.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                None if skip is None else skip.data_ptr(), out.data_ptr(), B * Di, Hi, Wi, self.cin, int(self.relu),
+                mt if mt in (2, 4) else 0, nt & 31, ops._stream())
+            _lib.check(rc, "conv_narrow")
+            return out
         if variant == 3:
             if self.w_small is None or skip_mode == SKIP_UPSAMPLE_ADD:
                 raise RuntimeError("conv_small: layer not eligible")

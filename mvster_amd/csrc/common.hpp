@@ -35,8 +35,22 @@ extern thread_local const char* mv_last_kernel;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// Cache policy of the persistent kernels' output stores (aux operand of the buffer-store builtins; 16 = sc1 = write-through).
+// A plain store leaves its line dirty in the XCD's L2, and a kernel that writes tens of MB ends with up to 32 MB of dirty
+// lines whose write-back the next kernel's start waits for.  Written through, the data leaves during the kernel: ISOLATED
+// (the same launch back to back) the 8 -> 8 narrow layer at 5 x 512 x 640 runs 26.3 instead of 29.7 us, 4 -> 8 17.3 instead of
+// 19.7 (profiles/r04_a_conv_narrow_writethrough.txt).  INSIDE the forward it is neutral: 1 092 / 1 094 against 1 093 / 1 088
+// depth-maps/s with two depth maps in flight, one forward alone 1.142 against 1.150 ms (same box, alternating runs,
+// profiles/r04_a_bench_writethrough_ab.txt) -- the other depth map's kernels fill the write-back window, and a consumer
+// whose tiles xcd_remap places on the producer's XCD finds the tail of the producer's output in that L2, which a
+// write-through store drops.  Plain stores stay the default; -DMV_STORE_AUX=16 builds the other form.
+#ifndef MV_STORE_AUX
+#define MV_STORE_AUX 0
+#endif
 
 // XCD-aware workgroup order.  MI355X dispatches workgroup b to XCD b % 8 and every XCD has its own 4 MB
 // L2, so spatially adjacent tiles (which share halo rows, source texels and weights) would land on eight

@@ -124,4 +124,11 @@ int dispatch_wino(const ConvArgs& a, int nt, int wpc, bool ring, hipStream_t s);
 // conv_pers.hip: persistent 1x1 kernel with all weights in LDS (variant 6)
 int dispatch_1x1(const ConvArgs& a, int mt, int wpc, hipStream_t s);
 
+// deconv_select.hip: reg2d's last layer + `prob` + the depth selection on MFMA tiles, persistent LDS-DMA ring (D in {4, 8};
+// MVSTER_ERR_UNSUPPORTED otherwise: the VALU kernel of conv_small.hip runs)
+int dispatch_deconv_select_mfma(const float* in, const float* w, const float* scale, const float* shift, const float* skip,
+                                const float* prob_w, const float* prob_b, const float* hypo, float* attn, float* depth,
+                                float* conf, float* inv_min, float* inv_max, float* logits_out, int B, int D, int Hi, int Wi,
+                                int relu, float split_itv, hipStream_t s);
+
 }  // namespace mvconv

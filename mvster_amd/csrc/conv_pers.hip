@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(LD ? 512 : 256) conv_pers_kernel(ConvArgs a, P
                     if (a.relu) v[j] = fmaxf(v[j], 0.0f);
                     if (SKIP) v[j] += skvv[mt][nt][j];
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, off[mt] + nt * 64, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, off[mt] + nt * 64, 0, MV_STORE_AUX);
             }
         }
     };
@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(512) conv_pers8_kernel(ConvArgs a, PersArgs p)
                 if (a.relu) v[j] = fmaxf(v[j], 0.0f);
                 if (SKIP) v[j] += skv[mt][j];
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, ooff[mt], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, ooff[mt], 0, MV_STORE_AUX);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);      // done reading this patch
         __builtin_amdgcn_s_barrier();
@@ -703,7 +703,7 @@ __global__ void __launch_bounds__(512) conv_tpers_kernel(ConvArgs a, PersArgs p)
                     if (a.relu) v[j] = fmaxf(v[j], 0.0f);
                     if (SKIP) v[j] += skv[mt][j];
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, ooff[mt], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, ooff[mt], 0, MV_STORE_AUX);
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);      // done reading this patch
@@ -898,7 +898,7 @@ __global__ void __launch_bounds__(512) conv_pp_kernel(ConvArgs a, PersArgs p) {
                     if (a.relu) v[j] = fmaxf(v[j], 0.0f);
                     if (SKIP) v[j] += skvv[mt][nt][j];
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, off[mt] + nt * 64, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, off[mt] + nt * 64, 0, MV_STORE_AUX);
             }
         }
     };
@@ -1148,7 +1148,7 @@ __global__ void __launch_bounds__(256) conv1x1_pers_kernel(ConvArgs a, unsigned 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = mv::bilerp(up[mt].ly, up[mt].lx, k00[j], k01[j], k10[j], k11[j]) + v[j];
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, off, 0, MV_STORE_AUX);
             }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) Bv[c] = Bn[c];

@@ -7,7 +7,7 @@
 // LDS (zero padding via the buffer range check), and the 9 x Cin x 8 weights are wave-uniform scalar
 // loads -- no padding waste, coalesced 32-byte stores.  fp32 FMA chain in (tap, cin) order.
 // Reference layers: models/mvs4net_utils.py:427-428 (FPN conv0), :875 (reg2d conv0), :459 (out4, composed).
-#include "common.hpp"
+#include "conv_args.hpp"
 
 namespace {
 
@@ -355,6 +355,12 @@ extern "C" int mvster_deconv_select(const float* in, const float* w, const float
     if (cin != 16) return MVSTER_ERR_UNSUPPORTED;
     const long in_elems = (long)B * D * Hi * Wi * cin;
     if (in_elems >= (1L << 30) || (long)B * D * Hi * Wi * 4 * 8 >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    {
+        // D in {4, 8} (the shipped cascade): MFMA tiles on the persistent LDS-DMA ring, same bits (deconv_select.hip)
+        const int rc = mvconv::dispatch_deconv_select_mfma(in, w, scale, shift, skip, prob_w, prob_b, hypo, attn, depth, conf, inv_min,
+                                                           inv_max, logits_out, B, D, Hi, Wi, relu, split_itv, (hipStream_t)stream);
+        if (rc != MVSTER_ERR_UNSUPPORTED) return rc;
+    }
     DeconvArgs a;
     a.in = in; a.w = w; a.scale = scale; a.shift = shift; a.skip = skip; a.prob_w = prob_w; a.prob_b = prob_b;
     a.out = nullptr; a.NB = B * D; a.Hi = Hi; a.Wi = Wi; a.relu = relu; a.in_bytes = (unsigned)(in_elems * 4);

@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256) conv_wino_kernel(ConvArgs a, PersArgs p) 
                         v[e] = fmaxf(fmaf(v[e], scv[nt][e], shv[nt][e]), floor_v);
                         if (SKIP) v[e] += skv[i][j][nt][e];
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, ooff[i][j] + nt * 64, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, ooff[i][j] + nt * 64, 0, MV_STORE_AUX);
                 }
             }
         }
@@ -768,7 +768,7 @@ __global__ void __launch_bounds__(512) conv_wino_ring_kernel(ConvArgs a, PersArg
                                 v[e] = fmaxf(fmaf(v[e], scv[nt][e], shv[nt][e]), floor_v);
                                 if (SKIP) v[e] += skv[i][j][nt][e];
                             }
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, ooff[i][j] + nt * 64, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, ooff[i][j] + nt * 64, 0, MV_STORE_AUX);
                         }
                     }
                 }

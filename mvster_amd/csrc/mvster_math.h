@@ -411,8 +411,9 @@ constexpr int kSelMaxD = 16;
 // (mvs4net_utils.py:900, :1068-1088).  All pointers are one batch item's; plane stride = hw.
 // feat: [D, hw, CF] channels-last or null (then logits [D, hw] is read).
 // softmax over D + first-max argmax + gather + inverse bounds from the D logits of one pixel (lg is overwritten)
-MV_HD void select_from_logits(float (&lg)[kSelMaxD], const float* hypo, float* attn, float* depth, float* conf,
-                              float* inv_min, float* inv_max, int D, long hw, long p, float split_itv) {
+// (hv = the pixel's D hypotheses, already in registers: the persistent kernel fetches them ahead of its MFMA phase)
+MV_HD void select_from_logits_vals(float (&lg)[kSelMaxD], const float (&hv)[kSelMaxD], float* attn, float* depth, float* conf,
+                                   float* inv_min, float* inv_max, int D, long hw, long p, float split_itv) {
     float mx = -INFINITY;
 #pragma unroll
     for (int d = 0; d < kSelMaxD; ++d) {
@@ -433,7 +434,7 @@ MV_HD void select_from_logits(float (&lg)[kSelMaxD], const float* hypo, float* a
         const long o = d * hw + p;
         const float pr = div_rn(lg[d], den);
         attn[o] = pr;
-        const float hd = hypo[o];
+        const float hd = hv[d];
         if (d == 1) h1 = hd;
         if (d == 2) h2 = hd;
         if (pr > best) { best = pr; hb = hd; }  // strict '>' : the first maximum wins ties (ATen max)
@@ -447,6 +448,17 @@ MV_HD void select_from_logits(float (&lg)[kSelMaxD], const float* hypo, float* a
         inv_min[p] = add_rn(inv_d, delta);
         inv_max[p] = sub_rn(inv_d, delta);
     }
+}
+
+MV_HD void select_from_logits(float (&lg)[kSelMaxD], const float* hypo, float* attn, float* depth, float* conf,
+                              float* inv_min, float* inv_max, int D, long hw, long p, float split_itv) {
+    float hv[kSelMaxD];
+#pragma unroll
+    for (int d = 0; d < kSelMaxD; ++d) {
+        if (d >= D) break;
+        hv[d] = hypo[d * hw + p];
+    }
+    select_from_logits_vals(lg, hv, attn, depth, conf, inv_min, inv_max, D, hw, p, split_itv);
 }
 
 MV_HD void select_pixel(const float* logits, const float* feat, const float* prob_w, const float* prob_b, int CF,

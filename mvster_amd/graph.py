@@ -9,14 +9,55 @@ launched on the capturing stream, so they are recorded like any other node) and 
 import torch
 
 
+def _sample_layout(imgs, proj_matrices, depth_values):
+    """Element offsets of a sample's tensors inside one flat fp32 buffer (each segment 256-byte aligned)."""
+    segs, off = [], 0
+    for name, t in ([("img%d" % i, t) for i, t in enumerate(imgs)] + [("proj_" + k, proj_matrices[k]) for k in sorted(proj_matrices)]
+                    + [("depth_values", depth_values)]):
+        segs.append((name, off, tuple(t.shape)))
+        off += (t.numel() + 63) // 64 * 64
+    return segs, off
+
+
+def pack_sample(imgs, proj_matrices, depth_values, pin=True):
+    """One flat (pinned) host buffer holding a sample in the layout of ``GraphedForward(..., packed=True).flat``:
+    a whole sample then moves host -> device as ONE copy (``load_packed``) instead of one per tensor."""
+    segs, total = _sample_layout(imgs, proj_matrices, depth_values)
+    flat = torch.zeros(total, dtype=torch.float32)
+    if pin:
+        flat = flat.pin_memory()
+    src = {("img%d" % i): t for i, t in enumerate(imgs)}
+    src.update({"proj_" + k: v for k, v in proj_matrices.items()})
+    src["depth_values"] = depth_values
+    for name, off, shape in segs:
+        flat[off:off + src[name].numel()].copy_(src[name].reshape(-1).float().cpu())
+    return flat
+
+
 class GraphedForward:
-    def __init__(self, model, imgs, proj_matrices, depth_values, warmup=2):
+    def __init__(self, model, imgs, proj_matrices, depth_values, warmup=2, packed=False):
+        """``packed=True``: the static inputs are views of ONE flat device buffer (``self.flat``, layout of
+        ``pack_sample``), so that a new sample arrives with a single host -> device copy (``load_packed``)."""
         if model.training:
             raise RuntimeError("GraphedForward captures the eval forward")
         self.model = model
-        self.imgs = [i.clone() for i in imgs]
-        self.proj = {k: v.clone() for k, v in proj_matrices.items()}
-        self.depth_values = depth_values.clone()
+        self.flat = None
+        if packed:
+            segs, total = _sample_layout(imgs, proj_matrices, depth_values)
+            self.flat = torch.zeros(total, dtype=torch.float32, device=depth_values.device)
+            views = {name: self.flat[off:off + int(torch.tensor(shape).prod())].view(shape) for name, off, shape in segs}
+            self.imgs = [views["img%d" % i] for i in range(len(imgs))]
+            self.proj = {k: views["proj_" + k] for k in proj_matrices}
+            self.depth_values = views["depth_values"]
+            for dst, src_ in zip(self.imgs, imgs):
+                dst.copy_(src_)
+            for k in self.proj:
+                self.proj[k].copy_(proj_matrices[k])
+            self.depth_values.copy_(depth_values)
+        else:
+            self.imgs = [i.clone() for i in imgs]
+            self.proj = {k: v.clone() for k, v in proj_matrices.items()}
+            self.depth_values = depth_values.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -27,6 +68,12 @@ class GraphedForward:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outputs = model(self.imgs, self.proj, self.depth_values)
+
+    def load_packed(self, host_flat):
+        """Queue ONE non-blocking copy of a ``pack_sample`` buffer into the static inputs (current stream)."""
+        if self.flat is None:
+            raise RuntimeError("GraphedForward.load_packed: build the graph with packed=True")
+        self.flat.copy_(host_flat, non_blocking=True)
 
     def __call__(self, imgs=None, proj_matrices=None, depth_values=None):
         """Copy new inputs (same shapes) into the static buffers and replay; returns the static

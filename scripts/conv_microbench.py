@@ -43,6 +43,9 @@ def timeit(fn, n=20):
 def candidates(layer, B, Di, Hi, Wi, sm):
     """Every (variant, mt, nt) the kernels support for this layer."""
     out = []
+    if layer.w_small is not None and sm in (0, 1):
+        # narrow layers: the VALU kernel or the shift-packed MFMA kernel (mt = tile rows / 4, nt = workgroups per CU)
+        return [("V", (0, 0, 3))] + [("N%d w%d" % (m, w), (m, w, 10)) for m in (2, 4) for w in (1, 2)]
     nts = [n for n in (1, 2, 3, 4, 5, 9) if n <= layer.ntile_total and layer.ntile_total % n == 0]
     for m in (1, 2, 4):
         for n in nts:

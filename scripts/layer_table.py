@@ -32,7 +32,7 @@ cp.ConvLayer.__call__ = rec
 model(imgs, proj, dv)
 cp.ConvLayer.__call__ = orig
 torch.cuda.synchronize()
-names = {0: "direct", 1: "lds", 2: "splitk", 3: "small", 4: "deconv_small", 5: "persistent", 6: "persistent1x1", 7: "pingpong", 8: "winograd", 9: "winograd-ring"}
+names = {0: "direct", 1: "lds", 2: "splitk", 3: "small", 4: "deconv_small", 5: "persistent", 6: "persistent1x1", 7: "pingpong", 8: "winograd", 9: "winograd-ring", 10: "narrow-mfma"}
 total = 0.0
 for i, (layer, xs, ss, sm) in enumerate(calls):
     x = torch.randn(*xs, device=dev)

@@ -198,11 +198,14 @@ def test_warp_agg_kernel_variants_bit_identical(C, G, D, fuse):
 
 
 @pytest.mark.parametrize("D,inverse,G,shape", [(4, True, 4, (1, 37, 53)), (8, True, 8, (2, 16, 24)), (4, False, 4, (1, 64, 80)),
-                                               (3, True, 4, (1, 9, 70)), (16, True, 8, (1, 10, 12)), (2, False, 4, (1, 6, 6))])
+                                               (3, True, 4, (1, 9, 70)), (16, True, 8, (1, 10, 12)), (2, False, 4, (1, 6, 6)),
+                                               (4, True, 4, (2, 72, 200)), (8, True, 8, (1, 40, 136)), (4, True, 4, (1, 256, 320))])
 def test_fused_conv11_selection_bit_identical(D, inverse, G, shape):
     """Reg2dPlan.select: reg2d's last layer + prob head + softmax / argmax / gather / bounds in one launch
     (mvster_deconv_select) against the two launches (deconv_small with the fused prob head, then select_depth): every
-    output equal, incl. the optional logits, odd sizes and every D the selection kernel takes."""
+    output equal, incl. the optional logits, odd sizes and every D the selection kernel takes.  D = 4 and 8 (the shipped
+    cascade) run the MFMA form on the persistent LDS-DMA ring (deconv_select.hip: two- and four-row tiles, ragged tiles,
+    several tiles per workgroup, B = 2), whose K order reproduces the VALU kernel's FMA chain: the same bits."""
     torch.manual_seed(D * 7 + G)
     m = M.reg2d(input_channel=G, base_channel=8)
     m.load_state_dict(randomize_state(m.state_dict(), seed=3, prob_gain=8.0))
@@ -218,7 +221,7 @@ def test_fused_conv11_selection_bit_identical(D, inverse, G, shape):
         cp.FUSE_SELECT = True
     got = plan.select(x, hypo, 0.5, inverse, want_logits=True)
     from mvster_amd import _lib
-    assert _lib.last_kernel() == "deconv_select_kernel<16>"
+    assert _lib.last_kernel().startswith("deconv_select_mfma_kernel<%d, " % D if D in (4, 8) else "deconv_select_kernel<16>")
     assert set(got) == set(want)
     for k in want:
         assert torch.equal(got[k], want[k]), (k, (got[k] - want[k]).abs().max().item())
@@ -313,6 +316,40 @@ CONV_CASES = [
     ("c2d_55s2_16_32", dict(cin=16, cout=32, k=(1, 5, 5), s=(1, 2, 2), p=(0, 2, 2)), (3, 16, 1, 44, 70)),
     ("c2d_33_64_8", dict(cin=64, cout=8, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1)), (2, 64, 1, 21, 45)),
 ]
+
+
+@pytest.mark.parametrize("cin", [4, 8])
+@pytest.mark.parametrize("shape", [(1, 1, 8, 32), (2, 3, 21, 45), (1, 4, 37, 130), (5, 1, 64, 96), (1, 2, 5, 7), (1, 8, 64, 80)])
+def test_narrow_mfma_conv_against_fp64_and_valu(cin, shape):
+    """Shift-packed MFMA form of the narrow 3x3 layers (variant 10, conv_narrow.hip) against an fp64 convolution and the VALU
+    kernel (variant 3): both tile heights, one and two workgroups per CU, ReLU on / off, with and without the skip tensor,
+    ragged tiles, maps narrower than a tile, several tiles per workgroup."""
+    from mvster_amd import _lib
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(cin * 100 + H)
+    w = torch.randn(8, cin, 1, 3, 3, generator=g) * 0.2
+    x = torch.randn(B, D, H, W, cin, generator=g).to(DEV)
+    skip = torch.randn(B, D, H, W, 8, generator=g).to(DEV)
+    worst = 0.0
+    for relu in (True, False):
+        layer = cp.ConvLayer(w.to(DEV), False, (1, 1, 1), (0, 1, 1), bias=torch.randn(8, generator=g).to(DEV), relu=relu, cin_pad=cin)
+        ref0 = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3).double().cpu(), w.double(), padding=(0, 1, 1))
+        ref0 = ref0 * layer.scale[:8].double().cpu().view(1, 8, 1, 1, 1) + layer.shift[:8].double().cpu().view(1, 8, 1, 1, 1)
+        ref0 = (ref0.clamp_min(0) if relu else ref0).permute(0, 2, 3, 4, 1)
+        for sk in (None, skip):
+            ref = ref0 if sk is None else ref0 + sk.double().cpu()
+            sm = cp.SKIP_NONE if sk is None else cp.SKIP_ADD
+            valu = layer(x, skip=sk, skip_mode=sm, tiles=(0, 0, 3))
+            scale = ref.abs().max().item()
+            for mt in (2, 4):
+                for wpc in (1, 2):
+                    got = layer(x, skip=sk, skip_mode=sm, tiles=(mt, wpc, 10))
+                    assert _lib.last_kernel().startswith("conv_narrow_kernel<%d, %d, " % (cin, mt)), _lib.last_kernel()
+                    e = (got.double().cpu() - ref).abs().max().item() / scale
+                    ev = (got - valu).abs().max().item() / scale
+                    worst = max(worst, e)
+                    assert e < 2e-6 and ev < 2e-6, (cin, shape, relu, sk is not None, mt, wpc, e, ev)
+    note("conv_narrow_mfma_%d_%s" % (cin, "x".join(map(str, shape))), err_over_max=worst)
 
 
 @pytest.mark.parametrize("name,cfg,shape", CONV_CASES)
