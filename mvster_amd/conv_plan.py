@@ -490,6 +490,32 @@ def _up3d(seq, prob=None):
     return ConvLayer(ct.weight, True, ct.stride, ct.padding, bn=bn, relu=True, prob=prob)
 
 
+def fused_conv11_select(L, t, c0, hypo, split_itv, inverse_depth, want_logits=False):
+    """reg2d's conv11 (+ BatchNorm, ReLU, skip c0) + `prob` + softmax / argmax / gather / bounds in one launch
+    (mvster_deconv_select): t [B,D,hi,wi,16], c0 [B,D,2hi,2wi,8], hypo [B,D,2hi,2wi] -> the stage's selection dict."""
+    B, D, hi, wi, _ = t.shape
+    dev = t.device
+    hypo = hypo.contiguous()
+    attn = torch.empty(B, D, 2 * hi, 2 * wi, device=dev, dtype=torch.float32)
+    depth = torch.empty(B, 2 * hi, 2 * wi, device=dev, dtype=torch.float32)
+    conf = torch.empty_like(depth)
+    imin = torch.empty_like(depth) if inverse_depth else None
+    imax = torch.empty_like(depth) if inverse_depth else None
+    lo = torch.empty_like(attn) if want_logits else None
+    rc = _lib.load().mvster_deconv_select(
+        t.data_ptr(), L.w_deconv.data_ptr(), L.scale.data_ptr(), L.shift.data_ptr(), c0.data_ptr(),
+        L.prob[0].data_ptr(), L.prob[1].data_ptr(), hypo.data_ptr(), attn.data_ptr(), depth.data_ptr(), conf.data_ptr(),
+        None if imin is None else imin.data_ptr(), None if imax is None else imax.data_ptr(),
+        None if lo is None else lo.data_ptr(), B, D, hi, wi, L.cin, int(L.relu), float(split_itv), ops._stream())
+    _lib.check(rc, "deconv_select")
+    out = {"attn_weight": attn, "depth": depth, "conf": conf}
+    if inverse_depth:
+        out["inverse_min_depth"], out["inverse_max_depth"] = imin, imax
+    if want_logits:
+        out["logits"] = lo
+    return out
+
+
 class Reg2dPlan:
     """reg2d U-Net (models/mvs4net_utils.py:870-912) on channels-last volumes; the 1x1x1 ``prob``
     head is left to the selection kernel (fused with the softmax)."""
@@ -534,26 +560,7 @@ class Reg2dPlan:
         B, D, hi, wi, _ = t.shape
         if (FUSE_SELECT and L.w_deconv is not None and L.prob is not None and L.cin == 16 and FORCE_VARIANT in (None, 4)
                 and 2 <= D <= 16 and t.is_contiguous() and c0.is_contiguous()):
-            dev = t.device
-            hypo = hypo.contiguous()
-            attn = torch.empty(B, D, 2 * hi, 2 * wi, device=dev, dtype=torch.float32)
-            depth = torch.empty(B, 2 * hi, 2 * wi, device=dev, dtype=torch.float32)
-            conf = torch.empty_like(depth)
-            imin = torch.empty_like(depth) if inverse_depth else None
-            imax = torch.empty_like(depth) if inverse_depth else None
-            lo = torch.empty_like(attn) if want_logits else None
-            rc = _lib.load().mvster_deconv_select(
-                t.data_ptr(), L.w_deconv.data_ptr(), L.scale.data_ptr(), L.shift.data_ptr(), c0.data_ptr(),
-                L.prob[0].data_ptr(), L.prob[1].data_ptr(), hypo.data_ptr(), attn.data_ptr(), depth.data_ptr(), conf.data_ptr(),
-                None if imin is None else imin.data_ptr(), None if imax is None else imax.data_ptr(),
-                None if lo is None else lo.data_ptr(), B, D, hi, wi, L.cin, int(L.relu), float(split_itv), ops._stream())
-            _lib.check(rc, "deconv_select")
-            out = {"attn_weight": attn, "depth": depth, "conf": conf}
-            if inverse_depth:
-                out["inverse_min_depth"], out["inverse_max_depth"] = imin, imax
-            if want_logits:
-                out["logits"] = lo
-            return out
+            return fused_conv11_select(L, t, c0, hypo, split_itv, inverse_depth, want_logits)
         res = self.conv11(t, skip=c0, skip_mode=SKIP_ADD)
         if self.fused_prob:
             return ops.select_depth(hypo, split_itv, inverse_depth, feat_cl=res, prob_w=self.prob_w, prob_b=self.prob_b,

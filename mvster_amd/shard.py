@@ -46,6 +46,39 @@ def shard_scans(scans, views_per_scan, rank, world):
     return [units[i] for i in shard_units(len(units), rank, world)]
 
 
+def parse_cpulist(text):
+    """'0-3,8,10-11' (sysfs cpulist) -> [0, 1, 2, 3, 8, 10, 11]."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa(device_index, sysfs="/sys"):
+    """Restrict this process to the cores of the NUMA node its GPU hangs off (one process per GPU: launches and pinned
+    copies then never cross the socket interconnect).  Best effort: returns the node, or None when the topology cannot be
+    read (no sysfs entry, single-node host, node -1) -- in which case nothing is changed."""
+    try:
+        prop = torch.cuda.get_device_properties(device_index)
+        addr = "%04x:%02x:%02x.0" % (prop.pci_domain_id, prop.pci_bus_id, prop.pci_device_id)
+        with open(os.path.join(sysfs, "bus/pci/devices", addr, "numa_node")) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)) as f:
+            cpus = parse_cpulist(f.read())
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return node
+    except (OSError, ValueError, AttributeError, RuntimeError, AssertionError):
+        return None
+
+
 def max_over_ranks(value, device=None):
     """MAX all-reduce of a python float (timing protocol of bench.py)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

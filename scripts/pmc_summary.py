@@ -37,7 +37,7 @@ if len(sys.argv) > 3:
     mine = {k: round(m["hbm_bytes_per_launch"]) for k, m in out.items()
             if "hbm_bytes_per_launch" in m and k.split("<")[0] in (
                 "conv_lds_kernel", "conv_mfma_kernel", "conv_pers_kernel", "conv_pers8_kernel", "conv_tpers_kernel", "conv1x1_pers_kernel", "conv_wino_kernel", "conv_wino_ring_kernel",
-                "conv_small_kernel", "deconv_small_kernel", "deconv_select_kernel",
+                "conv_small_kernel", "conv_narrow_kernel", "deconv_small_kernel", "deconv_select_kernel", "deconv_select_mfma_kernel",
                 "warp_agg_fwd_kernel", "warp_agg_fwd_lanes_kernel", "warp_agg_fwd_wave_kernel",
                 "warp_agg_fwd_pix_kernel", "fpn_tail_gather_lds_kernel")}
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -35,6 +35,17 @@ def test_train_mode_protocol_two_ranks():
     assert line["value"] > 0
 
 
+def test_four_ranks_train_protocol():
+    """Four gloo ranks through the training protocol (bucketed all-reduce): every rank reports, the windows are timed on all
+    of them (fastest / slowest rank of the reported window in the line), parameters agree afterwards."""
+    line = _run(["--gpus", "4", "--mode", "train"])
+    assert line["n_gpus"] == 4 and line["ranks_seen"] == 4 and abs(line["param_digest_spread"]) <= 1e-9
+    t = line["timing"]
+    assert t["windows"] >= 3 and t["windows"] % 2 == 1 and len(t["window_ms"]) == t["windows"] and t["steps_per_window"] == 5
+    assert 0 < t["rank_ms_per_step_min"] <= t["rank_ms_per_step_max"]
+    assert abs(line["ms_per_step"] * 5 - sorted(t["window_ms"])[t["windows"] // 2]) < 1e-2        # the median window is the one reported
+
+
 def test_single_rank_needs_no_launcher():
     line = _run(["--gpus", "1"])
     assert line["n_gpus"] == 1 and line["ranks_seen"] == 1

@@ -155,3 +155,12 @@ def test_grad_bucket_single_process_is_a_pack():
     lin[1](torch.randn(5, 3)).sum().backward()
     b.sync()
     assert lin[0].weight.grad.abs().max() == 0 and lin[1].weight.grad.abs().max() > 0
+
+
+def test_cpulist_parser_and_numa_pin_is_best_effort(tmp_path):
+    from mvster_amd import shard
+    assert shard.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert shard.parse_cpulist("5") == [5] and shard.parse_cpulist("") == []
+    before = os.sched_getaffinity(0)
+    assert shard.pin_to_gpu_numa(0, sysfs=str(tmp_path)) is None           # no GPU / no sysfs entry: nothing changes
+    assert os.sched_getaffinity(0) == before
