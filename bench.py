@@ -447,7 +447,7 @@ def train_measure(args, rank, local_rank, world, steps, warmup, min_total_s=0.5)
         return MVS4net_loss(o, g_, m_, stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10, ot_eps=1,
                             ot_continous=False, mono=True)
 
-    bucket = shard.GradBucket(params) if world > 1 or os.environ.get("MVSTER_FORCE_BUCKET") else None
+    bucket = shard.GradBucket(params) if world > 1 else None
     opt = torch.optim.Adam(params, lr=1e-4, capturable=not args.no_graph, fused=True)
     if args.no_graph:
         def step():
@@ -553,6 +553,8 @@ def main():
                     help="skip the second instrumented pass (warp kernels on smooth depth maps: rooflines_warp_smooth_depth)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the few graph replays of the 1152x1600x5 and 1024x1920x7 workloads (other_configs)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="profiling passes: the fine FPN levels on the main stream too (no co-running kernels)")
     ap.add_argument("--no-train", action="store_true",
                     help="eval mode, N = 1: skip the embedded training measurement (line['train']: ten captured steps of config 4)")
     ap.add_argument("--mode", choices=("eval", "train"), default="eval",
@@ -587,9 +589,7 @@ def main():
     model = MVS4net(**SHIPPED)
     model.load_state_dict(load_weights(), strict=True)
     model.to(dev).eval()
-    if os.environ.get("MVSTER_WARP_VARIANT"):
-        model.warp_variant = int(os.environ["MVSTER_WARP_VARIANT"])
-    if os.environ.get("MVSTER_NO_OVERLAP"):
+    if args.no_overlap:
         model.overlap_streams = False      # profiling passes: one stream, no co-running kernels
     # every rank works on its own depth maps: disjoint seeds = disjoint units of the shard
     units = shard.shard_units(world * (args.steps + args.warmup), rank, world)

@@ -308,6 +308,11 @@ int mvster_gather_batch(const void* descs, int ndesc, int total_blocks, void* st
  * with it; there is no reference counterpart -- the reference's dispatch lives inside cuDNN.) */
 const char* mvster_last_kernel(void);
 
+/* Build flags of the loaded library: bit 0 = probe build (make -C mvster_amd/csrc probes).  The product library (0) reads no
+ * environment variable and returns MVSTER_ERR_UNSUPPORTED for the kernel forms kept for the record only: warp variants 4
+ * (pixel-major) and 5 (LDS-staged source windows), convolution variant 7 (ping-pong). */
+int mvster_build_flags(void);
+
 /* One v_mfma_f32_16x16x4_f32: A [16,4], B [4,16] -> D [16,16] (row major).  Test hook that pins the
  * fragment layout the convolution kernels assume. */
 int mvster_mfma_probe(const float* A, const float* B, float* D, void* stream);

@@ -58,6 +58,7 @@ SIGNATURES = {
     "mvster_mfma_probe": [_f, _f, _f, _f],
     "mvster_gather_batch": [_f, _i, _i, _f],
     "mvster_last_kernel": [],
+    "mvster_build_flags": [],
 }
 RESTYPES = {"mvster_last_kernel": ctypes.c_char_p}     # everything else returns an int status
 
@@ -87,6 +88,12 @@ def load():
 def check(rc, what):
     if rc != 0:
         raise RuntimeError("%s failed: %s (code %d)" % (what, ERRORS.get(rc, "unknown error"), rc))
+
+
+def has_probes():
+    """True when the loaded library is the probe build (experiment switches, kernel forms kept for the record)."""
+    lib = load()
+    return hasattr(lib, "mvster_build_flags") and bool(lib.mvster_build_flags() & 1)
 
 
 def last_kernel():

@@ -65,8 +65,54 @@ def layer_signature(layer, B, Di, Hi, Wi, skip_mode):
         "T" if layer.transposed else "C", layer.cin, layer.cout, *layer.kernel, *layer.stride, B, Di, Hi, Wi, skip_mode)
 
 
+# The measured table is keyed on exact shapes; any other resolution used to fall straight to the heuristics.  Its choices
+# are a function of the layer FAMILY (channels, kernel, stride, skip mode) and of the map's size far more than of the exact
+# shape (217 of its 238 (family, log2 voxels) buckets hold one choice), so an unknown shape takes the choice of the family's
+# entry nearest in log2(B * Di * Hi * Wi) -- within FAMILY_REACH octaves -- before the heuristics; exact entries override.
+FAMILY_REACH = 1.6
+_FAMILIES = None
+_SIG = None
+
+
+def _families():
+    global _FAMILIES, _SIG
+    if _FAMILIES is None:
+        import math
+        import re
+        _SIG = re.compile(r"^([CT]\d+-\d+_k\dx\dx\d_s\dx\dx\d)_(\d+)x(\d+)x(\d+)x(\d+)_sk([012])$")
+        fam = {}
+        for sig, val in _tuning().items():
+            m = _SIG.match(sig)
+            if not m:
+                continue
+            vox = 1
+            for i in (2, 3, 4, 5):
+                vox *= int(m.group(i))
+            fam.setdefault((m.group(1), int(m.group(6))), []).append((math.log2(vox), list(val)))
+        for lst in fam.values():
+            lst.sort(key=lambda e: e[0])
+        _FAMILIES = fam
+    return _FAMILIES
+
+
+def tuned_choice(layer, B, Di, Hi, Wi, skip_mode):
+    """([variant word, mt, nt], "exact" | "family") from the measured table, or (None, None)."""
+    import math
+    sig = layer_signature(layer, B, Di, Hi, Wi, skip_mode)
+    hit = _tuning().get(sig)
+    if hit:
+        return hit, "exact"
+    lst = _families().get((sig[:sig.index("_", sig.index("_s") + 1)], skip_mode))
+    if lst:
+        lv = math.log2(max(1, B * Di * Hi * Wi))
+        d, val = min((abs(l - lv), v) for l, v in lst)
+        if d <= FAMILY_REACH:
+            return list(val), "family"
+    return None, None
+
+
 import os as _os
-FUSE_SELECT = not _os.environ.get("MVSTER_NO_FUSE_SELECT")      # reg2d conv11 + prob + selection in one launch (A/B switch)
+FUSE_SELECT = True              # reg2d conv11 + prob + selection in one launch (tests set it to False for the two-launch form)
 LDS_BUDGET = 12 * 256 * 16      # bytes of staged patch the LDS variant accepts (conv_mfma.hip kMaxStage)
 FORCE_VARIANT = None            # None = choose per layer; 0 / 1 pin the kernel variant (experiments, tests)
 NARROW_MIN_VOXELS = 64 * 256    # untuned narrow layers take the MFMA kernel from this many output voxels (one 8 x 32 tile per CU)
@@ -90,6 +136,14 @@ def _lds_plan(B, Do, Ho, Wo, kernel, stride, ntile_total):
     return None
 
 
+# (mode, cin / 16, kd) instances of conv_wino_ring_kernel (dispatch_wino, conv_wino.hip): mode 0 = one N tile, waves 4-7 load;
+# 1 = the two halves of the workgroup compute one N tile each; 2 = the compute waves hold both N tiles, waves 4-7 load
+WINO_RING_INSTANCES = {(0, 1, 3), (0, 2, 3), (1, 2, 3), (2, 2, 3), (0, 4, 3), (1, 4, 3), (2, 4, 3),
+                       (0, 4, 1), (1, 4, 1), (2, 4, 1), (0, 2, 1), (1, 2, 1), (2, 2, 1), (0, 1, 1), (2, 1, 1)}
+# (nt, cin / 16) instances of conv_wino_kernel (1 x 3 x 3 only)
+WINO_INSTANCES = {(1, 1), (2, 1), (2, 2), (1, 2)}
+
+
 def _wino_plan(layer, B, Do, Ho, Wo):
     """(variant, mt, nt) of the Winograd kernel for an eligible layer, or None when the map is too small to fill the chip
     with 8 x 32 tiles (the split-K / direct kernels are faster there: scripts/conv_wino_check.py)."""
@@ -101,7 +155,9 @@ def _wino_plan(layer, B, Do, Ho, Wo):
             return 8 | (1 << 8), 2, nt
         return None
     nt = 2 if (layer.ntile_total % 2 == 0 and tiles * (layer.ntile_total // 2) >= 224) else 1
-    if tiles * (layer.ntile_total // nt) >= 160:
+    if (1, layer.cin // 16, kd) not in WINO_RING_INSTANCES:
+        nt = 1                          # (16 input channels: the ring kernel has its one-N-tile form only)
+    if tiles * (layer.ntile_total // nt) >= 160 and (0 if nt == 1 else 1, layer.cin // 16, kd) in WINO_RING_INSTANCES:
         return 9, 2, nt
     return None
 
@@ -382,7 +438,7 @@ class ConvLayer:
                 wv = _wino_plan(self, B, Do, Ho, Wo)
                 if wv is not None:
                     variant, mt, nt = wv
-            tuned = _tuning().get(layer_signature(self, B, Di, Hi, Wi, skip_mode)) if FORCE_VARIANT is None else None
+            tuned = tuned_choice(self, B, Di, Hi, Wi, skip_mode)[0] if FORCE_VARIANT is None else None
             if tuned:
                 variant, mt, nt = tuned
             if self.w_small is not None and skip_mode in (SKIP_NONE, SKIP_ADD) and FORCE_VARIANT in (None, 3, 10):
@@ -467,6 +523,15 @@ class ConvLayer:
             None if self.prob is None else self.prob[0].data_ptr(), None if self.prob is None else self.prob[1].data_ptr(),
             out.data_ptr(), geom.ctypes.data_as(ctypes.c_void_p), int(geom.size), self.woff.ctypes.data_as(ctypes.c_void_p), self.cin,
             mt, nt, variant, ops._stream())
+        if rc == -3 and tiles is None and variant != 0:
+            # a heuristic (or stale table) choice the library has no instance for: the direct kernel takes every layer
+            mt, nt = _tiles(B * geom[4] * geom[5] * geom[6], self.ntile_total, len(self.classes))
+            rc = _lib.load().mvster_conv_mfma(
+                x.data_ptr(), self.wpk.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                None if skip is None else skip.data_ptr(), self.zeros.data_ptr(),
+                None if self.prob is None else self.prob[0].data_ptr(), None if self.prob is None else self.prob[1].data_ptr(),
+                out.data_ptr(), geom.ctypes.data_as(ctypes.c_void_p), int(geom.size), self.woff.ctypes.data_as(ctypes.c_void_p),
+                self.cin, mt, nt, 0, ops._stream())
         _lib.check(rc, "conv_mfma")
         return out
 

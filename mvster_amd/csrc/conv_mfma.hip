@@ -358,7 +358,7 @@ struct LdsDivs {
 };
 constexpr int kMaxStage = 12;   // float4 loads per thread per chunk (patch <= 48 KB)
 __device__ __forceinline__ int patch_plane(int npix) { return ((npix * 2 + 7) & ~7) + 4; }   // float4 units, = 4 mod 8
-static const bool g_no_wlds = getenv("MVSTER_NO_WLDS") != nullptr;   // experiment switch: weights from L1 again
+static const bool g_no_wlds = MV_PROBE_ENV("MVSTER_NO_WLDS") != nullptr;   // experiment switch: weights from L1 again
 
 // WN > 0: the chunk's weights are staged in LDS too, WN float4 per thread (taps * NT * 64 <= WN * 256).
 // Used with WN = 3 (2-D 3x3, NT = 1); WN = 7 (3x3x3, 28 KB) was measured slower: it costs a workgroup of occupancy.

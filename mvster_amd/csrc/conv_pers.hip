@@ -711,6 +711,7 @@ __global__ void __launch_bounds__(512) conv_tpers_kernel(ConvArgs a, PersArgs p)
     }
 }
 
+#ifdef MVSTER_PROBES   // ping-pong form (variant 7): probe build only
 // ------------------------------------------------------------------------------------------------------------------
 // Ping-pong form of the persistent kernel (variant 7): a workgroup of EIGHT waves, two per SIMD.  The model fitted to
 // conv_pers_kernel's measurements says its steady state is 58-61 % MFMA-busy because a wavefront's
@@ -1020,6 +1021,7 @@ __global__ void __launch_bounds__(512) conv_pp_kernel(ConvArgs a, PersArgs p) {
         __builtin_amdgcn_s_barrier();
     }
 }
+#endif  // MVSTER_PROBES
 
 // ------------------------------------------------------------------------------------------------------------------
 // 1x1 convolutions with many output channels (variant 6): the 64 -> 144 / 64 -> 72 "tap" convolutions of the
@@ -1248,6 +1250,7 @@ int launch_pers8(const ConvArgs& a, int wpc, hipStream_t s) {
     return mv_check_launch();
 }
 
+#ifdef MVSTER_PROBES
 template <int MT, int NT, int KW, int SW, int NCH, int KD, bool WREG, int PF, bool SKIP>
 int launch_pp(const ConvArgs& a, hipStream_t s) {
     using G = PersGeom<MT, KW, SW, KD>;
@@ -1275,6 +1278,7 @@ int launch_pp(const ConvArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, ny, 1), dim3(512), lds, s, a, p);
     return mv_check_launch();
 }
+#endif  // MVSTER_PROBES
 
 }  // namespace
 
@@ -1338,6 +1342,10 @@ int dispatch_1x1(const ConvArgs& a, int mt, int wpc, hipStream_t s) {
     return MVSTER_ERR_UNSUPPORTED;
 }
 
+// variant 7: the ping-pong form (probe build only: measured no faster than variant 5)
+#ifndef MVSTER_PROBES
+int dispatch_pp(const ConvArgs&, int, int, hipStream_t) { return MVSTER_ERR_UNSUPPORTED; }
+#else
 // variant 7: the ping-pong form; the instances whose four patch buffers (+ resident weights) fit 160 KB of LDS
 int dispatch_pp(const ConvArgs& a, int mt, int nt, hipStream_t s) {
     if (a.nclass != 1 || a.osd != 1 || a.osh != 1 || a.osw != 1 || a.skip_mode > 1 || a.prob_w || a.cout % 16 != 0 ||
@@ -1354,6 +1362,7 @@ int dispatch_pp(const ConvArgs& a, int mt, int nt, hipStream_t s) {
 #undef MV_PP
     return MVSTER_ERR_UNSUPPORTED;
 }
+#endif  // MVSTER_PROBES
 
 // Layers the family covers: ordinary (non-transposed) convolutions, cin in {16, 32, 64}, cout % 16 == 0, kernel (1|3) x 3 x 3
 // or 1 x 5 x 5 with "same" padding geometry handled by the generic bounds checks, stride 1 or 2 in-plane.

@@ -403,7 +403,7 @@ int launch_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, hipStream_t
 // overlapped with its own math, so it is occupancy that hides it -- measured over the 64 weight gradients of a config-4
 // step: limit 40 -> 6.09 ms, 20 -> 5.49 ms, 12 -> 5.28 ms, 4 -> 5.22 ms.  MVSTER_WGRAD_ACC overrides (experiments).
 static int wgrad_acc_limit() {
-    static const int v = getenv("MVSTER_WGRAD_ACC") ? atoi(getenv("MVSTER_WGRAD_ACC")) : 12;
+    static const int v = MV_PROBE_ENV("MVSTER_WGRAD_ACC") ? atoi(MV_PROBE_ENV("MVSTER_WGRAD_ACC")) : 12;
     return v;
 }
 
@@ -437,7 +437,7 @@ int dispatch_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, int packe
     return MVSTER_ERR_UNSUPPORTED;
 }
 
-static const bool g_wgrad_no_lds = getenv("MVSTER_WGRAD_NO_LDS") != nullptr;   // experiment switch: the per-tap kernels
+static const bool g_wgrad_no_lds = MV_PROBE_ENV("MVSTER_WGRAD_NO_LDS") != nullptr;   // experiment switch: the per-tap kernels
 
 int try_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, int packed, hipStream_t s) {
     if (g_wgrad_no_lds || (a.CO & 3) || (a.CI & 3)) return MVSTER_ERR_UNSUPPORTED;

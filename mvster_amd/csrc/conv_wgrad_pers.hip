@@ -25,6 +25,13 @@
 #include "conv_wgrad.hpp"
 
 namespace mvwgrad {
+// (timing experiments of the probe build: bit 0 drops the MFMAs, bit 1 the loads; the product kernel has neither switch)
+#ifdef MVSTER_PROBES
+#define MV_WG_DBG(bit) (dbg & (bit))
+#else
+#define MV_WG_DBG(bit) false
+#endif
+
 namespace {
 
 using mvconv::f32x4v;
@@ -155,10 +162,10 @@ __global__ void __launch_bounds__(512) conv_wgrad_pers_kernel(WgradArgs a, int m
         for (int it = 0; u < nunits; u += active, ++it) {
             const int cur = it & 1;
             if (loader) {
-                if (u + active < nunits && !(dbg & 2)) request(u + active, cur ^ 1);
+                if (u + active < nunits && !MV_WG_DBG(2)) request(u + active, cur ^ 1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the next unit has landed
             } else {
-                if (!(dbg & 1)) compute(cur);
+                if (!MV_WG_DBG(1)) compute(cur);
                 __builtin_amdgcn_s_waitcnt(0xc07f);                              // done reading this unit
             }
             __builtin_amdgcn_s_barrier();
@@ -226,19 +233,19 @@ int launch_wgrad_pers(const WgradArgs& a, int nblk, int cot, int cit, hipStream_
     if (active < 1) active = 1;
     if (active > nblk) active = nblk;
     MV_NOTE_KERNEL("conv_wgrad_pers_kernel<%d, %d, %d, %d>", MT, NT, KD, R);
-    static const int dbg = getenv("MVSTER_WGRAD_DBG") ? atoi(getenv("MVSTER_WGRAD_DBG")) : 0;     // timing experiments only
+    static const int dbg = MV_PROBE_ENV("MVSTER_WGRAD_DBG") ? atoi(MV_PROBE_ENV("MVSTER_WGRAD_DBG")) : 0;     // timing experiments only
     hipLaunchKernelGGL(kern, dim3(active, mgroups * ngroups), dim3(512), lds, s, a, mgroups, nblk, (unsigned)x_bytes, (unsigned)gy_bytes, dbg);
     return mv_check_launch();
 }
 
-const bool g_no_pers = getenv("MVSTER_WGRAD_NO_PERS") != nullptr;     // experiment switch: the staged kernels instead
+const bool g_no_pers = MV_PROBE_ENV("MVSTER_WGRAD_NO_PERS") != nullptr;     // experiment switch: the staged kernels instead
 
 }  // namespace
 
 // slots the persistent kernel fills for this layer (= workgroups that walk units), 0 if it does not cover the layer
 int wgrad_pers_slots(const WgradArgs& a, int cot, int cit) {
     if (g_no_pers || a.sd != 1 || a.sh != 1 || a.sw != 1 || a.kh != 3 || a.kw != 3 || a.ph != 1 || a.pw != 1 || (a.CO & 15) ||
-        (a.CI & 15) || a.CO > 64 || a.CI > 64 || cot == 3 || cit == 3)
+        (a.CI & 15) || a.CO > 64 || a.CI > 64 || a.CO == 48 || a.CI == 48)     // (48: the callers round 3 tiles up to 4, the planes here hold 16 * tiles channels)
         return 0;
     if (!((a.kd == 1 && a.pd == 0) || (a.kd == 3 && a.pd == 1))) return 0;
     const int ncu = mvconv::num_cus();
@@ -255,7 +262,7 @@ int wgrad_pers_slots(const WgradArgs& a, int cot, int cit) {
 
 int try_wgrad_pers(const WgradArgs& a, int nblk, int cot, int cit, hipStream_t s) {
     if (g_no_pers || a.sd != 1 || a.sh != 1 || a.sw != 1 || a.kh != 3 || a.kw != 3 || a.ph != 1 || a.pw != 1 || (a.CO & 15) ||
-        (a.CI & 15) || a.CO > 64 || a.CI > 64 || cot == 3 || cit == 3)
+        (a.CI & 15) || a.CO > 64 || a.CI > 64 || a.CO == 48 || a.CI == 48)     // (48: the callers round 3 tiles up to 4, the planes here hold 16 * tiles channels)
         return MVSTER_ERR_UNSUPPORTED;
     if (!((a.kd == 1 && a.pd == 0) || (a.kd == 3 && a.pd == 1))) return MVSTER_ERR_UNSUPPORTED;
     if (a.kd == 1) {

@@ -38,6 +38,21 @@ static inline FastDiv mv_fastdiv(unsigned d) {
     return f;
 }
 
+// the same constants computed in a kernel (divisors that only exist on the device: a tile's patch width)
+MV_HD FastDiv mv_fastdiv_dev(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    f.mul = 0;
+    f.shr = 0;
+    if (d <= 1) return f;
+    int lg = 0;
+    while ((1u << lg) < d) ++lg;                 // ceil(log2 d)
+    const int p = 31 + lg;
+    f.mul = (unsigned)(((1ull << p) + d - 1) / d);
+    f.shr = (unsigned)(p - 32);
+    return f;
+}
+
 MV_HD unsigned fdiv(unsigned n, const FastDiv& f) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.shr);

@@ -259,6 +259,150 @@ __global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* _
     for (int c = 0; c < CO; c += 4) st4(o + c, (f32x4){acc[c / 2][0], acc[c / 2][1], acc[c / 2 + 1][0], acc[c / 2 + 1][1]});
 }
 
+// The finest FPN level's lateral step AND its gather-sum in one launch (round 4): the 72-channel half-resolution map
+//   G4[h] = bias + A x[h] + up2(q)[h]        (fpn_lateral_up_kernel: 118 MB written at 5 x 512 x 640 ...)
+// only exists to be gathered from (... and 170 MB read back with tile halos by fpn_tail_gather_lds_kernel).  Here a workgroup
+// builds the <= 8 x 20 half-resolution patch of G4 that its 8 x 32 output tile reads straight into LDS -- the 16 -> 72
+// lateral product on v_mfma_f32_16x16x4_f32 (M = patch pixels, N = 72 channels in five tiles, K = 16 = four steps; D^T form,
+// so a lane ends up with four consecutive channels of one pixel), the bilinear x2 of q added in the epilogue -- and then
+// runs the gather-sum of fpn_tail_gather_lds_kernel on it unchanged.  HBM traffic: x (26 MB) + q (29 MB) + P (52 MB).
+// Per element the arithmetic is the two kernels' (bias first, channel-ordered products, up2(q) + that, then the flat
+// 36-weight gather), with the lateral product's summation order that of the MFMA K steps.
+template <int CI>
+__global__ void __launch_bounds__(256) fpn_tail_fused_kernel(const float* __restrict__ x, const float* __restrict__ A,
+                                                             const float* __restrict__ bias, const float* __restrict__ qmap,
+                                                             const float* __restrict__ vb, float* __restrict__ P, int NB,
+                                                             int H, int W, FastDiv tiles_x, FastDiv tiles_y) {
+    static_assert(CI == 16, "one 16-wide K block");
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int CO = 8, CG = 72, Q = CG / 4;
+    constexpr int PR = 8, PC = 20;
+    __shared__ f32x4 patch[PR * PC * Q];
+    __shared__ float vbsum[9][CO];
+    const int Hh = H / 2, Wh = W / 2, Hq = Hh / 2, Wq = Wh / 2;
+    unsigned txu, tyu;
+    const int b = (int)fdivmod(fdivmod(xcd_remap(blockIdx.x, gridDim.x), tiles_x, txu), tiles_y, tyu);
+    const int y0 = (int)tyu * 8, x0 = (int)txu * 32;
+    const int ylo = max(y0 - 1, 0), yhi = min(y0 + 8, H - 1), xlo = max(x0 - 1, 0), xhi = min(x0 + 32, W - 1);
+    const int r0 = mv::make_lerp(ylo, Hh, H).i0, r1 = mv::make_lerp(yhi, Hh, H).i1;
+    const int c0 = mv::make_lerp(xlo, Wh, W).i0, c1 = mv::make_lerp(xhi, Wh, W).i1;
+    const int nr = r1 - r0 + 1, nc = c1 - c0 + 1;       // <= PR, <= PC
+    const int npix = nr * nc;
+
+    // ---- phase A: the lateral step of this tile's patch, into LDS --------------------------------------------------------
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lm = lane & 15, lq = lane >> 4;
+        // weights as the A operand: row lm of N tile nt = channel nt * 16 + lm, K slot (j, lq) = input channel 4 lq + j
+        float aw[5][4];
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) {
+            const int co = nt * 16 + lm;
+            const f32x4 v = co < CG ? ld4(A + co * CI + 4 * lq) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) aw[nt][j] = v[j];
+        }
+        const float* xb = x + (long)b * Hh * Wh * CI;
+        const float* qb = qmap + (long)b * Hq * Wq * CG;
+        const FastDiv ncd = mv_fastdiv_dev((unsigned)nc);
+        for (int mt = wave; mt * 16 < npix; mt += 4) {
+            const int i = mt * 16 + lm;
+            const bool valid = i < npix;
+            unsigned pcu;
+            const int pr = (int)fdivmod((unsigned)(valid ? i : 0), ncd, pcu), pc = (int)pcu;
+            const int hy = r0 + pr, hx = c0 + pc;
+            const f32x4 xv = ld4(xb + ((long)hy * Wh + hx) * CI + 4 * lq);
+            const mv::Lerp ly = mv::make_lerp(hy, Hq, Hh), lx = mv::make_lerp(hx, Wq, Wh);
+            const float* q00p = qb + ((long)ly.i0 * Wq + lx.i0) * CG + 4 * lq;
+            const float* q01p = qb + ((long)ly.i0 * Wq + lx.i1) * CG + 4 * lq;
+            const float* q10p = qb + ((long)ly.i1 * Wq + lx.i0) * CG + 4 * lq;
+            const float* q11p = qb + ((long)ly.i1 * Wq + lx.i1) * CG + 4 * lq;
+            f32x4 q00[5], q01[5], q10[5], q11[5], acc[5];
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) {
+                const bool has = nt * 4 + lq < Q;                 // (the fifth N tile holds channels 64..71 only)
+                const int o = has ? nt * 16 : 0;
+                q00[nt] = ld4(q00p + o); q01[nt] = ld4(q01p + o); q10[nt] = ld4(q10p + o); q11[nt] = ld4(q11p + o);
+                acc[nt] = ld4(bias + (has ? nt * 16 + 4 * lq : 0));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[nt][j], xv[j], acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) {
+                if (valid && nt * 4 + lq < Q) {
+                    f32x4 r;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) r[k] = mv::bilerp(ly, lx, q00[nt][k], q01[nt][k], q10[nt][k], q11[nt][k]) + acc[nt][k];
+                    patch[(pr * PC + pc) * Q + nt * 4 + lq] = r;
+                }
+            }
+        }
+    }
+    if (threadIdx.x < 9 * CO) {
+        const int cls = threadIdx.x / CO, c = threadIdx.x % CO;
+        const int yc = cls / 3, xc = cls % 3;          // 0 = first row/column, 1 = interior, 2 = last
+        float sacc = 0.0f;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const bool in = !(yc == 0 && ky == 0) && !(yc == 2 && ky == 2) && !(xc == 0 && kx == 0) && !(xc == 2 && kx == 2);
+                if (in) sacc += vb[(ky * 3 + kx) * CO + c];
+            }
+        vbsum[cls][c] = sacc;
+    }
+    __syncthreads();
+
+    // ---- phase B: the gather-sum (fpn_tail_gather_lds_kernel<8>, verbatim) ----------------------------------------------
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int y = y0 + ty, xo = x0 + tx;
+    if (y >= H || xo >= W) return;
+    int ry0[3], ry1[3], cx0[3], cx1[3];
+    float wy0[3], wy1[3], wx0[3], wx1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int qy = y + k - 1, qx = xo + k - 1;
+        const bool iy = (unsigned)qy < (unsigned)H, ix = (unsigned)qx < (unsigned)W;
+        const mv::Lerp ly = mv::make_lerp(iy ? qy : y, Hh, H), lx = mv::make_lerp(ix ? qx : xo, Wh, W);
+        ry0[k] = (ly.i0 - r0) * PC * Q; ry1[k] = (ly.i1 - r0) * PC * Q;
+        cx0[k] = (lx.i0 - c0) * Q;      cx1[k] = (lx.i1 - c0) * Q;
+        wy0[k] = iy ? ly.w0 : 0.0f; wy1[k] = iy ? ly.w1 : 0.0f;
+        wx0[k] = ix ? lx.w0 : 0.0f; wx1[k] = ix ? lx.w1 : 0.0f;
+    }
+    const int cls = (y == 0 ? 0 : (y == H - 1 ? 2 : 1)) * 3 + (xo == 0 ? 0 : (xo == W - 1 ? 2 : 1));
+    f32x2 acc[CO / 2];
+#pragma unroll
+    for (int c = 0; c < CO / 2; ++c) acc[c] = (f32x2){vbsum[cls][2 * c], vbsum[cls][2 * c + 1]};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int tap = ky * 3 + kx;
+            const float w00 = wy0[ky] * wx0[kx], w01 = wy0[ky] * wx1[kx], w10 = wy1[ky] * wx0[kx], w11 = wy1[ky] * wx1[kx];
+            const f32x4* p00 = patch + ry0[ky] + cx0[kx] + tap * (CO / 4);
+            const f32x4* p01 = patch + ry0[ky] + cx1[kx] + tap * (CO / 4);
+            const f32x4* p10 = patch + ry1[ky] + cx0[kx] + tap * (CO / 4);
+            const f32x4* p11 = patch + ry1[ky] + cx1[kx] + tap * (CO / 4);
+#pragma unroll
+            for (int c4 = 0; c4 < CO / 4; ++c4) {
+                const f32x4 a = p00[c4], bq = p01[c4], cq = p10[c4], dq = p11[c4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x2 t = acc[c4 * 2 + h];
+                    t += (f32x2){a[2 * h], a[2 * h + 1]} * (f32x2){w00, w00};
+                    t += (f32x2){bq[2 * h], bq[2 * h + 1]} * (f32x2){w01, w01};
+                    t += (f32x2){cq[2 * h], cq[2 * h + 1]} * (f32x2){w10, w10};
+                    t += (f32x2){dq[2 * h], dq[2 * h + 1]} * (f32x2){w11, w11};
+                    acc[c4 * 2 + h] = t;
+                }
+            }
+        }
+    }
+    float* o = P + (((long)b * H + y) * W + xo) * CO;
+#pragma unroll
+    for (int c = 0; c < CO; c += 4) st4(o + c, (f32x4){acc[c / 2][0], acc[c / 2][1], acc[c / 2 + 1][0], acc[c / 2 + 1][1]});
+}
+
 // Adjoint of the gather-sum above with respect to G (training): gG [NB, H/2, W/2, pitch] <- gP [NB, H, W, CO],
 //   gG[q][tap*CO + co] = sum over full-resolution positions r = p + tap (both p and r inside the image) of
 //                        w(r -> q) * gP[p][co],     w = the bilinear x2 weight with which r reads q,
@@ -633,6 +777,22 @@ extern "C" int mvster_fpn_lateral_up(const float* x, const float* A, const float
     return mv_check_launch();
 }
 
+// mvster_fpn_lateral_up (16 -> 72) followed by mvster_fpn_tail_gather (CO = 8) in one launch, the 72-channel map kept in
+// LDS: x [NB,H/2,W/2,16], A [72,16], bias [72], q [NB,H/4,W/4,72], vb [9,8] -> P [NB,H,W,8].  H, W multiples of 4,
+// H >= 16, W >= 64 (the LDS-tiled gather's domain); MVSTER_ERR_UNSUPPORTED otherwise (the two launches cover the rest).
+extern "C" int mvster_fpn_tail_fused(const float* x, const float* A, const float* bias, const float* q, const float* vb,
+                                     float* P, int NB, int H, int W, int CI, void* stream) {
+    if (!x || !A || !bias || !q || !vb || !P) return MVSTER_ERR_NULL;
+    if (NB <= 0 || H < 4 || W < 4) return MVSTER_ERR_SHAPE;
+    if (CI != 16 || (H & 3) || (W & 3) || H < 16 || W < 64) return MVSTER_ERR_UNSUPPORTED;
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
+    if ((long)tiles_x * tiles_y * NB >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    MV_NOTE_KERNEL("fpn_tail_fused_kernel<16>");
+    hipLaunchKernelGGL(fpn_tail_fused_kernel<16>, dim3(tiles_x * tiles_y * NB), dim3(256), 0, (hipStream_t)stream, x, A, bias, q, vb,
+                       P, NB, H, W, mv_fastdiv(tiles_x), mv_fastdiv(tiles_y));
+    return mv_check_launch();
+}
+
 extern "C" int mvster_pack_images(const float* const* imgs, int N, float* out, int B, int H, int W, void* stream) {
     if (!imgs || !out) return MVSTER_ERR_NULL;
     if (N < 1 || N > 16 || B <= 0 || H <= 0 || W <= 0) return MVSTER_ERR_SHAPE;
@@ -740,6 +900,15 @@ thread_local const char* mv_last_kernel = "";
 // Name (profiler spelling, template arguments included) of the kernel the most recent mvster_conv_mfma / mvster_conv_small /
 // mvster_deconv_small / mvster_warp_agg_fwd call on this thread launched; "" before the first one.
 extern "C" const char* mvster_last_kernel() { return mv_last_kernel; }
+
+// bit 0: probe build (-DMVSTER_PROBES: experiment switches honoured, kernel forms kept for the record compiled in)
+extern "C" int mvster_build_flags() {
+#ifdef MVSTER_PROBES
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Batched gather: dst[i] = idx[i] > 0 ? src[idx[i] - 1] : 0 for a table of (src, dst, idx, n) records, ONE launch.

@@ -426,6 +426,7 @@ __global__ void __launch_bounds__(256) warp_agg_fwd_wave_kernel(WarpAggArgs a) {
     }
 }
 
+#ifdef MVSTER_PROBES   // pixel-major form (variant 4): probe build only
 // ------------------------------------------------------------------------------------------
 // Pixel-major variant for the two fine stages (C <= 16, where the time is): lane = (pixel, sub), and the lane
 // walks ALL D hypotheses of its pixel.  The wave-local kernel above is VALU-issue-bound (PMC: ~205 VALU
@@ -648,8 +649,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
 
 // launch shape of the pixel-major kernel: hypotheses per lane (0 = all D) and the occupancy target handed to the
 // register allocator; MVSTER_PIX_DPL / MVSTER_PIX_WPE override the defaults for experiments
-static const int g_pix_dpl = getenv("MVSTER_PIX_DPL") ? atoi(getenv("MVSTER_PIX_DPL")) : 2;
-static const int g_pix_wpe = getenv("MVSTER_PIX_WPE") ? atoi(getenv("MVSTER_PIX_WPE")) : 4;
+[[maybe_unused]] static const int g_pix_dpl = MV_PROBE_ENV("MVSTER_PIX_DPL") ? atoi(MV_PROBE_ENV("MVSTER_PIX_DPL")) : 2;
+[[maybe_unused]] static const int g_pix_wpe = MV_PROBE_ENV("MVSTER_PIX_WPE") ? atoi(MV_PROBE_ENV("MVSTER_PIX_WPE")) : 4;
 
 template <int C, int G, int D, int DPL, int WPE>
 int launch_fwd_pix_cfg(const WarpAggArgs& a, hipStream_t stream) {
@@ -682,6 +683,8 @@ int dispatch_fwd_pix(const WarpAggArgs& a, hipStream_t stream) {
     return MVSTER_ERR_UNSUPPORTED;
 }
 
+#endif  // MVSTER_PROBES
+
 template <int C, int G, int D>
 int launch_fwd_wave(const WarpAggArgs& a, hipStream_t stream) {
     constexpr int PPB = 4 * (64 / ((C / 8) * D));
@@ -693,6 +696,7 @@ int launch_fwd_wave(const WarpAggArgs& a, hipStream_t stream) {
     return mv_check_launch();
 }
 
+#ifdef MVSTER_PROBES   // LDS-window form (variant 5): probe build only
 // ------------------------------------------------------------------------------------------
 // LDS-staged source windows (variant 5; C in {8, 16}: the two fine stages, where the time is).
 // The wave-local kernel gathers every tap through the texture path: 4 taps x 32 bytes per (pixel, d, view), 671 MB
@@ -934,6 +938,8 @@ int dispatch_fwd_tile(const WarpAggArgs& a, hipStream_t stream) {
     if (a.D == 8) return launch_fwd_tile<C, G, 8>(a, stream);
     return MVSTER_ERR_UNSUPPORTED;
 }
+
+#endif  // MVSTER_PROBES
 
 template <int C, int G>
 int dispatch_fwd_wave(const WarpAggArgs& a, hipStream_t stream) {
@@ -1195,8 +1201,8 @@ __device__ __forceinline__ void scatter_taps(u64* win, int cpitch, int rpitch, T
 }
 
 constexpr int kWinX = 96, kWinY = 6;
-static const bool g_bwd_no_tiles = getenv("MVSTER_BWD_NO_TILES") != nullptr;   // experiment switch
-static const bool g_pix = getenv("MVSTER_PIX") != nullptr;   // experiment switch: pixel-major kernel at the fine stages
+static const bool g_bwd_no_tiles = MV_PROBE_ENV("MVSTER_BWD_NO_TILES") != nullptr;   // experiment switch
+[[maybe_unused]] static const bool g_pix = MV_PROBE_ENV("MVSTER_PIX") != nullptr;   // experiment switch: pixel-major kernel at the fine stages
 
 template <int C, int G, bool GROUP, int DMAX>
 __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs ba) {
@@ -1768,6 +1774,7 @@ extern "C" int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat,
     // variant: 0 = choose; 1 = one thread per (pixel, d); 2 = workgroup-level lane split (C >= 16);
     // 3 = wave-local kernel (what 0 picks whenever it applies); 4 = pixel-major kernel (faster on cache-resident inputs,
     // slower inside the forward: kept as a tested alternative)
+#ifdef MVSTER_PROBES
     if (group_cor && (D == 4 || D == 8) && (variant == 4 || (variant == 0 && C <= 16 && g_pix))) {
         int rc = MVSTER_ERR_UNSUPPORTED;
         if (C == 8 && G == 4) rc = dispatch_fwd_pix<8, 4>(a, s);
@@ -1786,6 +1793,9 @@ extern "C" int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat,
         if (C == 16 && G == 8) return dispatch_fwd_tile<16, 8>(a, s);
         return MVSTER_ERR_UNSUPPORTED;
     }
+#else
+    if (variant == 4 || variant == 5) return MVSTER_ERR_UNSUPPORTED;      // (the probe library has them)
+#endif
     if (group_cor && (D == 4 || D == 8) && (variant == 0 || variant == 3)) {
         if (C == 8 && G == 4) return dispatch_fwd_wave<8, 4>(a, s);
         if (C == 8 && G == 8) return dispatch_fwd_wave<8, 8>(a, s);

@@ -173,4 +173,7 @@ class GraphedTrainStep:
         if depth_values is not None:
             self.depth_values.copy_(depth_values, non_blocking=True)
         self.graph.replay()
+        # the replayed optimizer update moved the parameters without touching their version counters: everything folded or
+        # packed from them outside this graph (the eval plans, the cached training layers of an eager step) is stale now
+        self._cache.epoch += 1
         return self.loss

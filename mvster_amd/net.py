@@ -165,11 +165,12 @@ class MVS4net(nn.Module):
 
     def _state_stamp(self):
         """Changes whenever a parameter or buffer the eval plans were folded from is written in place through the tensor
-        (``p.mul_()``, ``copy_``, an optimizer step, an EMA swap: ``_version``) or replaced (``p.data = t``: the storage
-        address).  348 Python attribute reads per forward, ~60 us; writes through a detached alias of the storage cannot be
+        (``p.mul_()``, ``copy_``, an eager optimizer step, an EMA swap: ``_version``), replaced (``p.data = t``: the storage
+        address) or updated by a captured training step's replay (``train_ops.CACHE.epoch``).  348 Python attribute reads per forward, ~60 us; writes through a detached alias of the storage cannot be
         seen from here -- call ``invalidate_plans()`` after those."""
         import itertools
-        acc = 0
+        from . import train_ops
+        acc = train_ops.CACHE.epoch          # (parameter updates inside hipGraph replays: GraphedTrainStep bumps it)
         for t in itertools.chain(self.feature.parameters(), self.feature.buffers(), self.reg.parameters(), self.reg.buffers()):
             acc = (acc * 1000003 + t._version * 7919 + t.data_ptr()) & 0xFFFFFFFFFFFF
         return acc

@@ -71,6 +71,9 @@ def pack_images(imgs):
     return out
 
 
+WGRAD_MAX_SLOTS = 1024        # weight-gradient partial-sum slots per launch (a module attribute: experiments set it)
+
+
 def to_channels_last(feat_nchw):
     """[B,C,H,W] -> [B,H,W,C] contiguous."""
     return feat_nchw.permute(0, 2, 3, 1).contiguous()
@@ -323,10 +326,8 @@ def conv_wgrad(x_cl, gy_cl, kernel, stride, padding, co_keep=None, ci_keep=None,
     slot_bytes = ngrp * cop * width * 4
     # workgroups = slots of `partial` (added in a fixed order by the finish kernel: deterministic).  Measured on the
     # config-4 step: 1024 slots 26.0 ms, 512 26.4 ms, 256 27.9 ms -- the kernels want the parallelism more than the
-    # reduction minds the size.  MVSTER_WGRAD_NBLK overrides (experiments).
-    import os
-    cap = int(os.environ.get("MVSTER_WGRAD_NBLK", "1024"))
-    nblk = max(1, min((rows + 3) // 4, (32 << 20) // slot_bytes, cap))
+    # reduction minds the size.
+    nblk = max(1, min((rows + 3) // 4, (32 << 20) // slot_bytes, WGRAD_MAX_SLOTS))
     lib = _lib.load()
     pers = _wgrad_pers_slots(lib, CI, CO, kernel, stride, padding, packed)
     if pers > 0:

@@ -152,21 +152,28 @@ class GradBucket:
 
     def sync(self):
         grads = [p.grad for p in self.params]
-        if all(g is not None for g in grads):
-            # (gradients that already live in the bucket -- an eager loop without zero_grad(set_to_none=True) -- are packed
-            #  onto themselves: the copy is skipped for them)
-            if not all(g.data_ptr() == v.data_ptr() for g, v in zip(grads, self.views)):
-                torch.cat([g.reshape(-1) for g in grads], out=self.flat)
+        aliased = [g is not None and g.data_ptr() == v.data_ptr() for g, v in zip(grads, self.views)]
+        if all(g is not None for g in grads) and not any(aliased):
+            # the captured step: every gradient freshly produced by backward -> one batched copy into the bucket
+            torch.cat([g.reshape(-1) for g in grads], out=self.flat)
         else:
-            self.flat.zero_()
-            for g, v in zip(grads, self.views):
-                if g is not None and g.data_ptr() != v.data_ptr():
+            # an eager loop: gradients that already live in the bucket (p.grad still is its slice from the last step, i.e.
+            # no zero_grad(set_to_none=True) in between) stay where they are -- never an input of a copy into the bucket
+            # that overlaps them; a parameter WITHOUT a gradient contributes zeros to the average (another rank may have
+            # one: the collective is over the whole bucket), and only ITS slice is zeroed
+            for g, v, same in zip(grads, self.views, aliased):
+                if g is None:
+                    v.zero_()
+                elif not same:
                     v.copy_(g)
         w = self.world()
         if w > 1 or (self.always_reduce and dist.is_available() and dist.is_initialized()):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             if w > 1:
                 self.flat.div_(w)
+        # (every parameter ends up with a gradient, zeros where no rank produced one -- DistributedDataParallel leaves those
+        #  at None instead; the difference is visible only to optimizers that skip parameters without a gradient, and
+        #  keeping the list of launches fixed is what makes the step capturable)
         for p, v in zip(self.params, self.views):
             p.grad = v
         return self.flat

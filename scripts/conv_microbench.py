@@ -105,6 +105,70 @@ def candidates(layer, B, Di, Hi, Wi, sm):
     return out
 
 
+def record_eval_calls(model, H, W, N, dev):
+    """[(layer, input shape, skip shape or None, skip mode)] of one eval forward at H x W with N views (distinct signatures)."""
+    calls, seen = [], set()
+    orig = cp.ConvLayer.__call__
+
+    def rec(layer, x, skip=None, skip_mode=0, tiles=None):
+        sm = skip_mode if skip is not None else 0
+        sig = cp.layer_signature(layer, *x.shape[:4], sm)
+        if sig not in seen:
+            seen.add(sig)
+            calls.append((layer, tuple(x.shape), None if skip is None else tuple(skip.shape), sm))
+        return orig(layer, x, skip, skip_mode, tiles)
+    imgs, proj, dv = make_inputs(N, H, W, seed=0, device=dev)
+    cp.ConvLayer.__call__ = rec
+    try:
+        model(imgs, proj, dv)
+    finally:
+        cp.ConvLayer.__call__ = orig
+    torch.cuda.synchronize()
+    return calls
+
+
+def auto_vs_best(calls, dev, n=6):
+    """Per recorded call: (signature, us of the plan's own choice, us of the best candidate, its name, how the choice was made)."""
+    rows = []
+    for layer, xs, ss, sm in calls:
+        B, Di, Hi, Wi, _ = xs
+        x = torch.randn(*xs, device=dev)
+        skip = torch.randn(*ss, device=dev) if ss else None
+        auto = timeit(lambda: layer(x, skip=skip, skip_mode=sm), n=n)
+        best, best_name = auto, "auto"
+        for name, tiles in candidates(layer, B, Di, Hi, Wi, sm):
+            try:
+                us = timeit(lambda: layer(x, skip=skip, skip_mode=sm, tiles=tiles), n=n)
+            except RuntimeError:
+                continue
+            if us < best:
+                best, best_name = us, name
+        how = cp.tuned_choice(layer, B, Di, Hi, Wi, sm)[1] or "heuristic"
+        rows.append((cp.layer_signature(layer, B, Di, Hi, Wi, sm), auto, best, best_name, how))
+        del x, skip
+    return rows
+
+
+def retune_narrow(path, shapes):
+    """Re-time the narrow-layer signatures (VALU kernel vs the shift-packed MFMA kernel, its tile heights and workgroups per CU)
+    of the given eval workloads and write them into the table at ``path``; every other entry is left alone."""
+    import json
+    dev = torch.device("cuda:0")
+    model = MVS4net(**SHIPPED)
+    model.load_state_dict(load_weights(), strict=True)
+    model.to(dev).eval()
+    with open(path) as f:
+        table = json.load(f)
+    for (H, W, N) in shapes:
+        calls = [c for c in record_eval_calls(model, H, W, N, dev) if c[0].w_small is not None]
+        for c in calls:
+            table.pop(cp.layer_signature(c[0], *c[1][:4], c[3]), None)
+        _tune(calls, table, dev)
+    with open(path, "w") as f:
+        json.dump(table, f, indent=0, sort_keys=True)
+    print("wrote", path, len(table), "entries")
+
+
 def _tune(calls, table, dev):
     """Time every candidate of every recorded call that is not in the table yet; keep the winners."""
     for layer, xs, ss, sm in calls:
@@ -173,6 +237,22 @@ def emit_table(shapes, path, train_shapes=((512, 640, 5, 2),)):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--retune-narrow":
+        retune_narrow(sys.argv[2], [(512, 640, 5), (1152, 1600, 5), (1024, 1920, 7), (832, 1152, 5), (128, 192, 5), (128, 192, 3), (64, 128, 3)])
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--untuned":
+        # an untuned resolution against the exhaustive per-layer search: what does the family fallback leave on the table?
+        H, W, N = (int(v) for v in sys.argv[2:5])
+        dev = torch.device("cuda:0")
+        model = MVS4net(**SHIPPED)
+        model.load_state_dict(load_weights(), strict=True)
+        model.to(dev).eval()
+        rows = auto_vs_best(record_eval_calls(model, H, W, N, dev), dev)
+        for sig, a, b, name, how in rows:
+            print("%-52s auto %7.1f us  best %7.1f us (%s)  [%s]%s" % (sig, a, b, name, how, "   <-- %.0f %%" % (100 * (a / b - 1)) if a > 1.05 * b else ""))
+        sa, sb = sum(r[1] for r in rows), sum(r[2] for r in rows)
+        print("%dx%dx%d: sum of distinct layers auto %.1f us, best-of-candidates %.1f us (+%.1f %%)" % (H, W, N, sa, sb, 100 * (sa / sb - 1)))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--emit":
         shapes = [(512, 640, 5), (1152, 1600, 5), (1024, 1920, 7), (128, 192, 5), (128, 192, 3), (64, 128, 3)]
         emit_table(shapes, sys.argv[2])

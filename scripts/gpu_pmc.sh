@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 cd /tmp
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY"; do
   tag=$(echo $pass | cut -d' ' -f1)
-  MVSTER_NO_OVERLAP=1 timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$REPO/gpurun_out/pmc/$tag" -o p -- python "$REPO/bench.py" --steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-coherent > /dev/null 2> "$REPO/gpurun_out/pmc/$tag.err"
+  timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$REPO/gpurun_out/pmc/$tag" -o p -- python "$REPO/bench.py" --steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-coherent --no-overlap --no-train > /dev/null 2> "$REPO/gpurun_out/pmc/$tag.err"
   echo "pmc $tag exit $?"
 done
 cd "$REPO"

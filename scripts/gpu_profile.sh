@@ -6,7 +6,7 @@ REPO=$PWD
 rm -rf gpurun_out/prof; mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof" -o bench -- python "$REPO/bench.py" --steps 20 --warmup 5 --no-graph --no-cpu-baseline --no-coherent > "$REPO/gpurun_out/prof/bench_under_rocprof.json" 2> "$REPO/gpurun_out/prof/rocprof.err"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof" -o bench -- python "$REPO/bench.py" --steps 20 --warmup 5 --no-graph --no-cpu-baseline --no-coherent --no-overlap --no-train --no-other-configs --no-stream-inputs > "$REPO/gpurun_out/prof/bench_under_rocprof.json" 2> "$REPO/gpurun_out/prof/rocprof.err"
 echo "rocprof exit $?"
 cd "$REPO"
 ls gpurun_out/prof | head

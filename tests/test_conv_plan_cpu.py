@@ -165,6 +165,26 @@ def test_tuning_table_is_well_formed():
             assert fam in (0, 1, 2, 6) and kernel == (1, 1, 1), sig
 
 
+def test_family_fallback_of_the_tuning_table():
+    """conv_plan.tuned_choice: exact entries win; a shape the table does not hold takes the choice of its layer family's entry
+    nearest in log2(voxels) (within FAMILY_REACH octaves); unknown families and far-away sizes fall to the heuristics."""
+    class L:
+        transposed, cin, cout, kernel, stride = False, 16, 16, (1, 3, 3), (1, 1, 1)
+    exact, how = cp.tuned_choice(L, 5, 1, 256, 320, 0)
+    assert how == "exact" and exact == cp._tuning()["C16-16_k1x3x3_s1x1x1_5x1x256x320_sk0"]
+    # 832 x 1152 x 5 (the reference's real "mid" workload): half-resolution FPN level, not in the table
+    fam, how = cp.tuned_choice(L, 5, 1, 416, 576, 0)
+    assert how == "family" and fam == cp._tuning()["C16-16_k1x3x3_s1x1x1_5x1x576x800_sk0"]     # 1.2 M voxels -> the 2.3 M entry
+    assert cp.tuned_choice(L, 1, 1, 4, 4, 0) == (None, None)                                  # 16 voxels: nothing within reach
+    L.cin, L.cout = 16, 48
+    assert cp.tuned_choice(L, 5, 1, 256, 320, 0) == (None, None)                              # a family the table never saw
+    # the family choice is a copy (callers unpack / edit it) and every family list is sorted by size
+    fam[0] = -1
+    assert cp.tuned_choice(L, 5, 1, 256, 320, 0) == (None, None)
+    for lst in cp._families().values():
+        assert [e[0] for e in lst] == sorted(e[0] for e in lst)
+
+
 def test_winograd_plan_for_untuned_shapes():
     """_wino_plan: the heuristic behind shapes the table does not know -- a Winograd kernel wherever the map gives most CUs
     a work unit, nothing otherwise (the caller keeps the direct / split-K choice)."""
@@ -181,6 +201,41 @@ def test_winograd_plan_for_untuned_shapes():
     L.kernel, L.cin, L.ntile_total = (3, 3, 3), 16, 1
     assert cp._wino_plan(L, 1, 4, 128, 160) == (9, 2, 1)                # 4 x 16 x 5 = 320 tiles
     assert cp._wino_plan(L, 1, 4, 32, 40) is None
+
+
+def test_winograd_plan_only_names_instantiated_kernels():
+    """Every (kernel depth, input channels, N tiles, map size) the heuristic can be asked about leads to a kernel instance
+    the library has (cp.WINO_RING_INSTANCES / cp.WINO_INSTANCES mirror dispatch_wino's tables, which this test reads out
+    of conv_wino.hip) -- e.g. a 16 -> 32 3x3x3 layer on a large map must not be sent to a two-N-tile ring kernel."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(cp.__file__), "csrc", "conv_wino.hip")).read()
+    body = src[src.index("int dispatch_wino("):]
+    ring = {tuple(int(x) for x in m) for m in re.findall(r"MV_R\((\d), (\d), (\d)\)", body)}
+    plain = {(int(a), int(b)) for a, b in re.findall(r"MV_W\((\d), (\d), (?:true|false)\)", body)}
+    assert ring == cp.WINO_RING_INSTANCES and plain == cp.WINO_INSTANCES
+
+    class L:
+        pass
+    seen = 0
+    for kd in (1, 3):
+        for cin in (16, 32, 64):
+            for ntile_total in (1, 2, 3, 4):
+                for (B, D, H, W) in ((5, 1, 512, 640), (1, 8, 64, 80), (1, 4, 256, 320), (2, 4, 128, 160), (1, 1, 16, 32), (3, 1, 832, 1152)):
+                    L.kernel, L.cin, L.ntile_total = (kd, 3, 3), cin, ntile_total
+                    v = cp._wino_plan(L, B, D, H, W)
+                    if v is None:
+                        continue
+                    seen += 1
+                    word, mt, nt = v
+                    fam, wpc = word & 0xff, word >> 8
+                    assert mt == 2 and ntile_total % nt == 0
+                    if fam == 8:
+                        assert kd == 1 and (nt, cin // 16) in cp.WINO_INSTANCES, (kd, cin, ntile_total, v)
+                    else:
+                        mode = 0 if nt == 1 else (2 if wpc == 1 else 1)
+                        assert fam == 9 and (mode, cin // 16, kd) in cp.WINO_RING_INSTANCES, (kd, cin, ntile_total, v)
+    assert seen > 40
 
 
 @pytest.mark.parametrize("cin,cout,k,s,p", [(16, 8, (1, 5, 5), (1, 2, 2), (0, 2, 2)), (32, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1)),

@@ -18,6 +18,33 @@ DEV = "cuda:0"
 REPORT = {}
 
 
+def _probe_build():
+    from mvster_amd import _lib
+    return torch.cuda.is_available() and _lib.has_probes()
+
+
+# The kernel forms kept for the record only (warp variants 4 / 5, convolution variant 7) live in the probe library
+# (make -C mvster_amd/csrc probes); their tests run when that library is the one loaded:
+#     MVSTER_LIB=$PWD/mvster_amd/csrc/libmvster_hip_probes.so python -m pytest tests/test_gpu_kernels.py -m gpu -k "probe or variants or pingpong or window"
+PROBES = _probe_build()
+needs_probes = pytest.mark.skipif(not PROBES, reason="kernel form kept for the record: needs the probe library (MVSTER_LIB=...libmvster_hip_probes.so)")
+
+
+def test_product_library_has_no_probe_forms():
+    """The shipped library reads no environment switch and refuses the kernel forms kept for the record."""
+    from mvster_amd import _lib
+    if PROBES:
+        pytest.skip("probe library loaded")
+    assert _lib.load().mvster_build_flags() == 0
+    ref = torch.randn(1, 8, 16, 8, device=DEV)
+    src = torch.randn(2, 1, 8, 16, 8, device=DEV)
+    rt = torch.tensor([1., 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], device=DEV).view(1, 1, 12).repeat(1, 2, 1).contiguous()
+    hypo = 500 + torch.rand(1, 4, 8, 16, device=DEV)
+    for variant in (4, 5):
+        with pytest.raises(RuntimeError):
+            ops.warp_agg_fwd_cl(ref, src, rt, hypo, 4, True, True, 2.0, variant=variant)
+
+
 def note(name, **kv):
     REPORT[name] = {k: (float(v) if not isinstance(v, (list, str)) else v) for k, v in kv.items()}
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
@@ -155,7 +182,7 @@ def test_warp_agg_forward(golden, name):
     got = out.permute(0, 4, 1, 2, 3).cpu()
     tight = (got - want).abs().max().item()
     # the lane-split, wave-local and pixel-major kernels are bit-identical to the one-thread-per-(pixel, d) form
-    for variant in (0, 2, 3, 4):
+    for variant in (0, 2, 3) + ((4,) if PROBES else ()):            # (4 = pixel-major: probe library only)
         o2 = ops.warp_agg_fwd_cl(f_cl[0], f_cl[1:], _oracle_rt(pm).to(DEV), hypo.to(DEV), Gk, gc, fuse, temp,
                                  variant=variant)
         assert torch.equal(o2, out), (name, variant)
@@ -191,7 +218,7 @@ def test_warp_agg_kernel_variants_bit_identical(C, G, D, fuse):
         args = (ref.to(DEV), src.to(DEV), rt, hypo.to(DEV), G, True, fuse, 2.0)
         base, wbase = ops.warp_agg_fwd_cl(*args, want_wsum=True, variant=1)
         assert torch.isfinite(base).all() and base.abs().max() > 0
-        for variant in (0, 2, 3, 4):
+        for variant in (0, 2, 3) + ((4,) if PROBES else ()):
             o, ws = ops.warp_agg_fwd_cl(*args, want_wsum=True, variant=variant)
             assert torch.equal(o, base), (C, G, D, h, w, variant)
             assert torch.equal(ws, wbase), (C, G, D, h, w, variant)
@@ -232,6 +259,7 @@ def test_fused_conv11_selection_bit_identical(D, inverse, G, shape):
 @pytest.mark.parametrize("C,G,D", [(8, 4, 4), (16, 4, 4), (8, 8, 8), (16, 8, 4), (8, 4, 8), (16, 4, 8)])
 @pytest.mark.parametrize("fuse", [True, False])
 @pytest.mark.parametrize("regime", ["smooth", "random", "mixed", "planes"])
+@needs_probes
 def test_warp_agg_lds_window_variant_bit_identical(C, G, D, fuse, regime):
     """The LDS-staged source-window form (variant 5) against the one-thread form: equal bits whether every tap comes from
     the staged window (smooth hypotheses), almost none does (per-pixel random depths: the lane-by-lane buffer-load path),
@@ -521,6 +549,7 @@ PP_CASES = [(16, 16, (1, 1, 1), 1, (2, 1, 70, 100)), (16, 16, (1, 1, 1), 1, (1, 
 
 @pytest.mark.parametrize("cin,cout,stride,nt,shape", PP_CASES)
 @pytest.mark.parametrize("with_skip", [False, True])
+@needs_probes
 def test_pingpong_conv_bit_identical_to_direct(cin, cout, stride, nt, shape, with_skip):
     """Variant 7 (eight waves, the two halves of a workgroup in anti-phase) walks the same K order: EQUAL to the direct
     kernel, odd and even tile counts per workgroup, workgroups with no tile at all."""

@@ -91,11 +91,35 @@ def test_eval_golden_free_running(model, golden):
         note("free_stage%d" % s, depth_l1=(depth - want_depth).abs().mean(), agree_frac=close.float().mean(),
              hypo_max=(st["hypo_depth"].cpu() - g.t("stage%d_hypo_depth" % s)).abs().max())
         assert st["photometric_confidence"].shape[-2:] == (H, W)
+        # the free-running figure over ALL pixels, bounded (measured on G6: L1 0 / 1.2e-5 / 2.5e-5 / 1.15e-4 at stages 1-4,
+        # 99.996 % of the stage-4 pixels within 1e-3).  The north star's "depth L1 < 1e-4" holds under the tie-aware
+        # protocol only (clear-margin pixels, teacher forcing: test_eval_golden_teacher_forced, L1 = 0); all-pixel free
+        # running at the last stage sits just above it because of winner-take-all flips on near-ties
+        assert (depth - want_depth).abs().mean().item() < (1e-4 if s < 4 else 5e-4), s
+        assert close.float().mean().item() > 0.9995, s
     # stage 1 hypotheses are input-independent of earlier stages: exact
     assert torch.equal(out["stage1"]["hypo_depth"].cpu(), g.t("stage1_hypo_depth"))
     s1 = out["stage1"]["depth"].cpu()
     clear = g.t("stage1_margin") > 1e-3
     assert (s1 - g.t("stage1_depth"))[clear].abs().mean() < 1e-4
+
+
+@pytest.mark.parametrize("H,W,N", [(832, 1152, 5), (768, 1024, 3)])
+def test_untuned_resolution_close_to_exhaustive_choice(model, H, W, N):
+    """Resolutions the measured table does not hold (832 x 1152 x 5 is the reference's real "mid" workload, test_mvs4.py:41-42):
+    the plans' own choices -- exact entries, else the layer family's entry nearest in size, else the heuristics -- summed over
+    the distinct layers of a forward, against the best candidate per layer found by timing all of them here."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from scripts.conv_microbench import auto_vs_best, record_eval_calls
+    rows = auto_vs_best(record_eval_calls(model, H, W, N, torch.device(DEV)), torch.device(DEV), n=5)
+    sa, sb = sum(r[1] for r in rows), sum(r[2] for r in rows)
+    worst = max(rows, key=lambda r: r[1] / r[2])
+    note("untuned_%dx%dx%d" % (H, W, N), auto_us=sa, best_us=sb, excess=sa / sb - 1, layers=len(rows),
+         by_family=sum(1 for r in rows if r[4] == "family"), by_heuristic=sum(1 for r in rows if r[4] == "heuristic"),
+         worst_excess=worst[1] / worst[2] - 1)
+    print("untuned %dx%dx%d: worst layer %s" % (H, W, N, worst[0]))
+    assert sa <= 1.05 * sb, (sa, sb, worst)
 
 
 def test_graph_replay_is_bit_identical(model):

@@ -108,6 +108,26 @@ def test_conv_wgrad_many_rows_is_deterministic():
     assert ((a.cpu().double() - wd.grad).abs().max() / wd.grad.abs().max()).item() <= 2e-5
 
 
+@pytest.mark.parametrize("CI,CO,k", [(48, 16, (1, 3, 3)), (16, 48, (1, 3, 3)), (48, 48, (3, 3, 3)), (32, 64, (1, 3, 3)), (64, 64, (3, 3, 3))])
+def test_conv_wgrad_channel_counts_of_three_tiles(CI, CO, k):
+    """ops.conv_wgrad with 48 channels on either side (three 16-channel tiles: the callers round the tile count up to four,
+    so the persistent LDS-DMA kernel must not take these with its 16 * tiles planes) and two covered shapes for contrast,
+    against fp64 autograd."""
+    g = torch.Generator().manual_seed(CI + CO)
+    B, D, H, W = 2, 3, 12, 70
+    x = torch.randn(B, D, H, W, CI, generator=g).to(DEV)
+    gy = torch.randn(B, D, H, W, CO, generator=g).to(DEV)
+    pad = (k[0] // 2, 1, 1)
+    got = ops.conv_wgrad(x, gy, k, (1, 1, 1), pad)
+    xd = x.cpu().double().permute(0, 4, 1, 2, 3)
+    wd = torch.zeros(CO, CI, *k, dtype=torch.float64, requires_grad=True)
+    F.conv3d(xd, wd, None, padding=pad).backward(gy.cpu().double().permute(0, 4, 1, 2, 3))
+    assert tuple(got.shape) == tuple(wd.grad.shape)
+    err = ((got.cpu().double() - wd.grad).abs().max() / wd.grad.abs().max()).item()
+    note("conv_wgrad_%d_%d_k%d" % (CI, CO, k[0]), dw=err)
+    assert err <= 2e-5, err
+
+
 @pytest.mark.parametrize("C,relu", [(16, False), (8, True), (64, True), (4, True)])
 def test_batch_norm_cl_matches_torch(C, relu):
     g = torch.Generator().manual_seed(9 + C)
@@ -745,6 +765,38 @@ def test_graphed_step_gradients_equal_eager_gradients(monkeypatch):
             worst, worst_name = e, k
     note("graphed_vs_eager_gradients", worst_abs_over_global_max=worst, worst=worst_name, tensors=len(g1))
     assert worst <= 1e-5, (worst_name, worst)
+
+
+def test_eager_forward_after_graph_replays_sees_the_updated_weights():
+    """Optimizer updates that run inside a hipGraph replay bump no version counter: the packed forms of the training layers
+    (train_ops._LayerCache) and the folded eval plans would be stale for an eager forward that follows.  GraphedTrainStep
+    bumps the cache epoch after every replay; an eager training-mode forward and an eval forward after three replays must
+    equal those of a fresh model that loads the updated state."""
+    from mvster_amd.graph import GraphedTrainStep
+    build, loss_fn, (imgs, proj, dv, gt, mask) = _small_train_setup(seed_sd=8)
+    m = build()
+    opt = torch.optim.Adam(m.parameters(), lr=5e-3, capturable=True)         # (large steps: a stale layer is far off)
+    with torch.no_grad():
+        before = m(imgs, proj, dv)["stage2"]["attn_weight"].clone()
+    step = GraphedTrainStep(m, opt, loss_fn, imgs, proj, dv, gt, mask, warmup=2)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    fresh = build()
+    fresh.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        got = m(imgs, proj, dv)
+        want = fresh(imgs, proj, dv)
+    moved = (got["stage2"]["attn_weight"] - before).abs().max().item()
+    assert moved > 1e-3, moved                                               # the updates did change the network
+    for name in ("stage1", "stage2", "stage4"):
+        assert (got[name]["attn_weight"] - want[name]["attn_weight"]).abs().max().item() <= 1e-5, name
+    m.eval()
+    fresh.load_state_dict(m.state_dict())
+    fresh.eval()
+    with torch.no_grad():
+        a, b = m(imgs, proj, dv), fresh(imgs, proj, dv)
+    assert (a["stage3"]["attn_weight"] - b["stage3"]["attn_weight"]).abs().max().item() <= 1e-5
 
 
 def test_graphed_step_with_bucketed_all_reduce_single_rank():

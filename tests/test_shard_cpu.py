@@ -164,3 +164,22 @@ def test_cpulist_parser_and_numa_pin_is_best_effort(tmp_path):
     before = os.sched_getaffinity(0)
     assert shard.pin_to_gpu_numa(0, sysfs=str(tmp_path)) is None           # no GPU / no sysfs entry: nothing changes
     assert os.sched_getaffinity(0) == before
+
+
+def test_grad_bucket_mixed_and_aliased_gradients():
+    """GradBucket.sync outside the captured step: a gradient that already is its bucket slice survives a later step in which
+    another parameter has no gradient (only that parameter's slice is zeroed), and partially aliased gradients never feed a
+    copy that overlaps them."""
+    torch.manual_seed(0)
+    a, b, c = (torch.nn.Parameter(torch.randn(n)) for n in (3, 4, 2))
+    bucket = shard.GradBucket([a, b, c])
+    a.grad, b.grad, c.grad = torch.ones(3), 2 * torch.ones(4), 3 * torch.ones(2)
+    bucket.sync()
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip((a, b, c), bucket.views))
+    # next eager step: a accumulates in place (aliased), b gets a fresh tensor, c has no gradient this time
+    a.grad.add_(1.0)
+    b.grad = 5 * torch.ones(4)
+    c.grad = None
+    flat = bucket.sync()
+    assert torch.equal(flat, torch.tensor([2., 2, 2, 5, 5, 5, 5, 0, 0]))
+    assert torch.equal(a.grad, 2 * torch.ones(3)) and torch.equal(c.grad, torch.zeros(2))
