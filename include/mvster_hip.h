@@ -181,6 +181,14 @@ int mvster_fpn_tail_gather_bwd(const float* gP, float* gG, int NB, int H, int W,
 int mvster_fpn_lateral_up(const float* x, const float* A, const float* bias, const float* q, float* out, int NB,
                           int H, int W, int CI, int CO, void* stream);
 
+/* mvster_fpn_lateral_up (16 -> 72) + mvster_fpn_tail_gather (CO = 8) of the finest FPN level in ONE launch: a workgroup builds
+ * the half-resolution 72-channel patch its 8 x 32 output tile gathers from straight into LDS (lateral product on MFMA tiles,
+ * bilinear x2 of q in the epilogue), so the 118 MB map between the two kernels never touches HBM.  x [NB,H/2,W/2,16],
+ * A [72,16], bias [72], q [NB,H/4,W/4,72], vb [9,8] -> P [NB,H,W,8].  H, W multiples of 4, H >= 16, W >= 64, CI = 16;
+ * MVSTER_ERR_UNSUPPORTED otherwise.  models/mvs4net_utils.py:485-489 (section 4.3 of DESIGN.md). */
+int mvster_fpn_tail_fused(const float* x, const float* A, const float* bias, const float* q, const float* vb, float* P,
+                          int NB, int H, int W, int CI, void* stream);
+
 /* Packed-weight refresh on the device (training, once per layer and optimizer step): writes the fragment order
  * [K/16][N/16][64][4] that mvster_conv_mfma reads, Bm[tap*cin_pad + ci][n] = w[n*s_n + ci*s_c + kz*s_z + ky*s_y + kx*s_x]
  * (element strides of the parameter tensor; flip = 1 mirrors the taps: the input-gradient form of a stride-1 layer),

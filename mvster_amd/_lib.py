@@ -36,6 +36,7 @@ SIGNATURES = {
     "mvster_deconv_small": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f],
     "mvster_fpn_tail_gather": [_f, _f, _f, _f, _i, _i, _i, _i, _f],
     "mvster_fpn_lateral_up": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f],
+    "mvster_fpn_tail_fused": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f],
     "mvster_fpn_tail_gather_bwd": [_f, _f, _i, _i, _i, _i, _i, _f],
     "mvster_pack_conv_weights": [_f, _f] + [_i] * 6 + [_l] * 5 + [_i, _f],
     "mvster_pack_wino_weights": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _l, _l, _i, _f],

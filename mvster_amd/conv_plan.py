@@ -66,10 +66,12 @@ def layer_signature(layer, B, Di, Hi, Wi, skip_mode):
 
 
 # The measured table is keyed on exact shapes; any other resolution used to fall straight to the heuristics.  Its choices
-# are a function of the layer FAMILY (channels, kernel, stride, skip mode) and of the map's size far more than of the exact
-# shape (217 of its 238 (family, log2 voxels) buckets hold one choice), so an unknown shape takes the choice of the family's
-# entry nearest in log2(B * Di * Hi * Wi) -- within FAMILY_REACH octaves -- before the heuristics; exact entries override.
-FAMILY_REACH = 1.6
+# are a function of the layer FAMILY (channels, kernel, stride, skip mode) and of the map's size and depth far more than of
+# the exact shape, so an unknown shape takes the choice of the family's entry nearest in
+#     |log2 voxels ratio| + |log2 depth ratio| + 0.25 |log2 batch ratio|
+# (the depth split matters to the 3-D kernels and to how many slices share a tile row: 4 x 48 x 64 and 8 x 32 x 48 voxels
+# want different ring-kernel modes) within FAMILY_REACH before the heuristics; exact entries override.
+FAMILY_REACH = 2.0
 _FAMILIES = None
 _SIG = None
 
@@ -85,12 +87,10 @@ def _families():
             m = _SIG.match(sig)
             if not m:
                 continue
-            vox = 1
-            for i in (2, 3, 4, 5):
-                vox *= int(m.group(i))
-            fam.setdefault((m.group(1), int(m.group(6))), []).append((math.log2(vox), list(val)))
+            B, D, H, W = (int(m.group(i)) for i in (2, 3, 4, 5))
+            fam.setdefault((m.group(1), int(m.group(6))), []).append((math.log2(B * D * H * W), math.log2(D), math.log2(B), list(val)))
         for lst in fam.values():
-            lst.sort(key=lambda e: e[0])
+            lst.sort(key=lambda e: e[:3])
         _FAMILIES = fam
     return _FAMILIES
 
@@ -104,14 +104,14 @@ def tuned_choice(layer, B, Di, Hi, Wi, skip_mode):
         return hit, "exact"
     lst = _families().get((sig[:sig.index("_", sig.index("_s") + 1)], skip_mode))
     if lst:
-        lv = math.log2(max(1, B * Di * Hi * Wi))
-        d, val = min((abs(l - lv), v) for l, v in lst)
+        lv, ld, lb = math.log2(max(1, B * Di * Hi * Wi)), math.log2(max(1, Di)), math.log2(max(1, B))
+        d, val = min(((abs(e[0] - lv) + abs(e[1] - ld) + 0.25 * abs(e[2] - lb), e[3]) for e in lst), key=lambda t: t[0])
         if d <= FAMILY_REACH:
             return list(val), "family"
     return None, None
 
 
-import os as _os
+FUSE_TAIL = True                # finest FPN level: lateral step + gather-sum in one launch (tests set it to False for the two launches)
 FUSE_SELECT = True              # reg2d conv11 + prob + selection in one launch (tests set it to False for the two-launch form)
 LDS_BUDGET = 12 * 256 * 16      # bytes of staged patch the LDS variant accepts (conv_mfma.hip kMaxStage)
 FORCE_VARIANT = None            # None = choose per layer; 0 / 1 pin the kernel variant (experiments, tests)
@@ -757,8 +757,10 @@ class FpnPlan:
         H, W = c0.shape[2], c0.shape[3]
         p3 = ops.fpn_tail_gather(self.mid_g(f1), self.mid_vb, H // 2, W // 2)
         o3 = self.mid_c(c1, skip=p3, skip_mode=SKIP_ADD)
-        g4 = ops.fpn_lateral_up(c1, self.tail_a, self.tail_ab, self.tail_g(f1))
-        p4 = ops.fpn_tail_gather(g4, self.tail_vb, H, W)
+        q4 = self.tail_g(f1)
+        p4 = ops.fpn_tail_fused(c1, self.tail_a, self.tail_ab, q4, self.tail_vb, H, W) if FUSE_TAIL else None
+        if p4 is None:                                                       # (small / odd maps: two launches)
+            p4 = ops.fpn_tail_gather(ops.fpn_lateral_up(c1, self.tail_a, self.tail_ab, q4), self.tail_vb, H, W)
         o4 = self.tail_c(c0, skip=p4, skip_mode=SKIP_ADD)
         return o3, o4
 

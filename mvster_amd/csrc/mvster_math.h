@@ -291,6 +291,22 @@ MV_HD Lerp make_lerp(int dst, int in_size, int out_size) {
     return l;
 }
 
+// make_lerp with the scale (in_size - 1) / (out_size - 1) formed once by the caller (same fp32 quotient: same bits)
+MV_HD float lerp_scale(int in_size, int out_size) { return (out_size > 1) ? (float)(in_size - 1) / (float)(out_size - 1) : 0.0f; }
+MV_HD Lerp make_lerp_s(int dst, float scale, int in_size) {
+    Lerp l;
+    float src = mul_rn(scale, (float)dst);
+    int i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    float lam = sub_rn(src, (float)i0);
+    lam = lam < 0.0f ? 0.0f : (lam > 1.0f ? 1.0f : lam);
+    l.i0 = i0;
+    l.i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+    l.w1 = lam;
+    l.w0 = sub_rn(1.0f, lam);
+    return l;
+}
+
 // h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
 MV_HD float bilerp(const Lerp& ly, const Lerp& lx, float v00, float v01, float v10, float v11) {
     float top = add_rn(mul_rn(lx.w0, v00), mul_rn(lx.w1, v01));

@@ -156,7 +156,7 @@ template <int COT>
 __global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* __restrict__ G,
                                                                   const float* __restrict__ vb,
                                                                   float* __restrict__ P, int NB, int H, int W,
-                                                                  FastDiv tiles_x, FastDiv tiles_y) {
+                                                                  FastDiv tiles_x, FastDiv tiles_y, float sy, float sx) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     constexpr int CO = 8;
     constexpr int CGT = 9 * COT;               // channels of G per half-resolution pixel
@@ -171,8 +171,8 @@ __global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* _
     const int y0 = (int)tyu * 8, x0 = (int)txu * 32;
     // half-resolution footprint of output rows y0-1 .. y0+8 and columns x0-1 .. x0+32 (clamped to the image)
     const int ylo = max(y0 - 1, 0), yhi = min(y0 + 8, H - 1), xlo = max(x0 - 1, 0), xhi = min(x0 + 32, W - 1);
-    const int r0 = mv::make_lerp(ylo, Hh, H).i0, r1 = mv::make_lerp(yhi, Hh, H).i1;
-    const int c0 = mv::make_lerp(xlo, Wh, W).i0, c1 = mv::make_lerp(xhi, Wh, W).i1;
+    const int r0 = mv::make_lerp_s(ylo, sy, Hh).i0, r1 = mv::make_lerp_s(yhi, sy, Hh).i1;
+    const int c0 = mv::make_lerp_s(xlo, sx, Wh).i0, c1 = mv::make_lerp_s(xhi, sx, Wh).i1;
     const int nr = r1 - r0 + 1, nc = c1 - c0 + 1;       // <= PR, <= PC
     // Staging: ALL of a thread's loads are issued before the first one is consumed (up to 12 x 16 bytes in flight per
     // thread; unused slots fall outside the buffer descriptor and cost nothing).  As a load-store loop the 10-odd trips
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* _
     for (int k = 0; k < 3; ++k) {
         const int qy = y + k - 1, qx = x + k - 1;
         const bool iy = (unsigned)qy < (unsigned)H, ix = (unsigned)qx < (unsigned)W;
-        const mv::Lerp ly = mv::make_lerp(iy ? qy : y, Hh, H), lx = mv::make_lerp(ix ? qx : x, Wh, W);
+        const mv::Lerp ly = mv::make_lerp_s(iy ? qy : y, sy, Hh), lx = mv::make_lerp_s(ix ? qx : x, sx, Wh);   // (scales formed on the host: six divisions less per thread)
         ry0[k] = (ly.i0 - r0) * PC * Q; ry1[k] = (ly.i1 - r0) * PC * Q;
         cx0[k] = (lx.i0 - c0) * Q;      cx1[k] = (lx.i1 - c0) * Q;
         wy0[k] = iy ? ly.w0 : 0.0f; wy1[k] = iy ? ly.w1 : 0.0f;
@@ -266,75 +266,113 @@ __global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* _
 // lateral product on v_mfma_f32_16x16x4_f32 (M = patch pixels, N = 72 channels in five tiles, K = 16 = four steps; D^T form,
 // so a lane ends up with four consecutive channels of one pixel), the bilinear x2 of q added in the epilogue -- and then
 // runs the gather-sum of fpn_tail_gather_lds_kernel on it unchanged.  HBM traffic: x (26 MB) + q (29 MB) + P (52 MB).
-// Per element the arithmetic is the two kernels' (bias first, channel-ordered products, up2(q) + that, then the flat
-// 36-weight gather), with the lateral product's summation order that of the MFMA K steps.
+// Same mathematics as the two kernels; the lateral product is summed in the MFMA's K order and up2(q) is the flat
+// four-weight FMA form (the kernel is VALU-instruction-bound: 1 120 VALU instructions per wave, PMC), so values agree with
+// the two launches to ~3e-7 of the largest output, not bit for bit.
 template <int CI>
 __global__ void __launch_bounds__(256) fpn_tail_fused_kernel(const float* __restrict__ x, const float* __restrict__ A,
                                                              const float* __restrict__ bias, const float* __restrict__ qmap,
                                                              const float* __restrict__ vb, float* __restrict__ P, int NB,
-                                                             int H, int W, FastDiv tiles_x, FastDiv tiles_y) {
+                                                             int H, int W, FastDiv tiles_x, FastDiv tiles_y, float sy, float sx, float sqy, float sqx) {
     static_assert(CI == 16, "one 16-wide K block");
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     constexpr int CO = 8, CG = 72, Q = CG / 4;
-    constexpr int PR = 8, PC = 20;
+    constexpr int PR = 7, PC = 19;             // half-resolution patch of an 8 x 32 output tile (+ 1-pixel ring): <= 7 x 19
+    constexpr int QR = 6, QC = 12;             // its quarter-resolution footprint: <= 6 x 12
+    constexpr int MT = (PR * PC + 63) / 64;    // M tiles of 16 patch pixels per wave
     __shared__ f32x4 patch[PR * PC * Q];
+    __shared__ f32x4 qpatch[QR * QC * Q];
     __shared__ float vbsum[9][CO];
     const int Hh = H / 2, Wh = W / 2, Hq = Hh / 2, Wq = Wh / 2;
     unsigned txu, tyu;
     const int b = (int)fdivmod(fdivmod(xcd_remap(blockIdx.x, gridDim.x), tiles_x, txu), tiles_y, tyu);
     const int y0 = (int)tyu * 8, x0 = (int)txu * 32;
     const int ylo = max(y0 - 1, 0), yhi = min(y0 + 8, H - 1), xlo = max(x0 - 1, 0), xhi = min(x0 + 32, W - 1);
-    const int r0 = mv::make_lerp(ylo, Hh, H).i0, r1 = mv::make_lerp(yhi, Hh, H).i1;
-    const int c0 = mv::make_lerp(xlo, Wh, W).i0, c1 = mv::make_lerp(xhi, Wh, W).i1;
+    const int r0 = mv::make_lerp_s(ylo, sy, Hh).i0, r1 = mv::make_lerp_s(yhi, sy, Hh).i1;
+    const int c0 = mv::make_lerp_s(xlo, sx, Wh).i0, c1 = mv::make_lerp_s(xhi, sx, Wh).i1;
     const int nr = r1 - r0 + 1, nc = c1 - c0 + 1;       // <= PR, <= PC
     const int npix = nr * nc;
+    // quarter-resolution footprint of the patch
+    const int qr0 = mv::make_lerp_s(r0, sqy, Hq).i0, qr1 = mv::make_lerp_s(r1, sqy, Hq).i1;
+    const int qc0 = mv::make_lerp_s(c0, sqx, Wq).i0, qc1 = mv::make_lerp_s(c1, sqx, Wq).i1;
+    const int qnr = qr1 - qr0 + 1, qnc = qc1 - qc0 + 1;  // <= QR, <= QC
 
-    // ---- phase A: the lateral step of this tile's patch, into LDS --------------------------------------------------------
+    // ---- phase A: the lateral step of this tile's patch, into LDS ---------------------------------------------------------
+    // every global load of the phase is in flight before the first one is consumed: the quarter-resolution patch of q (staged
+    // in LDS: each of its values is a corner of ~9 patch pixels) and this lane's input pixels (the MFMA B operand)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lm = lane & 15, lq = lane >> 4;
     {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int lm = lane & 15, lq = lane >> 4;
+        const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(qmap + (long)b * Hq * Wq * CG), (short)0, (int)((long)Hq * Wq * CG * 4), 0x00020000);
+        constexpr int NIT = (QR * QC * Q + 255) / 256;
+        f32x4 stg[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = threadIdx.x + it * 256;
+            const int qd = i % Q, pix = i / Q;
+            const int pc = pix % QC, pr = pix / QC;
+            const bool ok = pr < qnr && pc < qnc;
+            const unsigned off = ok ? (unsigned)(((qr0 + pr) * Wq + (qc0 + pc)) * CG + qd * 4) * 4u : 0xFFFFFFF0u;
+            stg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrsrc, off, 0, 0));
+        }
+        // this lane's patch pixels (M tile 4 mt + wave: pixels (4 mt + wave) * 16 + lm) and their input vectors
+        const float* xb = x + (long)b * Hh * Wh * CI;
+        const FastDiv ncd = mv_fastdiv_dev((unsigned)nc);
+        f32x4 xv[MT];
+        int ppos[MT];                                   // pr | pc << 8, -1 = no pixel
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int i = (4 * mt + wave) * 16 + lm;
+            const bool valid = i < npix;
+            unsigned pcu;
+            const int pr = (int)fdivmod((unsigned)(valid ? i : 0), ncd, pcu), pc = (int)pcu;
+            ppos[mt] = valid ? (pr | (pc << 8)) : -1;
+            xv[mt] = ld4(xb + ((long)(r0 + pr) * Wh + (c0 + pc)) * CI + 4 * lq);
+        }
         // weights as the A operand: row lm of N tile nt = channel nt * 16 + lm, K slot (j, lq) = input channel 4 lq + j
         float aw[5][4];
+        f32x4 bv[5];
 #pragma unroll
         for (int nt = 0; nt < 5; ++nt) {
             const int co = nt * 16 + lm;
             const f32x4 v = co < CG ? ld4(A + co * CI + 4 * lq) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) aw[nt][j] = v[j];
+            bv[nt] = ld4(bias + (nt * 4 + lq < Q ? nt * 16 + 4 * lq : 0));
         }
-        const float* xb = x + (long)b * Hh * Wh * CI;
-        const float* qb = qmap + (long)b * Hq * Wq * CG;
-        const FastDiv ncd = mv_fastdiv_dev((unsigned)nc);
-        for (int mt = wave; mt * 16 < npix; mt += 4) {
-            const int i = mt * 16 + lm;
-            const bool valid = i < npix;
-            unsigned pcu;
-            const int pr = (int)fdivmod((unsigned)(valid ? i : 0), ncd, pcu), pc = (int)pcu;
-            const int hy = r0 + pr, hx = c0 + pc;
-            const f32x4 xv = ld4(xb + ((long)hy * Wh + hx) * CI + 4 * lq);
-            const mv::Lerp ly = mv::make_lerp(hy, Hq, Hh), lx = mv::make_lerp(hx, Wq, Wh);
-            const float* q00p = qb + ((long)ly.i0 * Wq + lx.i0) * CG + 4 * lq;
-            const float* q01p = qb + ((long)ly.i0 * Wq + lx.i1) * CG + 4 * lq;
-            const float* q10p = qb + ((long)ly.i1 * Wq + lx.i0) * CG + 4 * lq;
-            const float* q11p = qb + ((long)ly.i1 * Wq + lx.i1) * CG + 4 * lq;
-            f32x4 q00[5], q01[5], q10[5], q11[5], acc[5];
 #pragma unroll
-            for (int nt = 0; nt < 5; ++nt) {
-                const bool has = nt * 4 + lq < Q;                 // (the fifth N tile holds channels 64..71 only)
-                const int o = has ? nt * 16 : 0;
-                q00[nt] = ld4(q00p + o); q01[nt] = ld4(q01p + o); q10[nt] = ld4(q10p + o); q11[nt] = ld4(q11p + o);
-                acc[nt] = ld4(bias + (has ? nt * 16 + 4 * lq : 0));
-            }
+        for (int it = 0; it < NIT; ++it) {
+            const int i = threadIdx.x + it * 256;
+            if (i < QR * QC * Q) qpatch[i] = stg[it];          // (i = (pr * QC + pc) * Q + quad)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if ((4 * mt + wave) * 16 >= npix) break;           // (wave-uniform)
+            const bool valid = ppos[mt] >= 0;
+            const int pr = valid ? ppos[mt] & 255 : 0, pc = valid ? ppos[mt] >> 8 : 0;
+            const mv::Lerp ly = mv::make_lerp_s(r0 + pr, sqy, Hq), lx = mv::make_lerp_s(c0 + pc, sqx, Wq);
+            // (flat 4-weight form on FMAs: 4 instead of 10 packed operations per channel pair)
+            const float w00 = ly.w0 * lx.w0, w01 = ly.w0 * lx.w1, w10 = ly.w1 * lx.w0, w11 = ly.w1 * lx.w1;
+            const f32x4* q00p = qpatch + ((ly.i0 - qr0) * QC + (lx.i0 - qc0)) * Q + lq;
+            const f32x4* q01p = qpatch + ((ly.i0 - qr0) * QC + (lx.i1 - qc0)) * Q + lq;
+            const f32x4* q10p = qpatch + ((ly.i1 - qr0) * QC + (lx.i0 - qc0)) * Q + lq;
+            const f32x4* q11p = qpatch + ((ly.i1 - qr0) * QC + (lx.i1 - qc0)) * Q + lq;
+            f32x4 acc[5];
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) acc[nt] = bv[nt];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int nt = 0; nt < 5; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[nt][j], xv[j], acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < 5; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[nt][j], xv[mt][j], acc[nt], 0, 0, 0);
 #pragma unroll
             for (int nt = 0; nt < 5; ++nt) {
-                if (valid && nt * 4 + lq < Q) {
+                if (valid && nt * 4 + lq < Q) {                // (the fifth N tile holds channels 64..71 only)
+                    const f32x4 a00 = q00p[nt * 4], a01 = q01p[nt * 4], a10 = q10p[nt * 4], a11 = q11p[nt * 4];
                     f32x4 r;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) r[k] = mv::bilerp(ly, lx, q00[nt][k], q01[nt][k], q10[nt][k], q11[nt][k]) + acc[nt][k];
+                    for (int k = 0; k < 4; ++k) r[k] = fmaf(w00, a00[k], fmaf(w01, a01[k], fmaf(w10, a10[k], fmaf(w11, a11[k], acc[nt][k]))));
                     patch[(pr * PC + pc) * Q + nt * 4 + lq] = r;
                 }
             }
@@ -363,7 +401,7 @@ __global__ void __launch_bounds__(256) fpn_tail_fused_kernel(const float* __rest
     for (int k = 0; k < 3; ++k) {
         const int qy = y + k - 1, qx = xo + k - 1;
         const bool iy = (unsigned)qy < (unsigned)H, ix = (unsigned)qx < (unsigned)W;
-        const mv::Lerp ly = mv::make_lerp(iy ? qy : y, Hh, H), lx = mv::make_lerp(ix ? qx : xo, Wh, W);
+        const mv::Lerp ly = mv::make_lerp_s(iy ? qy : y, sy, Hh), lx = mv::make_lerp_s(ix ? qx : xo, sx, Wh);
         ry0[k] = (ly.i0 - r0) * PC * Q; ry1[k] = (ly.i1 - r0) * PC * Q;
         cx0[k] = (lx.i0 - c0) * Q;      cx1[k] = (lx.i1 - c0) * Q;
         wy0[k] = iy ? ly.w0 : 0.0f; wy1[k] = iy ? ly.w1 : 0.0f;
@@ -736,10 +774,10 @@ extern "C" int mvster_fpn_tail_gather(const float* G, const float* vb, float* P,
         const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
         if (CO == 8)
             hipLaunchKernelGGL(fpn_tail_gather_lds_kernel<8>, dim3(tiles_x * tiles_y * NB), block, 0, s, G, vb, P, NB, H, W,
-                               mv_fastdiv(tiles_x), mv_fastdiv(tiles_y));
+                               mv_fastdiv(tiles_x), mv_fastdiv(tiles_y), mv::lerp_scale(H / 2, H), mv::lerp_scale(W / 2, W));
         else
             hipLaunchKernelGGL(fpn_tail_gather_lds_kernel<16>, dim3(tiles_x * tiles_y * NB, 2), block, 0, s, G, vb, P, NB, H,
-                               W, mv_fastdiv(tiles_x), mv_fastdiv(tiles_y));
+                               W, mv_fastdiv(tiles_x), mv_fastdiv(tiles_y), mv::lerp_scale(H / 2, H), mv::lerp_scale(W / 2, W));
         return mv_check_launch();
     }
     dim3 grid((H * W + 255) / 256, NB);
@@ -789,7 +827,8 @@ extern "C" int mvster_fpn_tail_fused(const float* x, const float* A, const float
     if ((long)tiles_x * tiles_y * NB >= (1L << 31)) return MVSTER_ERR_SHAPE;
     MV_NOTE_KERNEL("fpn_tail_fused_kernel<16>");
     hipLaunchKernelGGL(fpn_tail_fused_kernel<16>, dim3(tiles_x * tiles_y * NB), dim3(256), 0, (hipStream_t)stream, x, A, bias, q, vb,
-                       P, NB, H, W, mv_fastdiv(tiles_x), mv_fastdiv(tiles_y));
+                       P, NB, H, W, mv_fastdiv(tiles_x), mv_fastdiv(tiles_y), mv::lerp_scale(H / 2, H), mv::lerp_scale(W / 2, W),
+                       mv::lerp_scale(H / 4, H / 2), mv::lerp_scale(W / 4, W / 2));
     return mv_check_launch();
 }
 

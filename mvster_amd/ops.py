@@ -286,6 +286,25 @@ def fpn_lateral_up(x, A, bias, q):
     return out
 
 
+def fpn_tail_fused(x, A, bias, q, vb, H, W):
+    """fpn_lateral_up + fpn_tail_gather of the finest FPN level in one launch (the 72-channel half-resolution map stays in
+    LDS): x [NB,1,H/2,W/2,16], A [72,16], bias [72], q [NB,1,H/4,W/4,72], vb [9,8] -> P [NB,1,H,W,8], or None where the
+    fused kernel does not apply (small or odd maps: the two launches cover those)."""
+    for t, n in ((x, "x"), (A, "A"), (bias, "bias"), (q, "q"), (vb, "vb")):
+        _chk(t, "fpn_tail_fused:" + n)
+    NB, _, Hh, Wh, CI = x.shape
+    lib = _lib.load()
+    if (CI != 16 or tuple(A.shape) != (72, 16) or tuple(vb.shape) != (9, 8) or H % 4 or W % 4 or H < 16 or W < 64
+            or not hasattr(lib, "mvster_fpn_tail_fused")):
+        return None
+    if (Hh, Wh) != (H // 2, W // 2) or bias.numel() != 72 or tuple(q.shape) != (NB, 1, H // 4, W // 4, 72):
+        raise RuntimeError("fpn_tail_fused: inconsistent shapes")
+    P = torch.empty(NB, 1, H, W, 8, device=x.device, dtype=torch.float32)
+    _lib.check(lib.mvster_fpn_tail_fused(_ptr(x), _ptr(A), _ptr(bias), _ptr(q), _ptr(vb), _ptr(P), NB, H, W, CI, _stream()),
+               "fpn_tail_fused")
+    return P
+
+
 def mfma_probe(A, Bm):
     """A [16,4] @ B [4,16] on one v_mfma_f32_16x16x4_f32 (layout test hook)."""
     A, Bm = A.contiguous(), Bm.contiguous()

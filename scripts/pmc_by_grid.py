@@ -24,7 +24,7 @@ for f in glob.glob(os.path.join(root, "*", "*counter_collection.csv")):
         for r in csv.DictReader(fh):
             cnt[(short(r["Kernel_Name"]), r.get("Grid_Size"))][r["Counter_Name"]].append(float(r["Counter_Value"] or 0))
 for key in sorted(cnt, key=lambda k: k[0]):
-    if not any(key[0].startswith(p) for p in ("conv_narrow", "conv_small", "deconv_select")):
+    if not any(key[0].startswith(p) for p in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("conv_narrow", "conv_small", "deconv_select"))):
         continue
     m = {c: sum(v[1:]) / max(len(v) - 1, 1) for c, v in cnt[key].items()}          # (first launch of a case dropped)
     d = sorted(dur.get(key, [0]))

@@ -127,9 +127,13 @@ class Emulated:
         cp.ops.fpn_tail_gather = fpn_tail_gather_reference
         orig_lateral = cp.ops.fpn_lateral_up
         cp.ops.fpn_lateral_up = fpn_lateral_up_reference
+        orig_fused = cp.ops.fpn_tail_fused
+        # the fused launch of the finest level = its two steps, restated
+        cp.ops.fpn_tail_fused = lambda x_, A, b, q, vb, H, W: fpn_tail_gather_reference(fpn_lateral_up_reference(x_, A, b, q), vb, H, W)
         try:
             return self.plan(x)
         finally:
             cp.ConvLayer.__call__ = orig
             cp.ops.fpn_tail_gather = orig_gather
             cp.ops.fpn_lateral_up = orig_lateral
+            cp.ops.fpn_tail_fused = orig_fused

@@ -137,7 +137,7 @@ def test_tuning_table_is_well_formed():
         table = json.load(f)
     assert len(table) > 300
     key = re.compile(r"^([CT])(\d+)-(\d+)_k(\d)x(\d)x(\d)_s(\d)x(\d)x(\d)_(\d+)x(\d+)x(\d+)x(\d+)_sk([012])$")
-    modes = {0: {0}, 1: {0}, 2: {0}, 5: {1, 2, 3, 33, 34}, 6: {2, 3}, 7: {0, 1, 2}, 8: {1, 2}, 9: {0, 1}}
+    modes = {0: {0}, 1: {0}, 2: {0}, 3: {0}, 5: {1, 2, 3, 33, 34}, 6: {2, 3}, 7: {0, 1, 2}, 8: {1, 2}, 9: {0, 1}, 10: {0}}
     for sig, val in table.items():
         m = key.match(sig)
         assert m, sig
@@ -145,6 +145,11 @@ def test_tuning_table_is_well_formed():
         variant, mt, nt = val
         fam, mode = variant & 0xff, variant >> 8
         assert fam in modes and mode in modes[fam], (sig, val)
+        if fam in (3, 10):      # narrow layers: VALU kernel (no tile arguments) or the shift-packed MFMA kernel (mt = tile rows / 4,
+            #                     nt = workgroups per CU)
+            assert (mt, nt) == (0, 0) if fam == 3 else (mt in (2, 4) and nt in (1, 2)), (sig, val)
+            assert sig.startswith(("C4-8_k1x3x3_s1x1x1_", "C8-8_k1x3x3_s1x1x1_")), sig
+            continue
         assert mt in (1, 2, 4) and nt in (1, 2, 3, 4, 5), (sig, val)
         transposed, cin, cout = m.group(1) == "T", int(m.group(2)), int(m.group(3))
         kernel = tuple(int(m.group(i)) for i in (4, 5, 6))
@@ -174,15 +179,24 @@ def test_family_fallback_of_the_tuning_table():
     assert how == "exact" and exact == cp._tuning()["C16-16_k1x3x3_s1x1x1_5x1x256x320_sk0"]
     # 832 x 1152 x 5 (the reference's real "mid" workload): half-resolution FPN level, not in the table
     fam, how = cp.tuned_choice(L, 5, 1, 416, 576, 0)
-    assert how == "family" and fam == cp._tuning()["C16-16_k1x3x3_s1x1x1_5x1x576x800_sk0"]     # 1.2 M voxels -> the 2.3 M entry
+    assert how == "family" and fam == cp._tuning()["C16-16_k1x3x3_s1x1x1_5x1x576x800_sk0"]     # 1.2 M voxels -> the 2.3 M entry (0.9 octaves; 5 x 256 x 320 is 1.5 away)
     assert cp.tuned_choice(L, 1, 1, 4, 4, 0) == (None, None)                                  # 16 voxels: nothing within reach
     L.cin, L.cout = 16, 48
     assert cp.tuned_choice(L, 5, 1, 256, 320, 0) == (None, None)                              # a family the table never saw
     # the family choice is a copy (callers unpack / edit it) and every family list is sorted by size
     fam[0] = -1
     assert cp.tuned_choice(L, 5, 1, 256, 320, 0) == (None, None)
-    for lst in cp._families().values():
-        assert [e[0] for e in lst] == sorted(e[0] for e in lst)
+    # depth counts: a 4-slice volume takes a 4-slice entry's choice even when an 8-slice entry is nearer in voxels
+    saved = cp._TUNING, cp._FAMILIES
+    try:
+        cp._TUNING = {"C64-64_k3x3x3_s1x1x1_1x8x32x48_sk0": [265, 2, 2], "C64-64_k3x3x3_s1x1x1_1x4x64x80_sk0": [9, 2, 1]}
+        cp._FAMILIES = None
+        L.cin, L.cout, L.kernel = 64, 64, (3, 3, 3)
+        assert cp.tuned_choice(L, 1, 4, 48, 64, 0) == ([9, 2, 1], "family")          # 12 288 voxels: equal to the 8-slice entry's
+        assert cp.tuned_choice(L, 1, 8, 32, 48, 0) == ([265, 2, 2], "exact")
+        assert cp.tuned_choice(L, 1, 8, 24, 32, 0) == ([265, 2, 2], "family")
+    finally:
+        cp._TUNING, cp._FAMILIES = saved
 
 
 def test_winograd_plan_for_untuned_shapes():

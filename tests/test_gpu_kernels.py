@@ -779,6 +779,33 @@ def test_fpn_lateral_up():
         assert err <= 1e-5 * want.abs().max().item()
 
 
+@pytest.mark.parametrize("NB,H,W", [(1, 16, 64), (2, 24, 100), (1, 40, 132), (5, 64, 96), (1, 128, 192), (1, 20, 68)])
+def test_fpn_tail_fused_equals_the_two_launches(NB, H, W):
+    """Finest FPN level: lateral step + gather-sum in one launch (the 72-channel map in LDS, lateral product on MFMA tiles)
+    against mvster_fpn_lateral_up followed by mvster_fpn_tail_gather, and against the fp64 restatement of both: ragged tiles,
+    maps barely inside the kernel's domain, several views."""
+    from mvster_amd import _lib
+    from tests.conv_emulator import fpn_lateral_up_reference, fpn_tail_gather_reference
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn(NB, 1, H // 2, W // 2, 16, generator=g)
+    A = torch.randn(72, 16, generator=g) * 0.3
+    bias = torch.randn(72, generator=g)
+    q = torch.randn(NB, 1, H // 4, W // 4, 72, generator=g)
+    vb = torch.randn(9, 8, generator=g)
+    two = ops.fpn_tail_gather(ops.fpn_lateral_up(x.to(DEV), A.to(DEV), bias.to(DEV), q.to(DEV)), vb.to(DEV), H, W)
+    one = ops.fpn_tail_fused(x.to(DEV), A.to(DEV), bias.to(DEV), q.to(DEV), vb.to(DEV), H, W)
+    assert one is not None and _lib.last_kernel() == "fpn_tail_fused_kernel<16>"
+    ref = fpn_tail_gather_reference(fpn_lateral_up_reference(x.double(), A.double(), bias.double(), q.double()), vb.double(), H, W)
+    scale = ref.abs().max().item()
+    e1 = (one.cpu().double() - ref).abs().max().item() / scale
+    e2 = (two.cpu().double() - ref).abs().max().item() / scale
+    d = (one - two).abs().max().item() / scale
+    note("fpn_tail_fused_%dx%dx%d" % (NB, H, W), fused_vs_fp64=e1, two_launches_vs_fp64=e2, fused_vs_two=d)
+    assert e1 <= 5e-6 and d <= 1e-6, (e1, e2, d)        # (measured: 1e-6 .. 2.2e-6 for both forms against fp64, 2-3e-7 between them)
+    assert ops.fpn_tail_fused(x[:, :, :4, :30].contiguous().to(DEV), A.to(DEV), bias.to(DEV), q[:, :, :2, :15].contiguous().to(DEV),
+                              vb.to(DEV), 8, 60) is None                 # outside the domain: the caller takes the two launches
+
+
 BWD_CASES = [
     # C, G, D, group_cor, attn_fuse_d
     (64, 8, 8, True, True), (32, 8, 8, True, True), (16, 4, 4, True, True), (8, 4, 4, True, True),       # the shipped stages
