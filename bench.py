@@ -71,6 +71,7 @@ class KernelTimer:
         self._orig_conv = cp.ConvLayer.__call__
         self._orig_warp = ops.warp_agg_fwd_cl
         self._orig_sel = cp.fused_conv11_select
+        self._orig_fpn = (ops.fpn_tail_fused, ops.fpn_tail_gather, ops.fpn_lateral_up)
 
         def conv_call(layer, x, skip=None, skip_mode=0, tiles=None):
             B, Di, Hi, Wi, _ = x.shape
@@ -104,9 +105,24 @@ class KernelTimer:
             timer.records.append((_lib.last_kernel(), e0, e1, 2 * t.numel() * 9 * 8, bytes_))
             return out
 
+        def fpn_op(idx):
+            # the FPN top-down kernels of the two fine levels: algorithmic bytes = every input read once + the output written
+            def call(*a, **k):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = timer._orig_fpn[idx](*a, **k)
+                e1.record()
+                if out is not None:
+                    bytes_ = 4 * (sum(t.numel() for t in a if torch.is_tensor(t)) + out.numel())
+                    timer.records.append((_lib.last_kernel() if idx == 0 else ("fpn_tail_gather_lds_kernel<%d>" % a[1].shape[1], "fpn_lateral_up_kernel<16, 72>")[idx - 1],
+                                          e0, e1, 0, bytes_))
+                return out
+            return call
+
         cp.ConvLayer.__call__ = conv_call
         ops.warp_agg_fwd_cl = warp_call
         cp.fused_conv11_select = select_call
+        ops.fpn_tail_fused, ops.fpn_tail_gather, ops.fpn_lateral_up = fpn_op(0), fpn_op(1), fpn_op(2)
 
     def remove(self):
         import mvster_amd.conv_plan as cp
@@ -114,6 +130,7 @@ class KernelTimer:
         cp.ConvLayer.__call__ = self._orig_conv
         ops.warp_agg_fwd_cl = self._orig_warp
         cp.fused_conv11_select = self._orig_sel
+        ops.fpn_tail_fused, ops.fpn_tail_gather, ops.fpn_lateral_up = self._orig_fpn
 
     def summary(self):
         agg = {}
@@ -791,6 +808,9 @@ def main():
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": a["n"] // ninstr,
                      "bytes_per_launch": a["bytes"] // a["n"]}
+                if name.startswith("fpn_tail"):
+                    e["limiter"] = ("fp32 VALU issue, not HBM: position-dependent bilinear weights (36 per output pixel) leave no "
+                                    "shared operand for the matrix cores; PMC: ~1 100 VALU instructions per wave (DESIGN.md section 4.3)")
                 if streaming and a["flops"] > 0:
                     e["frac_of_fp32_mfma_peak_algorithmic_flops"] = round(a["flops"] / (a["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
             if name in pmc.get("kernels", {}):

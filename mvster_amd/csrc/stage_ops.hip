@@ -11,6 +11,8 @@
 //   prob 1x1x1 + softmax + argmax + gather + confidence + inverse bounds  :900,:1068-1088
 //                                                 mvster_select_depth
 //   F.interpolate(bilinear, align_corners=True)   :1077   mvster_upsample_bilinear
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -278,10 +280,13 @@ __global__ void __launch_bounds__(256) fpn_tail_fused_kernel(const float* __rest
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     constexpr int CO = 8, CG = 72, Q = CG / 4;
     constexpr int PR = 7, PC = 19;             // half-resolution patch of an 8 x 32 output tile (+ 1-pixel ring): <= 7 x 19
-    constexpr int QR = 6, QC = 12;             // its quarter-resolution footprint: <= 6 x 12
+    constexpr int QR = 6, QC = 11;             // its quarter-resolution footprint: <= 6 x 11
+    constexpr int QH = 10;                     // q is staged in two channel halves (quads 0..7, then 8..17) through ONE buffer of
+    //                                            10 quads per pixel: 38.3 + 10.6 KB of LDS = three workgroups per CU (two with
+    //                                            all 18 quads resident)
     constexpr int MT = (PR * PC + 63) / 64;    // M tiles of 16 patch pixels per wave
     __shared__ f32x4 patch[PR * PC * Q];
-    __shared__ f32x4 qpatch[QR * QC * Q];
+    __shared__ f32x4 qpatch[QR * QC * QH];
     __shared__ float vbsum[9][CO];
     const int Hh = H / 2, Wh = W / 2, Hq = Hh / 2, Wq = Wh / 2;
     unsigned txu, tyu;
@@ -305,17 +310,19 @@ __global__ void __launch_bounds__(256) fpn_tail_fused_kernel(const float* __rest
     {
         const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(qmap + (long)b * Hq * Wq * CG), (short)0, (int)((long)Hq * Wq * CG * 4), 0x00020000);
-        constexpr int NIT = (QR * QC * Q + 255) / 256;
-        f32x4 stg[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = threadIdx.x + it * 256;
-            const int qd = i % Q, pix = i / Q;
+        constexpr int NIT0 = (QR * QC * 8 + 255) / 256, NIT1 = (QR * QC * 10 + 255) / 256;
+        f32x4 stg0[NIT0], stg1[NIT1];
+        auto stage_load = [&](int i, int nq, int q0) -> f32x4 {             // slot i of a half with nq quads per pixel from quad q0
+            const int qd = i % nq, pix = i / nq;
             const int pc = pix % QC, pr = pix / QC;
             const bool ok = pr < qnr && pc < qnc;
-            const unsigned off = ok ? (unsigned)(((qr0 + pr) * Wq + (qc0 + pc)) * CG + qd * 4) * 4u : 0xFFFFFFF0u;
-            stg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrsrc, off, 0, 0));
-        }
+            const unsigned off = ok ? (unsigned)(((qr0 + pr) * Wq + (qc0 + pc)) * CG + (q0 + qd) * 4) * 4u : 0xFFFFFFF0u;
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrsrc, off, 0, 0));
+        };
+#pragma unroll
+        for (int it = 0; it < NIT0; ++it) stg0[it] = stage_load(threadIdx.x + it * 256, 8, 0);
+#pragma unroll
+        for (int it = 0; it < NIT1; ++it) stg1[it] = stage_load(threadIdx.x + it * 256, 10, 8);
         // this lane's patch pixels (M tile 4 mt + wave: pixels (4 mt + wave) * 16 + lm) and their input vectors
         const float* xb = x + (long)b * Hh * Wh * CI;
         const FastDiv ncd = mv_fastdiv_dev((unsigned)nc);
@@ -341,42 +348,57 @@ __global__ void __launch_bounds__(256) fpn_tail_fused_kernel(const float* __rest
             for (int j = 0; j < 4; ++j) aw[nt][j] = v[j];
             bv[nt] = ld4(bias + (nt * 4 + lq < Q ? nt * 16 + 4 * lq : 0));
         }
+        // one half: N tiles NT0 .. NT1 - 1 of every M tile of this wave, q quads from QBASE in the buffer
+        auto half = [&](auto nt0c, auto nt1c, auto qbasec) {
+            constexpr int NT0 = decltype(nt0c)::value, NT1 = decltype(nt1c)::value, QBASE = decltype(qbasec)::value;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = threadIdx.x + it * 256;
-            if (i < QR * QC * Q) qpatch[i] = stg[it];          // (i = (pr * QC + pc) * Q + quad)
-        }
-        __syncthreads();
+            for (int mt = 0; mt < MT; ++mt) {
+                if ((4 * mt + wave) * 16 >= npix) break;           // (wave-uniform)
+                const bool valid = ppos[mt] >= 0;
+                const int pr = valid ? ppos[mt] & 255 : 0, pc = valid ? ppos[mt] >> 8 : 0;
+                const mv::Lerp ly = mv::make_lerp_s(r0 + pr, sqy, Hq), lx = mv::make_lerp_s(c0 + pc, sqx, Wq);
+                // (flat 4-weight form on FMAs: 4 instead of 10 packed operations per channel pair)
+                const float w00 = ly.w0 * lx.w0, w01 = ly.w0 * lx.w1, w10 = ly.w1 * lx.w0, w11 = ly.w1 * lx.w1;
+                const f32x4* q00p = qpatch + ((ly.i0 - qr0) * QC + (lx.i0 - qc0)) * QH + lq - QBASE;
+                const f32x4* q01p = qpatch + ((ly.i0 - qr0) * QC + (lx.i1 - qc0)) * QH + lq - QBASE;
+                const f32x4* q10p = qpatch + ((ly.i1 - qr0) * QC + (lx.i0 - qc0)) * QH + lq - QBASE;
+                const f32x4* q11p = qpatch + ((ly.i1 - qr0) * QC + (lx.i1 - qc0)) * QH + lq - QBASE;
+                f32x4 acc[NT1 - NT0];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if ((4 * mt + wave) * 16 >= npix) break;           // (wave-uniform)
-            const bool valid = ppos[mt] >= 0;
-            const int pr = valid ? ppos[mt] & 255 : 0, pc = valid ? ppos[mt] >> 8 : 0;
-            const mv::Lerp ly = mv::make_lerp_s(r0 + pr, sqy, Hq), lx = mv::make_lerp_s(c0 + pc, sqx, Wq);
-            // (flat 4-weight form on FMAs: 4 instead of 10 packed operations per channel pair)
-            const float w00 = ly.w0 * lx.w0, w01 = ly.w0 * lx.w1, w10 = ly.w1 * lx.w0, w11 = ly.w1 * lx.w1;
-            const f32x4* q00p = qpatch + ((ly.i0 - qr0) * QC + (lx.i0 - qc0)) * Q + lq;
-            const f32x4* q01p = qpatch + ((ly.i0 - qr0) * QC + (lx.i1 - qc0)) * Q + lq;
-            const f32x4* q10p = qpatch + ((ly.i1 - qr0) * QC + (lx.i0 - qc0)) * Q + lq;
-            const f32x4* q11p = qpatch + ((ly.i1 - qr0) * QC + (lx.i1 - qc0)) * Q + lq;
-            f32x4 acc[5];
+                for (int nt = NT0; nt < NT1; ++nt) acc[nt - NT0] = bv[nt];
 #pragma unroll
-            for (int nt = 0; nt < 5; ++nt) acc[nt] = bv[nt];
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                    for (int nt = NT0; nt < NT1; ++nt)
+                        acc[nt - NT0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[nt][j], xv[mt][j], acc[nt - NT0], 0, 0, 0);
 #pragma unroll
-                for (int nt = 0; nt < 5; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[nt][j], xv[mt][j], acc[nt], 0, 0, 0);
+                for (int nt = NT0; nt < NT1; ++nt) {
+                    if (valid && nt * 4 + lq < Q) {                // (the fifth N tile holds channels 64..71 only)
+                        const f32x4 a00 = q00p[nt * 4], a01 = q01p[nt * 4], a10 = q10p[nt * 4], a11 = q11p[nt * 4];
+                        f32x4 r;
 #pragma unroll
-            for (int nt = 0; nt < 5; ++nt) {
-                if (valid && nt * 4 + lq < Q) {                // (the fifth N tile holds channels 64..71 only)
-                    const f32x4 a00 = q00p[nt * 4], a01 = q01p[nt * 4], a10 = q10p[nt * 4], a11 = q11p[nt * 4];
-                    f32x4 r;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) r[k] = fmaf(w00, a00[k], fmaf(w01, a01[k], fmaf(w10, a10[k], fmaf(w11, a11[k], acc[nt][k]))));
-                    patch[(pr * PC + pc) * Q + nt * 4 + lq] = r;
+                        for (int k = 0; k < 4; ++k)
+                            r[k] = fmaf(w00, a00[k], fmaf(w01, a01[k], fmaf(w10, a10[k], fmaf(w11, a11[k], acc[nt - NT0][k]))));
+                        patch[(pr * PC + pc) * Q + nt * 4 + lq] = r;
+                    }
                 }
             }
+        };
+#pragma unroll
+        for (int it = 0; it < NIT0; ++it) {
+            const int i = threadIdx.x + it * 256;
+            if (i < QR * QC * 8) qpatch[(i / 8) * QH + (i % 8)] = stg0[it];
         }
+        __syncthreads();
+        half(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});      // channels 0..31
+        __syncthreads();                                           // everyone is done with the first half of q
+#pragma unroll
+        for (int it = 0; it < NIT1; ++it) {
+            const int i = threadIdx.x + it * 256;
+            if (i < QR * QC * 10) qpatch[(i / 10) * QH + (i % 10)] = stg1[it];
+        }
+        __syncthreads();
+        half(std::integral_constant<int, 2>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, 8>{});      // channels 32..71
     }
     if (threadIdx.x < 9 * CO) {
         const int cls = threadIdx.x / CO, c = threadIdx.x % CO;
