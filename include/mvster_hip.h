@@ -215,8 +215,6 @@ int mvster_pack_conv_weights_classes(const float* w, float* wpk, int cout, int c
  * Workgroup slot n of `partial` [nblk][kd*kh*kw][COP][CIP] (COP/CIP = CO/CI rounded up to 16, 48 -> 64)
  * receives the sum over the output rows that workgroup visited; the caller adds the nblk slots.  packed = 1 (CI <= 8):
  * 16/CIP taps share one N tile (CIP = 4 or 8), partial [nblk][ceil(taps/(16/CIP))][COP][16], column = (tap % TPN)*CIP + ci.
- * packed = 2 (CI <= 8 and CO <= 8, kh = kw = 3, stride 1, pw = 1): both operand halves of a tile carry a pixel shift, partial
- * [nblk][kd*kh][16][16] with tile g = kernel row g, row = sa*8 + co, column = hb*8 + ci = tap kx = 2 hb - sa of that row.
  * With x and gy swapped it is the weight gradient of the transposed convolution.  Replaces autograd's conv weight gradients
  * of nn.Conv3d / nn.Conv2d / nn.ConvTranspose3d (models/mvs4net_utils.py:116-123, :224-251, :870-965, :419-502). */
 int mvster_conv_wgrad(const float* x, const float* gy, float* partial, int nblk, int B, int Di, int Hi, int Wi, int CI,
@@ -229,8 +227,7 @@ int mvster_conv_wgrad_slots(int CI, int CO, int kd, int kh, int kw, int sd, int 
 
 /* Finish of the weight gradient: adds the nblk slots (fixed order) and writes dW in the parameter's layout in one launch.
  * Slot element (g, row, col) of [ngrp][cop][width]: co = row; cip = 0: tap = g, ci = col; cip = 4 / 8 (packed): tap =
- * g*(16/cip) + col/cip, ci = col % cip; cip = 9 (packed = 2 above): co = row % 8, ci = col % 8, tap = 3 g + 2 (col / 8) -
- * row / 8 (dropped when negative).  Kept when tap < ntaps, co < co_lim, ci < ci_lim; flip mirrors the taps
+ * g*(16/cip) + col/cip, ci = col % cip.  Kept when tap < ntaps, co < co_lim, ci < ci_lim; flip mirrors the taps
  * (tap -> ntaps-1-tap); dw is [co_lim][ci_lim][ntaps], or [ci_lim][co_lim][ntaps] with swap (the mirrored narrow-output
  * form and nothing else needs both). */
 int mvster_conv_wgrad_finish(const float* partial, float* dw, int nblk, int ngrp, int cop, int width, int ntaps, int cip,

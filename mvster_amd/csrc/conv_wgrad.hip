@@ -235,26 +235,17 @@ template <int MT, int NT, int TY, int KW, int PCB>
 __global__ void __launch_bounds__(256) conv_wgrad_lds_kernel(WgradArgs a, int mgroups) {
     constexpr int TAPS = TY * KW;
     constexpr bool PACKED = PCB > 0;
-    // PCB = 9 ("shift-packed", CO <= 8 and CI <= 8, KW = 3, stride 1): BOTH operand halves carry a pixel shift.  Rows 8..15
-    // of the M operand read gy one pixel to the right (sa = 1), the N halves read x at kx = 0 and kx = 2, so the four 8 x 8
-    // blocks of a tile are the taps kx = 2 hb - sa = {0, 2, (-1: unused), 1} of one kernel row: TY tiles per K step where
-    // PCB = 8 needs ceil(3 TY / 2) (scripts/probes/wgrad_shift_packing.py checks the algebra).  The chunk grid starts at
-    // column -1 so that the shifted rows meet output column 0; the staged gy chunk has one more pixel.
-    constexpr bool SHIFT = PCB == 9;
-    constexpr int PCBE = SHIFT ? 8 : PCB;                            // B channels per pixel of a packed layer
-    static_assert(!SHIFT || (KW == 3 && MT == 1), "shift-packed: 3-wide kernel rows, one M tile");
-    constexpr int TPN = SHIFT ? 3 : (PACKED ? 16 / PCBE : 1);
-    constexpr int NG = SHIFT ? TY : (PACKED ? (TAPS + TPN - 1) / TPN : TAPS);      // N-tile groups per (mt, nt)
+    constexpr int TPN = PACKED ? 16 / PCB : 1;
+    constexpr int NG = PACKED ? (TAPS + TPN - 1) / TPN : TAPS;      // N-tile groups per (mt, nt)
     constexpr int NTT = PACKED ? 1 : NT;
     constexpr int NACC = MT * NTT * NG;
-    constexpr int XA = kXC + (SHIFT ? 1 : 0);                        // staged gy pixels per chunk
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int PA = wg_pitch(MT * 16, 1);
-    const int CBB = PACKED ? PCBE : NT * 16;                         // B channels staged per pixel
+    const int CBB = PACKED ? PCB : NT * 16;                          // B channels staged per pixel
     const int PB = wg_pitch(CBB, a.sw);
     const int XB = (kXC - 1) * a.sw + KW;
-    float* As = lds;                                                 // [XA][PA]
-    float* Bs = lds + XA * PA;                                       // [TY][XB][PB]
+    float* As = lds;                                                 // [kXC][PA]
+    float* Bs = lds + kXC * PA;                                      // [TY][XB][PB]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, k = lane >> 4;
@@ -269,20 +260,20 @@ __global__ void __launch_bounds__(256) conv_wgrad_lds_kernel(WgradArgs a, int mg
     bool bval[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        const int tap = SHIFT ? g * KW + 2 * (r >> 3) : (PACKED ? g * TPN + r / PCBE : g);
+        const int tap = PACKED ? g * TPN + r / PCB : g;
         const int tapc = tap < TAPS ? tap : TAPS - 1;
         const int ty = tapc / KW, kx = tapc - ty * KW;
-        boff[g] = (ty * XB + kx) * PB + (PACKED ? r % PCBE : 0);
-        bval[g] = tap < TAPS && (!PACKED || (r % PCBE) < a.CI);
+        boff[g] = (ty * XB + kx) * PB + (PACKED ? r % PCB : 0);
+        bval[g] = tap < TAPS && (!PACKED || (r % PCB) < a.CI);
     }
 
     const int nrows = a.B * a.Do * a.Ho;
-    const int nchunks = (a.Wo + (SHIFT ? 1 : 0) + kXC - 1) / kXC;
-    constexpr int qa = MT * 4, qb = (PACKED ? PCBE : NT * 16) / 4;   // float4 per staged pixel
+    const int nchunks = (a.Wo + kXC - 1) / kXC;
+    constexpr int qa = MT * 4, qb = (PACKED ? PCB : NT * 16) / 4;    // float4 per staged pixel
     // A staging unit = one chunk of one output row.  Units are register-double-buffered: the global loads of unit u+1
     // are issued before the MFMAs of unit u and written to LDS after them (measured over the 64 weight gradients of a
     // config-4 step: 5.26 -> 4.40 ms; the 27-tap layers gain too, although the nine staged rows cost them 40 registers).
-    constexpr int NA = (XA * qa + 255) / 256;
+    constexpr int NA = (kXC * qa + 255) / 256;
     constexpr int NBX = (TY * (63 * wgrad_stride_bound(TY) + KW) * qb + 255) / 256;
     f32x4v ra[NA], rb[NBX];
     const int nb4 = TY * XB * qb;                                    // float4 of the B patch (<= NBX * 256)
@@ -293,7 +284,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_lds_kernel(WgradArgs a, int mg
         const int px = idx / qa, q = idx - px * qa;
         const int c = m0 + q * 4;
         f32x4v v = {0.f, 0.f, 0.f, 0.f};
-        if (idx < XA * qa && (unsigned)(x1 + px) < (unsigned)a.Wo && c < a.CO)
+        if (idx < kXC * qa && x1 + px < a.Wo && c < a.CO)
             v = *reinterpret_cast<const f32x4v*>(a.gy + ((long)row * a.Wo + (x1 + px)) * a.CO + c);
         return v;
     };
@@ -313,7 +304,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_lds_kernel(WgradArgs a, int mg
     };
     auto store_a = [&](int idx, const f32x4v& v) {
         const int px = idx / qa, q = idx - px * qa;
-        if (idx < XA * qa) *reinterpret_cast<f32x4v*>(As + px * PA + q * 4) = v;
+        if (idx < kXC * qa) *reinterpret_cast<f32x4v*>(As + px * PA + q * 4) = v;
     };
     auto store_b = [&](int idx, const f32x4v& v) {
         const int q = idx % qb;
@@ -327,7 +318,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_lds_kernel(WgradArgs a, int mg
             const int px = ks * 4 + k;
             float av[MT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) av[i] = SHIFT ? As[(px + (r >> 3)) * PA + (r & 7)] : As[px * PA + i * 16 + r];
+            for (int i = 0; i < MT; ++i) av[i] = As[px * PA + i * 16 + r];
             const float* bp = Bs + px * a.sw * PB + (PACKED ? 0 : r);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -343,7 +334,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_lds_kernel(WgradArgs a, int mg
         }
     };
     auto fetch = [&](int u) {
-        const int row = unit_row(u), x1 = (u % nchunks) * kXC - (SHIFT ? 1 : 0);
+        const int row = unit_row(u), x1 = (u % nchunks) * kXC;
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = load_a(row, x1, threadIdx.x + i * 256);
 #pragma unroll
@@ -396,10 +387,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_lds_kernel(WgradArgs a, int mg
 
 template <int MT, int NT, int TY, int KW, int PCB>
 int launch_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, hipStream_t s) {
-    const int PA = wg_pitch(MT * 16, 1), PB = wg_pitch(PCB == 9 ? 8 : (PCB > 0 ? PCB : NT * 16), a.sw);
+    const int PA = wg_pitch(MT * 16, 1), PB = wg_pitch(PCB > 0 ? PCB : NT * 16, a.sw);
     const int XB = (kXC - 1) * a.sw + KW;
-    const size_t lds = sizeof(float) * ((size_t)(kXC + (PCB == 9 ? 1 : 0)) * PA + (size_t)TY * XB * PB);
-    if (PCB == 9 && (a.sw != 1 || a.sh != 1 || a.sd != 1 || a.pw != 1 || a.CO > 8 || a.CI > 8)) return MVSTER_ERR_UNSUPPORTED;
+    const size_t lds = sizeof(float) * ((size_t)kXC * PA + (size_t)TY * XB * PB);
     // (layers that need more -- stride-2 3x3 from 32 channels, 3x3 from 64 -- were measured no faster here with the limit
     //  raised to 128 KB, one workgroup per CU, than on the per-tap kernels below: 105 vs 47+ us, 642 vs 588 us)
     if (lds > 64 * 1024 || a.sw > wgrad_stride_bound(TY)) return MVSTER_ERR_UNSUPPORTED;   // (prefetch register budget)
@@ -421,11 +411,6 @@ static int wgrad_acc_limit() {
 template <int TY, int KW>
 int dispatch_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, int packed, hipStream_t s) {
     constexpr int TAPS = TY * KW;
-    if (packed == 2) {
-        // shift-packed: both sides <= 8 channels, 3-wide kernel rows (the launcher checks strides and padding)
-        if constexpr (KW == 3) return launch_wgrad_lds<1, 1, TY, KW, 9>(a, nblk, cot, cit, s);
-        return MVSTER_ERR_UNSUPPORTED;
-    }
     if (packed) {
         const int pcb = a.CI <= 4 ? 4 : 8;
         if (TAPS == 1) return MVSTER_ERR_UNSUPPORTED;
@@ -507,15 +492,11 @@ __global__ void __launch_bounds__(1024) conv_wgrad_finish_kernel(FinishArgs a) {
 #pragma unroll
     for (int w = 1; w < 16; ++w) s += red[w][el];
     const int col = (int)(e % a.width), row = (int)((e / a.width) % a.cop), g = (int)(e / ((long)a.width * a.cop));
-    int tap = g, ci = col, co = row;
-    if (a.cip == 9) {           // shift-packed tile: rows = (sa, co), columns = (hb, ci), tap kx = 2 hb - sa of kernel row g
-        const int kx = 2 * (col >> 3) - (row >> 3);
-        if (kx < 0) return;
-        tap = g * 3 + kx; ci = col & 7; co = row & 7;
-    } else if (a.cip) { tap = g * (16 / a.cip) + col / a.cip; ci = col % a.cip; }
-    if (tap >= a.ntaps || co >= a.co_lim || ci >= a.ci_lim) return;
+    int tap = g, ci = col;
+    if (a.cip) { tap = g * (16 / a.cip) + col / a.cip; ci = col % a.cip; }
+    if (tap >= a.ntaps || row >= a.co_lim || ci >= a.ci_lim) return;
     if (a.flip) tap = a.ntaps - 1 - tap;
-    const long o = a.swap ? ((long)ci * a.co_lim + co) * a.ntaps + tap : ((long)co * a.ci_lim + ci) * a.ntaps + tap;
+    const long o = a.swap ? ((long)ci * a.co_lim + row) * a.ntaps + tap : ((long)row * a.ci_lim + ci) * a.ntaps + tap;
     a.dw[o] = s;
 }
 
@@ -526,8 +507,6 @@ __global__ void __launch_bounds__(1024) conv_wgrad_finish_kernel(FinishArgs a) {
 // packed = 0: partial [nblk][taps][COP][CIP16] (one kernel tap per N tile).
 // packed = 1 (CI <= 8): partial [nblk][ceil(taps/TPN)][COP][16] with TPN = 16/CIP taps per tile, CIP = 4 or 8 (CI rounded
 // up); column n of a tile = (tap % TPN) * CIP + ci.
-// packed = 2 (CI <= 8 and CO <= 8, kh = kw = 3, stride 1, pw = 1; "shift-packed"): partial [nblk][kd*kh][16][16], tile g =
-// kernel row g, row = sa * 8 + co, column = hb * 8 + ci, holding tap kx = 2 hb - sa (the block sa = 1, hb = 0 is unused).
 extern "C" int mvster_conv_wgrad(const float* x, const float* gy, float* partial, int nblk, int B, int Di, int Hi, int Wi,
                                  int CI, int Do, int Ho, int Wo, int CO, int kd, int kh, int kw, int sd, int sh, int sw,
                                  int pd, int ph, int pw, int packed, void* stream) {
@@ -547,7 +526,6 @@ extern "C" int mvster_conv_wgrad(const float* x, const float* gy, float* partial
     const int ntaps = kd * kh * kw;
     hipStream_t s = (hipStream_t)stream;
     if (packed && CI > 8) return MVSTER_ERR_UNSUPPORTED;
-    if (packed == 2 && (CO > 8 || kw != 3 || kh != 3)) return MVSTER_ERR_UNSUPPORTED;
     if (!packed) {
         const int rc = mvwgrad::try_wgrad_pers(a, nblk, cot, cit, s);
         if (rc != MVSTER_ERR_UNSUPPORTED) return rc;
@@ -556,7 +534,6 @@ extern "C" int mvster_conv_wgrad(const float* x, const float* gy, float* partial
         const int rc = try_wgrad_lds(a, nblk, cot, cit, packed, s);
         if (rc != MVSTER_ERR_UNSUPPORTED) return rc;
     }
-    if (packed == 2) return MVSTER_ERR_UNSUPPORTED;       // (the shift-packed slot layout exists on the LDS kernel only)
     if (packed) {
         const int cip = CI <= 4 ? 4 : 8;
 #define MV_P(A_, B_) if (cot == A_ && cip == B_) return launch_wgrad_packed<A_, B_>(a, nblk, ntaps, s);
@@ -588,10 +565,8 @@ extern "C" int mvster_conv_wgrad_finish(const float* partial, float* dw, int nbl
     if (!partial || !dw) return MVSTER_ERR_NULL;
     if (nblk <= 0 || ngrp <= 0 || cop <= 0 || width <= 0 || ntaps <= 0 || co_lim <= 0 || ci_lim <= 0 || co_lim > cop)
         return MVSTER_ERR_SHAPE;
-    if (cip != 0 && cip != 4 && cip != 8 && cip != 9) return MVSTER_ERR_UNSUPPORTED;
-    if (cip == 9) {
-        if (width != 16 || cop != 16 || ci_lim > 8 || co_lim > 8 || (long)ngrp * 3 != ntaps) return MVSTER_ERR_SHAPE;
-    } else if (cip ? (width != 16 || ci_lim > cip || (long)ngrp * (16 / cip) < ntaps) : (ci_lim > width || ngrp != ntaps))
+    if (cip != 0 && cip != 4 && cip != 8) return MVSTER_ERR_UNSUPPORTED;
+    if (cip ? (width != 16 || ci_lim > cip || (long)ngrp * (16 / cip) < ntaps) : (ci_lim > width || ngrp != ntaps))
         return MVSTER_ERR_SHAPE;
     FinishArgs a{partial, dw, nblk, ngrp, cop, width, ntaps, cip, co_lim, ci_lim, swap, flip};
     const long E = (long)ngrp * cop * width;

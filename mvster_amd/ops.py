@@ -318,10 +318,6 @@ def _wgrad_tiles(c):
     return 4 if t == 3 else t
 
 
-import os as _os
-_NO_SHIFT_PACKING = False       # module attribute (tests, A/B scripts): the tap-packed kernel instead of the shift-packed one
-
-
 def conv_wgrad(x_cl, gy_cl, kernel, stride, padding, co_keep=None, ci_keep=None, mirrored=False):
     """Weight gradient of the channels-last convolution y = conv(x; W[CO,CI,kd,kh,kw], stride, padding):
     x_cl [B,Di,Hi,Wi,CI], gy_cl [B,Do,Ho,Wo,CO] -> dW [co_keep,ci_keep,kd,kh,kw] (the leading channels; default all).
@@ -338,14 +334,7 @@ def conv_wgrad(x_cl, gy_cl, kernel, stride, padding, co_keep=None, ci_keep=None,
     ntaps = kd * kh * kw
     cop = _wgrad_tiles(CO) * 16
     packed = CI <= 8 and ntaps > 1            # narrow input side: 16/CIP kernel taps share one MFMA N tile
-    # both sides narrow, 3x3 rows, stride 1: both operand halves carry a pixel shift, one tile per kernel row
-    # (conv_wgrad_lds_kernel<..., 9>: kd*kh tiles per K step instead of ceil(9 kd / 2))
-    shift = (packed and CO <= 8 and (kh, kw) == (3, 3) and tuple(stride) == (1, 1, 1) and padding[2] == 1
-             and not _NO_SHIFT_PACKING)
-    if shift:
-        packed, cip = 2, 9
-        ngrp, width = kd * kh, 16
-    elif packed:
+    if packed:
         cip = 4 if CI <= 4 else 8
         tpn = 16 // cip
         ngrp, width = -(-ntaps // tpn), 16

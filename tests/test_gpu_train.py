@@ -108,31 +108,6 @@ def test_conv_wgrad_many_rows_is_deterministic():
     assert ((a.cpu().double() - wd.grad).abs().max() / wd.grad.abs().max()).item() <= 2e-5
 
 
-@pytest.mark.parametrize("ci,co,kd,W", [(8, 8, 1, 64), (8, 8, 1, 63), (8, 8, 1, 65), (8, 8, 1, 1), (8, 8, 1, 130), (4, 8, 1, 127),
-                                        (8, 4, 1, 70), (4, 4, 3, 66), (8, 8, 3, 40)])
-def test_shift_packed_wgrad_against_fp64_and_tap_packed(ci, co, kd, W, monkeypatch):
-    """conv_wgrad_lds_kernel<..., 9> (both operand halves of the MFMA tile carry a pixel shift, one tile per kernel row)
-    against the fp64 weight gradient of F.conv3d and against the tap-packed kernel it replaces, on widths around the
-    64-column chunk grid (which starts at column -1 in this mode)."""
-    from mvster_amd import _lib
-    g = torch.Generator().manual_seed(ci * 100 + co * 10 + W)
-    B, D, H = 2, 3, 9
-    x = torch.randn(B, D, H, W, ci, generator=g)
-    gy = torch.randn(B, D, H, W, co, generator=g)
-    k, p = (kd, 3, 3), (kd // 2, 1, 1)
-    got = ops.conv_wgrad(x.to(DEV), gy.to(DEV), k, (1, 1, 1), p)
-    assert "9>" in _lib.last_kernel(), _lib.last_kernel()
-    wd = torch.zeros(co, ci, *k, dtype=torch.float64, requires_grad=True)
-    yd = F.conv3d(x.double().permute(0, 4, 1, 2, 3), wd, None, padding=p)
-    yd.backward(gy.double().permute(0, 4, 1, 2, 3))
-    err = ((got.cpu().double() - wd.grad).abs().max() / wd.grad.abs().max()).item()
-    assert err <= 2e-5, err
-    monkeypatch.setattr(ops, "_NO_SHIFT_PACKING", True)
-    old = ops.conv_wgrad(x.to(DEV), gy.to(DEV), k, (1, 1, 1), p)
-    assert "9>" not in _lib.last_kernel()
-    assert ((got - old).abs().max() / old.abs().max()).item() <= 2e-5
-
-
 @pytest.mark.parametrize("CI,CO,k", [(48, 16, (1, 3, 3)), (16, 48, (1, 3, 3)), (48, 48, (3, 3, 3)), (32, 64, (1, 3, 3)), (64, 64, (3, 3, 3))])
 def test_conv_wgrad_channel_counts_of_three_tiles(CI, CO, k):
     """ops.conv_wgrad with 48 channels on either side (three 16-channel tiles: the callers round the tile count up to four,
