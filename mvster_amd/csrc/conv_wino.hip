@@ -49,6 +49,22 @@ __device__ unsigned long long* g_wtl = nullptr;
 // for a + b but four v_sub_f32 for a float4 subtraction -- the negation is an operand modifier of the packed form).
 // The hazard recogniser does not look inside inline assembly: results of MFMAs reach these only behind the explicit
 // s_nop block after the MFMA phase (see the main loop).
+#ifndef MV_WINO_SCALAR_ADDS
+#define MV_WINO_SCALAR_ADDS 0
+#endif
+#if MV_WINO_SCALAR_ADDS
+// two plain additions per register pair: a wave64 v_add_f32 issues in 2 cycles on gfx950, v_pk_add_f32 was measured at 8
+__device__ __forceinline__ f32x2v pk_add(f32x2v a, f32x2v b) {
+    float r0, r1;
+    asm("v_add_f32 %0, %2, %3\n\tv_add_f32 %1, %4, %5" : "=&v"(r0), "=&v"(r1) : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]));
+    return (f32x2v){r0, r1};
+}
+__device__ __forceinline__ f32x2v pk_sub(f32x2v a, f32x2v b) {
+    float r0, r1;
+    asm("v_sub_f32 %0, %2, %3\n\tv_sub_f32 %1, %4, %5" : "=&v"(r0), "=&v"(r1) : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]));
+    return (f32x2v){r0, r1};
+}
+#else
 __device__ __forceinline__ f32x2v pk_add(f32x2v a, f32x2v b) {
     f32x2v r;
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -59,6 +75,7 @@ __device__ __forceinline__ f32x2v pk_sub(f32x2v a, f32x2v b) {
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+#endif
 struct Q4 {                // a float4 kept as two register pairs
     f32x2v lo, hi;
 };

@@ -163,7 +163,8 @@ __global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* _
     constexpr int CO = 8;
     constexpr int CGT = 9 * COT;               // channels of G per half-resolution pixel
     constexpr int CG = 9 * CO, Q = CG / 4;     // float4 of them staged per pixel (this workgroup's 8 outputs x 9 taps)
-    constexpr int PR = 8, PC = 20;             // patch capacity (rows, cols)
+    constexpr int PR = 7, PC = 19;             // patch capacity (rows, cols): 10 output rows x 34 columns at scale < 1/2 touch <= 7 x 19
+    //                                            half-resolution pixels -- 38.3 KB of LDS, four workgroups per CU (8 x 20: 46 KB, three)
     const int cbase = blockIdx.y * CO;
     __shared__ f32x4 patch[PR * PC * Q];
     __shared__ float vbsum[9][CO];             // [3*yclass + xclass][c]: sum of vb over the in-bounds taps
