@@ -280,13 +280,15 @@ __global__ void __launch_bounds__(256) fpn_tail_fused_kernel(const float* __rest
     static_assert(CI == 16, "one 16-wide K block");
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     constexpr int CO = 8, CG = 72, Q = CG / 4;
+    constexpr int QP = Q + 1;                  // patch pitch in float4 per pixel: 19 (odd) spreads 16 neighbouring pixels over all 16
+    //                                            16-byte slot classes of a ds_read_b128 lane group; 18 aliases pixel k with k + 8
     constexpr int PR = 7, PC = 19;             // half-resolution patch of an 8 x 32 output tile (+ 1-pixel ring): <= 7 x 19
     constexpr int QR = 6, QC = 11;             // its quarter-resolution footprint: <= 6 x 11
     constexpr int QH = 10;                     // q is staged in two channel halves (quads 0..7, then 8..17) through ONE buffer of
     //                                            10 quads per pixel: 38.3 + 10.6 KB of LDS = three workgroups per CU (two with
     //                                            all 18 quads resident)
     constexpr int MT = (PR * PC + 63) / 64;    // M tiles of 16 patch pixels per wave
-    __shared__ f32x4 patch[PR * PC * Q];
+    __shared__ f32x4 patch[PR * PC * QP];
     __shared__ f32x4 qpatch[QR * QC * QH];
     __shared__ float vbsum[9][CO];
     const int Hh = H / 2, Wh = W / 2, Hq = Hh / 2, Wq = Wh / 2;
@@ -380,7 +382,7 @@ __global__ void __launch_bounds__(256) fpn_tail_fused_kernel(const float* __rest
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             r[k] = fmaf(w00, a00[k], fmaf(w01, a01[k], fmaf(w10, a10[k], fmaf(w11, a11[k], acc[nt - NT0][k]))));
-                        patch[(pr * PC + pc) * Q + nt * 4 + lq] = r;
+                        patch[(pr * PC + pc) * QP + nt * 4 + lq] = r;
                     }
                 }
             }
@@ -425,8 +427,8 @@ __global__ void __launch_bounds__(256) fpn_tail_fused_kernel(const float* __rest
         const int qy = y + k - 1, qx = xo + k - 1;
         const bool iy = (unsigned)qy < (unsigned)H, ix = (unsigned)qx < (unsigned)W;
         const mv::Lerp ly = mv::make_lerp_s(iy ? qy : y, sy, Hh), lx = mv::make_lerp_s(ix ? qx : xo, sx, Wh);
-        ry0[k] = (ly.i0 - r0) * PC * Q; ry1[k] = (ly.i1 - r0) * PC * Q;
-        cx0[k] = (lx.i0 - c0) * Q;      cx1[k] = (lx.i1 - c0) * Q;
+        ry0[k] = (ly.i0 - r0) * PC * QP; ry1[k] = (ly.i1 - r0) * PC * QP;
+        cx0[k] = (lx.i0 - c0) * QP;     cx1[k] = (lx.i1 - c0) * QP;
         wy0[k] = iy ? ly.w0 : 0.0f; wy1[k] = iy ? ly.w1 : 0.0f;
         wx0[k] = ix ? lx.w0 : 0.0f; wx1[k] = ix ? lx.w1 : 0.0f;
     }

@@ -39,7 +39,7 @@ if len(sys.argv) > 3:
                 "conv_lds_kernel", "conv_mfma_kernel", "conv_pers_kernel", "conv_pers8_kernel", "conv_tpers_kernel", "conv1x1_pers_kernel", "conv_wino_kernel", "conv_wino_ring_kernel",
                 "conv_small_kernel", "conv_narrow_kernel", "deconv_small_kernel", "deconv_select_kernel", "deconv_select_mfma_kernel",
                 "warp_agg_fwd_kernel", "warp_agg_fwd_lanes_kernel", "warp_agg_fwd_wave_kernel",
-                "warp_agg_fwd_pix_kernel", "fpn_tail_gather_lds_kernel")}
+                "warp_agg_fwd_pix_kernel", "fpn_tail_gather_lds_kernel", "fpn_tail_fused_kernel", "fpn_lateral_up_kernel")}
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import kernel_source_hash
     with open(sys.argv[3], "w") as f:

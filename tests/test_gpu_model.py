@@ -139,6 +139,29 @@ def test_graph_replay_is_bit_identical(model):
     assert torch.equal(out["depth"], want["depth"])
 
 
+def test_packed_graph_inputs_one_copy_per_sample(model):
+    """GraphedForward(packed=True): the static inputs are views of one flat device buffer in the layout of graph.pack_sample,
+    so a new sample arrives with ONE host -> device copy (load_packed) -- same outputs as the eager forward on that sample."""
+    from mvster_amd.graph import pack_sample
+    a = make_inputs(nviews=4, H=128, W=192, seed=11)
+    b = make_inputs(nviews=4, H=128, W=192, seed=12)
+    gf = GraphedForward(model, *to_dev(*a), packed=True)
+    assert gf.flat is not None and all(i.data_ptr() >= gf.flat.data_ptr() for i in gf.imgs)
+    want_a = {k: v.clone() for k, v in model(*to_dev(*a)).items() if torch.is_tensor(v)}
+    out = gf()
+    torch.cuda.synchronize()
+    assert torch.equal(out["depth"], want_a["depth"]) and torch.equal(out["attn_weight"], want_a["attn_weight"])
+    host = pack_sample(*b)                                   # pinned, same layout
+    assert host.is_pinned() and host.numel() == gf.flat.numel()
+    gf.load_packed(host)
+    out = gf()
+    torch.cuda.synchronize()
+    want_b = model(*to_dev(*b))
+    assert torch.equal(out["depth"], want_b["depth"]) and torch.equal(out["photometric_confidence"], want_b["photometric_confidence"])
+    with pytest.raises(RuntimeError):
+        GraphedForward(model, *to_dev(*a)).load_packed(host)
+
+
 FULL_SIZE = [(512, 640, 5),        # BASELINE config 2: DTU mid
              (1152, 1600, 5),      # config 3: DTU raw (1200x1600 cropped to a multiple of 64, SURVEY.md section 0)
              (1024, 1920, 7)]      # config 5: Tanks & Temples (1920x1056 -> 1024 rows), 7 views

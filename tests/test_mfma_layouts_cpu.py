@@ -1,0 +1,191 @@
+"""Index maps of the round-4 MFMA kernels, re-walked in NumPy exactly as the kernels walk them (conv_narrow.hip,
+deconv_select.hip): the lane-linear LDS-DMA slot decode with its source-address permutations, the per-lane operand offsets, the
+K-slot <-> (tap, channel) maps of the packed weight operands, the D^T accumulator layout and the epilogue's pixel / channel
+assignment -- checked end to end against a direct convolution, plus the bank-conflict freedom of every 16-lane group of the
+ds_read_b128 operand reads (MI355X_MICROARCH.md, LDS table).  No GPU involved: this pins the layout algebra, the GPU tests pin
+the kernels."""
+import numpy as np
+import pytest
+
+# lane groups of a wave64 ds_read_b128 (one LDS cycle each when the 16 lanes hit 16 distinct 16-byte slots modulo 256 B)
+_G0 = list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28))
+_G1 = list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))
+B128_GROUPS = [_G0, _G1, [g + 32 for g in _G0], [g + 32 for g in _G1]]
+
+
+def _conflicts(addrs):
+    """Number of 16-lane groups in which two DIFFERENT slots share a bank class (identical addresses broadcast)."""
+    bad = 0
+    for gr in B128_GROUPS:
+        slots = {int(addrs[l]) for l in gr}
+        if len({s % 16 for s in slots}) != len(slots):
+            bad += 1
+    return bad
+
+
+@pytest.mark.parametrize("CIN,MT,H,W,skip", [(8, 2, 11, 70, True), (4, 2, 9, 40, False), (8, 4, 17, 33, True), (4, 4, 16, 64, True)])
+def test_narrow_shift_packed_layout(CIN, MT, H, W, skip):
+    rng = np.random.default_rng(CIN * 10 + MT)
+    Q, TY, PW = CIN // 4, 4 * MT, 34
+    PH = TY + 2
+    PSLOTS = PH * PW * Q
+    NBLK = (PSLOTS + 63) // 64
+    NI = NBLK + (TY if skip else 0)
+    NKS = 3 * Q
+    x = rng.standard_normal((H, W, CIN))
+    w = rng.standard_normal((3, 3, CIN, 8))
+    sk = rng.standard_normal((H, W, 8)) if skip else np.zeros((H, W, 8))
+    xp = np.zeros((H + 2, W + 2, CIN))
+    xp[1:-1, 1:-1] = x
+    want = sum(np.einsum("hwi,io->hwo", xp[ky:ky + H, kx:kx + W], w[ky, kx]) for ky in range(3) for kx in range(3)) + sk
+    got = np.full((H, W, 8), np.nan)
+    for y0 in range(0, H, TY):
+        for x0 in range(0, W, 32):
+            stage = np.zeros((NI * 64, 4))
+            for i in range(NI):                                   # the loading waves' DMA decode
+                for lane in range(64):
+                    if i < NBLK:
+                        s = i * 64 + lane
+                        if s >= PSLOTS:
+                            continue
+                        quad, pp = s % Q, s // Q
+                        prow, pl = pp // PW, pp % PW
+                        px = pl ^ ((pl >> 3) & 1) if CIN == 8 else pl            # pixel held by LDS position pl
+                        iy, ix = y0 - 1 + prow, x0 - 1 + px
+                        if 0 <= iy < H and 0 <= ix < W:
+                            stage[s] = x[iy, ix, quad * 4:quad * 4 + 4]
+                    else:
+                        s = (i - NBLK) * 64 + lane
+                        row, xx, quad = s >> 6, (s >> 1) & 31, s & 1
+                        if y0 + row < H and x0 + xx < W:
+                            stage[i * 64 + lane] = sk[y0 + row, x0 + xx, quad * 4:quad * 4 + 4]
+            for wave in range(4):
+                for mt in range(MT):
+                    row = wave * MT + mt
+                    acc = np.zeros((16, 16))
+                    for s in range(NKS):
+                        addrs = np.zeros(64, int)
+                        for j in range(4):
+                            Am, Bm = np.zeros((16, 4)), np.zeros((4, 16))
+                            for lane in range(64):
+                                lm, lq = lane & 15, lane >> 4
+                                delta, co = lm >> 3, lm & 7
+                                if CIN == 8:
+                                    t = 2 * s + (lq >> 1)
+                                    ky, kxp, c0 = t >> 2, t & 3, (lq & 1) * 4
+                                    pxl = 2 * lm + kxp
+                                    toff = (ky * PW + (pxl ^ ((pxl >> 3) & 1))) * 2 + (lq & 1)
+                                else:
+                                    ky, kxp, c0 = s, lq, 0
+                                    toff = ky * PW + 2 * lm + kxp
+                                kx = kxp - delta
+                                Am[lm, lq] = w[ky, kx, c0 + j, co] if 0 <= kx <= 2 else 0.0    # structural zeros
+                                addrs[lane] = row * PW * Q + toff
+                                Bm[lq, lm] = stage[addrs[lane]][j]
+                            acc += Am @ Bm
+                        assert _conflicts(addrs) == 0, (CIN, s)
+                    sk_addr = np.array([NBLK * 64 + row * 64 + 4 * (l & 15) + (l >> 4) for l in range(64)])
+                    assert len(set(sk_addr)) == 64 and sk_addr.max() - sk_addr.min() == 63     # one linear 1 KB read
+                    for lane in range(64):
+                        lm, lq = lane & 15, lane >> 4
+                        col = 2 * lm + (lq >> 1)
+                        for r in range(4):
+                            if y0 + row < H and x0 + col < W:
+                                got[y0 + row, x0 + col, (lq & 1) * 4 + r] = acc[4 * lq + r, lm] + (stage[sk_addr[lane]][r] if skip else 0.0)
+    assert np.abs(got - want).max() < 1e-12
+
+
+@pytest.mark.parametrize("D,RI,Hi,Wi", [(4, 4, 9, 21), (4, 2, 5, 16), (8, 2, 4, 33)])
+def test_transposed_parity_class_layout(D, RI, Hi, Wi):
+    rng = np.random.default_rng(D * 10 + RI)
+    PSL = (RI + 1) * 68
+    PSLOTS = D * PSL
+    NBLK = (PSLOTS + 63) // 64
+    NI = NBLK + D * 2 * RI
+    Ho, Wo = 2 * Hi, 2 * Wi
+    x = rng.standard_normal((D, Hi, Wi, 16))
+    w = rng.standard_normal((3, 3, 16, 8))
+    sk = rng.standard_normal((D, Ho, Wo, 8))
+    full = np.zeros((D, Ho + 2, Wo + 2, 8))
+    for ky in range(3):                                           # ConvTranspose (1,3,3), stride 2, padding 1, output_padding 1
+        for kx in range(3):
+            full[:, ky:ky + Ho:2, kx:kx + Wo:2] += np.einsum("dhwi,io->dhwo", x, w[ky, kx])
+    want = full[:, 1:Ho + 1, 1:Wo + 1] + sk
+    got = np.full((D, Ho, Wo, 8), np.nan)
+    for i0 in range(0, Hi, RI):
+        for j0 in range(0, Wi, 16):
+            stage = np.zeros((NI * 64, 4))
+            for i in range(NI):
+                for lane in range(64):
+                    if i < NBLK:
+                        s = i * 64 + lane
+                        if s >= PSLOTS:
+                            continue
+                        d, r1 = s // PSL, s % PSL
+                        prow, r2 = r1 // 68, r1 % 68
+                        v, quad = r2 >> 2, (r2 & 3) ^ ((r2 >> 4) & 3)       # quad ^ ((v >> 2) & 3), v = r2 >> 2
+                        if i0 + prow < Hi and j0 + v < Wi:
+                            stage[s] = x[d, i0 + prow, j0 + v, quad * 4:quad * 4 + 4]
+                    else:
+                        s = (i - NBLK) * 64 + lane
+                        rowall, ox, half = s >> 6, (s >> 1) & 31, s & 1
+                        d, orow = rowall // (2 * RI), rowall % (2 * RI)
+                        if 2 * i0 + orow < Ho and 2 * j0 + ox < Wo:
+                            stage[i * 64 + lane] = sk[d, 2 * i0 + orow, 2 * j0 + ox, half * 4:half * 4 + 4]
+            for d in range(D):
+                for r in range(RI):
+                    acc = [np.zeros((16, 16)), np.zeros((16, 16))]
+                    for s in range(4):
+                        addrs, X = np.zeros(64, int), np.zeros((64, 4))
+                        for lane in range(64):
+                            lm, lq = lane & 15, lane >> 4
+                            vpos = lm + (lq & 1)
+                            addrs[lane] = d * PSL + r * 68 + ((lq >> 1) * 17 + vpos) * 4 + (s ^ ((vpos >> 2) & 3))
+                            X[lane] = stage[addrs[lane]]
+                        assert _conflicts(addrs) == 0
+                        for j in range(4):
+                            for dy in range(2):
+                                Am, Bm = np.zeros((16, 4)), np.zeros((4, 16))
+                                for lane in range(64):
+                                    lm, lq = lane & 15, lane >> 4
+                                    dx, co, di, dj = lm >> 3, lm & 7, lq >> 1, lq & 1
+                                    ky, kx = dy + 1 - 2 * di, dx + 1 - 2 * dj          # class q = 2 dy + dx takes block (di, dj) through this tap
+                                    Am[lm, lq] = w[ky, kx, 4 * s + j, co] if (0 <= ky <= 2 and 0 <= kx <= 2) else 0.0
+                                    Bm[lq, lm] = X[lane][j]
+                                acc[dy] += Am @ Bm
+                    for lane in range(64):
+                        lm, lq = lane & 15, lane >> 4
+                        for dy in range(2):
+                            sv = stage[NBLK * 64 + (d * 2 * RI + 2 * r + dy) * 64 + 4 * lm + lq]
+                            oy, ox = 2 * (i0 + r) + dy, 2 * (j0 + lm) + (lq >> 1)
+                            if i0 + r < Hi and j0 + lm < Wi:
+                                for k in range(4):
+                                    got[d, oy, ox, (lq & 1) * 4 + k] = acc[dy][4 * lq + k, lm] + sv[k]
+    assert not np.isnan(got).any() and np.abs(got - want).max() < 1e-12
+
+
+def _lerp_i(dst, in_size, out_size):
+    """(i0, i1) of mv::make_lerp for integer destinations (fp32 arithmetic as in mvster_math.h)."""
+    scale = np.float32(in_size - 1) / np.float32(out_size - 1) if out_size > 1 else np.float32(0)
+    src = (scale * np.asarray(dst, dtype=np.float32)).astype(np.float32)
+    i0 = np.minimum(src.astype(np.int64), in_size - 1)
+    return i0, i0 + (i0 < in_size - 1)
+
+
+@pytest.mark.parametrize("size", [16, 20, 64, 68, 128, 512, 640, 832, 1024, 1152, 1600, 1920, 2048, 4096])
+def test_fpn_gather_patch_capacities_hold_for_every_tile(size):
+    """The LDS patches of fpn_tail_gather_lds_kernel / fpn_tail_fused_kernel have compile-time capacities: the half-resolution
+    footprint of an 8 x 32 output tile with its 1-pixel ring fits 7 rows x 19 columns, its quarter-resolution footprint 6 x 11 --
+    for every tile position of every admissible map size (the align_corners scale is < 1/2, so 10 rows reach over at most
+    floor(4.5) + 2 source rows).  Walked with the kernels' own fp32 index arithmetic."""
+    n, nh, nq = size, size // 2, size // 4
+    for tile, ring_hi, cap, qcap in ((8, 8, 7, 6), (32, 32, 19, 11)):       # rows: y0 - 1 .. y0 + 8; columns: x0 - 1 .. x0 + 32
+        starts = np.arange(0, n, tile)
+        lo = np.maximum(starts - 1, 0)
+        hi = np.minimum(starts + ring_hi, n - 1)
+        r0 = _lerp_i(lo, nh, n)[0]
+        r1 = _lerp_i(hi, nh, n)[1]
+        assert (r1 - r0 + 1).max() <= cap and (r1 - r0 + 1).min() >= 1, (size, tile)
+        q0 = _lerp_i(r0, nq, nh)[0]
+        q1 = _lerp_i(r1, nq, nh)[1]
+        assert (q1 - q0 + 1).max() <= qcap, (size, tile)
