@@ -289,11 +289,17 @@ int dispatch_deconv_select_mfma(const float* in, const float* w, const float* sc
     a.in_bytes = (unsigned)in_bytes; a.skip_bytes = (unsigned)skip_bytes;
     const int ncu = num_cus();
     if (D == 4) {
-        // four-row tiles once they give every CU two tiles, else two-row tiles
+        // two-row tiles.  Large maps: two ring stages = 63 KB of LDS = two workgroups per CU (25.3 us at stage 4, 119 us at
+        // 4 x 576 x 800; four-row tiles with one 120 KB workgroup per CU measured 27.1 / 134.6 us); small maps: three stages, one
+        // workgroup per CU (stage 3: 10.9 against 11.8 us)
         const long t4 = (long)((Wi + 15) / 16) * ((Hi + 3) / 4) * B;
-        return t4 >= 2L * ncu ? launch_dsel<4, 4, 2>(a, s) : launch_dsel<4, 2, 3>(a, s);
+        return t4 >= 2L * ncu ? launch_dsel<4, 2, 2>(a, s) : launch_dsel<4, 2, 3>(a, s);
     }
-    if (D == 8) return launch_dsel<8, 2, 2>(a, s);
+    if (D == 8) {
+        // (the coarse stages' maps: one-row tiles while two-row tiles would leave CUs without one)
+        const long t2 = (long)((Wi + 15) / 16) * ((Hi + 1) / 2) * B;
+        return t2 >= ncu ? launch_dsel<8, 2, 2>(a, s) : launch_dsel<8, 1, 2>(a, s);
+    }
     return MVSTER_ERR_UNSUPPORTED;
 }
 
