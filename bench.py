@@ -318,7 +318,7 @@ def timed_windows(step, steps, shard, min_total_s=0.5, max_windows=41, sync=None
         out.append(el)
         spread.append((-shard.max_over_ranks(-mine), shard.max_over_ranks(mine)))
         if i == 0:
-            k = int(min(max_windows, max(3, -(-min_total_s // max(el, 1e-6)))))
+            k = int(min(max_windows, max(3, -(-1.1 * min_total_s // max(el, 1e-6)))))       # (10 % margin: the first window is the slowest)
             k += 1 - k % 2
         i += 1
     order = sorted(range(len(out)), key=lambda j: out[j])
