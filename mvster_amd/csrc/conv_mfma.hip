@@ -391,15 +391,23 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
 
     // chunk-independent global element offset of each patch pixel this thread stages (-1 = zero padding): a thread owns
     // all four quads of its pixels, so the pixel -> (row, column) arithmetic and the bounds checks are done once per pixel
+    // Stride-2 layers keep the even columns of a patch row first, then the odd ones: a lane's A operand for tap kx is
+    // column 2*(xs*16 + lm) + kx, so with the plain layout the 16 lanes of a ds_read_b128 are 64 bytes apart (a 2-way bank
+    // conflict on every read: SQ_LDS_BANK_CONFLICT = 50 % of the LDS cycles of the 32 -> 64 5x5 layer, r03 / r04 PMC); split
+    // by parity they are 32 bytes apart, as in a stride-1 layer.
+    const bool split = a.sw == 2;
+    const int PWH = (PW + 1) >> 1;
     const int npix = KD * PH * PW;
-    int goff[NG];
+    int goff[NG], gslot[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const unsigned pix = threadIdx.x + g * 256;
         int off = -1;
+        gslot[g] = (int)pix;
         if ((int)pix < npix) {
             const unsigned prow = fast_div(pix, PW, dv.mul[3], dv.shr[3]);       // = pz * PH + py
             const int px = pix - prow * PW;
+            if (split) gslot[g] = (int)(prow * PW) + (px & 1) * PWH + (px >> 1);
             const int pz = fast_div(prow, PH, dv.mul[4], dv.shr[4]);
             const int py = prow - pz * PH;
             const int iz = zo * a.sd - a.pd[0] + pz, iy = ty0 * a.sh - a.ph[0] + py, ix = tx0 * a.sw - a.pw[0] + px;
@@ -443,7 +451,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
 #pragma unroll
         for (int i = 0; i < NG * 4; ++i) {
             const int pix = threadIdx.x + (i >> 2) * 256, quad = i & 3;
-            if (pix < npix) dst[(quad >> 1) * plane + pix * 2 + (quad & 1)] = stg[i];
+            if (pix < npix) dst[(quad >> 1) * plane + gslot[i >> 2] * 2 + (quad & 1)] = stg[i];
         }
         if (WL) {
 #pragma unroll
@@ -458,8 +466,11 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     for (int mt = 0; mt < MT; ++mt) {
         const int t = wave * MT + mt;
         const int row = t >> 1, xs = t & 1;
-        abase[mt] = ((row * a.sh) * PW + (xs * 16 + lm) * a.sw) * 2 + (lq >> 1) * plane + (lq & 1);
+        abase[mt] = ((row * a.sh) * PW + (xs * 16 + lm) * (split ? 1 : a.sw)) * 2 + (lq >> 1) * plane + (lq & 1);
     }
+    int kxo[KW];          // float4 offset of tap column kx within a patch row (wave-uniform)
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) kxo[kx] = split ? ((kx & 1) * PWH + (kx >> 1)) * 2 : kx * 2;
 
     f32x4v acc[MT][NT];
 #pragma unroll
@@ -497,7 +508,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
 #pragma unroll
             for (int kx = 0; kx < KW; ++kx) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) A[kx][mt] = patch[abase[mt] + rowoff + kx * 2];
+                for (int mt = 0; mt < MT; ++mt) A[kx][mt] = patch[abase[mt] + rowoff + kxo[kx]];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     Bv[kx][nt] = WL ? wl[((r * KW + kx) * NT + nt) * 64 + lane]

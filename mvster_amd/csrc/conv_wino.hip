@@ -114,7 +114,10 @@ __global__ void __launch_bounds__(256) conv_wino_kernel(ConvArgs a, PersArgs p) 
         const int c = i / (2 * NBLK), r = i - c * 2 * NBLK, pl = r / NBLK, blk = r - pl * NBLK;
         const int s = blk * 64 + lane;
         const int q1 = s & 1, pix = s >> 1;
-        const int py = pix / PW, px = pix - py * PW;
+        // a patch row holds its even columns first, then the odd ones (as the ring kernel below: a lane's 4x4 block starts
+        // at column 2*lm, so the 16 lanes of a ds_read_b128 are 32 bytes apart instead of 64 -- no 2-way bank conflict)
+        const int py = pix / PW, ps = pix - py * PW;
+        const int px = ps < G::PWH ? 2 * ps : 2 * (ps - G::PWH) + 1;
         const bool valid = i < NI && py < G::ROWS;
         dpos[n] = px | (py << 8);
         dbase[n] = valid ? (unsigned)((py * a.Wi + px) * (CIN * 4) + (c * 16 + pl * 8 + q1 * 4) * 4) : 0x80000000u;
@@ -179,8 +182,8 @@ __global__ void __launch_bounds__(256) conv_wino_kernel(ConvArgs a, PersArgs p) 
         scv[nt] = *reinterpret_cast<const f32x4v*>(a.scale + n0);
         shv[nt] = *reinterpret_cast<const f32x4v*>(a.shift + n0);
     }
-    // float4 index of this lane's 4x4 block origin: patch row 2*wave, column 2*lm, its channel quad
-    const int abase = 2 * wave * RS + 4 * lm + (lq >> 1) * PLANE + (lq & 1);
+    // float4 index of this lane's 4x4 block origin: patch row 2*wave, column 2*lm (even-column slot lm), its channel quad
+    const int abase = 2 * wave * RS + 2 * lm + (lq >> 1) * PLANE + (lq & 1);
     const __amdgpu_buffer_rsrc_t out_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (int)p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t skip_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -227,7 +230,7 @@ __global__ void __launch_bounds__(256) conv_wino_kernel(ConvArgs a, PersArgs p) 
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
-                    const f32x4v v = patch[c * 2 * PLANE + r * RS + x * 2];
+                    const f32x4v v = patch[c * 2 * PLANE + r * RS + (x & 1) * (G::PWH * 2) + (x >> 1) * 2];
                     d[r][x] = {{v[0], v[1]}, {v[2], v[3]}};
                 }
 #pragma unroll

@@ -189,3 +189,76 @@ def test_fpn_gather_patch_capacities_hold_for_every_tile(size):
         q0 = _lerp_i(r0, nq, nh)[0]
         q1 = _lerp_i(r1, nq, nh)[1]
         assert (q1 - q0 + 1).max() <= qcap, (size, tile)
+
+
+def test_resident_winograd_patch_rows_split_by_column_parity():
+    """conv_wino_kernel (the resident form): the LDS-DMA slot decode stores a patch row as 17 even + 17 odd columns, the
+    transform reads column 2*lm + x of row 2*wave + r at slot (x & 1)*17 + lm + (x >> 1).  Every read returns the pixel the
+    F(2x2, 3x3) tile needs and every 16-lane group of the ds_read_b128 is conflict-free (the plain layout had the lanes 64
+    bytes apart: a 2-way conflict on every read, 50 % in the PMC passes of rounds 3 and 4)."""
+    PW, PWH, ROWS, RS = 34, 17, 10, 68
+    NBLK = (ROWS * RS + 63) // 64
+    PLANE = ((NBLK * 64 + 7) & ~7) + 4
+    NCH = 2
+    NI = NCH * 2 * NBLK
+    # what each LDS float4 slot holds: (channel chunk, plane, quad, patch row, patch column)
+    held = {}
+    for i in range(NI):
+        c, r = divmod(i, 2 * NBLK)
+        pl, blk = divmod(r, NBLK)
+        for lane in range(64):
+            s = blk * 64 + lane
+            q1, pix = s & 1, s >> 1
+            py, ps = divmod(pix, PW)
+            if py >= ROWS:
+                continue
+            px = 2 * ps if ps < PWH else 2 * (ps - PWH) + 1
+            dst = (i // NBLK) * PLANE + (i % NBLK) * 64 + lane
+            assert dst not in held
+            held[dst] = (c, pl, q1, py, px)
+    for wave in range(4):
+        for c in range(NCH):
+            for r in range(4):
+                for x in range(4):
+                    addrs = np.zeros(64, int)
+                    for lane in range(64):
+                        lm, lq = lane & 15, lane >> 4
+                        abase = 2 * wave * RS + 2 * lm + (lq >> 1) * PLANE + (lq & 1)
+                        addrs[lane] = abase + c * 2 * PLANE + r * RS + (x & 1) * (PWH * 2) + (x >> 1) * 2
+                        assert held[int(addrs[lane])] == (c, lq >> 1, lq & 1, 2 * wave + r, 2 * lm + x)
+                    assert _conflicts(addrs) == 0
+
+
+@pytest.mark.parametrize("KW,MT", [(5, 2), (3, 2), (5, 1)])
+def test_lds_staged_stride2_patch_rows_split_by_column_parity(KW, MT):
+    """conv_lds_kernel, stride 2: staged pixel (row, px) goes to slot row*PW + (px & 1)*PWH + (px >> 1); the lane of output
+    column xs*16 + lm reads tap kx at slot row*PW + xs*16 + lm + (kx & 1)*PWH + (kx >> 1) = column 2*(xs*16 + lm) + kx, with the
+    16 lanes of a read 32 bytes apart (64 with the plain layout: the 49.7 % bank conflicts of the 32 -> 64 5x5 layer)."""
+    sw = sh = 2
+    TY = 2 * MT
+    PW, PH = 31 * sw + KW, (TY - 1) * sh + KW
+    PWH = (PW + 1) >> 1
+    npix = PH * PW
+    plane = ((npix * 2 + 7) & ~7) + 4
+    held = {}
+    for pix in range(npix):
+        prow, px = divmod(pix, PW)
+        slot = prow * PW + (px & 1) * PWH + (px >> 1)
+        for quad in range(4):
+            dst = (quad >> 1) * plane + slot * 2 + (quad & 1)
+            assert dst not in held
+            held[dst] = (prow, px, quad)
+    assert len(held) == npix * 4
+    for wave in range(4):
+        for mt in range(MT):
+            t = wave * MT + mt
+            row, xs = t >> 1, t & 1
+            for ky in range(KW):
+                for kx in range(KW):
+                    addrs = np.zeros(64, int)
+                    for lane in range(64):
+                        lm, lq = lane & 15, lane >> 4
+                        abase = ((row * sh) * PW + (xs * 16 + lm)) * 2 + (lq >> 1) * plane + (lq & 1)
+                        addrs[lane] = abase + ky * PW * 2 + ((kx & 1) * PWH + (kx >> 1)) * 2
+                        assert held[int(addrs[lane])] == (row * sh + ky, (xs * 16 + lm) * sw + kx, lq)
+                    assert _conflicts(addrs) == 0
