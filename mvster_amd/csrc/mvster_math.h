@@ -515,6 +515,56 @@ MV_HD void select_pixel(const float* logits, const float* feat, const float* pro
     select_from_logits(lg, hypo, attn, depth, conf, inv_min, inv_max, D, hw, p, split_itv);
 }
 
+// The same selection for any number of hypotheses (D > kSelMaxD: a free --ndepths of the reference): three passes over the
+// pixel's D logits through the attn plane instead of a register array; every value goes through the same operations in the
+// same order as select_pixel, so the two agree bit for bit where both apply.
+MV_HD void select_pixel_any(const float* logits, const float* feat, const float* prob_w, const float* prob_b, int CF,
+                            const float* hypo, float* attn, float* depth, float* conf, float* inv_min, float* inv_max,
+                            float* logits_out, int D, long hw, long p, float split_itv) {
+    float mx = -INFINITY;
+    for (int d = 0; d < D; ++d) {
+        const long o = d * hw + p;
+        float v;
+        if (feat) {
+            const float* f = feat + o * CF;
+            v = 0.0f;
+            for (int c = 0; c < CF; ++c) v = fmaf(f[c], prob_w[c], v);
+            v = add_rn(v, prob_b[0]);
+            if (logits_out) logits_out[o] = v;
+        } else {
+            v = logits[o];
+        }
+        attn[o] = v;
+        mx = fmaxf(mx, v);
+    }
+    float den = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        const long o = d * hw + p;
+        const float e = expf(sub_rn(attn[o], mx));
+        attn[o] = e;
+        den = add_rn(den, e);
+    }
+    float best = -1.0f, hb = 0.f, h1 = 0.f, h2 = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const long o = d * hw + p;
+        const float pr = div_rn(attn[o], den);
+        attn[o] = pr;
+        const float hd = hypo[o];
+        if (d == 1) h1 = hd;
+        if (d == 2) h2 = hd;
+        if (pr > best) { best = pr; hb = hd; }  // strict '>' : the first maximum wins ties (ATen max)
+    }
+    depth[p] = hb;
+    if (conf) conf[p] = best;
+    if (inv_min) {
+        const float itv = sub_rn(div_rn(1.0f, h2), div_rn(1.0f, h1));
+        const float inv_d = div_rn(1.0f, hb);
+        const float delta = mul_rn(split_itv, itv);
+        inv_min[p] = add_rn(inv_d, delta);
+        inv_max[p] = sub_rn(inv_d, delta);
+    }
+}
+
 // F.interpolate(bilinear, align_corners=True) of one [hi, wi] map at output pixel p
 MV_HD float upsample_pixel(const float* in, int hi, int wi, int ho, int wo, int p) {
     const int y = p / wo, x = p - y * wo;

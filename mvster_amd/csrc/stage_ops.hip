@@ -18,6 +18,7 @@
 namespace {
 
 constexpr int kMaxD = mv::kSelMaxD;
+constexpr int kMaxSelectD = 1024;       // select_depth_any_kernel: hypotheses per pixel held in memory, not registers
 
 __global__ void relative_projection_kernel(const float* __restrict__ pm, float* __restrict__ rt, int B, int N) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -86,6 +87,17 @@ __global__ void select_depth_kernel(SelectArgs a) {
                      a.CF, a.hypo + vol, a.attn + vol, a.depth + img, a.conf ? a.conf + img : nullptr,
                      a.inv_min ? a.inv_min + img : nullptr, a.inv_max ? a.inv_max + img : nullptr,
                      a.logits_out ? a.logits_out + vol : nullptr, a.D, a.hw, p, a.split_itv);
+}
+
+__global__ void select_depth_any_kernel(SelectArgs a) {      // D > kMaxD (mv::select_pixel_any)
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (p >= a.hw) return;
+    const long vol = (long)b * a.D * a.hw, img = (long)b * a.hw;
+    mv::select_pixel_any(a.logits ? a.logits + vol : nullptr, a.feat ? a.feat + vol * a.CF : nullptr, a.prob_w, a.prob_b,
+                         a.CF, a.hypo + vol, a.attn + vol, a.depth + img, a.conf ? a.conf + img : nullptr,
+                         a.inv_min ? a.inv_min + img : nullptr, a.inv_max ? a.inv_max + img : nullptr,
+                         a.logits_out ? a.logits_out + vol : nullptr, a.D, a.hw, p, a.split_itv);
 }
 
 __global__ void upsample_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int hi, int wi,
@@ -757,14 +769,15 @@ extern "C" int mvster_select_depth(const float* logits, const float* feat, const
     if ((!logits && !feat) || !hypo || !attn || !depth) return MVSTER_ERR_NULL;
     if (feat && (!prob_w || !prob_b)) return MVSTER_ERR_NULL;
     if ((inv_min == nullptr) != (inv_max == nullptr)) return MVSTER_ERR_NULL;
-    if (B <= 0 || D < 1 || D > kMaxD || h <= 0 || w <= 0) return MVSTER_ERR_SHAPE;
+    if (B <= 0 || D < 1 || D > kMaxSelectD || h <= 0 || w <= 0) return MVSTER_ERR_SHAPE;
     if (inv_min && D < 3) return MVSTER_ERR_SHAPE;
     if (feat && (CF <= 0 || CF % 4 != 0)) return MVSTER_ERR_SHAPE;
     SelectArgs a;
     a.logits = logits; a.feat = feat; a.prob_w = prob_w; a.prob_b = prob_b; a.hypo = hypo; a.attn = attn;
     a.depth = depth; a.conf = conf; a.inv_min = inv_min; a.inv_max = inv_max; a.logits_out = logits_out;
     a.B = B; a.D = D; a.hw = h * w; a.CF = CF; a.split_itv = split_itv;
-    hipLaunchKernelGGL(select_depth_kernel, dim3((h * w + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, a);
+    if (D <= kMaxD) hipLaunchKernelGGL(select_depth_kernel, dim3((h * w + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(select_depth_any_kernel, dim3((h * w + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, a);
     return mv_check_launch();
 }
 

@@ -29,6 +29,7 @@
 namespace {
 
 constexpr int kMaxD = 16;
+constexpr int kMaxFwdD = 64;      // forward only (warp_agg_fwd_kernel with fewer pixels per workgroup)
 
 struct WarpAggArgs {
     const float* ref;
@@ -46,8 +47,10 @@ struct WarpAggArgs {
     int fuse_d;
 };
 
-template <int C, int G, bool GROUP, int DMAX>
-__global__ void __launch_bounds__(64 * DMAX) warp_agg_fwd_kernel(WarpAggArgs a) {
+// PX pixels x D hypotheses per workgroup: 64 pixels for D <= 16 (the shipped cascade's fallback form), 32 / 16 pixels for up
+// to 32 / 64 hypotheses per stage (free --ndepths of the reference; evaluation only, the backward keeps D <= 16).
+template <int C, int G, bool GROUP, int DMAX, int PX = 64>
+__global__ void __launch_bounds__(PX * DMAX) warp_agg_fwd_kernel(WarpAggArgs a) {
     static_assert(C % 8 == 0, "channels-last taps are read as float4 pairs");
     static_assert(GROUP ? (C % G == 0) : (C == G), "group layout");
     constexpr int CG = C / G;                // channels per correlation group
@@ -56,15 +59,15 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_fwd_kernel(WarpAggArgs a) 
     static_assert(C % CB == 0, "channel block");
     // per-view correlations live in LDS (G floats per thread) so that the gather loop can
     // stay rolled: ~45 VGPRs for every C instead of 4*C registers of in-flight taps
-    __shared__ float sc[2][DMAX][64];
-    __shared__ float corL[G][DMAX * 64];
+    __shared__ float sc[2][DMAX][PX];
+    __shared__ float corL[G][DMAX * PX];
 
     const int tx = threadIdx.x;
     const int d = threadIdx.y;
-    const int tid = d * 64 + tx;
+    const int tid = d * PX + tx;
     const int b = blockIdx.y;
     const int hw = a.h * a.w;
-    const int p = xcd_remap(blockIdx.x, gridDim.x) * 64 + tx;
+    const int p = xcd_remap(blockIdx.x, gridDim.x) * PX + tx;
     const bool valid = p < hw;
     const int pc = valid ? p : hw - 1;  // clamped: every lane takes part in the barriers
     const int y = pc / a.w;
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_fwd_kernel(WarpAggArgs a) 
         }
         if (a.fuse_d) score = mv::div_rn(score, a.attn_temp);
 
-        float (*buf)[64] = sc[v & 1];
+        float (*buf)[PX] = sc[v & 1];
         buf[d][tx] = score;
         __syncthreads();
         float mx = buf[0][tx];
@@ -969,9 +972,17 @@ int launch_fwd(const WarpAggArgs& a, hipStream_t stream) {
     } else {
         // 1024-thread blocks; the per-thread correlations of the widest ungrouped case do not fit LDS
         if constexpr (G * kMaxD * 64 * 4 > 120 * 1024) return MVSTER_ERR_UNSUPPORTED;
-        else {
+        else if (a.D <= kMaxD) {
             MV_NOTE_KERNEL("warp_agg_fwd_kernel<%d, %d, %s, %d>", C, G, GROUP ? "true" : "false", kMaxD);
             hipLaunchKernelGGL((warp_agg_fwd_kernel<C, G, GROUP, kMaxD>), grid, block, 0, stream, a);
+        } else if (a.D <= 32) {          // the same 1024 threads as 32 pixels x 32 hypotheses
+            MV_NOTE_KERNEL("warp_agg_fwd_kernel<%d, %d, %s, 32, 32>", C, G, GROUP ? "true" : "false");
+            hipLaunchKernelGGL((warp_agg_fwd_kernel<C, G, GROUP, 32, 32>), dim3((a.h * a.w + 31) / 32, a.B), dim3(32, a.D), 0,
+                               stream, a);
+        } else {                         // ... 16 pixels x 64 hypotheses
+            MV_NOTE_KERNEL("warp_agg_fwd_kernel<%d, %d, %s, 64, 16>", C, G, GROUP ? "true" : "false");
+            hipLaunchKernelGGL((warp_agg_fwd_kernel<C, G, GROUP, 64, 16>), dim3((a.h * a.w + 15) / 16, a.B), dim3(16, a.D), 0,
+                               stream, a);
         }
     }
     return mv_check_launch();
@@ -1763,7 +1774,7 @@ extern "C" int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat,
                                    int Hs, int Ws, long ref_batch_stride, long src_view_stride, long src_batch_stride,
                                    int group_cor, int attn_fuse_d, float attn_temp, int variant, void* stream) {
     if (!ref_feat || !src_feat || !rt || !hypo || !out) return MVSTER_ERR_NULL;
-    if (B <= 0 || NV <= 0 || D <= 0 || D > kMaxD || h <= 0 || w <= 0 || Hs <= 0 || Ws <= 0) return MVSTER_ERR_SHAPE;
+    if (B <= 0 || NV <= 0 || D <= 0 || D > kMaxFwdD || h <= 0 || w <= 0 || Hs <= 0 || Ws <= 0) return MVSTER_ERR_SHAPE;
     if (!group_cor && G != C) return MVSTER_ERR_SHAPE;
     WarpAggArgs a;
     a.ref = ref_feat; a.src = src_feat; a.rt = rt; a.hypo = hypo; a.out = out; a.wsum_out = wsum_out;

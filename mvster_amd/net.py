@@ -94,6 +94,12 @@ class _SelectDepthCL(torch.autograd.Function):
 
 
 class MVS4net(nn.Module):
+    # hypotheses per stage: the fused forward kernels of the shipped cascade hold up to 16 per pixel in registers; beyond
+    # that the forward runs on the general warp kernel (32 / 16 pixels per workgroup) and the memory-walking selection
+    # kernel.  The backward kernels, the fused stage selection and the Sinkhorn kernel keep 16.
+    MAX_HYPOTHESES = 64
+    MAX_HYPOTHESES_TRAIN = 16
+
     def __init__(self, arch_mode="fpn", reg_net="reg2d", num_stage=4, fpn_base_channel=8, reg_channel=8,
                  stage_splits=[8, 8, 4, 4], depth_interals_ratio=[0.5, 0.5, 0.5, 1], group_cor=False,
                  group_cor_dim=[8, 8, 8, 8], inverse_depth=False, agg_type="ConvBnReLU3D", dcn=False, pos_enc=0,
@@ -104,9 +110,17 @@ class MVS4net(nn.Module):
         if dcn or asff or pos_enc or vis_ETA or vis_mono:
             raise NotImplementedError("dcn / asff / pos_enc / vis_* ablation switches are out of scope "
                                       "(SURVEY.md section 2, #10): not enabled by the shipped scripts")
-        if max(stage_splits) > 16 or min(stage_splits) < 3:
-            raise NotImplementedError("stage_splits %r: the fused kernels hold 3..16 depth hypotheses per pixel (the "
-                                      "shipped cascade uses 8/8/4/4; inverse-depth ranges need at least 3)" % (stage_splits,))
+        lo = 3 if inverse_depth else 2           # (the inverse-depth bounds read hypotheses 1 and 2, mvs4net_utils.py:1083)
+        if max(stage_splits) > self.MAX_HYPOTHESES or min(stage_splits) < lo:
+            raise NotImplementedError("stage_splits %r: the kernels take %d..%d depth hypotheses per stage in evaluation "
+                                      "(%d..%d in training; the shipped cascade uses 8/8/4/4)"
+                                      % (stage_splits, lo, self.MAX_HYPOTHESES, lo, self.MAX_HYPOTHESES_TRAIN))
+        if not group_cor:
+            # the squared-difference volume has one correlation per CHANNEL; the general warp kernel keeps them in LDS
+            for s_, d_ in enumerate(stage_splits[:num_stage]):
+                if d_ > 8 and fpn_base_channel * 2 ** (3 - s_) >= 32:
+                    raise NotImplementedError("stage_splits %r with group_cor=False: stages with 32 or more feature channels "
+                                              "take at most 8 hypotheses (stage %d has %d)" % (stage_splits, s_ + 1, d_))
         self.arch_mode = arch_mode
         self.num_stage = num_stage
         self.depth_interals_ratio = list(depth_interals_ratio)
@@ -380,6 +394,10 @@ class MVS4net(nn.Module):
         return outputs
 
     def forward(self, imgs, proj_matrices, depth_values, filename=None):
+        if self.training and max(self.stage_splits) > self.MAX_HYPOTHESES_TRAIN:
+            raise NotImplementedError("training with stage_splits %r: the backward kernels (warp / aggregation, stage "
+                                      "selection, Sinkhorn) hold at most %d hypotheses per pixel; evaluation takes up to %d"
+                                      % (self.stage_splits, self.MAX_HYPOTHESES_TRAIN, self.MAX_HYPOTHESES))
         self._check_inputs(imgs, proj_matrices, depth_values)
         if self.training:
             return self._forward_train(imgs, proj_matrices, depth_values)

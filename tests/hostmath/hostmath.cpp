@@ -79,4 +79,12 @@ void hm_select(const float* logits, const float* feat, const float* prob_w, cons
         mv::select_pixel(logits, feat, prob_w, prob_b, CF, hypo, attn, depth, conf, inv_min, inv_max, logits_out, D, hw,
                          p, split_itv);
 }
+
+void hm_select_any(const float* logits, const float* feat, const float* prob_w, const float* prob_b, int CF,
+                   const float* hypo, float* attn, float* depth, float* conf, float* inv_min, float* inv_max,
+                   float* logits_out, int D, int hw, float split_itv) {
+    for (int p = 0; p < hw; ++p)
+        mv::select_pixel_any(logits, feat, prob_w, prob_b, CF, hypo, attn, depth, conf, inv_min, inv_max, logits_out, D, hw,
+                             p, split_itv);
+}
 }

@@ -90,6 +90,25 @@ def test_unsupported_switches_fail_loudly():
         MVS4net(asff=True)
 
 
+def test_hypothesis_counts_accepted_and_rejected():
+    """stage_splits: the reference takes any --ndepths (mvs4net_utils.py:61-99); here evaluation takes 2..64 per stage (3..64
+    with inverse depth: the bounds read hypotheses 1 and 2, :1083), a squared-difference volume at most 8 on the stages with
+    32 or more channels, and training at most 16 -- everything else is refused at construction / at the training forward."""
+    from mvster_amd import MVS4net
+    from mvster_amd.synthetic import make_inputs
+    MVS4net(stage_splits=[48, 32, 8, 4], group_cor=True, inverse_depth=True)
+    MVS4net(stage_splits=[64, 17, 2, 3], group_cor=True)
+    MVS4net(stage_splits=[8, 8, 64, 4])
+    for kw in (dict(stage_splits=[65, 8, 4, 4], group_cor=True), dict(stage_splits=[8, 8, 2, 4], group_cor=True, inverse_depth=True),
+               dict(stage_splits=[8, 1, 4, 4], group_cor=True), dict(stage_splits=[16, 8, 4, 4]), dict(stage_splits=[8, 9, 4, 4])):
+        with pytest.raises(NotImplementedError, match="stage_splits"):
+            MVS4net(**kw)
+    m = MVS4net(stage_splits=[32, 8, 4, 4], group_cor=True).train()
+    imgs, proj, dv = make_inputs(nviews=3, H=64, W=64)
+    with pytest.raises(NotImplementedError, match="training"):
+        m(imgs, proj, dv)
+
+
 def test_boundary_rejects_malformed_inputs(shipped_cfg):
     """MVS4net.forward validates what it hands to the kernels as raw pointers: view count, per-stage projection stacks,
     the depth range (shape errors come before the device check, so this runs without a GPU)."""

@@ -199,6 +199,62 @@ def test_warp_agg_forward(golden, name):
     assert (got2 - want).abs().mean().item() <= 3e-6 * max(scale, 1.0)
 
 
+@pytest.mark.parametrize("C,G,gc,D,fuse", [(64, 8, True, 48, True), (32, 8, True, 32, True), (16, 4, True, 17, False),
+                                           (8, 4, True, 64, True), (16, 16, False, 40, True), (8, 8, False, 24, False),
+                                           (32, 4, True, 12, True)])
+def test_warp_agg_forward_any_hypothesis_count(C, G, gc, D, fuse):
+    """More hypotheses per stage than the shipped cascade's 8 / 4 (a free --ndepths of the reference): the general kernel with
+    64 / 32 / 16 pixels x D hypotheses per workgroup against the oracle's restatement of mvs4net_utils.py:1015-1060 fed with
+    the oracle's own relative projection (ragged pixel counts, two batch items).  Bound: these inputs draw every pixel's
+    hypotheses from the whole depth range (disparities of hundreds of pixels) and unit-variance features, which puts the fp32
+    coordinate arithmetic of grid_sample and of the kernel 4-7e-6 apart relative to the output scale -- the same on the
+    D = 12 case, which runs the form the golden cases pin at 7e-7 on realistic hypotheses."""
+    from mvster_amd.synthetic import make_inputs as mk
+    h, w, nv, B = 21, 37, 3, 2
+    g = torch.Generator().manual_seed(C + D)
+    _, proj, dv = mk(nviews=nv + 1, H=h * 8, W=w * 8, batch=B, seed=D, rotate=True)
+    pm = proj["stage1"]
+    feats = torch.randn(nv + 1, B, C, h, w, generator=g)
+    hypo = dv[:, :1, None, None] + (dv[:, -1:, None, None] - dv[:, :1, None, None]) * torch.rand(B, D, h, w, generator=g)
+    with torch.no_grad():
+        want = O.aggregate_views(list(feats), pm, hypo, gc, G, attn_temp=2.0, attn_fuse_d=fuse)
+    f_cl = feats.permute(0, 1, 3, 4, 2).contiguous().to(DEV)
+    out = ops.warp_agg_fwd_cl(f_cl[0], f_cl[1:], _oracle_rt(pm).to(DEV), hypo.to(DEV), G, gc, fuse, 2.0)
+    from mvster_amd import _lib
+    form = "8" if D <= 8 else "16" if D <= 16 else "32, 32" if D <= 32 else "64, 16"
+    assert _lib.last_kernel() == "warp_agg_fwd_kernel<%d, %d, %s, %s>" % (C, G, "true" if gc else "false", form)
+    got = out.permute(0, 4, 1, 2, 3).cpu()
+    err = (got - want).abs().max().item()
+    note("warp_agg_D%d_C%d" % (D, C), max_abs=err, ref_absmax=want.abs().max().item())
+    assert err <= 1.2e-5 * max(want.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("D,inverse", [(17, True), (48, True), (200, False)])
+def test_select_depth_any_hypothesis_count(D, inverse):
+    """select_depth beyond the register form's 16 hypotheses (mv::select_pixel_any): against the oracle's restatement of
+    mvs4net_utils.py:1068-1088, exact ties included; with and without the fused prob head."""
+    g = torch.Generator().manual_seed(D)
+    B, h, w, CF = 2, 11, 19, 8
+    hypo = (400 + 300 * torch.rand(B, D, h, w, generator=g)).sort(1)[0]
+    logits = 2 * torch.randn(B, D, h, w, generator=g)
+    logits[:, 5, :2] = logits[:, 3, :2] = logits.max(1)[0][:, :2] + 1           # exact ties: the first maximum wins
+    r = ops.select_depth(hypo.to(DEV), 0.5, inverse, logits=logits.to(DEV))
+    want = O.select_depth(logits, hypo, 3, inverse, 0.5)
+    assert (r["attn_weight"].cpu() - want["attn_weight"]).abs().max() <= 3e-7
+    top2 = want["attn_weight"].topk(2, dim=1)[0]
+    clear = ((top2[:, 0] - top2[:, 1]) > 1e-6) | (top2[:, 0] == top2[:, 1])
+    assert torch.equal(r["depth"].cpu()[clear], want["depth"][clear])
+    assert torch.equal(r["depth"].cpu()[:, :2], hypo[:, 3, :2])
+    if inverse:
+        assert (r["inverse_min_depth"].cpu() - want["inverse_min_depth"])[clear].abs().max() <= 1e-9
+    feat = torch.randn(B, D, h, w, CF, generator=g)
+    pw, pb = torch.randn(CF, generator=g), torch.randn(1, generator=g)
+    r2 = ops.select_depth(hypo.to(DEV), 0.5, inverse, feat_cl=feat.to(DEV), prob_w=pw.to(DEV), prob_b=pb.to(DEV), want_logits=True)
+    assert (r2["logits"].cpu() - (feat @ pw + pb)).abs().max() <= 1e-5
+    want2 = O.select_depth(r2["logits"].cpu(), hypo, 3, inverse, 0.5)
+    assert (r2["attn_weight"].cpu() - want2["attn_weight"]).abs().max() <= 3e-7
+
+
 @pytest.mark.parametrize("C,G,D", [(64, 8, 8), (32, 8, 8), (16, 4, 4), (8, 4, 4), (8, 8, 8), (16, 8, 4), (32, 4, 8),
                                    (64, 8, 4), (8, 4, 8)])
 @pytest.mark.parametrize("fuse", [True, False])

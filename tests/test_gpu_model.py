@@ -351,10 +351,20 @@ def test_train_step_vs_golden(shipped_cfg, checkpoint, golden):
     ("reg2d_linear_depth", dict(reg_net="reg2d", group_cor=True, group_cor_dim=[8, 8, 4, 4], inverse_depth=False, mono=True)),
     ("reg2d_sqdiff_nofuse", dict(reg_net="reg2d", group_cor=False, inverse_depth=True, mono=False, attn_fuse_d=False,
                                  attn_temp=1)),
+    # a free --ndepths (the reference's schedulers and stagenet take any count, mvs4net_utils.py:61-99,1012-1094): more
+    # hypotheses than the fused forward kernels hold in registers (general warp kernel with 32 / 16 pixels per workgroup,
+    # memory-walking selection), odd counts, and the two-hypothesis minimum of the linear-depth cascade
+    ("reg2d_inverse_48_32_8_4", dict(reg_net="reg2d", group_cor=True, group_cor_dim=[8, 8, 4, 4], inverse_depth=True, mono=True,
+                                     stage_splits=[48, 32, 8, 4])),
+    ("reg2d_linear_24_17_2_3", dict(reg_net="reg2d", group_cor=True, group_cor_dim=[8, 8, 4, 4], inverse_depth=False, mono=False,
+                                    stage_splits=[24, 17, 2, 3])),
+    ("reg2d_sqdiff_8_8_64_4", dict(reg_net="reg2d", group_cor=False, inverse_depth=True, mono=False, attn_fuse_d=False,
+                                   attn_temp=1, stage_splits=[8, 8, 64, 4])),
 ])
 def test_other_configurations_vs_oracle(name, kw):
     """Options outside the shipped script (reg3d, linear-depth schedulers, squared-difference volume,
-    attn_fuse_d=False): the HIP eval path against the CPU oracle with the same weights, teacher-forced."""
+    attn_fuse_d=False, other hypothesis counts): the HIP eval path against the CPU oracle with the same weights,
+    teacher-forced."""
     from mvster_amd.synthetic import randomize_state
     cfg = dict(arch_mode="fpn", num_stage=4, fpn_base_channel=8, reg_channel=8, stage_splits=[8, 8, 4, 4],
                depth_interals_ratio=[0.5, 0.5, 0.5, 1], attn_temp=2, attn_fuse_d=True)
@@ -394,7 +404,7 @@ def test_other_configurations_vs_oracle(name, kw):
     if not cfg["inverse_depth"]:
         s2 = out["stage2"]["hypo_depth"].cpu()
         with torch.no_grad():
-            ref_h = O.schedule_range(out["stage1"]["depth"].cpu(), 8, 0.5 * (dv[:, -1] - dv[:, 0]) / dv.size(1), 32, 48)
+            ref_h = O.schedule_range(out["stage1"]["depth"].cpu(), cfg["stage_splits"][1], 0.5 * (dv[:, -1] - dv[:, 0]) / dv.size(1), 32, 48)
         assert (s2 - ref_h).abs().max() <= 5e-7 * ref_h.abs().max()
 
 

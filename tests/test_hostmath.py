@@ -157,6 +157,57 @@ def test_select_with_prob_head(hm):
     assert np.abs(attn - torch.softmax(torch.from_numpy(want), 0).numpy()).max() <= 1e-6
 
 
+def _run_select(fn, logits, feat, w, bias, hypo, inverse):
+    D, hw = hypo.shape
+    attn = np.zeros((D, hw), np.float32)
+    depth, conf, imin, imax = (np.zeros(hw, np.float32) for _ in range(4))
+    lo = np.zeros((D, hw), np.float32)
+    fn(None if logits is None else fp(logits), None if feat is None else fp(feat), None if w is None else fp(w),
+       None if bias is None else fp(bias), 0 if feat is None else feat.shape[-1], fp(hypo), fp(attn), fp(depth), fp(conf),
+       fp(imin) if inverse else None, fp(imax) if inverse else None, fp(lo) if feat is not None else None, D, hw,
+       ctypes.c_float(0.5))
+    return attn, depth, conf, imin, imax, lo
+
+
+@pytest.mark.parametrize("D,with_head", [(3, False), (8, False), (16, True), (4, True)])
+def test_select_any_equals_the_register_form_bit_for_bit(hm, D, with_head):
+    """mv::select_pixel_any (any number of hypotheses, through memory) against mv::select_pixel (D <= 16, registers) where
+    both apply: every output identical, exact ties included."""
+    rng = np.random.RandomState(D)
+    hw, CF = 97, 8
+    hypo = c(np.sort(400 + 300 * rng.rand(D, hw), axis=0))
+    logits = c(rng.randn(D, hw))
+    logits[1, :9] = logits[0, :9] = logits.max(0)[:9] + 1       # exact ties between the first two hypotheses
+    feat = c(rng.randn(D, hw, CF)) if with_head else None
+    w = c(rng.randn(CF)) if with_head else None
+    bias = c(np.array([0.1])) if with_head else None
+    a = _run_select(hm.hm_select, None if with_head else logits, feat, w, bias, hypo, True)
+    b = _run_select(hm.hm_select_any, None if with_head else logits, feat, w, bias, hypo, True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("D", [24, 48, 192])
+def test_select_any_many_hypotheses_vs_torch(hm, D):
+    """More hypotheses than the register form holds (a free --ndepths): softmax / first-max argmax / gather / inverse bounds
+    of mvs4net_utils.py:1068-1088 restated with torch."""
+    rng = np.random.RandomState(D)
+    hw = 61
+    hypo = c(np.sort(400 + 300 * rng.rand(D, hw), axis=0))
+    logits = c(2 * rng.randn(D, hw))
+    logits[5, :7] = logits[2, :7] = logits.max(0)[:7] + 1
+    attn, depth, conf, imin, imax, _ = _run_select(hm.hm_select_any, logits, None, None, None, hypo, True)
+    want = torch.softmax(torch.from_numpy(logits), 0)
+    assert np.abs(attn - want.numpy()).max() <= 3e-7
+    idx = torch.from_numpy(attn).max(0)[1]                      # ATen max: the first maximum of the probabilities we produced
+    assert np.array_equal(depth, np.take_along_axis(hypo, idx.numpy()[None], 0)[0])
+    assert np.array_equal(idx.numpy()[:7], np.full(7, 2))
+    assert np.array_equal(conf, attn.max(0))
+    itv = 1.0 / hypo[2] - 1.0 / hypo[1]
+    assert np.abs(imin - (1.0 / depth + 0.5 * itv)).max() <= 1e-9
+    assert np.abs(imax - (1.0 / depth - 0.5 * itv)).max() <= 1e-9
+
+
 def test_multiply_shift_division(hm):
     """FastDiv (mvster_math.h), the division by launch constants used in the kernels' index arithmetic: exact for every
     dividend below 2^31 -- checked here for the divisors the path produces (tile counts, patch widths, image sizes) and
