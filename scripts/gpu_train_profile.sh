@@ -8,8 +8,11 @@ export TMPDIR=/tmp
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_train" -o train -- python "$REPO/scripts/train_steps.py" 512 640 5 2 ${TRAIN_STEPS:-3} > "$REPO/gpurun_out/prof_train/train.json" 2> "$REPO/gpurun_out/prof_train/rocprof.err"
 echo "rocprof exit $?"
+# a shorter run of the same script: train_categories.py subtracts it (start-up work is not per-step work)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_train" -o train_short -- python "$REPO/scripts/train_steps.py" 512 640 5 2 ${TRAIN_STEPS_SHORT:-1} > /dev/null 2>> "$REPO/gpurun_out/prof_train/rocprof.err"
+echo "rocprof (short run) exit $?"
 cd "$REPO"
 cat gpurun_out/prof_train/train.json
-f=$(find gpurun_out/prof_train -name "*kernel_stats.csv" | head -1)
+f=gpurun_out/prof_train/train_kernel_stats.csv
 [ -n "$f" ] && head -30 "$f" | cut -c1-220
 find gpurun_out/prof_train -name "*kernel_trace.csv" -delete

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Group a rocprofv3 kernel_stats.csv of training steps into kernel families: ms and launches per step.
-usage: train_categories.py <kernel_stats.csv> <steps in the profile>"""
+usage: train_categories.py <kernel_stats.csv> <steps in the profile> [<kernel_stats.csv of a SHORTER run> <its steps>]
+With the second pair the shorter run is subtracted kernel by kernel and the difference divided by the difference of the step
+counts: start-up work (weight upload, first-call layer builds, allocator warm-up: ~400 fills and copies) then does not
+count as per-step work."""
 import collections
 import csv
 import re
@@ -8,6 +11,18 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2])
+if len(sys.argv) > 4:
+    short = {r["Name"]: r for r in csv.DictReader(open(sys.argv[3]))}
+    steps -= float(sys.argv[4])
+    kept = []
+    for r in rows:
+        b = short.get(r["Name"])
+        t = float(r["TotalDurationNs"]) - (float(b["TotalDurationNs"]) if b else 0.0)
+        c = int(r["Calls"]) - (int(b["Calls"]) if b else 0)
+        if c > 0 and t > 0:
+            kept.append(dict(r, TotalDurationNs=t, Calls=c))
+    rows = kept
+    print("  (steady state: %s minus %s, %d steps)" % (sys.argv[1].split("/")[-1], sys.argv[3].split("/")[-1], int(steps)))
 cat, cnt = collections.Counter(), collections.Counter()
 for r in rows:
     n = r["Name"]
