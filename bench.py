@@ -566,6 +566,8 @@ def main():
                     help="depth maps per forward call (the B of MVS4net.forward); the reference's eval driver uses 1")
     ap.add_argument("--no-stream-inputs", action="store_true",
                     help="skip the second timed loop that feeds the inputs from pinned host memory (value_with_h2d)")
+    ap.add_argument("--h2d-direct", action="store_true",
+                    help="value_with_h2d: copy straight into the graphs' static inputs (no staging buffers); A/B switch")
     ap.add_argument("--no-coherent", action="store_true",
                     help="skip the second instrumented pass (warp kernels on smooth depth maps: rooflines_warp_smooth_depth)")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -665,7 +667,19 @@ def main():
             e.record()
         k_h2d = [0]
 
-        def step_h2d():
+        # Staged (default): the host buffer lands in one of two device staging buffers of the slot on the copy stream -- it
+        # only has to wait for that staging buffer, not for the slot's running forward -- and a device-to-device copy
+        # (19.66 MB, ~10 us) moves it into the graph's static inputs on the slot's stream, behind the previous replay.
+        # --h2d-direct: the copy goes straight into the static inputs and so waits for the slot's previous replay, which
+        # keeps one of the two forwards from running for the length of a copy (the round-3 / r04_g form: 991/s).
+        staging = [[torch.empty_like(g.flat) for _ in range(2)] for g, _ in slots]
+        staged = [[torch.cuda.Event() for _ in range(2)] for _ in slots]
+        freed = [[torch.cuda.Event() for _ in range(2)] for _ in slots]
+        for pair in freed:
+            for e in pair:
+                e.record()
+
+        def step_h2d_direct():
             i = k_h2d[0] % len(slots)
             k_h2d[0] += 1
             g, st = slots[i]
@@ -677,6 +691,23 @@ def main():
                 st.wait_event(copied[i])
                 g.graph.replay()
                 done[i].record()
+
+        def step_h2d_staged():
+            n = k_h2d[0]
+            k_h2d[0] += 1
+            i, j = n % len(slots), (n // len(slots)) % 2
+            g, st = slots[i]
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(freed[i][j])        # the staging buffer's previous content has been consumed
+                staging[i][j].copy_(host[i], non_blocking=True)
+                staged[i][j].record()
+            with torch.cuda.stream(st):
+                st.wait_event(staged[i][j])
+                g.flat.copy_(staging[i][j], non_blocking=True)     # (stream order: after the slot's previous replay)
+                freed[i][j].record()
+                g.graph.replay()
+
+        step_h2d = step_h2d_direct if args.h2d_direct else step_h2d_staged
 
         # the pinned path is warmed on its own (first copies out of freshly pinned pages ran at a fraction of the rate on
         # some boxes: BENCH_r03 saw 6 GB/s in a 25-step run where the builder's boxes saw 16): plain copies first, then the loop
@@ -699,8 +730,11 @@ def main():
         mb = host[0].numel() * 4 / 1e6
         with_h2d = {"value": round(args.steps * world * args.batch / el2, 3), "unit": "depth-maps/s",
                     "ms_per_step": round(1e3 * el2 / args.steps, 4), "h2d_MB_per_depth_map": round(mb / args.batch, 2),
-                    "how": "one packed pinned buffer and ONE copy per depth map, one copy stream, copy of map k+1 under the "
-                           "forward of map k; median of %d windows of %d steps" % (len(win2), args.steps),
+                    "how": ("one packed pinned buffer and ONE host-to-device copy per depth map on one copy stream, %s; "
+                            "median of %d windows of %d steps"
+                            % ("straight into the graph's static inputs (waits for the slot's previous forward)" if args.h2d_direct
+                               else "into one of two staging buffers per slot, then a device-to-device copy into the graph's "
+                                    "static inputs on the slot's stream", len(win2), args.steps)),
                     "h2d_GBps": round(mb * args.steps / el2 / 1e3, 2),
                     "h2d_GBps_plain_copy": round(plain_gbps, 2),
                     "window_ms": [round(1e3 * w, 3) for w in win2]}
