@@ -671,7 +671,7 @@ def main():
         # only has to wait for that staging buffer, not for the slot's running forward -- and a device-to-device copy
         # (19.66 MB, ~10 us) moves it into the graph's static inputs on the slot's stream, behind the previous replay.
         # --h2d-direct: the copy goes straight into the static inputs and so waits for the slot's previous replay, which
-        # keeps one of the two forwards from running for the length of a copy (the round-3 / r04_g form: 991/s).
+        # keeps one of the two forwards from running for the length of a copy (the round-3 form: 985 against 1 055 depth-maps/s, same box).
         staging = [[torch.empty_like(g.flat) for _ in range(2)] for g, _ in slots]
         staged = [[torch.cuda.Event() for _ in range(2)] for _ in slots]
         freed = [[torch.cuda.Event() for _ in range(2)] for _ in slots]
