@@ -55,10 +55,13 @@ if stacks:
             if "mvster_amd/" in fr or "bench.py" in fr or "scripts/" in fr:
                 frame = fr.split("mvster_amd/")[-1] if "mvster_amd/" in fr else fr.split("/")[-1]
                 break
-        a = src[(ev.name, frame[:100])]
+        shp = str([tuple(x) for x in ev.input_shapes if x])[:60] if ev.self_device_time_total > 8 else ""
+        a = src[(ev.name, frame[:100] + "  " + shp)]
         a[0] += 1
         a[1] += ev.self_device_time_total
-    for (name, frame), (n, t) in sorted(src.items(), key=lambda kv: -kv[1][0])[:70]:
+    print("aten kernels by (op, calling line[, shapes of the large ones]), by time: %.2f ms in %d launches"
+          % (sum(v[1] for v in src.values()) / 1e3, sum(v[0] for v in src.values())))
+    for (name, frame), (n, t) in sorted(src.items(), key=lambda kv: -kv[1][1])[:70]:
         print("%5d x %8.1f us  %-24s %s" % (n, t, name, frame))
     sys.exit(0)
 agg = collections.defaultdict(lambda: [0, 0.0])
