@@ -326,12 +326,83 @@ def timed_windows(step, steps, shard, min_total_s=0.5, max_windows=41, sync=None
     return out[mid], out, spread[mid]
 
 
+def api_call_measure(args, model, dev, seed, shard):
+    """What the UNCHANGED reference driver gets: the plain ``model(imgs, proj_matrices, depth_values)`` call of
+    test_mvs4.py:205, one stream, a different sample's tensors at every call, freshly allocated outputs.  Four loops, each
+    EXACTLY ``steps`` calls between synchronisations, median window:
+      value_api_call          device-resident samples, calls back to back (MVS4net.forward's transparent hipGraph cache)
+      ..._eager               the same with ``model.graph_cache = False`` (every call issues its launches: the round-4 API path)
+      ..._synced              a device synchronisation after every call (the reference's loop reads the outputs back per sample)
+      ..._tocuda              the samples start in host memory and go through the reference's ``tocuda`` (utils.py:59-67:
+                              ``.to(torch.device("cuda"))`` per tensor, pageable memory, default DataLoader) before each call"""
+    from mvster_amd.synthetic import make_inputs
+    pool_n = 4
+    host = [make_inputs(nviews=args.views, H=args.height, W=args.width, seed=seed + 31 * k, batch=args.batch) for k in range(pool_n)]
+    pool = [([i.to(dev) for i in im], {k: v.to(dev) for k, v in pr.items()}, d.to(dev)) for im, pr, d in host]
+    cnt = [0]
+    keep = [None]
+
+    def call():
+        im, pr, d = pool[cnt[0] % pool_n]
+        cnt[0] += 1
+        keep[0] = model(im, pr, d)
+
+    def call_synced():
+        call()
+        torch.cuda.synchronize()
+
+    def call_tocuda():
+        im, pr, d = host[cnt[0] % pool_n]
+        cnt[0] += 1
+        keep[0] = model([i.to(dev) for i in im], {k: v.to(dev) for k, v in pr.items()}, d.to(dev))
+
+    def run(fn, warm):
+        for _ in range(warm):
+            fn()
+        el, win, _ = timed_windows(fn, args.steps, shard, min_total_s=0.3, max_windows=21)
+        return {"value": round(args.steps * args.batch / el, 3), "ms_per_call": round(1e3 * el / args.steps, 4), "windows": len(win)}
+
+    stats0 = dict(model._fwd_cache.stats)
+    out = {"unit": "depth-maps/s", "calls_per_window": args.steps, "samples_in_rotation": pool_n}
+    graphed = run(call, max(3, args.warmup))
+    out.update(value=graphed["value"], ms_per_call=graphed["ms_per_call"], windows=graphed["windows"])
+    out["synced_every_call"] = run(call_synced, 2)
+    out["from_host_tocuda"] = run(call_tocuda, 2)
+    out["from_host_tocuda"]["h2d_MB_per_call"] = round(sum(i.numel() for i in host[0][0]) * 4 / 1e6, 2)
+    stats1 = dict(model._fwd_cache.stats)
+    out["cache"] = {k: stats1[k] - stats0[k] for k in stats1}
+    # one replayed call against the eager forward on the same sample: the cache must not change a bit
+    im, pr, d = pool[0]
+    a = model(im, pr, d)
+    b = model.forward_eager(im, pr, d)
+    out["bit_identical_to_eager"] = bool(all(torch.equal(a["stage%d" % s][k], b["stage%d" % s][k]) for s in range(1, 5)
+                                             for k in ("depth", "attn_weight", "photometric_confidence")))
+    model.graph_cache = False
+    try:
+        out["eager"] = run(call, 3)
+    finally:
+        model.graph_cache = True
+    out["speedup_over_eager"] = round(out["value"] / out["eager"]["value"], 3)
+    return out
+
+
 def timing_note(steps, windows, rank_span):
     """How `value` was timed: the windows (each EXACTLY `steps` steps between barrier + synchronise pairs, MAX over ranks),
     which one is reported, and the fastest / slowest rank's own time for that window (stragglers show here)."""
     return {"windows": len(windows), "reported": "median window", "steps_per_window": steps,
             "window_ms": [round(1e3 * w, 3) for w in windows], "total_timed_s": round(sum(windows), 4),
             "rank_ms_per_step_min": round(1e3 * rank_span[0] / steps, 4), "rank_ms_per_step_max": round(1e3 * rank_span[1] / steps, 4)}
+
+
+def rank_local_s(step, steps):
+    """This rank's own wall time for ``steps`` more steps (collectives inside the step keep the ranks in lock-step, so
+    with a gradient all-reduce the per-rank figures differ only by what each rank does outside it)."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
 
 
 def stub_main(args):
@@ -360,6 +431,17 @@ def stub_main(args):
         step()
     elapsed, windows, rank_span = timed_windows(step, args.steps, shard, min_total_s=0.02, sync=lambda: None)
     ranks_seen = int(round(shard.sum_over_ranks(1.0)))
+    if ranks_seen != world:
+        raise SystemExit("bench.py: %d ranks answered the collective, WORLD_SIZE=%d" % (ranks_seen, world))
+    # (same reporting as the GPU line: every rank's own rate in rank order, one kernel fingerprint on all ranks)
+    r0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    per_rank = shard.gather_over_ranks(args.steps / max(time.perf_counter() - r0, 1e-9))
+    rank_ids = shard.gather_over_ranks(float(rank))
+    hashes = shard.gather_over_ranks(float(int(kernel_source_hash()[:12], 16)))
+    if len(set(hashes)) != 1:
+        raise SystemExit("bench.py: the ranks run different kernel sources")
     spread = None
     if args.mode == "train":
         # after the same number of averaged updates every rank holds the same parameters (collectives: every rank calls)
@@ -370,6 +452,7 @@ def stub_main(args):
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
                 "scaling": "weak", "ranks_seen": ranks_seen, "stub": True, "mode": args.mode,
+                "per_rank_value": [round(v, 3) for v in per_rank], "rank_order": [int(r) for r in rank_ids],
                 "timing": timing_note(args.steps, windows, rank_span)}
         if spread is not None:
             line["param_digest_spread"] = spread
@@ -488,6 +571,12 @@ def train_measure(args, rank, local_rank, world, steps, warmup, min_total_s=0.5)
     elapsed, windows, rank_span = timed_windows(timed_step, steps, shard, min_total_s=min_total_s, max_windows=9)
     loss = last[0]
     ranks_seen = int(round(shard.sum_over_ranks(1.0)))
+    if ranks_seen != world:
+        raise SystemExit("bench.py: %d ranks answered the collective, WORLD_SIZE=%d" % (ranks_seen, world))
+    per_rank = shard.gather_over_ranks(steps * B / max(rank_span[1] if world == 1 else rank_local_s(timed_step, steps), 1e-9))
+    hashes = shard.gather_over_ranks(float(int(kernel_source_hash()[:12], 16)))
+    if len(set(hashes)) != 1:
+        raise SystemExit("bench.py: the ranks run different kernel sources")
     last_loss = float(loss.item())
     # every rank must hold the same parameters after the same averaged updates (collectives: every rank calls)
     digest = float(sum(p.detach().double().sum() for p in params))
@@ -542,7 +631,8 @@ def train_measure(args, rank, local_rank, world, steps, warmup, min_total_s=0.5)
                    "gradient_sync": ("none (one rank)" if bucket is None else
                                      "one %.2f MB fp32 bucket, one all-reduce per step (RCCL), averaged" % (bucket.flat.numel() * 4 / 1e6)),
                    "depth_regime": "smooth (prob heads zeroed)" if args.coherent else "random-weight winners"},
-        "ranks_seen": ranks_seen, "timing": timing_note(steps, windows, rank_span),
+        "ranks_seen": ranks_seen, "per_rank_value": [round(v, 3) for v in per_rank],
+        "timing": timing_note(steps, windows, rank_span),
         "loss_last": round(last_loss, 5), "param_digest_spread_over_ranks": spread,
         "roofline": rooflines[0] if rooflines else None, "rooflines": rooflines[:8], "cpu_baseline": None,
     }
@@ -576,6 +666,9 @@ def main():
                     help="skip the few graph replays of the 1152x1600x5 and 1024x1920x7 workloads (other_configs)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="profiling passes: the fine FPN levels on the main stream too (no co-running kernels)")
+    ap.add_argument("--no-api-call", action="store_true",
+                    help="skip the plain model(imgs, proj, depth_values) loops (value_api_call: what the unchanged reference "
+                         "driver gets)")
     ap.add_argument("--no-train", action="store_true",
                     help="eval mode, N = 1: skip the embedded training measurement (line['train']: ten captured steps of config 4)")
     ap.add_argument("--mode", choices=("eval", "train"), default="eval",
@@ -618,7 +711,7 @@ def main():
 
     sequential = None
     if args.no_graph:
-        step = lambda: model(imgs, proj, dv)   # noqa: E731
+        step = lambda: model.forward_eager(imgs, proj, dv)   # noqa: E731
     elif args.inflight <= 1:
         graphed = GraphedForward(model, imgs, proj, dv)
         step = lambda: graphed()               # noqa: E731
@@ -650,6 +743,25 @@ def main():
         step()
     elapsed, windows, rank_span = timed_windows(step, args.steps, shard)
     ranks_seen = int(round(shard.sum_over_ranks(1.0)))
+    if ranks_seen != world:
+        raise SystemExit("bench.py: %d ranks answered the collective, WORLD_SIZE=%d" % (ranks_seen, world))
+    # every rank's own rate over one more window of the same loop (no MAX over ranks in it): a straggler GPU shows here;
+    # and every rank must run the same kernels (fingerprint of the sources the in-tree library was built from)
+    torch.cuda.synchronize()
+    shard.barrier()
+    r0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    per_rank = shard.gather_over_ranks(args.steps * args.batch / (time.perf_counter() - r0))
+    hashes = shard.gather_over_ranks(float(int(kernel_source_hash()[:12], 16)))
+    if len(set(hashes)) != 1:
+        raise SystemExit("bench.py: the ranks run different kernel sources (%s)" % sorted(set(hashes)))
+
+    # ---- the reference driver's own loop: model(imgs, proj, depth_values), nothing else (test_mvs4.py:202-207) -------
+    api_call = None
+    if rank == 0 and not args.no_graph and not args.no_api_call:
+        api_call = api_call_measure(args, model, dev, units[0], shard)
 
     # ---- the same loop with the inputs coming from the host: pinned buffers, one copy stream -----------------------
     # (the reference's loop moves every sample to the GPU first, test_mvs4.py:202-207).  `value` above keeps the inputs
@@ -821,13 +933,13 @@ def main():
         ninstr = max(1, min(args.steps, 20))
         try:
             for _ in range(3):
-                model(imgs, proj, dv)
+                model.forward_eager(imgs, proj, dv)
             timer.records.clear()
             for _ in range(ninstr):
                 # keep the GPU behind the host: a ~2 ms spin kernel first, so that every launch of this forward is already
                 # queued when the GPU reaches it and an event pair brackets kernel time, not the host's launch gaps
                 torch.cuda._sleep(5_000_000)
-                model(imgs, proj, dv)
+                model.forward_eager(imgs, proj, dv)
             torch.cuda.synchronize()
             table = timer.summary()
         finally:
@@ -918,11 +1030,11 @@ def main():
             timer2.install()
             try:
                 for _ in range(3):
-                    smooth(imgs, proj, dv)
+                    smooth.forward_eager(imgs, proj, dv)
                 timer2.records.clear()
                 for _ in range(ninstr):
                     torch.cuda._sleep(5_000_000)
-                    smooth(imgs, proj, dv)
+                    smooth.forward_eager(imgs, proj, dv)
                 torch.cuda.synchronize()
                 t2 = timer2.summary()
             finally:
@@ -984,6 +1096,11 @@ def main():
         if sequential is not None:
             line["single_forward_ms"] = round(1e3 * sequential, 4)       # one depth map at a time (latency)
             line["value_one_in_flight"] = round(world * args.batch / sequential, 3)
+        if api_call is not None:
+            line["value_api_call"] = api_call         # the plain model(...) call of the reference's drivers, one stream
+            if sequential is not None:
+                line["value_api_call"]["frac_of_value_one_in_flight"] = round(api_call["value"] * sequential / (world * args.batch), 3)
+        line["per_rank_value"] = [round(v, 3) for v in per_rank]
         if with_h2d is not None:
             line["value_with_h2d"] = with_h2d          # never `value`: the metric is defined on HBM-resident inputs
         if batched:

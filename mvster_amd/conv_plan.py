@@ -439,6 +439,10 @@ class ConvLayer:
                 if wv is not None:
                     variant, mt, nt = wv
             tuned = tuned_choice(self, B, Di, Hi, Wi, skip_mode)[0] if FORCE_VARIANT is None else None
+            if tuned and (tuned[0] & 0xff) in (8, 9) and (self.wpk_wino is None or self.prob is not None):
+                # a Winograd entry measured on a neighbouring layer (padding and the fused prob head are not part of the
+                # signature): this layer has no transformed weights -- keep the heuristic choice instead of raising later
+                tuned = None
             if tuned:
                 variant, mt, nt = tuned
             if self.w_small is not None and skip_mode in (SKIP_NONE, SKIP_ADD) and FORCE_VARIANT in (None, 3, 10):

@@ -5,7 +5,13 @@ depth map), so the ~90 kernel launches of one forward are launch-latency-bound w
 eagerly.  ``GraphedForward`` captures one ``MVS4net`` eval forward on static input buffers
 into a hipGraph (``torch.cuda.CUDAGraph`` is the hipGraph front-end on ROCm; our kernels are
 launched on the capturing stream, so they are recorded like any other node) and replays it.
+
+``ForwardCache`` is the same thing behind the reference's own call: ``MVS4net.forward`` keeps one and routes every
+eval call through it, so the unchanged ``model(imgs, proj_matrices, depth_values)`` loop of the reference's drivers
+(test_mvs4.py:202-207, train_mvs4.py:268) replays a graph from the second call of a shape on.
 """
+import collections
+
 import torch
 
 
@@ -34,10 +40,162 @@ def pack_sample(imgs, proj_matrices, depth_values, pin=True):
     return flat
 
 
+def _is_dense(t):
+    """True when ``t`` covers a gap-free, non-overlapping block of its storage in some dimension order (contiguous tensors
+    and their permutations): such a tensor is cloned as one flat run of ``numel`` elements from ``storage_offset``."""
+    expect = 1
+    for size, stride in sorted(((sz, st) for sz, st in zip(t.shape, t.stride()) if sz != 1), key=lambda p: p[1]):
+        if stride != expect:
+            return False
+        expect *= size
+    return True
+
+
+class _CachedForward:
+    """One captured eval forward of a ``ForwardCache``: static inputs (views of one flat buffer), the graph, the static
+    outputs and the recipe that clones them into one fresh allocation per call."""
+
+    def __init__(self, model, imgs, proj_matrices, depth_values):
+        dev = imgs[0].device
+        segs, total = _sample_layout(imgs, proj_matrices, depth_values)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        views = {}
+        for name, off, shape in segs:
+            n = 1
+            for d in shape:
+                n *= d
+            views[name] = self.flat[off:off + n].view(shape)
+        self.imgs = [views["img%d" % i] for i in range(len(imgs))]
+        self.proj = {k: views["proj_" + k] for k in proj_matrices}
+        self.depth_values = views["depth_values"]
+        self._dst = self.imgs + [self.proj[k] for k in sorted(self.proj)] + [self.depth_values]
+        self._proj_keys = sorted(self.proj)
+        self.load(imgs, proj_matrices, depth_values)
+        # the packed-weight plans the capture records pointers of: kept alive here, whatever happens to the model's own
+        self.plans = model._get_plans()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = model._forward_eval(self.imgs, self.proj, self.depth_values)
+        # ---- clone recipe: every distinct output tensor once, laid out back to back in one fresh buffer per call ---------
+        self._slots, self._paths, seen, off = [], [], {}, 0
+        for path, t in self._walk(self.outputs):
+            j = seen.get(id(t))
+            if j is None:
+                j = seen[id(t)] = len(self._slots)
+                if not _is_dense(t):
+                    t_src = t.contiguous()                      # (no output of the forward is like this today)
+                    raise RuntimeError("ForwardCache: output %r is not a dense tensor (%s / %s)" % (path, tuple(t.shape), t_src.stride()))
+                self._slots.append((t, off, tuple(t.shape), tuple(t.stride())))
+                off += (t.numel() + 63) // 64 * 64
+            self._paths.append((path, j))
+        self._out_total = off
+        self._src = [t for t, _, _, _ in self._slots]
+
+    @staticmethod
+    def _walk(outputs):
+        for k, v in outputs.items():
+            if isinstance(v, dict):
+                for k2, v2 in v.items():
+                    yield (k, k2), v2
+            else:
+                yield (k,), v
+
+    def load(self, imgs, proj_matrices, depth_values):
+        """The caller's sample into the static inputs: one multi-tensor copy launch (device fp32 tensors; anything else --
+        host tensors, other dtypes -- goes through ``copy_``'s conversions tensor by tensor)."""
+        src = list(imgs) + [proj_matrices[k] for k in self._proj_keys] + [depth_values]
+        torch._foreach_copy_(self._dst, src)
+
+    def replay(self):
+        """Replay on the current stream; -> a dict of the reference's structure whose tensors live in ONE freshly
+        allocated buffer (the caller owns them: the next replay does not touch them)."""
+        self.graph.replay()
+        fresh = torch.empty(self._out_total, dtype=torch.float32, device=self.flat.device)
+        new = [fresh.as_strided(shape, stride, off) for _, off, shape, stride in self._slots]
+        torch._foreach_copy_(new, self._src)
+        out = {}
+        for path, j in self._paths:
+            if len(path) == 1:
+                out[path[0]] = new[j]
+            else:
+                out.setdefault(path[0], {})[path[1]] = new[j]
+        # the reference's dict order: stageN sub-dict first, then its entries flattened (MVS4Net.py:104-105)
+        return {k: out[k] for k in self.outputs}
+
+
+class ForwardCache:
+    """Transparent hipGraph cache of ``MVS4net``'s eval forward, keyed on what decides the launch sequence: device, batch,
+    views, image size, width of ``depth_values``.  First call of a key (or first call after the model's parameters
+    changed): eager, like before.  Second call: capture + replay.  From then on: copy the caller's tensors into the
+    static inputs (one launch), replay (one launch), clone the outputs into a fresh buffer (one launch) -- the caller
+    gets freshly allocated tensors every time, which is the reference's contract.
+
+    A captured entry is only ever replayed while ``model._state_stamp()`` equals the stamp it was captured at (in-place
+    weight updates, ``p.data = ...``, ``load_state_dict``, ``.to()``, a captured training step's replay all change it);
+    it holds its own reference to the packed-weight plans it recorded, so rebuilding the model's plans in between (a
+    ``train()`` / ``eval()`` round trip without a parameter change) does not invalidate it.
+    One host thread per model and device, as in the reference's drivers; least-recently-used entries beyond ``capacity``
+    are dropped (each keeps the activations of one forward resident: ~0.7 GB at 512x640x5, ~4 GB at 1152x1600x5)."""
+
+    def __init__(self, capacity=4):
+        self.capacity = capacity
+        self.entries = collections.OrderedDict()       # key -> [stamp, _CachedForward or None]
+        self.stats = {"eager": 0, "captured": 0, "replayed": 0, "capture_failed": 0}
+        self.disabled_keys = set()
+
+    @staticmethod
+    def key(model, imgs, proj_matrices, depth_values):
+        im = imgs[0]
+        # (the attributes of the model that pick kernels or streams: flipping one between two calls is a different graph)
+        cfg = (model.warp_variant, model.overlap_streams, float(model.attn_temp), model.attn_fuse_d, model.num_stage,
+               tuple(model.stage_splits), tuple(model.depth_interals_ratio), tuple(model.group_cor_dim))
+        return (im.device.index, len(imgs), tuple(im.shape), int(depth_values.shape[1]), tuple(sorted(proj_matrices.keys())), cfg)
+
+    def clear(self):
+        self.entries.clear()
+
+    def __call__(self, model, imgs, proj_matrices, depth_values):
+        key = self.key(model, imgs, proj_matrices, depth_values)
+        if key in self.disabled_keys:
+            self.stats["eager"] += 1
+            return model._forward_eval(imgs, proj_matrices, depth_values)
+        stamp = model._state_stamp()
+        hit = self.entries.get(key)
+        if hit is not None and hit[0] == stamp:
+            self.entries.move_to_end(key)
+            if hit[1] is None:
+                try:
+                    hit[1] = _CachedForward(model, imgs, proj_matrices, depth_values)
+                    self.stats["captured"] += 1
+                except RuntimeError as e:
+                    # a forward that cannot be captured keeps working eagerly; said once, not silently
+                    import warnings
+                    warnings.warn("mvster_amd: hipGraph capture of the eval forward failed for %r (%s): this shape stays on "
+                                  "eager launches" % (key, str(e)[:200]))
+                    self.stats["capture_failed"] += 1
+                    self.disabled_keys.add(key)
+                    del self.entries[key]
+                    return model._forward_eval(imgs, proj_matrices, depth_values)
+            else:
+                hit[1].load(imgs, proj_matrices, depth_values)
+            self.stats["replayed"] += 1
+            return hit[1].replay()
+        # first sight of this shape, or the parameters moved since: eager now, capture when the same state comes back
+        self.entries[key] = [stamp, None]
+        self.entries.move_to_end(key)
+        while len(self.entries) > self.capacity:
+            self.entries.popitem(last=False)
+        self.stats["eager"] += 1
+        return model._forward_eval(imgs, proj_matrices, depth_values)
+
+
 class GraphedForward:
     def __init__(self, model, imgs, proj_matrices, depth_values, warmup=2, packed=False):
         """``packed=True``: the static inputs are views of ONE flat device buffer (``self.flat``, layout of
-        ``pack_sample``), so that a new sample arrives with a single host -> device copy (``load_packed``)."""
+        ``pack_sample``), so that a new sample arrives with a single host -> device copy (``load_packed``).
+        The captured graph reads the weights as they were folded at capture: ``__call__`` compares the model's state
+        stamp with the one recorded here and raises if the parameters have changed since (``check_state=False`` skips
+        the ~60 us check; ``self.graph.replay()`` is the raw replay)."""
         if model.training:
             raise RuntimeError("GraphedForward captures the eval forward")
         self.model = model
@@ -62,12 +220,19 @@ class GraphedForward:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):                    # builds the plans, warms the allocator
-                model(self.imgs, self.proj, self.depth_values)
+                self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self.plans = model._get_plans()                # (kept alive: the graph holds raw pointers into them)
+        self.stamp = model._state_stamp()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.outputs = model(self.imgs, self.proj, self.depth_values)
+            self.outputs = self._eager()
+
+    def _eager(self):
+        # (plain launches: MVS4net.forward itself would route the warm-up calls through its own graph cache)
+        fn = getattr(self.model, "forward_eager", self.model)
+        return fn(self.imgs, self.proj, self.depth_values)
 
     def load_packed(self, host_flat):
         """Queue ONE non-blocking copy of a ``pack_sample`` buffer into the static inputs (current stream)."""
@@ -75,9 +240,12 @@ class GraphedForward:
             raise RuntimeError("GraphedForward.load_packed: build the graph with packed=True")
         self.flat.copy_(host_flat, non_blocking=True)
 
-    def __call__(self, imgs=None, proj_matrices=None, depth_values=None):
+    def __call__(self, imgs=None, proj_matrices=None, depth_values=None, check_state=True):
         """Copy new inputs (same shapes) into the static buffers and replay; returns the static
         output dict (overwritten by the next replay)."""
+        if check_state and self.model._state_stamp() != self.stamp:
+            raise RuntimeError("GraphedForward: the model's parameters or buffers changed after the capture (the graph "
+                               "replays the weights folded at capture time): build a new GraphedForward")
         if imgs is not None:
             for dst, src in zip(self.imgs, imgs):
                 dst.copy_(src, non_blocking=True)
@@ -132,6 +300,15 @@ class GraphedTrainStep:
         # the ~130 per-layer weight refreshes a captured step would record become one launch (train_ops._LayerCache)
         from . import train_ops
         self._cache = train_ops.CACHE
+        # the captured optimizer update moves the parameters (and BatchNorm's running statistics) without touching their
+        # version counters: one epoch cell for everything this step owns, bumped after every replay
+        self._cell = [0]
+        bare = model.module if hasattr(model, "module") and isinstance(model.module, torch.nn.Module) else model
+        owned = {id(p): p for g in optimizer.param_groups for p in g["params"]}
+        for t in list(bare.parameters()) + list(bare.buffers()):
+            owned.setdefault(id(t), t)
+        for i in owned:
+            self._cache.cells[i] = self._cell
         self._batch = self._cache.build_batch(list(model.parameters()))      # (kept alive here: the graph reads its tables)
         self.graph = torch.cuda.CUDAGraph()
         # (with a collective in the step, RCCL's watchdog thread touches the device during the capture: relaxed mode)
@@ -175,5 +352,5 @@ class GraphedTrainStep:
         self.graph.replay()
         # the replayed optimizer update moved the parameters without touching their version counters: everything folded or
         # packed from them outside this graph (the eval plans, the cached training layers of an eager step) is stale now
-        self._cache.epoch += 1
+        self._cell[0] += 1
         return self.loss

@@ -113,8 +113,8 @@ class MVS4net(nn.Module):
         lo = 3 if inverse_depth else 2           # (the inverse-depth bounds read hypotheses 1 and 2, mvs4net_utils.py:1083)
         if max(stage_splits) > self.MAX_HYPOTHESES or min(stage_splits) < lo:
             raise NotImplementedError("stage_splits %r: the kernels take %d..%d depth hypotheses per stage in evaluation "
-                                      "(%d..%d in training; the shipped cascade uses 8/8/4/4)"
-                                      % (stage_splits, lo, self.MAX_HYPOTHESES, lo, self.MAX_HYPOTHESES_TRAIN))
+                                      "(3..%d in training; the shipped cascade uses 8/8/4/4)"
+                                      % (stage_splits, lo, self.MAX_HYPOTHESES, self.MAX_HYPOTHESES_TRAIN))
         if not group_cor:
             # the squared-difference volume has one correlation per CHANNEL; the general warp kernel keeps them in LDS
             for s_, d_ in enumerate(stage_splits[:num_stage]):
@@ -154,6 +154,11 @@ class MVS4net(nn.Module):
         self.overlap_streams = True
         self._side_streams = {}
         self.warp_variant = 0          # mvster_warp_agg_fwd variant (0 = per-shape default)
+        # eval calls replay a captured hipGraph from the second call of a shape on (graph.ForwardCache); False = every
+        # call issues its ~76 launches eagerly, as before round 5.  Shared by nn.DataParallel's single-device pass-through.
+        self.graph_cache = True
+        from .graph import ForwardCache
+        self._fwd_cache = ForwardCache()
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_plans())
 
     # ------------------------------------------------------------------ plan cache
@@ -163,6 +168,7 @@ class MVS4net(nn.Module):
         mode actually changes and by .to()/.cuda(); call it by hand after modifying parameters in place while
         in eval mode, or through ``p.data`` in training mode (see ``train_ops._LayerCache``)."""
         self._plans.clear()            # in place: nn.DataParallel replicas share the dict
+        self._fwd_cache.clear()
         from . import train_ops
         train_ops.CACHE.clear()
 
@@ -175,18 +181,26 @@ class MVS4net(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         self._plans.clear()
+        self._fwd_cache.clear()        # (.to() / .cuda() / .float(): the captured graphs point at the old storage)
         return super()._apply(fn, *args, **kwargs)
 
     def _state_stamp(self):
         """Changes whenever a parameter or buffer the eval plans were folded from is written in place through the tensor
         (``p.mul_()``, ``copy_``, an eager optimizer step, an EMA swap: ``_version``), replaced (``p.data = t``: the storage
-        address) or updated by a captured training step's replay (``train_ops.CACHE.epoch``).  348 Python attribute reads per forward, ~60 us; writes through a detached alias of the storage cannot be
-        seen from here -- call ``invalidate_plans()`` after those."""
+        address) or updated by a captured training step's replay (the per-parameter epoch cells of ``train_ops.CACHE``:
+        a ``GraphedTrainStep`` bumps the cell of the parameters ITS optimizer owns, so another model in the process --
+        a frozen teacher, an EMA copy -- keeps its plans).  348 Python attribute reads per forward, ~60 us; writes
+        through a detached alias of the storage cannot be seen from here -- call ``invalidate_plans()`` after those."""
         import itertools
         from . import train_ops
-        acc = train_ops.CACHE.epoch          # (parameter updates inside hipGraph replays: GraphedTrainStep bumps it)
+        cells = train_ops.CACHE.cells
+        acc = 0
         for t in itertools.chain(self.feature.parameters(), self.feature.buffers(), self.reg.parameters(), self.reg.buffers()):
             acc = (acc * 1000003 + t._version * 7919 + t.data_ptr()) & 0xFFFFFFFFFFFF
+            if cells:
+                c = cells.get(id(t))
+                if c is not None:
+                    acc += c[0] * 104729
         return acc
 
     def _get_plans(self):
@@ -345,11 +359,12 @@ class MVS4net(nn.Module):
             st["inverse_max_depth"] = 1 / depth - self.depth_interals_ratio[s] * itv
         return st
 
-    def _forward_train(self, imgs, proj_matrices, depth_values):
+    def _forward_train(self, imgs, proj_matrices, depth_values, teacher=None):
         """Differentiable forward with every convolution pass (forward, input and weight gradients) and the
         fused warp/correlation/aggregation on the gfx950 kernels.  The FPN runs once over all views (view-major
         batch) with BatchNorm on batch statistics per view, i.e. the numbers of the reference's per-view
-        ``self.feature(img)`` calls (MVS4Net.py:65-68) in one pass."""
+        ``self.feature(img)`` calls (MVS4Net.py:65-68) in one pass.  ``teacher`` (tests): stage name -> hypotheses
+        [B,D,h,w] to use instead of the ones scheduled from the previous stage's winners."""
         dev = imgs[0].device
         depth_values = depth_values.to(dev, torch.float32)
         depth_interval = (depth_values[:, -1] - depth_values[:, 0]) / depth_values.size(1)
@@ -370,7 +385,10 @@ class MVS4net(nn.Module):
             G = self.group_cor_dim[s] if self.group_cor else C
             with torch.no_grad():
                 rt = ops.relative_projection(proj_matrices[name].to(dev, torch.float32))
-                hypo = self._hypotheses(s, depth_values, depth_interval, prev, h, w)
+                if teacher is not None and name in teacher:
+                    hypo = teacher[name].detach().contiguous()
+                else:
+                    hypo = self._hypotheses(s, depth_values, depth_interval, prev, h, w)
             cor, ref_maps = _WarpAggPyr.apply(pyr, B, rt, hypo, G, self.group_cor, self.attn_fuse_d, float(self.attn_temp))
             reg = self.reg[s]
             if isinstance(reg, reg2d) and self.training and self.stage_splits[s] >= (3 if self.inverse_depth else 1):
@@ -393,12 +411,28 @@ class MVS4net(nn.Module):
             outputs = self.mono_depth_decoder.forward_cl(outputs, ref_feats, depth_values[:, 0], depth_values[:, 1])
         return outputs
 
+    def forward_eager(self, imgs, proj_matrices, depth_values):
+        """The eval forward as plain launches on the current stream (what ``graph.GraphedForward`` captures and what
+        ``forward`` runs on the first call of a shape)."""
+        self._check_inputs(imgs, proj_matrices, depth_values)
+        return self._forward_eval(imgs, proj_matrices, depth_values)
+
     def forward(self, imgs, proj_matrices, depth_values, filename=None):
         if self.training and max(self.stage_splits) > self.MAX_HYPOTHESES_TRAIN:
             raise NotImplementedError("training with stage_splits %r: the backward kernels (warp / aggregation, stage "
                                       "selection, Sinkhorn) hold at most %d hypotheses per pixel; evaluation takes up to %d"
                                       % (self.stage_splits, self.MAX_HYPOTHESES_TRAIN, self.MAX_HYPOTHESES))
+        if self.training and min(self.stage_splits) < 3:
+            # (MVS4net_loss reads hypotheses 1 and 2 of every stage for its range term, models/MVS4Net.py:139-144, in both
+            #  depth modes: say so here, not from inside the loss after a whole forward)
+            raise NotImplementedError("training with stage_splits %r: the loss (mvster_amd.loss.stage_losses, as "
+                                      "MVS4net_loss in the reference) needs at least 3 hypotheses per stage; evaluation "
+                                      "with inverse_depth=False takes 2" % (self.stage_splits,))
         self._check_inputs(imgs, proj_matrices, depth_values)
         if self.training:
             return self._forward_train(imgs, proj_matrices, depth_values)
-        return self._forward_eval(imgs, proj_matrices, depth_values)
+        # nn.DataParallel over several devices hands every call a throw-away replica with freshly broadcast parameters:
+        # nothing to cache there.  Inside somebody else's capture (GraphedForward) the launches are what gets recorded.
+        if (not self.graph_cache or getattr(self, "_is_replica", False) or torch.cuda.is_current_stream_capturing()):
+            return self._forward_eval(imgs, proj_matrices, depth_values)
+        return self._fwd_cache(self, imgs, proj_matrices, depth_values)

@@ -100,6 +100,18 @@ def sum_over_ranks(value, device=None):
     return float(t.item())
 
 
+def gather_over_ranks(value, device=None):
+    """Every rank's python float, in rank order, on every rank (bench.py: per-rank rates, kernel fingerprints)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -51,12 +51,14 @@ class _LayerCache:
     call ``train_ops.CACHE.clear()`` / ``model.invalidate_plans()`` after such an update or set
     ``train_ops.CACHE.always_repack = True`` (one small kernel per layer and pass; already what a captured
     ``GraphedTrainStep`` replays every step).  An optimizer update that runs inside a hipGraph replay is such a write too
-    (the replay bumps no ``_version``): ``GraphedTrainStep.__call__`` bumps ``CACHE.epoch`` after every replay, which is
-    part of every stamp here and of ``MVS4net._state_stamp``, so the next eager forward -- training or eval -- re-packs."""
+    (the replay bumps no ``_version``): a ``GraphedTrainStep`` registers ONE epoch cell (a one-element list) under the id
+    of every parameter and buffer of its model in ``CACHE.cells`` and bumps it after every replay; the cell's value is part
+    of the stamp of those tensors here and in ``MVS4net._state_stamp``, so the next eager forward of THAT model --
+    training or eval -- re-packs, and other models in the process are left alone."""
 
     def __init__(self):
         self._d = {}
-        self.epoch = 0                 # bumped by whoever updates parameters behind autograd's back (GraphedTrainStep replays)
+        self.cells = {}                # id(parameter / buffer) -> [epoch]; see above
         self.always_repack = False
         self._batch = None             # see build_batch()
         self._batch_active = False
@@ -72,7 +74,8 @@ class _LayerCache:
             weight = owner
         key = (id(weight), role)
         hit = self._d.get(key)
-        stamp = (weight._version, weight.data_ptr(), self.epoch)
+        cell = self.cells.get(id(weight)) if self.cells else None
+        stamp = (weight._version, weight.data_ptr(), 0 if cell is None else cell[0])
         if hit is not None and hit[0] is weight and hit[2].wpk.device == weight.device:
             if self._batch_active and key in self._batch["keys"]:
                 return hit[2]                  # refreshed (bias included) by run_batch() at the top of this step

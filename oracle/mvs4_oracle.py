@@ -326,6 +326,53 @@ class FPN4(nn.Module):
         o4 = self.out4(f)
         return {"stage1": o1, "stage2": o2, "stage3": o3, "stage4": o4}
 
+    def forward_window(self, x_win, origin, full_size):
+        """The pyramid of a WINDOW of a large image: ``x_win`` = image[:, :, y0:y0+wh, x0:x0+ww] with ``origin`` = (y0, x0)
+        and the window size multiples of 8, ``full_size`` = (H, W) of the whole image.  Same layers as ``forward``; the
+        only step of FPN4 that is not translation-invariant -- the x2 bilinear up-sampling with align_corners=True
+        (models/mvs4net_utils.py:485-495), whose source coordinate is dst * (n_in - 1) / (n_out - 1) of the WHOLE map --
+        is evaluated in whole-map coordinates (``_up2_window``).  Window pixels closer than ~64 pixels to a window edge
+        that is not an image edge see the window's zero padding instead of the image: compare the interior only.
+        Lets tests check the full-size pyramid (minutes on the CPU as a whole) window by window in seconds;
+        tests/test_oracle_golden.py checks it against ``forward`` itself."""
+        (y0, x0), (H, W) = origin, full_size
+        if y0 % 8 or x0 % 8 or x_win.shape[2] % 8 or x_win.shape[3] % 8:
+            raise ValueError("forward_window: origin and size must be multiples of 8")
+        c0 = self.conv0(x_win)
+        c1 = self.conv1(c0)
+        c2 = self.conv2(c1)
+        c3 = self.conv3(c2)
+        f = c3
+        o1 = self.out1(f)
+        f = _up2_window(f, (y0 // 8, x0 // 8), (H // 8, W // 8)) + self.inner1(c2)
+        o2 = self.out2(f)
+        f = _up2_window(f, (y0 // 4, x0 // 4), (H // 4, W // 4)) + self.inner2(c1)
+        o3 = self.out3(f)
+        f = _up2_window(f, (y0 // 2, x0 // 2), (H // 2, W // 2)) + self.inner3(c0)
+        o4 = self.out4(f)
+        return {"stage1": o1, "stage2": o2, "stage3": o3, "stage4": o4}
+
+
+def _up2_window(t, origin, full):
+    """x2 bilinear up-sampling, align_corners=True, of the window ``t`` [B,C,n_y,n_x] (origin ``origin``) of a map of size
+    ``full``, in the coordinates of the whole map: output sample Y of 2*full reads source Y * (full-1)/(2*full-1) (fp32,
+    as ATen's area_pixel_compute_scale / compute_source_index_and_lambda do), taps i0 = floor and min(i0+1, full-1).  Taps
+    that fall outside the window are clamped into it (window-edge samples only: outside the interior a caller compares)."""
+    def axis(n0, n, size):
+        Y = torch.arange(2 * n0, 2 * (n0 + n), dtype=torch.float32)
+        scale = torch.tensor(float(size - 1), dtype=torch.float32) / torch.tensor(float(2 * size - 1), dtype=torch.float32)
+        src = scale * Y
+        i0 = src.floor().long()
+        lam = src - i0.float()
+        i1 = torch.clamp(i0 + 1, max=size - 1)
+        return (i0 - n0).clamp(0, n - 1), (i1 - n0).clamp(0, n - 1), lam
+    y0i, y1i, ly = axis(origin[0], t.shape[2], full[0])
+    x0i, x1i, lx = axis(origin[1], t.shape[3], full[1])
+    ly, lx = ly.view(1, 1, -1, 1).to(t.device), lx.view(1, 1, 1, -1).to(t.device)
+    top, bot = t[:, :, y0i], t[:, :, y1i]
+    return ((1 - ly) * ((1 - lx) * top[:, :, :, x0i] + lx * top[:, :, :, x1i]) +
+            ly * ((1 - lx) * bot[:, :, :, x0i] + lx * bot[:, :, :, x1i]))
+
 
 class MonoDepthDecoder(nn.Module):
     """Training-only auxiliary head.  models/mvs4net_utils.py:833-868."""

@@ -166,6 +166,7 @@ def retune_narrow(path, shapes):
     model = MVS4net(**SHIPPED)
     model.load_state_dict(load_weights(), strict=True)
     model.to(dev).eval()
+    model.graph_cache = False          # instrumented eager launches (MVS4net.forward would replay a captured graph)
     with open(path) as f:
         table = json.load(f)
     for (H, W, N) in shapes:
@@ -208,6 +209,7 @@ def emit_table(shapes, path, train_shapes=((512, 640, 5, 2),)):
     model = MVS4net(**SHIPPED)
     model.load_state_dict(load_weights(), strict=True)
     model.to(dev).eval()
+    model.graph_cache = False          # instrumented eager launches (MVS4net.forward would replay a captured graph)
     table = {}
     orig = cp.ConvLayer.__call__
     cp.FORCE_VARIANT = None
@@ -256,6 +258,7 @@ def main():
         model = MVS4net(**SHIPPED)
         model.load_state_dict(load_weights(), strict=True)
         model.to(dev).eval()
+        model.graph_cache = False          # instrumented eager launches (MVS4net.forward would replay a captured graph)
         rows = auto_vs_best(record_eval_calls(model, H, W, N, dev), dev)
         for sig, a, b, name, how in rows:
             print("%-52s auto %7.1f us  best %7.1f us (%s)  [%s]%s" % (sig, a, b, name, how, "   <-- %.0f %%" % (100 * (a / b - 1)) if a > 1.05 * b else ""))
@@ -270,6 +273,7 @@ def main():
     model = MVS4net(**SHIPPED)
     model.load_state_dict(load_weights(), strict=True)
     model.to(dev).eval()
+    model.graph_cache = False          # instrumented eager launches (MVS4net.forward would replay a captured graph)
     imgs, proj, dv = make_inputs(5, 512, 640, seed=0, device=dev)
     calls = []
     orig = cp.ConvLayer.__call__

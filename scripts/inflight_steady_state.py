@@ -25,6 +25,7 @@ def run():
     model = MVS4net(**SHIPPED)
     model.load_state_dict(load_weights(), strict=True)
     model.to(dev).eval()
+    model.graph_cache = False          # instrumented eager launches (MVS4net.forward would replay a captured graph)
     slots = []
     for k in range(2):
         im, pr, d = make_inputs(nviews=5, H=512, W=640, seed=k, device=dev)

@@ -18,6 +18,7 @@ dev = torch.device("cuda:0")
 model = MVS4net(**SHIPPED)
 model.load_state_dict(load_weights(), strict=True)
 model.to(dev).eval()
+model.graph_cache = False          # instrumented eager launches (MVS4net.forward would replay a captured graph)
 imgs, proj, dv = make_inputs(N, H, W, seed=0, device=dev)
 calls = []
 orig = cp.ConvLayer.__call__

@@ -24,6 +24,8 @@ def test_self_launch_two_ranks():
     line = _run(["--gpus", "2"])
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["steps"] == 5 and line["warmup"] == 2
     assert line["value"] > 0 and line["scaling"] == "weak" and line["higher_is_better"] is True
+    # every rank's own rate, in rank order (a straggler GPU is visible in the driver's first scaling run)
+    assert line["rank_order"] == [0, 1] and len(line["per_rank_value"]) == 2 and min(line["per_rank_value"]) > 0
 
 
 def test_train_mode_protocol_two_ranks():
@@ -40,6 +42,7 @@ def test_four_ranks_train_protocol():
     of them (fastest / slowest rank of the reported window in the line), parameters agree afterwards."""
     line = _run(["--gpus", "4", "--mode", "train"])
     assert line["n_gpus"] == 4 and line["ranks_seen"] == 4 and abs(line["param_digest_spread"]) <= 1e-9
+    assert line["rank_order"] == [0, 1, 2, 3] and len(line["per_rank_value"]) == 4
     t = line["timing"]
     assert t["windows"] >= 3 and t["windows"] % 2 == 1 and len(t["window_ms"]) == t["windows"] and t["steps_per_window"] == 5
     assert 0 < t["rank_ms_per_step_min"] <= t["rank_ms_per_step_max"]

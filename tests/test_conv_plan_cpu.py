@@ -289,3 +289,30 @@ def test_tap_bias_gradient_of_the_fpn_gather():
     gP = torch.randn(NB, 1, H, W, co, generator=g, dtype=torch.float64)
     fpn_tail_gather_reference(G, vb, H, W).backward(gP)
     assert (tap_bias_grad(gP) - vb.grad).abs().max() <= 1e-10
+
+
+def test_winograd_table_entry_is_dropped_for_a_layer_without_transformed_weights():
+    """A tuning-table choice of the Winograd kernels (variant word 8 / 9) reaches a layer through its signature, which holds
+    neither the padding nor the fused prob head: a layer of the same signature that is NOT Winograd-eligible (here: on the
+    CPU no transformed weights exist at all, ``wpk_wino`` is None) keeps the heuristic choice instead of raising
+    'conv_wino: layer not eligible' at call time."""
+    torch.manual_seed(0)
+    m = M.ConvBnReLU3D(16, 16, kernel_size=(1, 3, 3), stride=1, pad=(0, 1, 1))
+    m.eval()
+    L = cp._cbr3d(m)
+    assert L.wpk_wino is None
+    sig = cp.layer_signature(L, 1, 1, 96, 128, 0)
+    saved = cp._TUNING, cp._FAMILIES
+    try:
+        cp._TUNING, cp._FAMILIES = {sig: [8, 2, 1]}, None
+        assert cp.tuned_choice(L, 1, 1, 96, 128, 0) == ([8, 2, 1], "exact")
+        variant = L._geom(1, 1, 96, 128, 0)[4]
+        assert (variant & 0xff) not in (8, 9)
+        # and the layer still computes (emulated direct kernel)
+        x = torch.randn(1, 16, 1, 96, 128)
+        with torch.no_grad():
+            want = twin(O._CBR3d(16, 16, kernel_size=(1, 3, 3), stride=1, pad=(0, 1, 1)), m)(x)
+        got = run_layer(L, cl(x))
+        assert (got - cl(want)).abs().max() <= 2e-5 * want.abs().max()
+    finally:
+        cp._TUNING, cp._FAMILIES = saved

@@ -436,6 +436,42 @@ def test_narrow_mfma_conv_against_fp64_and_valu(cin, shape):
     note("conv_narrow_mfma_%d_%s" % (cin, "x".join(map(str, shape))), err_over_max=worst)
 
 
+@pytest.mark.parametrize("cin", [4, 8])
+def test_narrow_mfma_conv_non_finite_footprint(cin):
+    """Pins the one documented divergence of the shift-packed MFMA kernel (variant 10, the default for narrow layers with
+    >= 16 384 output voxels) on NON-FINITE inputs: its N operand multiplies structural-zero weights with real inputs (a pixel
+    pair shares four tap columns), so a NaN / Inf input pixel at column c poisons, besides the reference's 3x3 footprint
+    (rows y-1..y+1, columns c-1..c+1, which the VALU kernel reproduces exactly), ONE more output column of the same rows --
+    c-2 for even c, c+2 for odd c (the other pixel of the pair on that side).  Nothing else changes, bit for bit.
+    INTEGRATION.md ("Non-finite inputs") states this; finite inputs are unaffected (0 * finite = 0 exactly)."""
+    B, D, H, W = 1, 1, 24, 96
+    g = torch.Generator().manual_seed(7 + cin)
+    w = torch.randn(8, cin, 1, 3, 3, generator=g) * 0.2
+    layer = cp.ConvLayer(w.to(DEV), False, (1, 1, 1), (0, 1, 1), relu=False, cin_pad=cin)
+    base = torch.randn(B, D, H, W, cin, generator=g).to(DEV)
+    for (y, c, bad) in ((10, 40, float("nan")), (11, 41, float("inf")), (5, 33, float("nan")), (6, 62, float("-inf"))):
+        x = base.clone()
+        x[0, 0, y, c, 1] = bad
+        x0 = base.clone()
+        x0[0, 0, y, c, :] = 0.0
+        for variant, extra in ((3, None), (10, c - 2 if c % 2 == 0 else c + 2)):
+            got = layer(x, tiles=(0, 0, variant) if variant == 3 else (2, 1, 10))
+            clean = layer(x0, tiles=(0, 0, variant) if variant == 3 else (2, 1, 10))
+            nonfinite = ~torch.isfinite(got).all(-1)[0, 0]                    # [H, W]
+            want = torch.zeros(H, W, dtype=torch.bool, device=DEV)
+            want[y - 1:y + 2, c - 1:c + 2] = True
+            allowed = want.clone()
+            if extra is not None:
+                allowed[y - 1:y + 2, extra] = True
+            assert (nonfinite & want).sum() == want.sum(), (cin, variant, y, c)          # the reference's footprint
+            stray = (nonfinite & ~allowed).nonzero().tolist()
+            assert not stray, (cin, variant, y, c, stray[:8])
+            if extra is not None:
+                assert nonfinite[y - 1:y + 2, extra].all(), (cin, y, c, extra)        # the documented extra column IS there
+            keep = ~allowed
+            assert torch.equal(got[0, 0][keep], clean[0, 0][keep]), (cin, variant, y, c)
+
+
 @pytest.mark.parametrize("name,cfg,shape", CONV_CASES)
 def test_conv_bn_relu(name, cfg, shape):
     torch.manual_seed(hash(name) % 1000)

@@ -219,3 +219,32 @@ def test_g9_losses(golden, name):
     assert abs(r[0].item() - float(g.np("blend_%s_total" % name))) <= 1e-5 * abs(float(g.np("blend_%s_total" % name)))
     assert torch.equal(torch.stack(r[3]), g.t("blend_%s_range" % name))
     assert torch.allclose(torch.stack(list(r[4:])), g.t("blend_%s_epe_err3_err1" % name), rtol=1e-6)
+
+
+def test_fpn_window_equals_the_whole_map(checkpoint, shipped_cfg):
+    """``FPN4.forward_window`` (the pyramid of a window, up-sampling in whole-map coordinates) against ``FPN4.forward`` on the
+    whole image, which the golden vectors pin (G6): interior of an inner window, and windows that touch image borders (where
+    the window's zero padding is the real one).  This is what lets the GPU tests check the full-size pyramid window by window."""
+    oracle = O.OracleMVS4net(**shipped_cfg)
+    oracle.load_state_dict(checkpoint, strict=True)
+    oracle.eval()
+    H, W = 320, 384
+    img = make_inputs(nviews=2, H=H, W=W, seed=3)[0][0]
+    margin = 96
+    with torch.no_grad():
+        full = oracle.feature(img)
+        for (y0, x0, wh, ww) in ((32, 48, 256, 288), (0, 0, 224, 256), (H - 224, W - 256, 224, 256), (0, 128, 232, 256)):
+            win = oracle.feature.forward_window(img[:, :, y0:y0 + wh, x0:x0 + ww].contiguous(), (y0, x0), (H, W))
+            for s in range(1, 5):
+                sc = 2 ** (4 - s)
+                a = win["stage%d" % s]
+                b = full["stage%d" % s][:, :, y0 // sc:(y0 + wh) // sc, x0 // sc:(x0 + ww) // sc]
+                m = margin // sc
+                iy = slice(0 if y0 == 0 else m, a.shape[2] if y0 + wh == H else a.shape[2] - m)
+                ix = slice(0 if x0 == 0 else m, a.shape[3] if x0 + ww == W else a.shape[3] - m)
+                assert a[:, :, iy, ix].numel() > 0
+                err = maxdiff(a[:, :, iy, ix], b[:, :, iy, ix])
+                assert err <= 2e-6 * max(b.abs().max().item(), 1.0), (s, (y0, x0), err)
+            # and a window WITHOUT the margin is visibly wrong at its edge (the test above is not vacuous)
+        bad = maxdiff(win["stage4"][:, :, :, :4], full["stage4"][:, :, 0:232, 128:132])
+        assert bad > 1e-3
