@@ -204,7 +204,7 @@ class ConvLayer:
         self._cin_raw = cin
         self.classes, self.woff = self._class_table()
         self.wpk = None
-        self.w_small = self.w_deconv = self.wpk_wino = None
+        self.w_small = self.w_deconv = self.wpk_wino = self.wpk_b3 = None
         self._pack(w)
         self.ntile_total = (cout + 15) // 16
         npad = self.ntile_total * 16
@@ -303,6 +303,16 @@ class ConvLayer:
                 ws = torch.nn.functional.pad(ws, (0, 0, 0, self.cin - cin))
             self.w_small = ws.contiguous().to(dev)
         self._pack_wino(w)
+        self._pack_b3(w)
+
+    def b3_eligible(self):
+        """(1|3)x3x3 stride-1 layers of 16 / 32 / 64 channels that the bf16-split kernel (variant 11, conv_b3.hip) covers."""
+        return (not self.transposed and self.kernel in ((1, 3, 3), (3, 3, 3)) and self.stride == (1, 1, 1)
+                and self.padding == (self.kernel[0] // 2, 1, 1) and self.cin in (16, 32, 64) and self.cout in (16, 32, 64))
+
+    def _pack_b3(self, w):
+        """(Re)build the bf16-split weight fragments of an eligible layer (device tensors only: the kernel is the consumer)."""
+        self.wpk_b3 = pack_b3(w, self.cin, self.cout, self.kernel[0]) if (self.b3_eligible() and w.is_cuda) else None
 
     def wino_eligible(self):
         """(1|3)x3x3 stride-1 layers the Winograd kernels (variants 8 / 9, conv_wino.hip) cover."""
@@ -341,6 +351,11 @@ class ConvLayer:
                                                   kh, kw, s_n, s_c, st[2], st[3], st[4], int(flip),
                                                   ops._stream())
         _lib.check(rc, "pack_conv_weights")
+        if self.wpk_b3 is not None:
+            # (the bf16-split fragments are built by torch ops at plan build only: a layer whose weights are refreshed in place
+            #  -- the training path -- stays on the fp32 kernels)
+            self.wpk_b3 = None
+            self._geom_cache.clear()
         if self.wpk_wino is not None:
             self._pack_wino(w, swap, flip)
         if self.w_small is not None:
@@ -521,6 +536,10 @@ class ConvLayer:
             if self.wpk_wino is None:
                 raise RuntimeError("conv_wino: layer not eligible")
             wpk = self.wpk_wino
+        if (variant & 0xff) == 11:
+            if self.wpk_b3 is None or skip_mode == SKIP_UPSAMPLE_ADD or self.prob is not None:
+                raise RuntimeError("conv_b3: layer not eligible")
+            wpk, nt = self.wpk_b3, 1
         rc = _lib.load().mvster_conv_mfma(
             x.data_ptr(), wpk.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
             None if skip is None else skip.data_ptr(), self.zeros.data_ptr(),
@@ -546,6 +565,28 @@ class ConvLayer:
         if self.transposed:
             return 2 * B * Di * Hi * Wi * kd * kh * kw * self.cin * self.cout
         return 2 * B * Do * Ho * Wo * kd * kh * kw * self.cin * self.cout
+
+
+def pack_b3(w, cin, cout, kd):
+    """w [cout, cin_raw, kd, 3, 3] -> the weights as THREE bf16 planes (w = w1 + w2 + w3 exactly: round-to-nearest bf16 of the
+    value, of the residual, of the residual's residual) in the fragment order of conv_b3.hip: per stage (kd, 16 input
+    channels) and N split a block [tap pair 5][N tile NTW][plane 3][lane 64][8 bf16], zero-padded to 1024 NTW 16-byte
+    units; lane (n = lane & 15, g = lane >> 4) holds channels 8 (g & 1) .. + 7 of tap 2 tp + (g >> 1) (tap 9 = 0) of output
+    channel 16 (ns NTW + j) + n.  -> bf16 tensor [kd, cin / 16, nsplit, 1024 NTW * 8].  Torch ops, once per plan build."""
+    if w.shape[1] != cin:
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cin - w.shape[1]))
+    w = w.reshape(cout, cin, kd, 9).float()
+    w1 = w.to(torch.bfloat16)
+    r = w - w1.float()
+    w2 = r.to(torch.bfloat16)
+    w3 = (r - w2.float()).to(torch.bfloat16)
+    planes = torch.nn.functional.pad(torch.stack([w1, w2, w3]), (0, 1))        # [3, cout, cin, kd, 10]: tap 9 = 0
+    ntw = 1 if cout == 16 else 2
+    nsplit = cout // (16 * ntw)
+    # [pl, ns, j, n, ch, c8, e, kd, tp, th] -> [kd, ch, ns, tp, j, pl, th, c8, n, e]
+    t = planes.reshape(3, nsplit, ntw, 16, cin // 16, 2, 8, kd, 5, 2).permute(7, 4, 1, 8, 2, 0, 9, 5, 3, 6)
+    t = t.reshape(kd, cin // 16, nsplit, 5 * ntw * 3 * 64 * 8)
+    return torch.nn.functional.pad(t, (0, 1024 * ntw * 8 - t.shape[-1])).contiguous()
 
 
 def _cbr3d(m, **kw):

@@ -121,6 +121,9 @@ int dispatch_pers(const ConvArgs& a, int mt, int nt, int wpc, hipStream_t s);
 int dispatch_pp(const ConvArgs& a, int mt, int nt, hipStream_t s);
 // conv_wino.hip: Winograd F(2x2, 3x3) forms of the persistent kernel (variants 8 and 9 = ring; `wpk` = the transformed weights)
 int dispatch_wino(const ConvArgs& a, int nt, int wpc, bool ring, hipStream_t s);
+// conv_b3.hip: fp32 products as six bf16 MFMAs (3-way split operands), 3x3 / 3x3x3 stride-1 layers (variant 11; `wpk` = the
+// pre-split bf16 weight fragments)
+int dispatch_b3(const ConvArgs& a, int mt, int wpc, hipStream_t s);
 // conv_pers.hip: persistent 1x1 kernel with all weights in LDS (variant 6)
 int dispatch_1x1(const ConvArgs& a, int mt, int wpc, hipStream_t s);
 

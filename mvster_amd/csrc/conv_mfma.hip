@@ -673,6 +673,7 @@ extern "C" int mvster_conv_mfma(const float* in, const float* wpk, const float* 
     if ((variant & 0xff) == 7) return dispatch_pp(a, mt, nt, s);                   // persistent, eight waves in ping-pong
     if ((variant & 0xff) == 8) return dispatch_wino(a, nt, variant >> 8, false, s);   // Winograd F(2x2,3x3); wpk = transformed weights
     if ((variant & 0xff) == 9) return dispatch_wino(a, nt, variant >> 8, true, s);   // ... deep layers: slices and weights streamed
+    if ((variant & 0xff) == 11) return dispatch_b3(a, mt, variant >> 8, s);                       // 3 x bf16-split operands on the bf16 MFMA (conv_b3.hip)
     if (prob_w && (a.cout != 8 || a.skip_mode == 2 || variant == 1)) return MVSTER_ERR_UNSUPPORTED;
     if (variant == 1) return dispatch_lds(a, mt, nt, s);
     if (variant != 0 && variant != 2) return MVSTER_ERR_UNSUPPORTED;

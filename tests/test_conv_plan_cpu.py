@@ -316,3 +316,30 @@ def test_winograd_table_entry_is_dropped_for_a_layer_without_transformed_weights
         assert (got - cl(want)).abs().max() <= 2e-5 * want.abs().max()
     finally:
         cp._TUNING, cp._FAMILIES = saved
+
+
+@pytest.mark.parametrize("cin,cout,kd", [(16, 16, 1), (32, 32, 3), (64, 64, 1), (64, 32, 3), (12, 16, 1)])
+def test_bf16_split_weight_fragments(cin, cout, kd):
+    """conv_plan.pack_b3 (operand of conv_b3.hip, variant 11): the three bf16 planes add up to the fp32 weight EXACTLY, and
+    every value sits where the kernel's fragment rule reads it -- written out here element by element from the rule in the
+    kernel's header (lane = (n, g), tap = 2 tp + (g >> 1), channel = 16 ch + 8 (g & 1) + e, tap 9 = zero)."""
+    g = torch.Generator().manual_seed(cin + cout + kd)
+    w = torch.randn(cout, cin, kd, 3, 3, generator=g) * torch.rand(cout, cin, kd, 3, 3, generator=g).exp()
+    cin_pad = (cin + 15) // 16 * 16
+    packed = cp.pack_b3(w, cin_pad, cout, kd)
+    ntw = 1 if cout == 16 else 2
+    nsplit = cout // (16 * ntw)
+    assert packed.dtype == torch.bfloat16 and tuple(packed.shape) == (kd, cin_pad // 16, nsplit, 1024 * ntw * 8)
+    frag = packed[..., :5 * ntw * 3 * 64 * 8].reshape(kd, cin_pad // 16, nsplit, 5, ntw, 3, 64, 8).double()
+    assert (packed[..., 5 * ntw * 3 * 64 * 8:] == 0).all()
+    total = frag.sum(5)                                       # w1 + w2 + w3 in fp64
+    rng = np.random.RandomState(0)
+    for _ in range(400):
+        z, ch, ns, tp, j, lane, e = (rng.randint(n) for n in (kd, cin_pad // 16, nsplit, 5, ntw, 64, 8))
+        n, gg = lane & 15, lane >> 4
+        tap, ci, co = 2 * tp + (gg >> 1), 16 * ch + 8 * (gg & 1) + e, 16 * (ns * ntw + j) + n
+        want = float(w[co, ci, z, tap // 3, tap % 3]) if (tap < 9 and ci < cin) else 0.0
+        assert total[z, ch, ns, tp, j, lane, e].item() == want, (z, ch, ns, tp, j, lane, e)
+    # the planes are ordered by magnitude: |w2| <= 2^-8 |w1|, |w3| <= 2^-16 |w1| (up to rounding at the boundaries)
+    a1, a2, a3 = (frag[:, :, :, :, :, k].abs() for k in range(3))
+    assert (a2 <= a1 * 2.0 ** -7.9 + 1e-40).all() and (a3 <= a1 * 2.0 ** -15.9 + 1e-40).all()
