@@ -204,7 +204,7 @@ class ConvLayer:
         self._cin_raw = cin
         self.classes, self.woff = self._class_table()
         self.wpk = None
-        self.w_small = self.w_deconv = self.wpk_wino = self.wpk_b3 = None
+        self.w_small = self.w_deconv = self.wpk_wino = self.wpk_b3 = self._b3_src = None
         self._pack(w)
         self.ntile_total = (cout + 15) // 16
         npad = self.ntile_total * 16
@@ -311,8 +311,10 @@ class ConvLayer:
                 and self.padding == (self.kernel[0] // 2, 1, 1) and self.cin in (16, 32, 64) and self.cout in (16, 32, 64))
 
     def _pack_b3(self, w):
-        """(Re)build the bf16-split weight fragments of an eligible layer (device tensors only: the kernel is the consumer)."""
-        self.wpk_b3 = pack_b3(w, self.cin, self.cout, self.kernel[0]) if (self.b3_eligible() and w.is_cuda) else None
+        """The bf16-split weight fragments of an eligible layer are built on first use (variant 11 is a probe: the plan
+        never selects it); here only the source is remembered (no copy: the parameter's own storage when it is fp32)."""
+        self.wpk_b3 = None
+        self._b3_src = w if (self.b3_eligible() and w.is_cuda) else None
 
     def wino_eligible(self):
         """(1|3)x3x3 stride-1 layers the Winograd kernels (variants 8 / 9, conv_wino.hip) cover."""
@@ -351,11 +353,7 @@ class ConvLayer:
                                                   kh, kw, s_n, s_c, st[2], st[3], st[4], int(flip),
                                                   ops._stream())
         _lib.check(rc, "pack_conv_weights")
-        if self.wpk_b3 is not None:
-            # (the bf16-split fragments are built by torch ops at plan build only: a layer whose weights are refreshed in place
-            #  -- the training path -- stays on the fp32 kernels)
-            self.wpk_b3 = None
-            self._geom_cache.clear()
+        self.wpk_b3 = self._b3_src = None          # (probe variant 11: not for layers whose weights are refreshed in place)
         if self.wpk_wino is not None:
             self._pack_wino(w, swap, flip)
         if self.w_small is not None:
@@ -537,8 +535,10 @@ class ConvLayer:
                 raise RuntimeError("conv_wino: layer not eligible")
             wpk = self.wpk_wino
         if (variant & 0xff) == 11:
-            if self.wpk_b3 is None or skip_mode == SKIP_UPSAMPLE_ADD or self.prob is not None:
+            if self._b3_src is None or skip_mode == SKIP_UPSAMPLE_ADD or self.prob is not None:
                 raise RuntimeError("conv_b3: layer not eligible")
+            if self.wpk_b3 is None:
+                self.wpk_b3 = pack_b3(self._b3_src, self.cin, self.cout, self.kernel[0])
             wpk, nt = self.wpk_b3, 1
         rc = _lib.load().mvster_conv_mfma(
             x.data_ptr(), wpk.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Probe: fp32 products on the bf16 matrix cores (3-way split operands, six MFMAs, fp32 accumulate; conv_b3.hip, variant 11)
 against the kernels the plan runs today, layer by layer: max error against an fp64 convolution (in units of max |y|) and
-hipGraph-timed duration.  GPU only.  `python scripts/conv_b3_check.py [quick]`."""
+hipGraph-timed duration.  GPU only, probe library:
+`MVSTER_LIB=$PWD/mvster_amd/csrc/libmvster_hip_probes.so python scripts/conv_b3_check.py [quick]`."""
 import os
 import sys
 
@@ -56,13 +57,13 @@ for cin, cout, kd, (B, D, H, W), with_skip in LAYERS:
     direct = layer(x, skip=skip, skip_mode=sm, tiles=(1, 1, 0))
     e_dir = (direct.double() - ref).abs().max().item() / scale
     res = []
-    for tyq, wpc in ((2, 0), (1, 0), (2, 2), (1, 2)):
-        word = 11 | (wpc << 8)
+    for tyq, wpc, prio in ((2, 1, 1), (1, 1, 1), (1, 1, 0), (1, 1, 2)):
+        word = 11 | ((wpc | (prio << 2)) << 8)
         got = layer(x, skip=skip, skip_mode=sm, tiles=(tyq, 1, word))
         k_b3 = _lib.last_kernel()
         e = (got.double() - ref).abs().max().item() / scale
         t = min(timeit(lambda: layer(x, skip=skip, skip_mode=sm, tiles=(tyq, 1, word)), n=10) for _ in range(2))
-        res.append((t, e, "TY%d/wpc%d" % (4 * tyq, max(wpc, 1))))
+        res.append((t, e, "TY%d/w%d/p%d" % (4 * tyq, wpc, prio)))
     best = min(res)
     fl = layer.flops(B, D, H, W)
     big = B * D * H * W >= 20000

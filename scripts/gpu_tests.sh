@@ -12,6 +12,6 @@ for f in tests/test_gpu_kernels.py tests/test_gpu_model.py tests/test_gpu_train.
 done
 # the kernel forms kept for the record (probe library: make -C mvster_amd/csrc probes)
 if [ -f mvster_amd/csrc/libmvster_hip_probes.so ]; then
-  MVSTER_LIB=$PWD/mvster_amd/csrc/libmvster_hip_probes.so timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout=600 -k "variants_bit_identical or lds_window or pingpong or warp_agg_forward" 2>&1 | tail -5 > gpurun_out/test_gpu_probes.log
+  MVSTER_LIB=$PWD/mvster_amd/csrc/libmvster_hip_probes.so timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout=600 -k "variants_bit_identical or lds_window or pingpong or warp_agg_forward or bf16_split" 2>&1 | tail -5 > gpurun_out/test_gpu_probes.log
   echo "== probe library"; tail -2 gpurun_out/test_gpu_probes.log
 fi

@@ -472,6 +472,39 @@ def test_narrow_mfma_conv_non_finite_footprint(cin):
             assert torch.equal(got[0, 0][keep], clean[0, 0][keep]), (cin, variant, y, c)
 
 
+@needs_probes
+@pytest.mark.parametrize("cin,cout,kd,shape", [(16, 16, 1, (2, 1, 37, 50)), (32, 32, 1, (1, 1, 64, 96)), (64, 64, 1, (1, 1, 9, 33)),
+                                               (64, 32, 1, (2, 1, 21, 45)), (16, 16, 3, (1, 3, 21, 45)), (32, 32, 3, (1, 4, 32, 40)),
+                                               (64, 64, 3, (1, 8, 8, 10)), (16, 16, 1, (5, 1, 128, 160))])
+def test_bf16_split_conv_probe(cin, cout, kd, shape):
+    """Probe (variant 11, conv_b3.hip): fp32 products as six bf16 MFMAs on 3-way split operands, fp32 accumulation.  Accuracy
+    gate of the round-5 probe: against an fp64 convolution its error stays within the direct fp32 MFMA kernel's on the same
+    layer (measured 0.44x), with and without the skip tensor, ragged tiles, one and three depth taps, both tile heights."""
+    from mvster_amd import _lib
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(cin + 7 * cout + kd + H)
+    w = torch.randn(cout, cin, kd, 3, 3, generator=g) * (2.0 / (cin * 9 * kd)) ** 0.5
+    layer = cp.ConvLayer(w.to(DEV), False, (1, 1, 1), (kd // 2, 1, 1), bias=torch.randn(cout, generator=g).to(DEV) * 0.1, relu=True)
+    x = torch.randn(B, D, H, W, cin, generator=g).to(DEV)
+    skip = torch.randn(B, D, H, W, cout, generator=g).to(DEV)
+    ref0 = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3).double(), w.to(DEV).double(), padding=(kd // 2, 1, 1))
+    ref0 = ref0 * layer.scale[:cout].double().view(1, -1, 1, 1, 1) + layer.shift[:cout].double().view(1, -1, 1, 1, 1)
+    ref0 = ref0.clamp_min(0).permute(0, 2, 3, 4, 1)
+    worst = 0.0
+    for sk in (None, skip):
+        ref = ref0 if sk is None else ref0 + sk.double()
+        sm = cp.SKIP_NONE if sk is None else cp.SKIP_ADD
+        scale = ref.abs().max().item()
+        e_dir = (layer(x, skip=sk, skip_mode=sm, tiles=(1, 1, 0)).double() - ref).abs().max().item() / scale
+        for tyq in (1, 2):
+            got = layer(x, skip=sk, skip_mode=sm, tiles=(tyq, 1, 11 | (1 << 8)))
+            assert _lib.last_kernel().startswith("conv_b3_kernel<%d, " % cin), _lib.last_kernel()
+            e = (got.double() - ref).abs().max().item() / scale
+            worst = max(worst, e / max(e_dir, 1e-12))
+            assert e <= max(1.0 * e_dir, 3e-7), (cin, cout, kd, shape, sk is not None, tyq, e, e_dir)
+    note("conv_b3_probe_%d_%d_k%d_%s" % (cin, cout, kd, "x".join(map(str, shape))), err_over_direct_fp32=worst)
+
+
 @pytest.mark.parametrize("name,cfg,shape", CONV_CASES)
 def test_conv_bn_relu(name, cfg, shape):
     torch.manual_seed(hash(name) % 1000)
