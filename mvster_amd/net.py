@@ -153,7 +153,6 @@ class MVS4net(nn.Module):
         # latency-bound launches that leave most of the chip idle)
         self.overlap_streams = True
         self._side_streams = {}
-        self._conf_streams = {}
         self.warp_variant = 0          # mvster_warp_agg_fwd variant (0 = per-shape default)
         # eval calls replay a captured hipGraph from the second call of a shape on (graph.ForwardCache); False = every
         # call issues its ~76 launches eagerly, as before round 5.  Shared by nn.DataParallel's single-device pass-through.
@@ -292,11 +291,6 @@ class MVS4net(nn.Module):
             # a 1- or 2-stage cascade (BASELINE config 1) never reads the two fine levels
             o3, o4 = fpn.tail(c0, c1, f1) if self.num_stage > 2 else (None, None)
         pyramid = [o1, o2, o3, o4]
-        conf_stream = None
-        if self.overlap_streams and self.num_stage > 1:
-            conf_stream = self._conf_streams.get(dev)
-            if conf_stream is None:
-                conf_stream = self._conf_streams[dev] = torch.cuda.Stream(device=dev)
 
         outputs = {}
         prev = None
@@ -333,18 +327,11 @@ class MVS4net(nn.Module):
             if capture is not None:
                 capture[name] = {"cor_feats": cor.permute(0, 4, 1, 2, 3), "logits": sel["logits"],
                                  "feats_cl": f}                                  # [N,B,h,w,C], view 0 = reference
-            # (x1 at the last stage is the identity, exactly: src = dst, lambda = 0)
-            if s < 3 and conf_stream is not None:
-                # nothing in the cascade reads the up-sampled confidence of a coarse stage: off the critical path, on a
-                # stream of its own, joined at the end of the forward (three launches that ran alone before: 14 us per forward)
-                conf_stream.wait_stream(main)
-                with torch.cuda.stream(conf_stream):
-                    conf = ops.upsample_bilinear(sel["conf"], 2 ** (3 - s))
-                if not torch.cuda.is_current_stream_capturing():
-                    sel["conf"].record_stream(conf_stream)
-                    conf.record_stream(main)
-            else:
-                conf = ops.upsample_bilinear(sel["conf"], 2 ** (3 - s)) if s < 3 else sel["conf"]
+            # (x1 at the last stage is the identity, exactly: src = dst, lambda = 0.  The three coarse-stage launches stay on the
+            #  main stream: on a stream of their own -- nothing in the cascade reads them -- the captured forward got SLOWER,
+            #  1.174 against 1.129 ms alone and 850 against 1 108 depth-maps/s with two in flight, same box, alternating runs
+            #  (profiles/r05_conf_stream_ab.txt): every cross-stream edge of a hipGraph costs more than these 4 us kernels)
+            conf = ops.upsample_bilinear(sel["conf"], 2 ** (3 - s)) if s < 3 else sel["conf"]
             st = {"depth": sel["depth"], "photometric_confidence": conf, "hypo_depth": hypo,
                   "attn_weight": sel["attn_weight"]}
             if self.inverse_depth:
@@ -355,8 +342,6 @@ class MVS4net(nn.Module):
             prev = st
             outputs[name] = st
             outputs.update(st)
-        if conf_stream is not None:
-            main.wait_stream(conf_stream)
         return outputs
 
     # ------------------------------------------------------------------ train: autograd
