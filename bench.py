@@ -70,6 +70,7 @@ class KernelTimer:
         timer = self
         self._orig_conv = cp.ConvLayer.__call__
         self._orig_warp = ops.warp_agg_fwd_cl
+        self._orig_warp_sched = ops.warp_agg_fwd_sched_cl
         self._orig_sel = cp.fused_conv11_select
         self._orig_fpn = (ops.fpn_tail_fused, ops.fpn_tail_gather, ops.fpn_lateral_up)
 
@@ -91,6 +92,17 @@ class KernelTimer:
             e1.record()
             bytes_ = 4 * (ref_cl.numel() + src_cl.numel() + hypo.numel() + hypo.numel() * G)
             timer.records.append((_lib.last_kernel(), e0, e1, 0, bytes_))
+            return out
+
+        def warp_sched_call(ref_cl, src_cl, rt, G, D, *a, **k):
+            # (the stage's hypotheses are computed inside this launch: written instead of read, same byte count)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = timer._orig_warp_sched(ref_cl, src_cl, rt, G, D, *a, **k)
+            e1.record()
+            if out is not None:
+                nh = out[1].numel()
+                timer.records.append((_lib.last_kernel(), e0, e1, 0, 4 * (ref_cl.numel() + src_cl.numel() + nh + nh * G)))
             return out
 
         def select_call(L, t, c0, hypo, *a, **k):
@@ -121,6 +133,7 @@ class KernelTimer:
 
         cp.ConvLayer.__call__ = conv_call
         ops.warp_agg_fwd_cl = warp_call
+        ops.warp_agg_fwd_sched_cl = warp_sched_call
         cp.fused_conv11_select = select_call
         ops.fpn_tail_fused, ops.fpn_tail_gather, ops.fpn_lateral_up = fpn_op(0), fpn_op(1), fpn_op(2)
 
@@ -129,6 +142,7 @@ class KernelTimer:
         import mvster_amd.ops as ops
         cp.ConvLayer.__call__ = self._orig_conv
         ops.warp_agg_fwd_cl = self._orig_warp
+        ops.warp_agg_fwd_sched_cl = self._orig_warp_sched
         cp.fused_conv11_select = self._orig_sel
         ops.fpn_tail_fused, ops.fpn_tail_gather, ops.fpn_lateral_up = self._orig_fpn
 
@@ -666,6 +680,8 @@ def main():
                     help="skip the few graph replays of the 1152x1600x5 and 1024x1920x7 workloads (other_configs)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="profiling passes: the fine FPN levels on the main stream too (no co-running kernels)")
+    ap.add_argument("--no-fuse-hypotheses", action="store_true",
+                    help="A/B switch: hypothesis scheduling as its own launch per stage (as before round 5)")
     ap.add_argument("--no-api-call", action="store_true",
                     help="skip the plain model(imgs, proj, depth_values) loops (value_api_call: what the unchanged reference "
                          "driver gets)")
@@ -705,6 +721,8 @@ def main():
     model.to(dev).eval()
     if args.no_overlap:
         model.overlap_streams = False      # profiling passes: one stream, no co-running kernels
+    if args.no_fuse_hypotheses:
+        model.fuse_hypotheses = False
     # every rank works on its own depth maps: disjoint seeds = disjoint units of the shard
     units = shard.shard_units(world * (args.steps + args.warmup), rank, world)
     imgs, proj, dv = make_inputs(nviews=args.views, H=args.height, W=args.width, seed=units[0], device=dev, batch=args.batch)

@@ -52,6 +52,19 @@ int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat, const floa
                         int Ws, long ref_batch_stride, long src_view_stride, long src_batch_stride, int group_cor,
                         int attn_fuse_d, float attn_temp, int variant, void* stream);
 
+/* mvster_warp_agg_fwd with the stage's depth-hypothesis scheduling fused in: one launch instead of
+ * (mvster_schedule_inverse_range | mvster_init_range) + mvster_warp_agg_fwd.  mode 1: the hypotheses are
+ * schedule_inverse_range(inv_min, inv_max) of the previous stage's bounds [B,h/2,w/2] (models/mvs4net_utils.py:79-86);
+ * mode 2: init_inverse_range of depth_values [B,ndv] (:71-77).  hypo_out [B,D,h,w] receives them, bit-identical to the
+ * scheduler kernels' (the stage's selection and the API's `hypo_depth` read it).  Group correlation on the wave-local
+ * kernel only: D in {4, 8}, (C, G) in {(8,4), (16,4), (32,8), (64,8)} -- the shipped cascade; MVSTER_ERR_UNSUPPORTED (-3)
+ * otherwise: run the two launches.  Other arguments as mvster_warp_agg_fwd.  Reference call site: models/MVS4Net.py:88-99. */
+int mvster_warp_agg_fwd_sched(const float* ref_feat, const float* src_feat, const float* rt, const float* inv_min,
+                              const float* inv_max, const float* depth_values, int ndv, float* hypo_out, float* out,
+                              float* wsum_out, int B, int NV, int C, int G, int D, int h, int w, int Hs, int Ws,
+                              long ref_batch_stride, long src_view_stride, long src_batch_stride, int attn_fuse_d,
+                              float attn_temp, int mode, void* stream);
+
 /* Backward of mvster_warp_agg_fwd w.r.t. the features (the sampling grid carries no gradient,
  * models/mvs4net_utils.py:23).  grad_out/out [B,D,h,w,G], wsum [B,D,h,w] from the forward; both attention forms,
  * D <= 16.  grad_ref [B,h,w,C] is written; grad_src [NV][B,Hs,Ws,C] must be zero-initialised.

@@ -21,6 +21,7 @@ SIGNATURES = {
     "mvster_relative_projection_multi": [_f, _i, _f, _i, _i, _f],
     "mvster_pack_images": [_f, _i, _f, _i, _i, _i, _f],
     "mvster_warp_agg_fwd": [_f, _f, _f, _f, _f, _f] + [_i] * 9 + [_l] * 3 + [_i, _i, _fl, _i, _f],
+    "mvster_warp_agg_fwd_sched": [_f] * 6 + [_i, _f, _f, _f] + [_i] * 9 + [_l] * 3 + [_i, _fl, _i, _f],
     "mvster_warp_agg_bwd": [_f] * 11 + [_i] * 9 + [_l] * 3 + [_i, _i, _fl, _f],
     "mvster_warp_agg_bwd_scratch": [_i] * 8 + [_f, _f],
     "mvster_init_range": [_f, _i, _f, _i, _i, _i, _i, _i, _f],

@@ -384,14 +384,17 @@ MV_HD bool relative_projection(const float* ref_pm, const float* src_pm, RT& out
 // ---------------------------------------------------------------------------------------
 
 // init_inverse_range / init_range (mvs4net_utils.py:61-77): out[d*hw + p] for one batch item
+// one hypothesis of init_inverse_range (the loop below and the warp kernel's fused form share it: same bits)
+MV_HD float init_inverse_one(float dmin, float dmax, int D, int d) {
+    const float inv_near = div_rn(1.0f, dmin), inv_far = div_rn(1.0f, dmax);
+    const float span = sub_rn(inv_near, inv_far);
+    const float itv = div_rn((float)d, (float)(D - 1));
+    return div_rn(1.0f, add_rn(inv_far, mul_rn(span, itv)));
+}
+
 MV_HD void init_range_pixel(float dmin, float dmax, float* out, int D, long hw, long p, int inverse) {
     if (inverse) {
-        const float inv_near = div_rn(1.0f, dmin), inv_far = div_rn(1.0f, dmax);
-        const float span = sub_rn(inv_near, inv_far);
-        for (int d = 0; d < D; ++d) {
-            const float itv = div_rn((float)d, (float)(D - 1));
-            out[d * hw + p] = div_rn(1.0f, add_rn(inv_far, mul_rn(span, itv)));
-        }
+        for (int d = 0; d < D; ++d) out[d * hw + p] = init_inverse_one(dmin, dmax, D, d);
     } else {
         const float step = div_rn(sub_rn(dmax, dmin), (float)(D - 1));
         for (int d = 0; d < D; ++d) out[d * hw + p] = add_rn(dmin, mul_rn((float)d, step));
@@ -400,20 +403,32 @@ MV_HD void init_range_pixel(float dmin, float dmax, float* out, int D, long hw, 
 
 // schedule_inverse_range (mvs4net_utils.py:79-86): inv_min/inv_max are one batch item's
 // [hi, wi] maps; trilinear with the depth size unchanged is bilinear per slice.
+// the four corners of a pixel's inverse-depth range at the previous stage's resolution
+struct InvCorners { Lerp ly, lx; float mx[4], sp[4]; };
+MV_HD InvCorners schedule_inverse_corners(const float* inv_min, const float* inv_max, int y, int x, int h, int w, int hi, int wi) {
+    InvCorners c;
+    c.ly = make_lerp(y, hi, h);
+    c.lx = make_lerp(x, wi, w);
+    const int idx[4] = {c.ly.i0 * wi + c.lx.i0, c.ly.i0 * wi + c.lx.i1, c.ly.i1 * wi + c.lx.i0, c.ly.i1 * wi + c.lx.i1};
+    for (int k = 0; k < 4; ++k) {
+        c.mx[k] = inv_max[idx[k]];
+        c.sp[k] = sub_rn(inv_min[idx[k]], c.mx[k]);
+    }
+    return c;
+}
+// one hypothesis of schedule_inverse_range (the loop below and the warp kernel's fused form share it: same bits)
+MV_HD float schedule_inverse_one(const InvCorners& c, int D, int d) {
+    const float itv = div_rn((float)d, (float)(D - 1));
+    const float v00 = add_rn(c.mx[0], mul_rn(c.sp[0], itv)), v01 = add_rn(c.mx[1], mul_rn(c.sp[1], itv));
+    const float v10 = add_rn(c.mx[2], mul_rn(c.sp[2], itv)), v11 = add_rn(c.mx[3], mul_rn(c.sp[3], itv));
+    return div_rn(1.0f, bilerp(c.ly, c.lx, v00, v01, v10, v11));
+}
+
 MV_HD void schedule_inverse_pixel(const float* inv_min, const float* inv_max, float* out, int D, int h, int w,
                                   int hi, int wi, int p) {
     const int y = p / w, x = p - y * w;
-    const Lerp ly = make_lerp(y, hi, h), lx = make_lerp(x, wi, w);
-    const int i00 = ly.i0 * wi + lx.i0, i01 = ly.i0 * wi + lx.i1, i10 = ly.i1 * wi + lx.i0, i11 = ly.i1 * wi + lx.i1;
-    const float mx00 = inv_max[i00], mx01 = inv_max[i01], mx10 = inv_max[i10], mx11 = inv_max[i11];
-    const float sp00 = sub_rn(inv_min[i00], mx00), sp01 = sub_rn(inv_min[i01], mx01);
-    const float sp10 = sub_rn(inv_min[i10], mx10), sp11 = sub_rn(inv_min[i11], mx11);
-    for (int d = 0; d < D; ++d) {
-        const float itv = div_rn((float)d, (float)(D - 1));
-        const float v00 = add_rn(mx00, mul_rn(sp00, itv)), v01 = add_rn(mx01, mul_rn(sp01, itv));
-        const float v10 = add_rn(mx10, mul_rn(sp10, itv)), v11 = add_rn(mx11, mul_rn(sp11, itv));
-        out[(long)d * h * w + p] = div_rn(1.0f, bilerp(ly, lx, v00, v01, v10, v11));
-    }
+    const InvCorners c = schedule_inverse_corners(inv_min, inv_max, y, x, h, w, hi, wi);
+    for (int d = 0; d < D; ++d) out[(long)d * h * w + p] = schedule_inverse_one(c, D, d);
 }
 
 // schedule_range (mvs4net_utils.py:88-99)

@@ -45,6 +45,13 @@ struct WarpAggArgs {
     float attn_temp;
     float sqrt_c;
     int fuse_d;
+    // fused hypothesis scheduling (wave-local kernel, SCHED != 0): the hypotheses are computed here instead of read, and
+    // written to hypo_out [B, D, h, w] for the stage's selection and the API
+    const float* inv_min;    // SCHED 1: previous stage's inverse_min_depth [B, h/2, w/2]
+    const float* inv_max;    //          ... inverse_max_depth
+    const float* dvals;      // SCHED 2: depth_values [B, ndv] (first and last column = the range)
+    float* hypo_out;
+    int ndv;
 };
 
 // PX pixels x D hypotheses per workgroup: 64 pixels for D <= 16 (the shipped cascade's fallback form), 32 / 16 pixels for up
@@ -285,7 +292,11 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_fwd_lanes_kernel(WarpAggAr
 // gathered), hence the shared-reciprocal divisions, the single expf per lane and the packed blend.
 // Arithmetic and summation order are those of the one-thread form: results are bit-identical to it.
 // ------------------------------------------------------------------------------------------
-template <int C, int G, int D>
+// SCHED: 0 = the hypotheses are read from a.hypo; 1 = schedule_inverse_range of the previous stage's inverse bounds and
+// 2 = init_inverse_range of depth_values, both computed per lane with the scheduler kernels' own per-hypothesis functions
+// (mvster_math.h: bit-identical) and written to a.hypo_out by lane sub 0 -- one launch and one dependency edge less per
+// stage (schedule_inverse_kernel ran alone for ~5 us three times per forward).
+template <int C, int G, int D, int SCHED = 0>
 __global__ void __launch_bounds__(256) warp_agg_fwd_wave_kernel(WarpAggArgs a) {
     constexpr int LPP = C / 8;           // lanes per (pixel, d)
     constexpr int CG = C / G;            // channels per group
@@ -302,7 +313,20 @@ __global__ void __launch_bounds__(256) warp_agg_fwd_wave_kernel(WarpAggArgs a) {
     const int pc = valid ? p : hw - 1;   // clamped: every lane takes part in the shuffles
     const int y = pc / a.w;
     const int x = pc - y * a.w;
-    const float depth = a.hypo[((long)b * D + d) * hw + pc];
+    float depth;
+    if constexpr (SCHED == 0) {
+        depth = a.hypo[((long)b * D + d) * hw + pc];
+    } else {
+        if constexpr (SCHED == 1) {
+            const int hi = a.h / 2, wi = a.w / 2;
+            const mv::InvCorners cn = mv::schedule_inverse_corners(a.inv_min + (long)b * hi * wi, a.inv_max + (long)b * hi * wi,
+                                                                   y, x, a.h, a.w, hi, wi);
+            depth = mv::schedule_inverse_one(cn, D, d);
+        } else {
+            depth = mv::init_inverse_one(a.dvals[(long)b * a.ndv], a.dvals[(long)b * a.ndv + a.ndv - 1], D, d);
+        }
+        if (valid && sub == 0) a.hypo_out[((long)b * D + d) * hw + pc] = depth;
+    }
     const float* rp = a.ref + (long)b * a.ref_bs + (long)pc * C + sub * 8;
     const f32x4 R0 = ld4(rp), R1 = ld4(rp + 4);
     // per-launch divisors with their reciprocals (mvster_math.h: same bits as '/', 5 instead of 11 VALU ops)
@@ -689,13 +713,21 @@ int dispatch_fwd_pix(const WarpAggArgs& a, hipStream_t stream) {
 #endif  // MVSTER_PROBES
 
 template <int C, int G, int D>
-int launch_fwd_wave(const WarpAggArgs& a, hipStream_t stream) {
+int launch_fwd_wave(const WarpAggArgs& a, hipStream_t stream, int sched = 0) {
     constexpr int PPB = 4 * (64 / ((C / 8) * D));
     // 24-bit multiply-add on texel indices, 32-bit byte offsets inside one (view, batch) map
     if ((long)a.Hs * a.Ws >= (1L << 23) || (long)a.Hs * a.Ws * C * 4 >= (1L << 31)) return MVSTER_ERR_SHAPE;
     dim3 grid((a.h * a.w + PPB - 1) / PPB, a.B);
-    MV_NOTE_KERNEL("warp_agg_fwd_wave_kernel<%d, %d, %d>", C, G, D);
-    hipLaunchKernelGGL((warp_agg_fwd_wave_kernel<C, G, D>), grid, dim3(256), 0, stream, a);
+    if (sched == 1) {
+        MV_NOTE_KERNEL("warp_agg_fwd_wave_kernel<%d, %d, %d, 1>", C, G, D);
+        hipLaunchKernelGGL((warp_agg_fwd_wave_kernel<C, G, D, 1>), grid, dim3(256), 0, stream, a);
+    } else if (sched == 2) {
+        MV_NOTE_KERNEL("warp_agg_fwd_wave_kernel<%d, %d, %d, 2>", C, G, D);
+        hipLaunchKernelGGL((warp_agg_fwd_wave_kernel<C, G, D, 2>), grid, dim3(256), 0, stream, a);
+    } else {
+        MV_NOTE_KERNEL("warp_agg_fwd_wave_kernel<%d, %d, %d>", C, G, D);
+        hipLaunchKernelGGL((warp_agg_fwd_wave_kernel<C, G, D>), grid, dim3(256), 0, stream, a);
+    }
     return mv_check_launch();
 }
 
@@ -945,9 +977,9 @@ int dispatch_fwd_tile(const WarpAggArgs& a, hipStream_t stream) {
 #endif  // MVSTER_PROBES
 
 template <int C, int G>
-int dispatch_fwd_wave(const WarpAggArgs& a, hipStream_t stream) {
-    if (a.D == 4) return launch_fwd_wave<C, G, 4>(a, stream);
-    if (a.D == 8) return launch_fwd_wave<C, G, 8>(a, stream);
+int dispatch_fwd_wave(const WarpAggArgs& a, hipStream_t stream, int sched = 0) {
+    if (a.D == 4) return launch_fwd_wave<C, G, 4>(a, stream, sched);
+    if (a.D == 8) return launch_fwd_wave<C, G, 8>(a, stream, sched);
     return MVSTER_ERR_UNSUPPORTED;
 }
 
@@ -1769,6 +1801,35 @@ int launch_bwd(const WarpAggBwdArgs& ba, hipStream_t stream) {
 
 }  // namespace
 
+// mvster_warp_agg_fwd with the stage's hypothesis scheduling fused in (wave-local kernel only: group correlation, D in
+// {4, 8}, C / 8 * D <= 64 -- every stage of the shipped cascade; MVSTER_ERR_UNSUPPORTED otherwise and the caller runs the
+// scheduler launch + mvster_warp_agg_fwd).  mode 1: schedule_inverse_range of inv_min / inv_max [B, h/2, w/2]
+// (models/mvs4net_utils.py:79-86); mode 2: init_inverse_range of depth_values [B, ndv] (:71-77).  hypo_out [B, D, h, w]
+// receives the hypotheses (bit-identical to the scheduler kernels').
+extern "C" int mvster_warp_agg_fwd_sched(const float* ref_feat, const float* src_feat, const float* rt, const float* inv_min,
+                                         const float* inv_max, const float* depth_values, int ndv, float* hypo_out, float* out,
+                                         float* wsum_out, int B, int NV, int C, int G, int D, int h, int w, int Hs, int Ws,
+                                         long ref_batch_stride, long src_view_stride, long src_batch_stride, int attn_fuse_d,
+                                         float attn_temp, int mode, void* stream) {
+    if (!ref_feat || !src_feat || !rt || !hypo_out || !out) return MVSTER_ERR_NULL;
+    if (mode == 1 ? (!inv_min || !inv_max) : (mode == 2 ? !depth_values : true)) return mode == 1 || mode == 2 ? MVSTER_ERR_NULL : MVSTER_ERR_SHAPE;
+    if (B <= 0 || NV <= 0 || h <= 0 || w <= 0 || Hs <= 0 || Ws <= 0 || (mode == 1 && ((h | w) & 1)) || (mode == 2 && ndv < 2))
+        return MVSTER_ERR_SHAPE;
+    if (D != 4 && D != 8) return MVSTER_ERR_UNSUPPORTED;
+    WarpAggArgs a;
+    a.ref = ref_feat; a.src = src_feat; a.rt = rt; a.hypo = nullptr; a.out = out; a.wsum_out = wsum_out;
+    a.ref_bs = ref_batch_stride; a.src_vs = src_view_stride; a.src_bs = src_batch_stride;
+    a.B = B; a.NV = NV; a.D = D; a.h = h; a.w = w; a.Hs = Hs; a.Ws = Ws;
+    a.attn_temp = attn_temp; a.sqrt_c = sqrtf((float)C); a.fuse_d = attn_fuse_d;
+    a.inv_min = inv_min; a.inv_max = inv_max; a.dvals = depth_values; a.hypo_out = hypo_out; a.ndv = ndv;
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 8 && G == 4) return dispatch_fwd_wave<8, 4>(a, s, mode);
+    if (C == 16 && G == 4) return dispatch_fwd_wave<16, 4>(a, s, mode);
+    if (C == 32 && G == 8) return dispatch_fwd_wave<32, 8>(a, s, mode);
+    if (C == 64 && G == 8) return dispatch_fwd_wave<64, 8>(a, s, mode);
+    return MVSTER_ERR_UNSUPPORTED;
+}
+
 extern "C" int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat, const float* rt, const float* hypo,
                                    float* out, float* wsum_out, int B, int NV, int C, int G, int D, int h, int w,
                                    int Hs, int Ws, long ref_batch_stride, long src_view_stride, long src_batch_stride,
@@ -1781,6 +1842,7 @@ extern "C" int mvster_warp_agg_fwd(const float* ref_feat, const float* src_feat,
     a.ref_bs = ref_batch_stride; a.src_vs = src_view_stride; a.src_bs = src_batch_stride;
     a.B = B; a.NV = NV; a.D = D; a.h = h; a.w = w; a.Hs = Hs; a.Ws = Ws;
     a.attn_temp = attn_temp; a.sqrt_c = sqrtf((float)C); a.fuse_d = attn_fuse_d;
+    a.inv_min = a.inv_max = a.dvals = nullptr; a.hypo_out = nullptr; a.ndv = 0;
     hipStream_t s = (hipStream_t)stream;
     // variant: 0 = choose; 1 = one thread per (pixel, d); 2 = workgroup-level lane split (C >= 16);
     // 3 = wave-local kernel (what 0 picks whenever it applies); 4 = pixel-major kernel (faster on cache-resident inputs,

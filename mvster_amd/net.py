@@ -154,6 +154,11 @@ class MVS4net(nn.Module):
         self.overlap_streams = True
         self._side_streams = {}
         self.warp_variant = 0          # mvster_warp_agg_fwd variant (0 = per-shape default)
+        # hypothesis scheduling inside the warp launch (mvster_warp_agg_fwd_sched: bit-identical, one launch less per stage).
+        # Off: measured 1 091 against 1 109 depth-maps/s and 1.131 against 1.123 ms for one forward alone (same box, alternating
+        # runs, profiles/r05_fused_hypotheses_ab.txt) -- the warp kernels are VALU-bound and the ~35 instructions per lane cost
+        # more than the 5 us scheduler launches, which co-run with the other depth map's kernels anyway
+        self.fuse_hypotheses = False
         # eval calls replay a captured hipGraph from the second call of a shape on (graph.ForwardCache); False = every
         # call issues its ~76 launches eagerly, as before round 5.  Shared by nn.DataParallel's single-device pass-through.
         self.graph_cache = True
@@ -307,12 +312,22 @@ class MVS4net(nn.Module):
             ref_cl, src_cl = f[0], f[1:]
             G = self.group_cor_dim[s] if self.group_cor else C
             rt = rts[s]
+            cor = hypo = None
             if teacher is not None and name in teacher:
                 hypo = teacher[name].contiguous()
-            else:
+            elif self.inverse_depth and self.group_cor and self.warp_variant == 0 and self.fuse_hypotheses:
+                # the stage's hypotheses are computed inside the warp launch (one kernel and one dependency edge less per stage)
+                fused = ops.warp_agg_fwd_sched_cl(
+                    ref_cl.contiguous(), src_cl.contiguous(), rt, G, self.stage_splits[s], self.attn_fuse_d, float(self.attn_temp),
+                    inv_min=None if s == 0 else prev["inverse_min_depth"], inv_max=None if s == 0 else prev["inverse_max_depth"],
+                    depth_values=depth_values.contiguous() if s == 0 else None)
+                if fused is not None:
+                    cor, hypo = fused
+            if hypo is None:
                 hypo = self._hypotheses(s, depth_values, depth_interval, prev, h, w)
-            cor = ops.warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, self.group_cor, self.attn_fuse_d,
-                                      float(self.attn_temp), variant=self.warp_variant)
+            if cor is None:
+                cor = ops.warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, self.group_cor, self.attn_fuse_d,
+                                          float(self.attn_temp), variant=self.warp_variant)
             plan = regs[s]
             want_logits = capture is not None
             if isinstance(plan, Reg2dPlan):

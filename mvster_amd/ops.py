@@ -99,6 +99,40 @@ def warp_agg_fwd_cl(ref_cl, src_cl, rt, hypo, G, group_cor=True, attn_fuse_d=Tru
     return (out, wsum) if want_wsum else out
 
 
+def warp_agg_fwd_sched_cl(ref_cl, src_cl, rt, G, D, attn_fuse_d=True, attn_temp=2.0, inv_min=None, inv_max=None,
+                          depth_values=None):
+    """``warp_agg_fwd_cl`` with the stage's hypothesis scheduling in the same launch: the hypotheses are
+    ``schedule_inverse_range(inv_min, inv_max)`` of the previous stage's bounds [B,h/2,w/2] (mvs4net_utils.py:79-86) or, with
+    ``depth_values`` [B,ndv], ``init_inverse_range`` (:71-77).  -> (cor_feats [B,D,h,w,G], hypo [B,D,h,w]), or None where
+    the fused kernel does not apply (the caller runs the two launches; same bits either way)."""
+    for t, n in ((ref_cl, "ref"), (src_cl, "src"), (rt, "rt"), (inv_min, "inv_min"), (inv_max, "inv_max"), (depth_values, "depth_values")):
+        _chk(t, "warp_agg_fwd_sched:" + n)
+    B, h, w, C = ref_cl.shape
+    NV, B2, Hs, Ws, C2 = src_cl.shape
+    if B2 != B or C2 != C or tuple(rt.shape) != (B, NV, 12):
+        raise RuntimeError("warp_agg_fwd_sched: inconsistent shapes")
+    lib = _lib.load()
+    if not hasattr(lib, "mvster_warp_agg_fwd_sched"):
+        return None
+    if depth_values is None:
+        if inv_min is None or inv_max is None or tuple(inv_min.shape) != (B, h // 2, w // 2) or inv_max.shape != inv_min.shape or (h | w) & 1:
+            raise RuntimeError("warp_agg_fwd_sched: the previous stage's bounds must be [B, h/2, w/2]")
+        mode, ndv = 1, 0
+    else:
+        if depth_values.dim() != 2 or depth_values.shape[0] != B or depth_values.shape[1] < 2:
+            raise RuntimeError("warp_agg_fwd_sched: depth_values must be [B, >= 2]")
+        mode, ndv = 2, depth_values.shape[1]
+    out = torch.empty(B, D, h, w, G, device=ref_cl.device, dtype=torch.float32)
+    hypo = torch.empty(B, D, h, w, device=ref_cl.device, dtype=torch.float32)
+    rc = lib.mvster_warp_agg_fwd_sched(_ptr(ref_cl), _ptr(src_cl), _ptr(rt), _ptr(inv_min), _ptr(inv_max), _ptr(depth_values),
+                                       ndv, _ptr(hypo), _ptr(out), None, B, NV, C, G, D, h, w, Hs, Ws, h * w * C,
+                                       B * Hs * Ws * C, Hs * Ws * C, int(attn_fuse_d), float(attn_temp), mode, _stream())
+    if rc == -3:
+        return None
+    _lib.check(rc, "warp_agg_fwd_sched")
+    return out, hypo
+
+
 def warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad_out, G, group_cor=True, attn_fuse_d=True, attn_temp=2.0,
                     deterministic=None, into=None):
     """Gradients of warp_agg_fwd_cl w.r.t. ref_cl and src_cl.  Inside a workgroup the gradients accumulate in 64-bit

@@ -505,6 +505,35 @@ def test_bf16_split_conv_probe(cin, cout, kd, shape):
     note("conv_b3_probe_%d_%d_k%d_%s" % (cin, cout, kd, "x".join(map(str, shape))), err_over_direct_fp32=worst)
 
 
+@pytest.mark.parametrize("C,G,D,h,w,B", [(64, 8, 8, 16, 24, 1), (32, 8, 8, 32, 48, 2), (16, 4, 4, 64, 96, 1), (8, 4, 4, 128, 192, 1),
+                                         (8, 4, 4, 66, 50, 2)])
+def test_warp_with_fused_hypothesis_scheduling_is_bit_identical(C, G, D, h, w, B):
+    """mvster_warp_agg_fwd_sched: the stage's hypotheses computed inside the warp launch (schedule_inverse_range of the
+    previous stage's inverse bounds, or init_inverse_range of depth_values at stage 1) against the two launches
+    (models/mvs4net_utils.py:71-86 + :1025-1060): same hypotheses and same aggregated correlation, bit for bit."""
+    g = torch.Generator().manual_seed(C + h)
+    NV = 3
+    ref = torch.randn(B, h, w, C, generator=g).to(DEV)
+    src = torch.randn(NV, B, h, w, C, generator=g).to(DEV)
+    _, proj, dv = make_inputs(nviews=NV + 1, H=8 * h, W=8 * w, seed=3, batch=B)
+    rt = ops.relative_projection(proj["stage1"].to(DEV))
+    dv = dv.to(DEV)
+    # stage-1 form: init_inverse_range
+    hypo = ops.init_range(dv, D, h, w, inverse=True)
+    want = ops.warp_agg_fwd_cl(ref, src, rt, hypo, G, True, True, 2.0)
+    got = ops.warp_agg_fwd_sched_cl(ref, src, rt, G, D, True, 2.0, depth_values=dv)
+    assert got is not None and torch.equal(got[1], hypo) and torch.equal(got[0], want)
+    # later stages: schedule_inverse_range of half-resolution bounds
+    inv_max = (1.0 / (500 + 300 * torch.rand(B, h // 2, w // 2, generator=g))).to(DEV)
+    inv_min = inv_max + (2e-4 * torch.rand(B, h // 2, w // 2, generator=g)).to(DEV)
+    hypo = ops.schedule_inverse_range(inv_min, inv_max, D, h, w)
+    want = ops.warp_agg_fwd_cl(ref, src, rt, hypo, G, True, True, 2.0)
+    got = ops.warp_agg_fwd_sched_cl(ref, src, rt, G, D, True, 2.0, inv_min=inv_min, inv_max=inv_max)
+    assert got is not None and torch.equal(got[1], hypo) and torch.equal(got[0], want)
+    # a shape the wave-local kernel does not cover: the caller is told to run the two launches
+    assert ops.warp_agg_fwd_sched_cl(ref[..., :8].contiguous(), src[..., :8].contiguous(), rt, 8, D, True, 2.0, depth_values=dv) is None
+
+
 @pytest.mark.parametrize("name,cfg,shape", CONV_CASES)
 def test_conv_bn_relu(name, cfg, shape):
     torch.manual_seed(hash(name) % 1000)
