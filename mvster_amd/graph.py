@@ -275,11 +275,15 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, optimizer, loss_fn, imgs, proj_matrices, depth_values, depth_gt_ms, mask_ms, warmup=3,
-                 grad_sync=None):
+                 grad_sync=None, capture=True):
+        """``capture=False``: the same object without the hipGraph -- every call runs the identical sequence (static input
+        buffers, zero_grad, forward, loss, backward, ``grad_sync.sync()``, optimizer step) eagerly.  That is what the
+        multi-process CPU test drives over gloo (tests/test_shard_cpu.py: two ranks end to end against DistributedDataParallel);
+        it is also the fallback when a step cannot be captured."""
         if not model.training:
             raise RuntimeError("GraphedTrainStep captures a training step: call model.train() first")
         for group in optimizer.param_groups:
-            if not group.get("capturable", False):
+            if capture and not group.get("capturable", False):
                 raise RuntimeError("GraphedTrainStep: build the optimizer with capturable=True")
         if isinstance(model, torch.nn.parallel.DistributedDataParallel):
             raise RuntimeError("GraphedTrainStep: pass the bare model and grad_sync=shard.GradBucket(model.parameters()) "
@@ -290,6 +294,13 @@ class GraphedTrainStep:
         self.depth_values = depth_values.clone()
         self.gt = {k: v.clone() for k, v in depth_gt_ms.items()}
         self.mask = {k: v.clone() for k, v in mask_ms.items()}
+        self.graph = None
+        from . import train_ops
+        self._cache = train_ops.CACHE
+        self._cell = [0]
+        if not capture:
+            self.loss = None
+            return
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -298,11 +309,8 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         # the ~130 per-layer weight refreshes a captured step would record become one launch (train_ops._LayerCache)
-        from . import train_ops
-        self._cache = train_ops.CACHE
         # the captured optimizer update moves the parameters (and BatchNorm's running statistics) without touching their
         # version counters: one epoch cell for everything this step owns, bumped after every replay
-        self._cell = [0]
         bare = model.module if hasattr(model, "module") and isinstance(model.module, torch.nn.Module) else model
         owned = {id(p): p for g in optimizer.param_groups for p in g["params"]}
         for t in list(bare.parameters()) + list(bare.buffers()):
@@ -349,6 +357,9 @@ class GraphedTrainStep:
                     static[k].copy_(new[k], non_blocking=True)
         if depth_values is not None:
             self.depth_values.copy_(depth_values, non_blocking=True)
+        if self.graph is None:
+            self.loss = self._step()                   # (capture=False: the same sequence, eagerly)
+            return self.loss
         self.graph.replay()
         # the replayed optimizer update moved the parameters without touching their version counters: everything folded or
         # packed from them outside this graph (the eval plans, the cached training layers of an eager step) is stale now

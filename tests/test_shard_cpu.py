@@ -183,3 +183,87 @@ def test_grad_bucket_mixed_and_aliased_gradients():
     flat = bucket.sync()
     assert torch.equal(flat, torch.tensor([2., 2, 2, 5, 5, 5, 5, 0, 0]))
     assert torch.equal(a.grad, 2 * torch.ones(3)) and torch.equal(c.grad, torch.zeros(2))
+
+
+class _ToyNet(torch.nn.Module):
+    """A module with MVS4net's call signature (imgs list, proj dict, depth_values) -> dict, small enough for the CPU."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(6, 4, 3, padding=1)
+        self.bn = torch.nn.BatchNorm2d(4)
+        self.head = torch.nn.Conv2d(4, 1, 1)
+
+    def forward(self, imgs, proj_matrices, depth_values):
+        x = torch.cat(imgs, 1) * proj_matrices["stage1"].mean() + depth_values.mean()
+        return {"depth": self.head(torch.relu(self.bn(self.conv(x)))).squeeze(1)}
+
+
+def _graphed_step_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    shard.init_distributed(backend="gloo")
+    from mvster_amd.graph import GraphedTrainStep
+
+    def sample(seed):
+        g = torch.Generator().manual_seed(seed)
+        imgs = [torch.rand(2, 3, 8, 12, generator=g) for _ in range(2)]
+        proj = {"stage1": torch.rand(2, 2, 2, 4, 4, generator=g)}
+        dv = torch.rand(2, 2, generator=g)
+        gt = {"stage1": torch.rand(2, 8, 12, generator=g)}
+        mask = {"stage1": (torch.rand(2, 8, 12, generator=g) > 0.3).float()}
+        return imgs, proj, dv, gt, mask
+
+    def loss_fn(out, gt, mask):
+        return (((out["depth"] - gt["stage1"]) ** 2) * mask["stage1"]).mean(), None
+
+    torch.manual_seed(0)
+    bare = _ToyNet().train()
+    torch.manual_seed(0)
+    ref = _ToyNet().train()
+    ddp = shard.wrap_ddp(ref)
+    opt_a = torch.optim.Adam(bare.parameters(), lr=1e-2)
+    opt_b = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    # the captured step's object and call sequence, without the capture (no GPU here): static buffers, zero_grad, forward,
+    # loss, backward, ONE bucketed all-reduce, optimizer step
+    step = GraphedTrainStep(bare, opt_a, loss_fn, *sample(1000 + rank), grad_sync=shard.GradBucket(bare.parameters()), capture=False)
+    losses = []
+    for it in range(4):
+        imgs, proj, dv, gt, mask = sample(10 * it + rank)              # every rank its own samples, new ones every step
+        la = step(imgs, proj, dv, gt, mask)
+        opt_b.zero_grad(set_to_none=True)
+        lb = loss_fn(ddp(imgs, proj, dv), gt, mask)[0]
+        lb.backward()
+        opt_b.step()
+        losses.append((float(la), float(lb)))
+    worst = max((pa.detach() - pb.detach()).abs().max().item() for pa, pb in zip(bare.parameters(), ref.parameters()))
+    flat = torch.cat([p.detach().reshape(-1) for p in bare.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    bn_same = [torch.zeros_like(bare.bn.running_mean) for _ in range(world)]
+    dist.all_gather(bn_same, bare.bn.running_mean)
+    q.put((rank, losses, worst, all(torch.equal(gathered[0], t) for t in gathered), bool(torch.equal(bn_same[0], bn_same[1]))))
+    dist.destroy_process_group()
+
+
+def test_graphed_train_step_call_sequence_two_ranks_equals_ddp():
+    """``GraphedTrainStep(..., grad_sync=GradBucket, capture=False)`` on two gloo ranks, end to end: the step object the GPU
+    captures (static input buffers fed per call, one bucketed all-reduce between backward and the optimizer step) trains
+    exactly like the reference's DistributedDataParallel loop (train_mvs4.py:389-392, :207-218) -- same losses, same
+    parameters after four steps on per-rank data, identical parameters on both ranks, BatchNorm statistics per rank.
+    (The capture itself and the RCCL collective inside it: tests/test_gpu_train.py on one rank; > 1 rank needs the driver's node.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graphed_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, losses, worst, same_params, same_bn in res:
+        for la, lb in losses:
+            assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb)), (rank, losses)
+        assert worst <= 1e-6, (rank, worst)
+        assert same_params and not same_bn
