@@ -1015,8 +1015,11 @@ def main():
                                     "shared operand for the matrix cores; PMC: ~1 100 VALU instructions per wave (DESIGN.md section 4.3)")
                 if streaming and a["flops"] > 0:
                     e["frac_of_fp32_mfma_peak_algorithmic_flops"] = round(a["flops"] / (a["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
-            if name in pmc.get("kernels", {}):
-                e["traffic"] = int(pmc["kernels"][name])
+            # (the profiler spells the wave-local warp kernel with its fourth template argument, the library's
+            #  mvster_last_kernel() without it when it is 0: same kernel)
+            pname = name if name in pmc.get("kernels", {}) else name[:-1] + ", 0>"
+            if pname in pmc.get("kernels", {}):
+                e["traffic"] = int(pmc["kernels"][pname])
                 e["traffic_unit"] = "bytes/launch"
                 e["traffic_source"] = pmc.get("source", "profiles/pmc_traffic.json")
             elif pmc_note:

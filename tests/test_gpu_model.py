@@ -535,6 +535,25 @@ def test_forward_graph_cache_follows_weight_updates_shapes_and_mode_changes(ship
     assert torch.equal(m(*a)["stage4"]["attn_weight"], before)
 
 
+def test_fused_hypothesis_scheduling_gives_the_same_forward(shipped_cfg, checkpoint):
+    """``MVS4net.fuse_hypotheses`` (off by default: measured slower): every stage's hypotheses computed inside the warp launch
+    (mvster_warp_agg_fwd_sched) -- the same forward, bit for bit, eager and through the graph cache (the switch is part of
+    the cache key)."""
+    m = MVS4net(**shipped_cfg)
+    m.load_state_dict(checkpoint, strict=True)
+    m.to(DEV).eval()
+    a = to_dev(*make_inputs(nviews=4, H=128, W=192, seed=31, batch=2))
+    want = _clone_out(m.forward_eager(*a))
+    m.fuse_hypotheses = True
+    for got in (m(*a), m(*a), m(*a)):                     # eager, captured, replayed
+        for path, t in _all_leaves(got):
+            w_ = want[path[0]] if len(path) == 1 else want[path[0]][path[1]]
+            assert torch.equal(t, w_), path
+    assert m._fwd_cache.stats["captured"] == 1
+    m.fuse_hypotheses = False
+    assert torch.equal(m(*a)["depth"], want["depth"]) and m._fwd_cache.stats["eager"] == 2      # another key: eager first
+
+
 def test_graphed_forward_refuses_stale_weights(shipped_cfg, checkpoint):
     """``GraphedForward`` records the model's state stamp at capture: after an in-place parameter update its ``__call__``
     raises instead of replaying the weights folded at capture time."""
