@@ -93,6 +93,11 @@ class _SelectDepthCL(torch.autograd.Function):
         return dfeat, dw.reshape(ctx.shapes[0]), db.reshape(ctx.shapes[1]), None, None, None
 
 
+def _invalidate_after_load(module, incompatible):
+    """load_state_dict() post hook (a module-level function: a lambda would make the module unpicklable)."""
+    module.invalidate_plans()
+
+
 class MVS4net(nn.Module):
     # hypotheses per stage: the fused forward kernels of the shipped cascade hold up to 16 per pixel in registers; beyond
     # that the forward runs on the general warp kernel (32 / 16 pixels per workgroup) and the memory-walking selection
@@ -164,7 +169,15 @@ class MVS4net(nn.Module):
         self.graph_cache = True
         from .graph import ForwardCache
         self._fwd_cache = ForwardCache()
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_plans())
+        self.register_load_state_dict_post_hook(_invalidate_after_load)
+
+    def __getstate__(self):
+        # copy.deepcopy(model) (EMA helpers) and torch.save(model): the caches hold device-side plans, HIP streams and
+        # captured graphs -- none of it state; the copy rebuilds its own on first use
+        from .graph import ForwardCache
+        state = dict(self.__dict__)
+        state["_plans"], state["_side_streams"], state["_fwd_cache"] = {}, {}, ForwardCache()
+        return state
 
     # ------------------------------------------------------------------ plan cache
     def invalidate_plans(self):

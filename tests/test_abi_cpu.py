@@ -130,3 +130,28 @@ def test_boundary_rejects_malformed_inputs(shipped_cfg):
         m([imgs[0], imgs[1][:, :, :32], imgs[2]], proj, dv)
     with pytest.raises(RuntimeError, match="multiples of 64"):
         m([i[:, :, :48] for i in imgs], proj, dv)
+
+
+def test_model_copies_and_pickles_without_its_caches(shipped_cfg):
+    """``copy.deepcopy(model)`` (EMA helpers) and whole-module pickling leave the per-process caches behind (packed-weight plans,
+    side streams, captured hipGraphs of the forward cache): the copy has the same parameters and empty caches of its own."""
+    import copy
+    import io
+
+    import torch
+    from mvster_amd import MVS4net
+    m = MVS4net(**shipped_cfg).eval()
+    m._fwd_cache.entries["some key"] = [1, object()]          # (stands for a captured graph: must not travel)
+    m._plans["cuda:0"] = ("plans",)
+    c = copy.deepcopy(m)
+    assert len(c._fwd_cache.entries) == 0 and c._plans == {} and c._fwd_cache is not m._fwd_cache
+    assert len(m._fwd_cache.entries) == 1                       # the original keeps its own
+    for (ka, va), (kb, vb) in zip(m.state_dict().items(), c.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    m._fwd_cache.entries.clear()
+    m._plans.clear()
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    r = torch.load(buf, weights_only=False)
+    assert isinstance(r, MVS4net) and len(r._fwd_cache.entries) == 0 and r.graph_cache is True
