@@ -871,7 +871,7 @@ def main():
     #  runtime's copy path in a state that slows a later pinned pipeline by 20 % -- 758 against 948 depth-maps/s, same box,
     #  alternating runs, gpurun_out/r5q -- while this leg measures the same after it as before it)
     api_call = None
-    if rank == 0 and not args.no_graph and not args.no_api_call:
+    if rank == 0 and world == 1 and not args.no_graph and not args.no_api_call:      # (N = 1 only: its windows use the barrier / MAX protocol)
         api_call = api_call_measure(args, model, dev, units[0], shard)
 
     # ---- the same workload with several depth maps per forward call (the B of MVS4net.forward; the reference's eval driver
