@@ -799,15 +799,22 @@ class FpnPlan:
     def tail(self, c0, c1, f1):
         """The two fine levels (needed from stage 3 on); independent of the coarse outputs and of cascade
         stages 1-2, so the model runs it on a second HIP stream underneath them."""
+        return self.tail_mid(c0, c1, f1), self.tail_fine(c0, c1, f1)
+
+    def tail_mid(self, c0, c1, f1):
+        """Level 3 (half resolution): what cascade stage 3 reads."""
         H, W = c0.shape[2], c0.shape[3]
         p3 = ops.fpn_tail_gather(self.mid_g(f1), self.mid_vb, H // 2, W // 2)
-        o3 = self.mid_c(c1, skip=p3, skip_mode=SKIP_ADD)
+        return self.mid_c(c1, skip=p3, skip_mode=SKIP_ADD)
+
+    def tail_fine(self, c0, c1, f1):
+        """Level 4 (full resolution): what cascade stage 4 reads."""
+        H, W = c0.shape[2], c0.shape[3]
         q4 = self.tail_g(f1)
         p4 = ops.fpn_tail_fused(c1, self.tail_a, self.tail_ab, q4, self.tail_vb, H, W) if FUSE_TAIL else None
         if p4 is None:                                                       # (small / odd maps: two launches)
             p4 = ops.fpn_tail_gather(ops.fpn_lateral_up(c1, self.tail_a, self.tail_ab, q4), self.tail_vb, H, W)
-        o4 = self.tail_c(c0, skip=p4, skip_mode=SKIP_ADD)
-        return o3, o4
+        return self.tail_c(c0, skip=p4, skip_mode=SKIP_ADD)
 
     def __call__(self, x):
         c0, c1, f1, o1, o2 = self.head(x)
