@@ -682,6 +682,8 @@ def main():
                     help="profiling passes: the fine FPN levels on the main stream too (no co-running kernels)")
     ap.add_argument("--no-fuse-hypotheses", action="store_true",
                     help="A/B switch: hypothesis scheduling as its own launch per stage (as before round 5)")
+    ap.add_argument("--no-merge-launches", action="store_true",
+                    help="A/B switch: the forward's first three launches and the three confidence up-samplings separately")
     ap.add_argument("--no-api-call", action="store_true",
                     help="skip the plain model(imgs, proj, depth_values) loops (value_api_call: what the unchanged reference "
                          "driver gets)")
@@ -723,6 +725,8 @@ def main():
         model.overlap_streams = False      # profiling passes: one stream, no co-running kernels
     if args.no_fuse_hypotheses:
         model.fuse_hypotheses = False
+    if args.no_merge_launches:
+        model.merge_launches = False
     # every rank works on its own depth maps: disjoint seeds = disjoint units of the shard
     units = shard.shard_units(world * (args.steps + args.warmup), rank, world)
     imgs, proj, dv = make_inputs(nviews=args.views, H=args.height, W=args.width, seed=units[0], device=dev, batch=args.batch)

@@ -38,6 +38,13 @@ int mvster_relative_projection_multi(const float* const* proj_matrices, int nsta
  * out [N*B,H,W,4] channels-last RGB0, view-major: the batch FPN4 runs on. */
 int mvster_pack_images(const float* const* imgs, int N, float* out, int B, int H, int W, void* stream);
 
+/* The three launches a forward starts with in one (MVS4Net.py:60-76): mvster_pack_images (imgs -> packed),
+ * mvster_relative_projection_multi (proj_matrices -> rt) and mvster_init_range (depth_values [B,ndv] -> hypo [B,D,h,w], the
+ * first stage's hypotheses; h*w <= H*W).  Same arithmetic as the three, bit for bit. */
+int mvster_forward_prologue(const float* const* imgs, int N, float* packed, int B, int H, int W,
+                            const float* const* proj_matrices, int nstage, float* rt, const float* depth_values, int ndv,
+                            float* hypo, int D, int h, int w, int inverse, void* stream);
+
 /* Fused homography warp + group-wise (or squared-difference) correlation + epipolar attention
  * aggregation over all NV source views.  Channels-last features:
  *   ref_feat [B,h,w,C] (batch stride given), src_feat view v / batch b at
@@ -114,6 +121,11 @@ int mvster_select_depth_bwd(const float* attn, const float* gattn, const float* 
 
 /* in [B,hi,wi] -> out [B,ho,wo], bilinear, align_corners=True.  models/mvs4net_utils.py:1077. */
 int mvster_upsample_bilinear(const float* in, float* out, int B, int hi, int wi, int ho, int wo, void* stream);
+
+/* n <= 8 maps of one batch to one output size in one launch: ins / outs / his / wis = HOST arrays (device pointers,
+ * input sizes); ins[k] [B,his[k],wis[k]] -> outs[k] [B,ho,wo].  The coarse stages' confidence maps (MVS4Net.py:1077 per stage). */
+int mvster_upsample_bilinear_multi(const float* const* ins, float* const* outs, const int* his, const int* wis, int n, int B,
+                                   int ho, int wo, void* stream);
 
 /* Channels-last implicit-GEMM convolution on the fp32 matrix cores with a fused
  * scale/shift (+ReLU, +skip) epilogue.  in [B,Di,Hi,Wi,cin]; wpk = weights packed by

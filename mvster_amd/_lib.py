@@ -20,6 +20,7 @@ SIGNATURES = {
     "mvster_relative_projection": [_f, _f, _i, _i, _f],
     "mvster_relative_projection_multi": [_f, _i, _f, _i, _i, _f],
     "mvster_pack_images": [_f, _i, _f, _i, _i, _i, _f],
+    "mvster_forward_prologue": [_f, _i, _f, _i, _i, _i, _f, _i, _f, _f, _i, _f, _i, _i, _i, _i, _f],
     "mvster_warp_agg_fwd": [_f, _f, _f, _f, _f, _f] + [_i] * 9 + [_l] * 3 + [_i, _i, _fl, _i, _f],
     "mvster_warp_agg_fwd_sched": [_f] * 6 + [_i, _f, _f, _f] + [_i] * 9 + [_l] * 3 + [_i, _fl, _i, _f],
     "mvster_warp_agg_bwd": [_f] * 11 + [_i] * 9 + [_l] * 3 + [_i, _i, _fl, _f],
@@ -30,6 +31,7 @@ SIGNATURES = {
     "mvster_select_depth": [_f, _f, _f, _f, _i, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _f],
     "mvster_select_depth_bwd": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f],
     "mvster_upsample_bilinear": [_f, _f, _i, _i, _i, _i, _i, _f],
+    "mvster_upsample_bilinear_multi": [_f, _f, _f, _f, _i, _i, _i, _i, _f],
     "mvster_conv_mfma": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f, _i, _i, _i, _i, _f],
     "mvster_conv_small": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f],
     "mvster_conv_narrow": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f],

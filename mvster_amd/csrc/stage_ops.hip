@@ -724,6 +724,61 @@ __global__ void relative_projection_multi_kernel(MultiProjArgs a) {
     for (int k = 0; k < 3; ++k) o[9 + k] = m.t[k];
 }
 
+// The three launches every forward starts with, in one: pack the views (blockIdx.y < N*B), the first stage's hypotheses
+// (blockIdx.y == N*B: mvs4net_utils.py:61-86 on the [first, last] depth of depth_values) and every stage's relative
+// projections (blockIdx.y == N*B + 1, first workgroups).  Same device functions as the separate kernels: the same bits.
+struct PrologueArgs {
+    PackArgs pack;
+    MultiProjArgs proj;
+    const float* dv;        // [B, ndv]
+    float* hypo;            // [B, D, h, w]
+    int ndv, D, hw, inverse;
+};
+
+__global__ void __launch_bounds__(256) forward_prologue_kernel(PrologueArgs a) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int vb = blockIdx.y;
+    const int NB = a.pack.N * a.pack.B;
+    if (vb < NB) {
+        if (p >= a.pack.HW) return;
+        const int v = vb / a.pack.B, b = vb - v * a.pack.B;
+        const float* src = a.pack.img[v] + (long)b * 3 * a.pack.HW + p;
+        const f32x4 px = {src[0], src[a.pack.HW], src[2 * (long)a.pack.HW], 0.0f};
+        st4(a.pack.out + ((long)vb * a.pack.HW + p) * 4, px);
+    } else if (vb == NB) {
+        if (p >= a.hw) return;
+        for (int b = 0; b < a.pack.B; ++b)
+            mv::init_range_pixel(a.dv[b * a.ndv], a.dv[b * a.ndv + a.ndv - 1], a.hypo + (long)b * a.D * a.hw, a.D, a.hw, p,
+                                 a.inverse);
+    } else {
+        const int NV = a.proj.N - 1;
+        const int per = a.proj.B * NV;
+        if (p >= a.proj.nstage * per) return;
+        const int s = p / per, r = p - s * per;
+        const int b = r / NV, v = r - b * NV;
+        mv::RT m;
+        mv::relative_projection(a.proj.pm[s] + ((long)b * a.proj.N) * 32, a.proj.pm[s] + ((long)b * a.proj.N + v + 1) * 32, m);
+        float* o = a.proj.rt + (long)p * 12;
+        for (int k = 0; k < 9; ++k) o[k] = m.r[k];
+        for (int k = 0; k < 3; ++k) o[9 + k] = m.t[k];
+    }
+}
+
+struct MultiUpArgs {
+    const float* in[8];     // [B, hi[k], wi[k]]
+    float* out[8];          // [B, ho, wo]
+    int hi[8], wi[8];
+    int ho, wo;
+};
+
+// several maps of one batch to one output size in one launch (the coarse stages' confidence maps, MVS4Net.py:1077 per stage)
+__global__ void __launch_bounds__(256) upsample_bilinear_multi_kernel(MultiUpArgs a) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y, k = blockIdx.z;
+    if (p >= a.ho * a.wo) return;
+    a.out[k][(long)b * a.ho * a.wo + p] = mv::upsample_pixel(a.in[k] + (long)b * a.hi[k] * a.wi[k], a.hi[k], a.wi[k], a.ho, a.wo, p);
+}
+
 }  // namespace
 
 extern "C" int mvster_relative_projection(const float* proj_matrices, float* rt, int B, int N, void* stream) {
@@ -895,6 +950,45 @@ extern "C" int mvster_relative_projection_multi(const float* const* proj_matrice
     a.rt = rt; a.nstage = nstage; a.B = B; a.N = N;
     const int n = nstage * B * (N - 1);
     hipLaunchKernelGGL(relative_projection_multi_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
+    return mv_check_launch();
+}
+
+extern "C" int mvster_forward_prologue(const float* const* imgs, int N, float* packed, int B, int H, int W,
+                                       const float* const* proj_matrices, int nstage, float* rt, const float* depth_values,
+                                       int ndv, float* hypo, int D, int h, int w, int inverse, void* stream) {
+    if (!imgs || !packed || !proj_matrices || !rt || !depth_values || !hypo) return MVSTER_ERR_NULL;
+    if (N < 2 || N > 16 || B <= 0 || H <= 0 || W <= 0 || nstage < 1 || nstage > 8 || D < 2 || h <= 0 || w <= 0 || ndv < 1)
+        return MVSTER_ERR_SHAPE;
+    // (the side jobs ride on the pack grid's x extent: one row of workgroups each)
+    if ((long)h * w > (long)H * W || (long)nstage * B * (N - 1) > (long)H * W) return MVSTER_ERR_SHAPE;
+    PrologueArgs a;
+    for (int v = 0; v < N; ++v) {
+        if (!imgs[v]) return MVSTER_ERR_NULL;
+        a.pack.img[v] = imgs[v];
+    }
+    for (int s = 0; s < nstage; ++s) {
+        if (!proj_matrices[s]) return MVSTER_ERR_NULL;
+        a.proj.pm[s] = proj_matrices[s];
+    }
+    a.pack.out = packed; a.pack.N = N; a.pack.B = B; a.pack.HW = H * W;
+    a.proj.rt = rt; a.proj.nstage = nstage; a.proj.B = B; a.proj.N = N;
+    a.dv = depth_values; a.hypo = hypo; a.ndv = ndv; a.D = D; a.hw = h * w; a.inverse = inverse;
+    hipLaunchKernelGGL(forward_prologue_kernel, dim3((H * W + 255) / 256, N * B + 2), dim3(256), 0, (hipStream_t)stream, a);
+    return mv_check_launch();
+}
+
+extern "C" int mvster_upsample_bilinear_multi(const float* const* ins, float* const* outs, const int* his, const int* wis,
+                                              int n, int B, int ho, int wo, void* stream) {
+    if (!ins || !outs || !his || !wis) return MVSTER_ERR_NULL;
+    if (n < 1 || n > 8 || B <= 0 || ho <= 0 || wo <= 0) return MVSTER_ERR_SHAPE;
+    MultiUpArgs a;
+    for (int k = 0; k < n; ++k) {
+        if (!ins[k] || !outs[k]) return MVSTER_ERR_NULL;
+        if (his[k] <= 0 || wis[k] <= 0) return MVSTER_ERR_SHAPE;
+        a.in[k] = ins[k]; a.out[k] = outs[k]; a.hi[k] = his[k]; a.wi[k] = wis[k];
+    }
+    a.ho = ho; a.wo = wo;
+    hipLaunchKernelGGL(upsample_bilinear_multi_kernel, dim3((ho * wo + 255) / 256, B, n), dim3(256), 0, (hipStream_t)stream, a);
     return mv_check_launch();
 }
 

@@ -147,7 +147,7 @@ class ForwardCache:
     def key(model, imgs, proj_matrices, depth_values):
         im = imgs[0]
         # (the attributes of the model that pick kernels or streams: flipping one between two calls is a different graph)
-        cfg = (model.warp_variant, getattr(model, "fuse_hypotheses", None), model.overlap_streams, float(model.attn_temp), model.attn_fuse_d, model.num_stage,
+        cfg = (model.warp_variant, getattr(model, "fuse_hypotheses", None), getattr(model, "merge_launches", None), model.overlap_streams, float(model.attn_temp), model.attn_fuse_d, model.num_stage,
                tuple(model.stage_splits), tuple(model.depth_interals_ratio), tuple(model.group_cor_dim))
         return (im.device.index, len(imgs), tuple(im.shape), int(depth_values.shape[1]), tuple(sorted(proj_matrices.keys())), cfg)
 

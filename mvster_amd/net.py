@@ -164,6 +164,8 @@ class MVS4net(nn.Module):
         # runs, profiles/r05_fused_hypotheses_ab.txt) -- the warp kernels are VALU-bound and the ~35 instructions per lane cost
         # more than the 5 us scheduler launches, which co-run with the other depth map's kernels anyway
         self.fuse_hypotheses = False
+        # pack + projections + first hypotheses in one launch, the three coarse confidence up-samplings in one (same bits)
+        self.merge_launches = True
         # eval calls replay a captured hipGraph from the second call of a shape on (graph.ForwardCache); False = every
         # call issues its ~76 launches eagerly, as before round 5.  Shared by nn.DataParallel's single-device pass-through.
         self.graph_cache = True
@@ -292,8 +294,16 @@ class MVS4net(nn.Module):
         if not self.inverse_depth:
             depth_interval = (depth_values[:, -1] - depth_values[:, 0]) / depth_values.size(1)
         names = ["stage%d" % (s + 1) for s in range(self.num_stage)]
-        rts = ops.relative_projection_multi([proj_matrices[n].to(dev, torch.float32) for n in names])
-        c0, c1, c3, f1 = fpn.trunk(ops.pack_images(imgs))                        # channels-last [N*B,1,h,w,C]
+        pms = [proj_matrices[n].to(dev, torch.float32) for n in names]
+        hypo0 = None
+        if self.merge_launches and (teacher is None or "stage1" not in teacher) and not self.fuse_hypotheses:
+            # pack + projections + the first stage's hypotheses: one launch instead of three
+            # (stage 1 reads the coarsest FPN level: H/8 x W/8)
+            packed, rts, hypo0 = ops.forward_prologue(imgs, pms, depth_values, self.stage_splits[0], H // 8, W // 8,
+                                                      self.inverse_depth)
+        else:
+            packed, rts = ops.pack_images(imgs), ops.relative_projection_multi(pms)
+        c0, c1, c3, f1 = fpn.trunk(packed)                                       # channels-last [N*B,1,h,w,C]
         main = torch.cuda.current_stream()
         side = None
         if self.overlap_streams and self.num_stage > 2:
@@ -336,6 +346,8 @@ class MVS4net(nn.Module):
                     depth_values=depth_values.contiguous() if s == 0 else None)
                 if fused is not None:
                     cor, hypo = fused
+            if hypo is None and s == 0 and hypo0 is not None:
+                hypo = hypo0
             if hypo is None:
                 hypo = self._hypotheses(s, depth_values, depth_interval, prev, h, w)
             if cor is None:
@@ -359,7 +371,11 @@ class MVS4net(nn.Module):
             #  main stream: on a stream of their own -- nothing in the cascade reads them -- the captured forward got SLOWER,
             #  1.174 against 1.129 ms alone and 850 against 1 108 depth-maps/s with two in flight, same box, alternating runs
             #  (profiles/r05_conf_stream_ab.txt): every cross-stream edge of a hipGraph costs more than these 4 us kernels)
-            conf = ops.upsample_bilinear(sel["conf"], 2 ** (3 - s)) if s < 3 else sel["conf"]
+            #  With `merge_launches` the three are ONE launch after the last stage.
+            if s == 3 or self.merge_launches:
+                conf = sel["conf"]
+            else:
+                conf = ops.upsample_bilinear(sel["conf"], 2 ** (3 - s))
             st = {"depth": sel["depth"], "photometric_confidence": conf, "hypo_depth": hypo,
                   "attn_weight": sel["attn_weight"]}
             if self.inverse_depth:
@@ -370,6 +386,13 @@ class MVS4net(nn.Module):
             prev = st
             outputs[name] = st
             outputs.update(st)
+        if self.merge_launches:
+            coarse = [outputs["stage%d" % (k + 1)] for k in range(min(3, self.num_stage))]
+            ups = ops.upsample_bilinear_multi([st["photometric_confidence"] for st in coarse], H, W)
+            for st, u in zip(coarse, ups):
+                st["photometric_confidence"] = u
+            if self.num_stage < 4:
+                outputs["photometric_confidence"] = ups[-1]
         return outputs
 
     # ------------------------------------------------------------------ train: autograd

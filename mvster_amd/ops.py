@@ -71,6 +71,31 @@ def pack_images(imgs):
     return out
 
 
+def forward_prologue(imgs, proj_list, depth_values, D, h, w, inverse):
+    """``pack_images`` + ``relative_projection_multi`` + ``init_range`` (the first stage's hypotheses [B,D,h,w]) in one
+    launch -> (packed, rt, hypo); the same bits as the three calls."""
+    import ctypes
+    imgs = [i.contiguous() for i in imgs]
+    pms = [p.contiguous() for p in proj_list]
+    dv = depth_values.contiguous()
+    for t in imgs + pms + [dv]:
+        _chk(t, "forward_prologue")
+    B, C, H, W = imgs[0].shape
+    if C != 3 or len(imgs) > 16:
+        raise RuntimeError("forward_prologue: expects at most 16 views of [B,3,H,W]")
+    N = len(imgs)
+    dev = imgs[0].device
+    packed = torch.empty(N * B, 1, H, W, 4, device=dev, dtype=torch.float32)
+    rt = torch.empty(len(pms), B, N - 1, 12, device=dev, dtype=torch.float32)
+    hypo = torch.empty(B, D, h, w, device=dev, dtype=torch.float32)
+    ip = (ctypes.c_void_p * N)(*[i.data_ptr() for i in imgs])
+    pp = (ctypes.c_void_p * len(pms))(*[p.data_ptr() for p in pms])
+    _lib.check(_lib.load().mvster_forward_prologue(ctypes.cast(ip, ctypes.c_void_p), N, _ptr(packed), B, H, W,
+                                                   ctypes.cast(pp, ctypes.c_void_p), len(pms), _ptr(rt), _ptr(dv), dv.shape[1],
+                                                   _ptr(hypo), D, h, w, int(inverse), _stream()), "forward_prologue")
+    return packed, rt, hypo
+
+
 WGRAD_MAX_SLOTS = 1024        # weight-gradient partial-sum slots per launch (a module attribute: experiments set it)
 
 
@@ -278,6 +303,28 @@ def upsample_bilinear(x, scale):
     _lib.check(_lib.load().mvster_upsample_bilinear(_ptr(x), _ptr(out), B, h, w, h * scale, w * scale, _stream()),
                "upsample_bilinear")
     return out
+
+
+def upsample_bilinear_multi(xs, H, W):
+    """List of [B,h_k,w_k] maps -> list of [B,H,W] maps, align_corners=True, one launch (``upsample_bilinear`` per map, same
+    bits)."""
+    import ctypes
+    xs = [x.contiguous() for x in xs]
+    for x in xs:
+        _chk(x, "upsample_bilinear_multi")
+    if not 1 <= len(xs) <= 8:
+        raise RuntimeError("upsample_bilinear_multi: 1..8 maps per launch")
+    B = xs[0].shape[0]
+    outs = [torch.empty(B, H, W, device=x.device, dtype=torch.float32) for x in xs]
+    n = len(xs)
+    ip = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])
+    op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    hs = (ctypes.c_int * n)(*[x.shape[1] for x in xs])
+    ws = (ctypes.c_int * n)(*[x.shape[2] for x in xs])
+    _lib.check(_lib.load().mvster_upsample_bilinear_multi(ctypes.cast(ip, ctypes.c_void_p), ctypes.cast(op, ctypes.c_void_p),
+                                                          ctypes.cast(hs, ctypes.c_void_p), ctypes.cast(ws, ctypes.c_void_p),
+                                                          n, B, H, W, _stream()), "upsample_bilinear_multi")
+    return outs
 
 
 def fpn_tail_gather(G, vb, H, W, separable=False):

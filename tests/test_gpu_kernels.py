@@ -109,6 +109,35 @@ def test_pack_images_and_multi_projection():
         assert torch.equal(multi[s], ops.relative_projection(proj[n].to(DEV)).cpu())
 
 
+@pytest.mark.parametrize("inverse", [True, False])
+def test_forward_prologue_equals_its_three_launches(inverse):
+    """mvster_forward_prologue = pack_images + relative_projection_multi + init_range, bit for bit; odd sizes, 1..4 stages."""
+    g = torch.Generator().manual_seed(1)
+    for (B, N, H, W, D, h, w, nst) in ((2, 3, 12, 20, 8, 3, 5, 4), (1, 5, 64, 128, 8, 8, 16, 4), (3, 2, 9, 7, 5, 9, 7, 1)):
+        imgs = [torch.rand(B, 3, H, W, generator=g).to(DEV) for _ in range(N)]
+        _, proj, _ = make_inputs(N, 128, 192, seed=3, batch=B)
+        pms = [proj["stage%d" % (s + 1)].to(DEV) for s in range(nst)]
+        dv = (torch.rand(B, 3, generator=g).sort(1)[0] * 500 + 400).to(DEV)
+        packed, rt, hypo = ops.forward_prologue(imgs, pms, dv, D, h, w, inverse)
+        assert torch.equal(packed, ops.pack_images(imgs))
+        assert torch.equal(rt, ops.relative_projection_multi(pms))
+        assert torch.equal(hypo, ops.init_range(dv, D, h, w, inverse=inverse))
+    with pytest.raises(RuntimeError, match="bad shape"):                     # more hypothesis pixels than image pixels
+        ops.forward_prologue(imgs, pms, dv, D, 64, 64, inverse)
+
+
+def test_upsample_bilinear_multi_equals_single_launches():
+    g = torch.Generator().manual_seed(2)
+    xs = [torch.rand(2, 8 * k, 12 * k, generator=g).to(DEV) for k in (1, 2, 4)]
+    got = ops.upsample_bilinear_multi(xs, 64, 96)
+    for x, o, k in zip(xs, got, (8, 4, 2)):
+        assert o.shape == (2, 64, 96) and torch.equal(o, ops.upsample_bilinear(x, k))
+    one = ops.upsample_bilinear_multi(xs[:1], 8, 12)                          # x1: the identity, exactly
+    assert torch.equal(one[0], xs[0])
+    with pytest.raises(RuntimeError, match="1..8 maps"):
+        ops.upsample_bilinear_multi([], 8, 8)
+
+
 def test_schedulers(golden):
     g = golden("g5_sched")
     dv = g.t("dv", DEV)

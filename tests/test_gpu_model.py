@@ -554,6 +554,35 @@ def test_fused_hypothesis_scheduling_gives_the_same_forward(shipped_cfg, checkpo
     assert torch.equal(m(*a)["depth"], want["depth"]) and m._fwd_cache.stats["eager"] == 2      # another key: eager first
 
 
+@pytest.mark.parametrize("num_stage", [4, 2])
+def test_merged_launches_give_the_same_forward(shipped_cfg, checkpoint, num_stage):
+    """``MVS4net.merge_launches`` (default): pack + projections + first hypotheses in one launch, the coarse stages' confidence
+    up-samplings in one -- the forward of the separate launches, bit for bit, for every output of every stage."""
+    cfg = dict(shipped_cfg)
+    if num_stage != 4:
+        cfg.update(num_stage=num_stage, stage_splits=shipped_cfg["stage_splits"][:num_stage],
+                   group_cor_dim=shipped_cfg["group_cor_dim"][:num_stage],
+                   depth_interals_ratio=shipped_cfg["depth_interals_ratio"][:num_stage])
+    m = MVS4net(**cfg)
+    if num_stage == 4:
+        m.load_state_dict(checkpoint, strict=True)
+    m.to(DEV).eval()
+    a = to_dev(*make_inputs(nviews=4, H=128, W=192, seed=37, batch=2))
+    assert m.merge_launches
+    m.merge_launches = False
+    want = _clone_out(m.forward_eager(*a))
+    m.merge_launches = True
+    for got in (m(*a), m(*a), m(*a)):                     # eager, captured, replayed
+        n = 0
+        for path, t in _all_leaves(got):
+            w_ = want[path[0]] if len(path) == 1 else want[path[0]][path[1]]
+            assert t.shape == w_.shape and torch.equal(t, w_), path
+            n += 1
+        assert n == sum(1 for _ in _all_leaves(want))
+    for k in range(num_stage):
+        assert got["stage%d" % (k + 1)]["photometric_confidence"].shape == (2, 128, 192)
+
+
 def test_graphed_forward_refuses_stale_weights(shipped_cfg, checkpoint):
     """``GraphedForward`` records the model's state stamp at capture: after an in-place parameter update its ``__call__``
     raises instead of replaying the weights folded at capture time."""
