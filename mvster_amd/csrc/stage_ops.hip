@@ -724,9 +724,9 @@ __global__ void relative_projection_multi_kernel(MultiProjArgs a) {
     for (int k = 0; k < 3; ++k) o[9 + k] = m.t[k];
 }
 
-// The three launches every forward starts with, in one: pack the views (blockIdx.y < N*B), the first stage's hypotheses
-// (blockIdx.y == N*B: mvs4net_utils.py:61-86 on the [first, last] depth of depth_values) and every stage's relative
-// projections (blockIdx.y == N*B + 1, first workgroups).  Same device functions as the separate kernels: the same bits.
+// The three launches every forward starts with, in one: pack the views, the first stage's hypotheses (mvs4net_utils.py:61-86 on
+// the [first, last] depth of depth_values) and every stage's relative projections (first workgroups of their grid row).  Same
+// device functions as the separate kernels: the same bits.
 struct PrologueArgs {
     PackArgs pack;
     MultiProjArgs proj;
@@ -737,8 +737,10 @@ struct PrologueArgs {
 
 __global__ void __launch_bounds__(256) forward_prologue_kernel(PrologueArgs a) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const int vb = blockIdx.y;
+    // rows 0 and 1 of the grid are the side jobs (dispatched first: the serial 4x4 fp64 inverses take ~7 us and must not
+    // start after the pack has drained), rows 2.. the views
     const int NB = a.pack.N * a.pack.B;
+    const int vb = blockIdx.y == 0 ? NB + 1 : blockIdx.y == 1 ? NB : (int)blockIdx.y - 2;
     if (vb < NB) {
         if (p >= a.pack.HW) return;
         const int v = vb / a.pack.B, b = vb - v * a.pack.B;
