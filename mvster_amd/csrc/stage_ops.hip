@@ -284,30 +284,33 @@ __global__ void __launch_bounds__(256) fpn_tail_gather_lds_kernel(const float* _
 // Same mathematics as the two kernels; the lateral product is summed in the MFMA's K order and up2(q) is the flat
 // four-weight FMA form (the kernel is VALU-instruction-bound: 1 120 VALU instructions per wave, PMC), so values agree with
 // the two launches to ~3e-7 of the largest output, not bit for bit.
-template <int CI>
-__global__ void __launch_bounds__(256) fpn_tail_fused_kernel(const float* __restrict__ x, const float* __restrict__ A,
+template <int CI, int TH>
+__global__ void __launch_bounds__(32 * TH, TH == 8 ? 3 : TH == 16 ? 2 : 1) fpn_tail_fused_kernel(const float* __restrict__ x, const float* __restrict__ A,
                                                              const float* __restrict__ bias, const float* __restrict__ qmap,
                                                              const float* __restrict__ vb, float* __restrict__ P, int NB,
                                                              int H, int W, FastDiv tiles_x, FastDiv tiles_y, float sy, float sx, float sqy, float sqx) {
     static_assert(CI == 16, "one 16-wide K block");
+    static_assert(TH == 8 || TH == 16 || TH == 32, "8 x 32 (four waves), 16 x 32 (eight) or 32 x 32 (sixteen) output tiles");
+    constexpr int NW = TH / 2, NTHR = 64 * NW;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     constexpr int CO = 8, CG = 72, Q = CG / 4;
     constexpr int QP = Q + 1;                  // patch pitch in float4 per pixel: 19 (odd) spreads 16 neighbouring pixels over all 16
     //                                            16-byte slot classes of a ds_read_b128 lane group; 18 aliases pixel k with k + 8
-    constexpr int PR = 7, PC = 19;             // half-resolution patch of an 8 x 32 output tile (+ 1-pixel ring): <= 7 x 19
-    constexpr int QR = 6, QC = 11;             // its quarter-resolution footprint: <= 6 x 11
+    constexpr int PR = TH == 8 ? 7 : TH == 16 ? 11 : 19, PC = 19;   // half-resolution patch of a TH x 32 output tile (+ 1-pixel ring): <= 7 (11) x 19
+    constexpr int QR = TH == 8 ? 6 : TH == 16 ? 8 : 11, QC = 11;    // its quarter-resolution footprint: <= 6 (8) x 11
     constexpr int QH = 10;                     // q is staged in two channel halves (quads 0..7, then 8..17) through ONE buffer of
     //                                            10 quads per pixel: 38.3 + 10.6 KB of LDS = three workgroups per CU (two with
     //                                            all 18 quads resident)
-    constexpr int MT = (PR * PC + 63) / 64;    // M tiles of 16 patch pixels per wave
-    __shared__ f32x4 patch[PR * PC * QP];
-    __shared__ f32x4 qpatch[QR * QC * QH];
-    __shared__ float vbsum[9][CO];
+    constexpr int MT = (PR * PC + 16 * NW - 1) / (16 * NW);    // M tiles of 16 patch pixels per wave
+    extern __shared__ __attribute__((aligned(16))) float fused_lds[];
+    f32x4* const patch = reinterpret_cast<f32x4*>(fused_lds);                  // [PR * PC * QP]
+    f32x4* const qpatch = patch + PR * PC * QP;                                // [QR * QC * QH]
+    float (*const vbsum)[CO] = reinterpret_cast<float (*)[CO]>(qpatch + QR * QC * QH);   // [9][CO]
     const int Hh = H / 2, Wh = W / 2, Hq = Hh / 2, Wq = Wh / 2;
     unsigned txu, tyu;
     const int b = (int)fdivmod(fdivmod(xcd_remap(blockIdx.x, gridDim.x), tiles_x, txu), tiles_y, tyu);
-    const int y0 = (int)tyu * 8, x0 = (int)txu * 32;
-    const int ylo = max(y0 - 1, 0), yhi = min(y0 + 8, H - 1), xlo = max(x0 - 1, 0), xhi = min(x0 + 32, W - 1);
+    const int y0 = (int)tyu * TH, x0 = (int)txu * 32;
+    const int ylo = max(y0 - 1, 0), yhi = min(y0 + TH, H - 1), xlo = max(x0 - 1, 0), xhi = min(x0 + 32, W - 1);
     const int r0 = mv::make_lerp_s(ylo, sy, Hh).i0, r1 = mv::make_lerp_s(yhi, sy, Hh).i1;
     const int c0 = mv::make_lerp_s(xlo, sx, Wh).i0, c1 = mv::make_lerp_s(xhi, sx, Wh).i1;
     const int nr = r1 - r0 + 1, nc = c1 - c0 + 1;       // <= PR, <= PC
@@ -325,7 +328,7 @@ __global__ void __launch_bounds__(256) fpn_tail_fused_kernel(const float* __rest
     {
         const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(qmap + (long)b * Hq * Wq * CG), (short)0, (int)((long)Hq * Wq * CG * 4), 0x00020000);
-        constexpr int NIT0 = (QR * QC * 8 + 255) / 256, NIT1 = (QR * QC * 10 + 255) / 256;
+        constexpr int NIT0 = (QR * QC * 8 + NTHR - 1) / NTHR, NIT1 = (QR * QC * 10 + NTHR - 1) / NTHR;
         f32x4 stg0[NIT0], stg1[NIT1];
         auto stage_load = [&](int i, int nq, int q0) -> f32x4 {             // slot i of a half with nq quads per pixel from quad q0
             const int qd = i % nq, pix = i / nq;
@@ -335,17 +338,17 @@ __global__ void __launch_bounds__(256) fpn_tail_fused_kernel(const float* __rest
             return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrsrc, off, 0, 0));
         };
 #pragma unroll
-        for (int it = 0; it < NIT0; ++it) stg0[it] = stage_load(threadIdx.x + it * 256, 8, 0);
+        for (int it = 0; it < NIT0; ++it) stg0[it] = stage_load(threadIdx.x + it * NTHR, 8, 0);
 #pragma unroll
-        for (int it = 0; it < NIT1; ++it) stg1[it] = stage_load(threadIdx.x + it * 256, 10, 8);
-        // this lane's patch pixels (M tile 4 mt + wave: pixels (4 mt + wave) * 16 + lm) and their input vectors
+        for (int it = 0; it < NIT1; ++it) stg1[it] = stage_load(threadIdx.x + it * NTHR, 10, 8);
+        // this lane's patch pixels (M tile NW mt + wave: pixels (NW mt + wave) * 16 + lm) and their input vectors
         const float* xb = x + (long)b * Hh * Wh * CI;
         const FastDiv ncd = mv_fastdiv_dev((unsigned)nc);
         f32x4 xv[MT];
         int ppos[MT];                                   // pr | pc << 8, -1 = no pixel
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int i = (4 * mt + wave) * 16 + lm;
+            const int i = (NW * mt + wave) * 16 + lm;
             const bool valid = i < npix;
             unsigned pcu;
             const int pr = (int)fdivmod((unsigned)(valid ? i : 0), ncd, pcu), pc = (int)pcu;
@@ -368,7 +371,7 @@ __global__ void __launch_bounds__(256) fpn_tail_fused_kernel(const float* __rest
             constexpr int NT0 = decltype(nt0c)::value, NT1 = decltype(nt1c)::value, QBASE = decltype(qbasec)::value;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                if ((4 * mt + wave) * 16 >= npix) break;           // (wave-uniform)
+                if ((NW * mt + wave) * 16 >= npix) break;           // (wave-uniform)
                 const bool valid = ppos[mt] >= 0;
                 const int pr = valid ? ppos[mt] & 255 : 0, pc = valid ? ppos[mt] >> 8 : 0;
                 const mv::Lerp ly = mv::make_lerp_s(r0 + pr, sqy, Hq), lx = mv::make_lerp_s(c0 + pc, sqx, Wq);
@@ -401,7 +404,7 @@ __global__ void __launch_bounds__(256) fpn_tail_fused_kernel(const float* __rest
         };
 #pragma unroll
         for (int it = 0; it < NIT0; ++it) {
-            const int i = threadIdx.x + it * 256;
+            const int i = threadIdx.x + it * NTHR;
             if (i < QR * QC * 8) qpatch[(i / 8) * QH + (i % 8)] = stg0[it];
         }
         __syncthreads();
@@ -409,7 +412,7 @@ __global__ void __launch_bounds__(256) fpn_tail_fused_kernel(const float* __rest
         __syncthreads();                                           // everyone is done with the first half of q
 #pragma unroll
         for (int it = 0; it < NIT1; ++it) {
-            const int i = threadIdx.x + it * 256;
+            const int i = threadIdx.x + it * NTHR;
             if (i < QR * QC * 10) qpatch[(i / 10) * QH + (i % 10)] = stg1[it];
         }
         __syncthreads();
@@ -918,12 +921,50 @@ extern "C" int mvster_fpn_tail_fused(const float* x, const float* A, const float
     if (!x || !A || !bias || !q || !vb || !P) return MVSTER_ERR_NULL;
     if (NB <= 0 || H < 4 || W < 4) return MVSTER_ERR_SHAPE;
     if (CI != 16 || (H & 3) || (W & 3) || H < 16 || W < 64) return MVSTER_ERR_UNSUPPORTED;
-    const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
+    // 16 x 32 output tiles (eight waves, 78 KB of LDS, two workgroups per CU): the half-resolution patch of a tile carries
+    // 209 pixels for 128 interior ones instead of 133 for 64 (8 x 32 tiles, the round-4 form; probe switch MVSTER_FPN_TILE = 8 / 32)
+    // (same box, alternating, profiles/r05_fpn_tile_ab.txt: 8 rows 87.8 us / 1 145.5 depth-maps/s, 16 rows 79.3 / 1 154.0;
+    //  32 rows -- sixteen waves, one workgroup per CU -- 83.8 us against 77.3 and the same 1 162 depth-maps/s)
+    static const int tile_env = [] { const char* e = MV_PROBE_ENV("MVSTER_FPN_TILE"); return e ? atoi(e) : 0; }();
+    const int TH = tile_env == 8 || tile_env == 32 ? tile_env : 16;
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + TH - 1) / TH;
     if ((long)tiles_x * tiles_y * NB >= (1L << 31)) return MVSTER_ERR_SHAPE;
-    MV_NOTE_KERNEL("fpn_tail_fused_kernel<16>");
-    hipLaunchKernelGGL(fpn_tail_fused_kernel<16>, dim3(tiles_x * tiles_y * NB), dim3(256), 0, (hipStream_t)stream, x, A, bias, q, vb,
-                       P, NB, H, W, mv_fastdiv(tiles_x), mv_fastdiv(tiles_y), mv::lerp_scale(H / 2, H), mv::lerp_scale(W / 2, W),
-                       mv::lerp_scale(H / 4, H / 2), mv::lerp_scale(W / 4, W / 2));
+    const dim3 grid(tiles_x * tiles_y * NB);
+    const FastDiv dx = mv_fastdiv(tiles_x), dy = mv_fastdiv(tiles_y);
+    const float sy = mv::lerp_scale(H / 2, H), sx = mv::lerp_scale(W / 2, W), sqy = mv::lerp_scale(H / 4, H / 2),
+                sqx = mv::lerp_scale(W / 4, W / 2);
+    auto big_lds = [](const void* kern, size_t lds, unsigned long& done) {     // above the 64 KB default: once per device
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (dev >= 0 && dev < 64 && ((done >> dev) & 1ul)) return true;
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        if (dev >= 0 && dev < 64) done |= 1ul << dev;
+        return true;
+    };
+#ifdef MVSTER_PROBES      // the measured-but-not-chosen tile shapes compile into the probe library only
+    if (TH == 8) {
+        constexpr size_t lds = (size_t)(7 * 19 * 19 + 6 * 11 * 10) * 16 + 9 * 8 * 4;
+        MV_NOTE_KERNEL("fpn_tail_fused_kernel<16, 8>");
+        hipLaunchKernelGGL((fpn_tail_fused_kernel<16, 8>), grid, dim3(256), lds, (hipStream_t)stream, x, A, bias, q, vb, P, NB, H, W,
+                           dx, dy, sy, sx, sqy, sqx);
+        return mv_check_launch();
+    }
+    if (TH == 32) {
+        constexpr size_t lds = (size_t)(19 * 19 * 19 + 11 * 11 * 10) * 16 + 9 * 8 * 4;
+        static unsigned long done = 0;
+        if (!big_lds(reinterpret_cast<const void*>(fpn_tail_fused_kernel<16, 32>), lds, done)) return MVSTER_ERR_LAUNCH;
+        MV_NOTE_KERNEL("fpn_tail_fused_kernel<16, 32>");
+        hipLaunchKernelGGL((fpn_tail_fused_kernel<16, 32>), grid, dim3(1024), lds, (hipStream_t)stream, x, A, bias, q, vb, P, NB, H, W,
+                           dx, dy, sy, sx, sqy, sqx);
+        return mv_check_launch();
+    }
+#endif
+    constexpr size_t lds = (size_t)(11 * 19 * 19 + 8 * 11 * 10) * 16 + 9 * 8 * 4;        // 77 904 B
+    static unsigned long done = 0;
+    if (!big_lds(reinterpret_cast<const void*>(fpn_tail_fused_kernel<16, 16>), lds, done)) return MVSTER_ERR_LAUNCH;
+    MV_NOTE_KERNEL("fpn_tail_fused_kernel<16, 16>");
+    hipLaunchKernelGGL((fpn_tail_fused_kernel<16, 16>), grid, dim3(512), lds, (hipStream_t)stream, x, A, bias, q, vb, P, NB, H, W, dx,
+                       dy, sy, sx, sqy, sqx);
     return mv_check_launch();
 }
 

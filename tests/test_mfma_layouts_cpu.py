@@ -179,7 +179,9 @@ def test_fpn_gather_patch_capacities_hold_for_every_tile(size):
     for every tile position of every admissible map size (the align_corners scale is < 1/2, so 10 rows reach over at most
     floor(4.5) + 2 source rows).  Walked with the kernels' own fp32 index arithmetic."""
     n, nh, nq = size, size // 2, size // 4
-    for tile, ring_hi, cap, qcap in ((8, 8, 7, 6), (32, 32, 19, 11)):       # rows: y0 - 1 .. y0 + 8; columns: x0 - 1 .. x0 + 32
+    # rows: y0 - 1 .. y0 + 8 (the gather kernel; the fused kernel's 16-row tiles: y0 - 1 .. y0 + 16 in 11 / 8 rows);
+    # columns: x0 - 1 .. x0 + 32
+    for tile, ring_hi, cap, qcap in ((8, 8, 7, 6), (16, 16, 11, 8), (32, 32, 19, 11)):              # (32 rows: probe form)
         starts = np.arange(0, n, tile)
         lo = np.maximum(starts - 1, 0)
         hi = np.minimum(starts + ring_hi, n - 1)
