@@ -1016,7 +1016,8 @@ def main():
                      "bytes_per_launch": a["bytes"] // a["n"]}
                 if name.startswith("fpn_tail"):
                     e["limiter"] = ("fp32 VALU issue, not HBM: position-dependent bilinear weights (36 per output pixel) leave no "
-                                    "shared operand for the matrix cores; PMC: ~1 100 VALU instructions per wave (DESIGN.md section 4.3)")
+                                    "shared operand for the matrix cores; ~650 VALU / LDS instructions per wave, half of them the gather-sum "
+                                    "(DESIGN.md section 4.3)")
                 if streaming and a["flops"] > 0:
                     e["frac_of_fp32_mfma_peak_algorithmic_flops"] = round(a["flops"] / (a["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
             # (the profiler spells the wave-local warp kernel with its fourth template argument, the library's

@@ -923,7 +923,7 @@ def test_fpn_tail_gather():
     from tests.conv_emulator import fpn_tail_gather_reference
     g = torch.Generator().manual_seed(2)
     for (NB, H, W, CO) in ((2, 12, 20, 8), (1, 64, 34, 8), (1, 8, 8, 16), (2, 40, 96, 8), (1, 18, 70, 8),
-                           (2, 40, 96, 16), (1, 18, 70, 16)):
+                           (2, 40, 96, 16), (1, 18, 70, 16), (3, 16, 64, 16), (1, 64, 132, 16)):     # (16 channels: 16 x 32 tiles)
         G = torch.randn(NB, 1, H // 2, W // 2, 9 * CO, generator=g)
         vb = torch.randn(9, CO, generator=g)
         want = fpn_tail_gather_reference(G, vb, H, W)
