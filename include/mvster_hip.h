@@ -329,6 +329,55 @@ int mvster_geo_filter(const float* depth_ref, const float* depth_src, const doub
                       int* mask_sum, float* depth_sum, unsigned char* view_mask, float* view_depth, float* x_src,
                       float* y_src, int NS, int H, int W, float pix_thres, float rel_thres, void* stream);
 
+/* ---- training-step glue (csrc/train_glue.hip): the reference's chains of small tensor expressions, one launch each ---- */
+
+/* One stage of MVS4net_loss around the OT term (models/MVS4Net.py:126-153), forward: hypo [B,D,HW] (D >= 3), gt, mask
+ * (float, > 0.5 = valid), loss_pix [B,HW] (from mvster_sinkhorn*), mono [B,HW] or NULL, total_in: device scalar or NULL ->
+ * planes [2][B*HW] (valid, valid*sign(mono-gt): for the backward), partial [mvster_stage_loss_slots(B*HW)][4] (scratch),
+ * out [6] = #valid, l1 = mean|mono-gt| (:136-137), out-of-range ratio (:141-147), ot = masked mean of loss_pix,
+ * weighted = w_stage*(w_l1*l1 + w_ot*ot) (:151), total = total_in + weighted.  Two launches, deterministic. */
+int mvster_stage_loss_slots(long n);
+int mvster_stage_loss_fwd(const float* hypo, const float* gt, const float* mask, const float* loss_pix, const float* mono,
+                          const float* total_in, float* planes, float* partial, float* out, int B, int D, long HW,
+                          int inverse_depth, float w_l1, float w_ot, float w_stage, void* stream);
+
+/* Its backward: jac [B,D,HW] = d loss_pix / d attn (mvster_sinkhorn*), planes / out from the forward; g_total / g_l1 /
+ * g_ot = device scalars (NULL = 0), gradients of out[5] / out[1] / out[3]; w_l1 = w_stage*l1ot_lw[0], w_ot =
+ * w_stage*l1ot_lw[1] -> g_attn [B,D,HW] (or NULL), g_mono [B,HW] (or NULL).  One launch. */
+int mvster_stage_loss_bwd(const float* jac, const float* planes, const float* out, const float* g_total, const float* g_l1,
+                          const float* g_ot, float w_l1, float w_ot, float* g_attn, float* g_mono, int B, int D, long HW,
+                          void* stream);
+
+/* Monocular head, disparity -> depth (models/mvs4net_utils.py:858-866): depth [B,HW] = 1 / (1/d_max[b] + (1/d_min[b] -
+ * 1/d_max[b]) * sigmoid(z)); sig [B,HW] = sigmoid(z) is kept for the backward, gz = g * d depth / d z. */
+int mvster_mono_depth_fwd(const float* z, const float* dmin, const float* dmax, float* depth, float* sig, int B, long HW,
+                          void* stream);
+int mvster_mono_depth_bwd(const float* g, const float* depth, const float* sig, const float* dmin, const float* dmax, float* gz,
+                          int B, long HW, void* stream);
+
+/* out [NB,H,W,Ca+Cb] = concat(nearest x2 up-sampling of a [NB,H/2,W/2,Ca], b [NB,H,W,Cb]) -- the input of the monocular
+ * head's 3x3 convolutions (models/mvs4net_utils.py:854-857) -- and the adjoint g -> ga, gb.  H, W even; Ca, Cb % 4 == 0. */
+int mvster_upcat_fwd(const float* a, const float* b, float* out, int NB, int H, int W, int Ca, int Cb, void* stream);
+int mvster_upcat_bwd(const float* g, float* ga, float* gb, int NB, int H, int W, int Ca, int Cb, void* stream);
+
+/* Composed weights of the re-associated finest FPN level (out4(up(f) + inner3(c0)), models/mvs4net_utils.py:496-498):
+ * wo [CO,CM,3,3] = out4.weight, wi [CM,CI] = inner3.weight, bi [CM] = inner3.bias -> wg [9*CO,CM] (row tap*CO+o =
+ * wo[o,:,tap]), wc [CO,CI,3,3] = sum_c wo[o,c,tap] wi[c,i], vb [9,CO] = sum_c wo[o,c,tap] bi[c]; and the adjoint
+ * (g_wg / g_wc / g_vb may be NULL) -> g_wo, g_wi, g_bi.  One single-workgroup launch each. */
+int mvster_fine_weights_fwd(const float* wo, const float* wi, const float* bi, float* wg, float* wc, float* vb, int CO, int CM,
+                            int CI, void* stream);
+int mvster_fine_weights_bwd(const float* wo, const float* wi, const float* bi, const float* g_wg, const float* g_wc,
+                            const float* g_vb, float* g_wo, float* g_wi, float* g_bi, int CO, int CM, int CI, void* stream);
+
+/* Adam update (torch.optim.Adam semantics with L2 weight decay, no amsgrad; train_mvs4.py:367) of `count` fp32 tensors:
+ * params / grads = HOST arrays of `count` device pointers, sizes / state_offs = host int arrays (elements; offsets of a
+ * tensor's moments in the flat exp_avg / exp_avg_sq buffers).  step_cells [2] device floats: cell 0 = number of updates
+ * done so far, + 1 afterwards (cell 1 scratch).  ceil(count / 128) launches (+ 1 when that is odd); the pointers travel as
+ * kernel arguments, so a captured step records them with the launch. */
+int mvster_fused_adam(const void* const* params, const void* const* grads, const int* sizes, const int* state_offs, int count,
+                      float* exp_avg, float* exp_avg_sq, float* step_cells, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, void* stream);
+
 /* Batched gather, one launch: for every record r of the DEVICE table `descs` (32-byte records {const float* src; float* dst;
  * const int* idx; int n; int first_block}), dst[i] = idx[i] > 0 ? src[idx[i] - 1] : 0, i < n (n % 4 == 0); first_block =
  * prefix sum of ceil(n / 1024), total_blocks their sum.  Refreshes all packed / permuted weight forms of the training step

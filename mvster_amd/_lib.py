@@ -58,6 +58,16 @@ SIGNATURES = {
     "mvster_sinkhorn": [_f, _f, _f, _f, _f, _i, _i, _l, _i, _fl, _f],
     "mvster_sinkhorn_continuous": [_f, _f, _f, _f, _f, _f, _i, _i, _l, _i, _fl, _f],
     "mvster_stage_loss_terms": [_f, _f, _f, _f, _f, _f, _i, _i, _l, _i, _f],
+    "mvster_stage_loss_slots": [_l],
+    "mvster_stage_loss_fwd": [_f] * 9 + [_i, _i, _l, _i, _fl, _fl, _fl, _f],
+    "mvster_stage_loss_bwd": [_f] * 6 + [_fl, _fl, _f, _f, _i, _i, _l, _f],
+    "mvster_mono_depth_fwd": [_f] * 5 + [_i, _l, _f],
+    "mvster_mono_depth_bwd": [_f] * 6 + [_i, _l, _f],
+    "mvster_upcat_fwd": [_f, _f, _f, _i, _i, _i, _i, _i, _f],
+    "mvster_upcat_bwd": [_f, _f, _f, _i, _i, _i, _i, _i, _f],
+    "mvster_fine_weights_fwd": [_f] * 6 + [_i, _i, _i, _f],
+    "mvster_fine_weights_bwd": [_f] * 9 + [_i, _i, _i, _f],
+    "mvster_fused_adam": [_f, _f, _f, _f, _i, _f, _f, _f, _fl, _fl, _fl, _fl, _fl, _f],
     "mvster_geo_filter": [_f] * 10 + [_i, _i, _i, _fl, _fl, _f],
     "mvster_mfma_probe": [_f, _f, _f, _f],
     "mvster_gather_batch": [_f, _i, _i, _f],

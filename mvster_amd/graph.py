@@ -74,7 +74,10 @@ class _CachedForward:
         # the packed-weight plans the capture records pointers of: kept alive here, whatever happens to the model's own
         self.plans = model._get_plans()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread-local capture: this fires inside the reference's unchanged drivers, where other threads touch the device
+        # too (the DataLoader's pin-memory thread, RCCL's watchdog in a DDP run): in the default global mode their calls
+        # would invalidate the capture -- and raise in THEIR thread
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.outputs = model._forward_eval(self.imgs, self.proj, self.depth_values)
         # ---- clone recipe: every distinct output tensor once, laid out back to back in one fresh buffer per call ---------
         self._slots, self._paths, seen, off = [], [], {}, 0
@@ -85,6 +88,8 @@ class _CachedForward:
                 if not _is_dense(t):
                     t_src = t.contiguous()                      # (no output of the forward is like this today)
                     raise RuntimeError("ForwardCache: output %r is not a dense tensor (%s / %s)" % (path, tuple(t.shape), t_src.stride()))
+                if t.dtype != torch.float32:
+                    raise RuntimeError("ForwardCache: output %r is %s (the clone buffer is float32)" % (path, t.dtype))
                 self._slots.append((t, off, tuple(t.shape), tuple(t.stride())))
                 off += (t.numel() + 63) // 64 * 64
             self._paths.append((path, j))
@@ -147,7 +152,11 @@ class ForwardCache:
     def key(model, imgs, proj_matrices, depth_values):
         im = imgs[0]
         # (the attributes of the model that pick kernels or streams: flipping one between two calls is a different graph)
-        cfg = (model.warp_variant, getattr(model, "fuse_hypotheses", None), getattr(model, "merge_launches", None), model.overlap_streams, float(model.attn_temp), model.attn_fuse_d, model.num_stage,
+        from . import conv_plan, ops
+        # (+ the module-level switches that pick kernels: flipped between two calls they are a different launch sequence)
+        glob = (conv_plan.FORCE_VARIANT, conv_plan.FUSE_TAIL, conv_plan.FUSE_SELECT, conv_plan.LDS_BUDGET, conv_plan.NARROW_MIN_VOXELS,
+                id(conv_plan._TUNING), ops.WGRAD_MAX_SLOTS)
+        cfg = (glob, model.warp_variant, getattr(model, "fuse_hypotheses", None), getattr(model, "merge_launches", None), model.overlap_streams, float(model.attn_temp), model.attn_fuse_d, model.num_stage,
                tuple(model.stage_splits), tuple(model.depth_interals_ratio), tuple(model.group_cor_dim))
         return (im.device.index, len(imgs), tuple(im.shape), int(depth_values.shape[1]), tuple(sorted(proj_matrices.keys())), cfg)
 
@@ -315,8 +324,8 @@ class GraphedTrainStep:
         owned = {id(p): p for g in optimizer.param_groups for p in g["params"]}
         for t in list(bare.parameters()) + list(bare.buffers()):
             owned.setdefault(id(t), t)
-        for i in owned:
-            self._cache.cells[i] = self._cell
+        for t in owned.values():
+            self._cache.cells.set(t, self._cell)
         self._batch = self._cache.build_batch(list(model.parameters()))      # (kept alive here: the graph reads its tables)
         self.graph = torch.cuda.CUDAGraph()
         # (with a collective in the step, RCCL's watchdog thread touches the device during the capture: relaxed mode)
@@ -324,6 +333,16 @@ class GraphedTrainStep:
         mode = {"capture_error_mode": "thread_local"} if collective else {}
         with torch.cuda.graph(self.graph, **mode):
             self.loss = self._step()
+
+    def close(self):
+        """Unregister this step's epoch cell (the model's tensors are then stamped by version / address alone again)."""
+        self._cache.cells.drop(self._cell)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _step(self):
         # grads are re-created by every backward: inside the capture they come from the graph's private pool, so a replay

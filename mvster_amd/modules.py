@@ -44,9 +44,13 @@ class ConvBnReLU3D(nn.Module):
     def forward(self, x):
         return _from_cl5(self.forward_cl(_to_cl5(x)))
 
-    def forward_cl(self, x):
-        """Channels-last [B,D,H,W,C] form on the gfx950 kernels (mvster_amd/train_ops.py)."""
+    def forward_cl(self, x, tap=False):
+        """Channels-last [B,D,H,W,C] form on the gfx950 kernels (mvster_amd/train_ops.py).  ``tap``: -> (y, x') with x' the
+        alias of x that x's other consumers should read (train_ops.conv_cl)."""
         c = self.conv
+        if tap:
+            y, xt = T.conv_cl(x, c.weight, None, c.stride, c.padding, tap=True)
+            return T.batch_norm_cl(y, self.bn, relu=True), xt
         return T.batch_norm_cl(T.conv_cl(x, c.weight, None, c.stride, c.padding), self.bn, relu=True)
 
 
@@ -90,10 +94,15 @@ class reg2d(nn.Module):
     def forward_cl(self, x, return_features=False):
         """[B,D,h,w,G] -> logits [B,D,h,w]; ``return_features``: the 8-channel volume in front of the ``prob`` head instead
         (MVS4net's training forward applies the head inside its fused selection kernel)."""
+        # (c0 / c2 / c4 feed the next level AND a skip connection: the skip reads the tap, so that its gradient is added
+        #  inside the strided layer's input-gradient kernel)
         c0 = self.conv0.forward_cl(x)
-        c2 = self.conv2.forward_cl(self.conv1.forward_cl(c0))
-        c4 = self.conv4.forward_cl(self.conv3.forward_cl(c2))
-        x = self.conv6.forward_cl(self.conv5.forward_cl(c4))
+        x, c0 = self.conv1.forward_cl(c0, tap=True)
+        c2 = self.conv2.forward_cl(x)
+        x, c2 = self.conv3.forward_cl(c2, tap=True)
+        c4 = self.conv4.forward_cl(x)
+        x, c4 = self.conv5.forward_cl(c4, tap=True)
+        x = self.conv6.forward_cl(x)
         x = _deconv_bn_relu_cl(self.conv7, x, skip=c4)
         x = _deconv_bn_relu_cl(self.conv9, x, skip=c2)
         x = _deconv_bn_relu_cl(self.conv11, x, skip=c0)
@@ -128,14 +137,18 @@ class reg3d(nn.Module):
 
     def forward_cl(self, x):
         c0 = self.conv0.forward_cl(x)
-        c2 = self.conv2.forward_cl(self.conv1.forward_cl(c0))
+        x, c0 = self.conv1.forward_cl(c0, tap=True)
+        c2 = self.conv2.forward_cl(x)
         if self.down_size == 3:
-            c4 = self.conv4.forward_cl(self.conv3.forward_cl(c2))
-            x = self.conv6.forward_cl(self.conv5.forward_cl(c4))
+            x, c2 = self.conv3.forward_cl(c2, tap=True)
+            c4 = self.conv4.forward_cl(x)
+            x, c4 = self.conv5.forward_cl(c4, tap=True)
+            x = self.conv6.forward_cl(x)
             x = _deconv_bn_relu_cl(self.conv7, x, skip=c4)
             x = _deconv_bn_relu_cl(self.conv9, x, skip=c2)
         elif self.down_size == 2:
-            x = self.conv4.forward_cl(self.conv3.forward_cl(c2))
+            x, c2 = self.conv3.forward_cl(c2, tap=True)
+            x = self.conv4.forward_cl(x)
             x = _deconv_bn_relu_cl(self.conv9, x, skip=c2)
         else:
             x = c2
@@ -156,9 +169,13 @@ class Conv2d(nn.Module):
     def forward(self, x):
         return _from_cl4(self.forward_cl(_to_cl4(x)))
 
-    def forward_cl(self, x, groups=1):
-        """[B,1,H,W,C] channels-last; ``groups`` = number of equal batch slices normalised separately (views)."""
+    def forward_cl(self, x, groups=1, tap=False):
+        """[B,1,H,W,C] channels-last; ``groups`` = number of equal batch slices normalised separately (views); ``tap``: ->
+        (y, x') with x' the alias of x that x's other consumers should read (train_ops.conv_cl)."""
         c = self.conv
+        if tap:
+            y, xt = T.conv_cl(x, c.weight, None, c.stride, c.padding, tap=True)
+            return T.batch_norm_cl(y, self.bn, relu=self.relu, groups=groups), xt
         return T.batch_norm_cl(T.conv_cl(x, c.weight, None, c.stride, c.padding), self.bn, relu=self.relu, groups=groups)
 
 
@@ -195,23 +212,30 @@ class FPN4(nn.Module):
         the N views of every sample, view-major ([N*B,...]): the convolutions run once over all of them, BatchNorm
         normalises each view's slice on its own -- the same numbers as N separate calls (the reference calls the
         FPN once per view, MVS4Net.py:65-68), in a fifth of the launches."""
-        def seq(layers, t):
-            for l in layers:
-                t = l.forward_cl(t, groups)
-            return t
+        def seq(layers, t, tap=False):
+            # (`tap`: -> (y, t') with t' the alias of the input for its second consumer, see train_ops.conv_cl)
+            t0 = None
+            for i, l in enumerate(layers):
+                if tap and i == 0:
+                    t, t0 = l.forward_cl(t, groups, tap=True)
+                else:
+                    t = l.forward_cl(t, groups)
+            return (t, t0) if tap else t
 
-        def plain(m, t, up=None):
+        def plain(m, t, up=None, tap=False):
             # (`up`: the coarser level, up-sampled x2 and added inside the convolution's epilogue)
-            return T.conv_cl(t, m.weight, m.bias, m.stride, m.padding, skip=up, skip_upsample=up is not None)
+            return T.conv_cl(t, m.weight, m.bias, m.stride, m.padding, skip=up, skip_upsample=up is not None, tap=tap)
+        # every level's map has two consumers (the next level / output conv and a lateral): the second one reads the tap
         c0 = seq(self.conv0, x)
-        c1 = seq(self.conv1, c0)
-        c2 = seq(self.conv2, c1)
-        c3 = seq(self.conv3, c2)
-        out = {"stage1": plain(self.out1, c3)}
+        c1, c0 = seq(self.conv1, c0, tap=True)
+        c2, c1 = seq(self.conv2, c1, tap=True)
+        c3, c2 = seq(self.conv3, c2, tap=True)
+        out = {}
+        out["stage1"], c3 = plain(self.out1, c3, tap=True)
         f = plain(self.inner1, c2, up=c3)
-        out["stage2"] = plain(self.out2, f)
+        out["stage2"], f = plain(self.out2, f, tap=True)
         f = plain(self.inner2, c1, up=f)
-        out["stage3"] = plain(self.out3, f)
+        out["stage3"], f = plain(self.out3, f, tap=True)
         # finest level: re-associated, the full-resolution 64-channel map is never formed (train_ops.fpn_fine_level)
         out["stage4"] = T.fpn_fine_level(c0, f, self.inner3, self.out4)
         return out
@@ -232,11 +256,18 @@ class mono_depth_decoder(nn.Module):
 
     def forward_cl(self, outputs, feats_cl, d_min, d_max):
         """Same head on the channels-last reference features ``feats_cl`` [stage] -> [B,1,h,w,C]."""
+        d_min, d_max = d_min.detach().float().contiguous(), d_max.detach().float().contiguous()
+        # (stages 2 and 3 feed a conv block AND the next concatenation: the latter reads the block's tap)
+        blocks, feats = [], list(feats_cl)
+        for j in range(3):
+            if j == 0:
+                blocks.append(self.convblocks[j].forward_cl(feats[j]))
+            else:
+                y, feats[j] = self.convblocks[j].forward_cl(feats[j], tap=True)
+                blocks.append(y)
         for i in range(1, 4):
-            coarse = T.upsample2x_cl(self.convblocks[i - 1].forward_cl(feats_cl[i - 1]), "nearest")
             c = self.conv3x3[i - 1]
-            disp = torch.sigmoid(T.conv_cl(torch.cat([coarse, feats_cl[i]], -1), c.weight, c.bias, c.stride, c.padding))
-            lo = (1 / d_max)[:, None, None]
-            hi = (1 / d_min)[:, None, None]
-            outputs["stage%d" % (i + 1)]["mono_depth"] = 1 / (lo + (hi - lo) * disp[:, 0, :, :, 0])
+            # nearest x2 + concatenation in one launch; sigmoid -> disparity range -> reciprocal in one launch
+            z = T.conv_cl(T.upcat_cl(blocks[i - 1], feats[i]), c.weight, c.bias, c.stride, c.padding)
+            outputs["stage%d" % (i + 1)]["mono_depth"] = T.mono_depth_cl(z.view(z.shape[0], z.shape[2], z.shape[3]), d_min, d_max)
         return outputs

@@ -65,7 +65,7 @@ class _WarpAggPyr(torch.autograd.Function):
             ops.warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad.contiguous(), G, group_cor, attn_fuse_d,
                                 attn_temp, into=(g_ref, g_src))
         if grad_ref_maps is not None:
-            g_pyr[:B] += grad_ref_maps
+            g_pyr[:B].add_(grad_ref_maps)
         return g_pyr, None, None, None, None, None, None, None
 
 
@@ -82,12 +82,15 @@ class _SelectDepthCL(torch.autograd.Function):
         sel = ops.select_depth(hypo, split_itv, inverse_depth, feat_cl=feat_cl, prob_w=w, prob_b=prob_b.detach().reshape(-1))
         ctx.save_for_backward(sel["attn_weight"], feat_cl, w)
         ctx.shapes = (prob_w.shape, prob_b.shape)
+        ctx.set_materialize_grads(False)     # (no zero-filled gradients for the three non-differentiable outputs)
         outs = (sel["attn_weight"], sel["depth"]) + ((sel["inverse_min_depth"], sel["inverse_max_depth"]) if inverse_depth else ())
         ctx.mark_non_differentiable(*outs[1:])
         return outs
 
     @staticmethod
     def backward(ctx, gattn, *unused):
+        if gattn is None:
+            return (None,) * 6
         attn, feat_cl, w = ctx.saved_tensors
         dfeat, dw, db = ops.select_depth_bwd(attn, gattn, feat_cl, w)
         return dfeat, dw.reshape(ctx.shapes[0]), db.reshape(ctx.shapes[1]), None, None, None
@@ -214,11 +217,12 @@ class MVS4net(nn.Module):
         import itertools
         from . import train_ops
         cells = train_ops.CACHE.cells
-        acc = 0
+        # (running statistics written by a training-mode forward of the native BatchNorm: raw-pointer writes, no _version)
+        acc = train_ops.CACHE.stat_writes * 15485863
         for t in itertools.chain(self.feature.parameters(), self.feature.buffers(), self.reg.parameters(), self.reg.buffers()):
             acc = (acc * 1000003 + t._version * 7919 + t.data_ptr()) & 0xFFFFFFFFFFFF
             if cells:
-                c = cells.get(id(t))
+                c = cells.get(t)
                 if c is not None:
                     acc += c[0] * 104729
         return acc

@@ -604,3 +604,126 @@ def upsample2x_cl(x, backward=False, mode="bilinear"):
             rc = lib.mvster_upsample2x_cl_fwd(_ptr(x), _ptr(out), B, H, W, C, _stream())
     _lib.check(rc, "upsample2x_cl")
     return out
+
+
+# ---- training-step glue (csrc/train_glue.hip) ---------------------------------------------------------------------------
+def stage_loss_fwd(hypo, gt, mask, loss_pix, mono=None, total_in=None, inverse_depth=False, w_l1=0.0, w_ot=1.0, w_stage=1.0):
+    """One stage of MVS4net_loss around the OT term (models/MVS4Net.py:126-153): -> (planes [2, B*H*W], out [6] = #valid,
+    l1, out-of-range ratio, ot, weighted = w_stage*(w_l1*l1 + w_ot*ot), total = total_in + weighted).  Two launches."""
+    for t, n in ((hypo, "hypo"), (gt, "gt"), (mask, "mask"), (loss_pix, "loss_pix"), (mono, "mono"), (total_in, "total_in")):
+        _chk(t, "stage_loss_fwd:" + n)
+    B, D, H, W = hypo.shape
+    for t in (gt, mask, loss_pix) + (() if mono is None else (mono,)):
+        if tuple(t.shape) != (B, H, W):
+            raise RuntimeError("stage_loss_fwd: inconsistent shapes")
+    if D < 3:
+        raise RuntimeError("stage_loss_fwd: the range interval needs at least 3 hypotheses")
+    if total_in is not None and total_in.numel() != 1:
+        raise RuntimeError("stage_loss_fwd: total_in must be a scalar")
+    lib = _lib.load()
+    n = B * H * W
+    planes = torch.empty(2, n, device=hypo.device, dtype=torch.float32)
+    partial = torch.empty(lib.mvster_stage_loss_slots(n), 4, device=hypo.device, dtype=torch.float32)
+    out = torch.empty(6, device=hypo.device, dtype=torch.float32)
+    rc = lib.mvster_stage_loss_fwd(_ptr(hypo), _ptr(gt), _ptr(mask), _ptr(loss_pix), _ptr(mono), _ptr(total_in), _ptr(planes),
+                                   _ptr(partial), _ptr(out), B, D, H * W, int(bool(inverse_depth)), float(w_l1), float(w_ot),
+                                   float(w_stage), _stream())
+    _lib.check(rc, "stage_loss_fwd")
+    return planes, out
+
+
+def stage_loss_bwd(jac, planes, out, g_total, g_l1, g_ot, w_l1, w_ot, want_attn=True, want_mono=False):
+    """Backward of ``stage_loss_fwd``: jac [B,D,H,W]; g_* device scalars or None -> (g_attn [B,D,H,W] | None, g_mono [B,H,W]
+    | None).  One launch."""
+    B, D, H, W = jac.shape
+    for t, n in ((jac, "jac"), (planes, "planes"), (out, "out"), (g_total, "g_total"), (g_l1, "g_l1"), (g_ot, "g_ot")):
+        _chk(t, "stage_loss_bwd:" + n)
+    if planes.numel() != 2 * B * H * W or out.numel() != 6:
+        raise RuntimeError("stage_loss_bwd: inconsistent shapes")
+    g_attn = torch.empty_like(jac) if want_attn else None
+    g_mono = torch.empty(B, H, W, device=jac.device, dtype=torch.float32) if want_mono else None
+    rc = _lib.load().mvster_stage_loss_bwd(_ptr(jac), _ptr(planes), _ptr(out), _ptr(g_total), _ptr(g_l1), _ptr(g_ot), float(w_l1),
+                                           float(w_ot), _ptr(g_attn), _ptr(g_mono), B, D, H * W, _stream())
+    _lib.check(rc, "stage_loss_bwd")
+    return g_attn, g_mono
+
+
+def mono_depth_fwd(z, dmin, dmax):
+    """z [B,...] (H*W values per sample), dmin / dmax [B] -> (depth, sigmoid(z)), both of z's shape
+    (models/mvs4net_utils.py:858-866)."""
+    for t, n in ((z, "z"), (dmin, "dmin"), (dmax, "dmax")):
+        _chk(t, "mono_depth_fwd:" + n)
+    B = z.shape[0]
+    if dmin.numel() != B or dmax.numel() != B:
+        raise RuntimeError("mono_depth_fwd: d_min / d_max must hold one value per sample")
+    depth, sig = torch.empty_like(z), torch.empty_like(z)
+    rc = _lib.load().mvster_mono_depth_fwd(_ptr(z), _ptr(dmin), _ptr(dmax), _ptr(depth), _ptr(sig), B, z.numel() // B, _stream())
+    _lib.check(rc, "mono_depth_fwd")
+    return depth, sig
+
+
+def mono_depth_bwd(g, depth, sig, dmin, dmax):
+    for t, n in ((g, "g"), (depth, "depth"), (sig, "sig"), (dmin, "dmin"), (dmax, "dmax")):
+        _chk(t, "mono_depth_bwd:" + n)
+    B = depth.shape[0]
+    if g.numel() != depth.numel() or sig.numel() != depth.numel() or dmin.numel() != B or dmax.numel() != B:
+        raise RuntimeError("mono_depth_bwd: inconsistent shapes")
+    gz = torch.empty_like(depth)
+    rc = _lib.load().mvster_mono_depth_bwd(_ptr(g), _ptr(depth), _ptr(sig), _ptr(dmin), _ptr(dmax), _ptr(gz), B,
+                                           depth.numel() // B, _stream())
+    _lib.check(rc, "mono_depth_bwd")
+    return gz
+
+
+def upcat(a, b, backward=None):
+    """concat(nearest x2 of a [NB,1,H/2,W/2,Ca], b [NB,1,H,W,Cb]) along the channels, one launch; ``backward`` = the
+    gradient of that [NB,1,H,W,Ca+Cb] map -> (ga, gb) of a's and b's shapes (a, b: shape donors only)."""
+    NB, _, H, W, Cb = b.shape
+    Ca = a.shape[-1]
+    if tuple(a.shape) != (NB, 1, H // 2, W // 2, Ca) or (H | W) & 1:
+        raise RuntimeError("upcat: a must be [NB,1,H/2,W/2,Ca] for b [NB,1,H,W,Cb] with even H, W")
+    if (Ca | Cb) & 3:
+        raise NotImplementedError("upcat: channel counts %d + %d (the kernel moves 4 channels per lane)" % (Ca, Cb))
+    lib = _lib.load()
+    if backward is None:
+        _chk(a, "upcat:a")
+        _chk(b, "upcat:b")
+        out = torch.empty(NB, 1, H, W, Ca + Cb, device=b.device, dtype=torch.float32)
+        _lib.check(lib.mvster_upcat_fwd(_ptr(a), _ptr(b), _ptr(out), NB, H, W, Ca, Cb, _stream()), "upcat_fwd")
+        return out
+    _chk(backward, "upcat:g")
+    if tuple(backward.shape) != (NB, 1, H, W, Ca + Cb):
+        raise RuntimeError("upcat: gradient shape %s" % (tuple(backward.shape),))
+    ga = torch.empty(NB, 1, H // 2, W // 2, Ca, device=b.device, dtype=torch.float32)
+    gb = torch.empty(NB, 1, H, W, Cb, device=b.device, dtype=torch.float32)
+    _lib.check(lib.mvster_upcat_bwd(_ptr(backward), _ptr(ga), _ptr(gb), NB, H, W, Ca, Cb, _stream()), "upcat_bwd")
+    return ga, gb
+
+
+def fine_weights_fwd(wo, wi, bi):
+    """wo [CO,CM,3,3], wi [CM,CI(,1,1)], bi [CM] -> (wg [9*CO,CM,1,1], wc [CO,CI,3,3], vb [9,CO]): the composed weights
+    of the re-associated finest FPN level (train_ops.fpn_fine_level)."""
+    for t, n in ((wo, "wo"), (wi, "wi"), (bi, "bi")):
+        _chk(t, "fine_weights_fwd:" + n)
+    CO, CM = wo.shape[0], wo.shape[1]
+    CI = wi.shape[1]
+    if tuple(wo.shape) != (CO, CM, 3, 3) or wi.numel() != CM * CI or bi.numel() != CM:
+        raise RuntimeError("fine_weights_fwd: inconsistent shapes")
+    dev = wo.device
+    wg = torch.empty(9 * CO, CM, 1, 1, device=dev, dtype=torch.float32)
+    wc = torch.empty(CO, CI, 3, 3, device=dev, dtype=torch.float32)
+    vb = torch.empty(9, CO, device=dev, dtype=torch.float32)
+    _lib.check(_lib.load().mvster_fine_weights_fwd(_ptr(wo), _ptr(wi), _ptr(bi), _ptr(wg), _ptr(wc), _ptr(vb), CO, CM, CI,
+                                                   _stream()), "fine_weights_fwd")
+    return wg, wc, vb
+
+
+def fine_weights_bwd(wo, wi, bi, g_wg, g_wc, g_vb):
+    for t, n in ((wo, "wo"), (wi, "wi"), (bi, "bi"), (g_wg, "g_wg"), (g_wc, "g_wc"), (g_vb, "g_vb")):
+        _chk(t, "fine_weights_bwd:" + n)
+    CO, CM = wo.shape[0], wo.shape[1]
+    CI = wi.shape[1]
+    g_wo, g_wi, g_bi = torch.empty_like(wo), torch.empty_like(wi), torch.empty_like(bi)
+    _lib.check(_lib.load().mvster_fine_weights_bwd(_ptr(wo), _ptr(wi), _ptr(bi), _ptr(g_wg), _ptr(g_wc), _ptr(g_vb), _ptr(g_wo),
+                                                   _ptr(g_wi), _ptr(g_bi), CO, CM, CI, _stream()), "fine_weights_bwd")
+    return g_wo, g_wi, g_bi

@@ -41,6 +41,46 @@ def _triple(v, lead):
     return v if len(v) == 3 else (lead,) + v
 
 
+class _EpochCells:
+    """tensor -> epoch cell (a one-element list), held by identity WITHOUT keeping the tensor alive: entries die with
+    their tensor (a weakref callback removes them), and a lookup checks that the entry still belongs to the tensor
+    asked about -- a later tensor that reuses the id of a dead one never inherits its cell."""
+
+    def __init__(self):
+        self._d = {}
+
+    def __bool__(self):
+        return bool(self._d)
+
+    def __len__(self):
+        return len(self._d)
+
+    def set(self, tensor, cell):
+        import weakref
+        key = id(tensor)
+        d = self._d
+
+        def gone(_ref, key=key):
+            hit = d.get(key)
+            if hit is not None and hit[0] is _ref:
+                del d[key]
+        d[key] = (weakref.ref(tensor, gone), cell)
+
+    def get(self, tensor):
+        hit = self._d.get(id(tensor))
+        if hit is None or hit[0]() is not tensor:
+            return None
+        return hit[1]
+
+    def drop(self, cell):
+        """Forget every tensor registered under ``cell`` (a GraphedTrainStep going away)."""
+        for k in [k for k, v in self._d.items() if v[1] is cell]:
+            del self._d[k]
+
+    def clear(self):
+        self._d.clear()
+
+
 class _LayerCache:
     """ConvLayer objects per (parameter, role): built once, re-packed when the parameter changes, so a training step
     costs a few small device ops per layer instead of a plan build.
@@ -58,8 +98,11 @@ class _LayerCache:
 
     def __init__(self):
         self._d = {}
-        self.cells = {}                # id(parameter / buffer) -> [epoch]; see above
+        self.cells = _EpochCells()     # parameter / buffer -> [epoch]; see above
         self.always_repack = False
+        # bumped whenever a training-mode BatchNorm writes running statistics through raw pointers (ops.bn_batch_stats moves
+        # no ``_version``): part of ``MVS4net._state_stamp``, so an eval graph folded from the old statistics is not replayed
+        self.stat_writes = 0
         self._batch = None             # see build_batch()
         self._batch_active = False
 
@@ -74,7 +117,7 @@ class _LayerCache:
             weight = owner
         key = (id(weight), role)
         hit = self._d.get(key)
-        cell = self.cells.get(id(weight)) if self.cells else None
+        cell = self.cells.get(weight) if self.cells else None
         stamp = (weight._version, weight.data_ptr(), 0 if cell is None else cell[0])
         if hit is not None and hit[0] is weight and hit[2].wpk.device == weight.device:
             if self._batch_active and key in self._batch["keys"]:
@@ -174,7 +217,7 @@ CACHE = _LayerCache()
 
 class _ConvCL(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, transposed, skip=None, skip_upsample=False, owner=None):
+    def forward(ctx, x, weight, bias, stride, padding, transposed, skip=None, skip_upsample=False, owner=None, tap=False):
         w5 = weight if weight.dim() == 5 else weight.unsqueeze(2)
         own, tag = owner if owner is not None else (None, "")
         cin = w5.shape[0] if transposed else w5.shape[1]
@@ -197,10 +240,19 @@ class _ConvCL(torch.autograd.Function):
         ctx.save_for_backward(xp, weight, bias)
         ctx.cfg = (stride, padding, transposed, cin, x.shape[-1])
         ctx.owner = (own, tag)
+        ctx.tap = tap
+        if tap:
+            # second output: x itself, for the OTHER consumers of x (a U-Net skip connection, an FPN lateral).  Their gradient
+            # comes back here and is added in the input-gradient kernel's epilogue -- instead of the autograd engine's
+            # accumulate, a full-size read-read-write launch per fan-out (18 per step, 0.39 ms at 512x640x5, B = 2)
+            ctx.set_materialize_grads(False)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gtap=None):
+        if gy is None:                     # (only the tap was used)
+            return (gtap,) + (None,) * 9
         xp, weight, bias = ctx.saved_tensors
         stride, padding, transposed, cin, x_channels = ctx.cfg
         own, tag = ctx.owner
@@ -228,11 +280,20 @@ class _ConvCL(torch.autograd.Function):
                 # stride 2: the adjoint is the transposed conv with the same weights (parity classes)
                 layer = CACHE.get(weight, "dgrad" + tag, lambda: ConvLayer(w5, True, stride, padding, cin_pad=co_p),
                                   lambda L: L.repack_on_device(weight), owner=own, rargs=(False, False))
-            gx = layer(gyp)
+            fused_tap = gtap is not None and layer.cout == x_channels and tuple(gtap.shape[:4]) == tuple(xp.shape[:4])
+            if fused_tap:
+                from .conv_plan import SKIP_ADD
+                gx = layer(gyp, skip=gtap.contiguous(), skip_mode=SKIP_ADD)
+            else:
+                gx = layer(gyp)
             if tuple(gx.shape[:4]) != tuple(xp.shape[:4]):
                 raise RuntimeError("conv_cl: input gradient of a strided layer needs even input sizes (%s -> %s)"
                                    % (tuple(xp.shape), tuple(gx.shape)))
             gx = gx[..., :x_channels]
+            if gtap is not None and not fused_tap:
+                gx = gx + gtap
+        elif gtap is not None:
+            gx = gtap
         if ctx.needs_input_grad[1]:
             if transposed:
                 gw = ops.conv_wgrad(gyp, xp, kernel, stride, padding, co_keep=cin, ci_keep=co)   # [cin, cout, k]
@@ -253,16 +314,18 @@ class _ConvCL(torch.autograd.Function):
             if ctx.has_skip[1]:       # adjoint of the bilinear x2 (gather form, no atomics)
                 B_, D_, H_, W_, C_ = gy.shape
                 gskip = ops.upsample2x_cl(gy.reshape(B_ * D_, H_, W_, C_), backward=True).reshape(B_, D_, H_ // 2, W_ // 2, C_)
-        return gx, gw, gb, None, None, None, gskip, None, None
+        return gx, gw, gb, None, None, None, gskip, None, None, None
 
 
-def conv_cl(x, weight, bias=None, stride=1, padding=0, transposed=False, skip=None, skip_upsample=False, owner=None):
+def conv_cl(x, weight, bias=None, stride=1, padding=0, transposed=False, skip=None, skip_upsample=False, owner=None, tap=False):
     """x [B,D,H,W,Cin] channels-last -> [B,Do,Ho,Wo,Cout]; weight in nn.Conv3d / nn.Conv2d / nn.ConvTranspose3d
     layout (a 4-D weight is a depth-1 convolution).  ``skip`` is added in the kernel's epilogue: a tensor of the output's
-    shape, or with ``skip_upsample`` a [B,1,Ho/2,Wo/2,Cout] map that is bilinearly up-sampled x2 (align_corners) on the fly."""
+    shape, or with ``skip_upsample`` a [B,1,Ho/2,Wo/2,Cout] map that is bilinearly up-sampled x2 (align_corners) on the fly.
+    ``tap``: -> (y, x') with x' an alias of x for x's other consumers: what flows back into x' is added to the input
+    gradient inside the input-gradient kernel (use x' INSTEAD of x downstream, or the fan-out costs an add launch again)."""
     lead_s, lead_p = 1, 0
     return _ConvCL.apply(x, weight, bias, _triple(stride, lead_s), _triple(padding, lead_p), transposed, skip, skip_upsample,
-                         owner)
+                         owner, tap)
 
 
 def tap_bias_grad(gP):
@@ -318,6 +381,28 @@ class _FpnGather(torch.autograd.Function):
         return gf, gwg, gvb, None, None, None
 
 
+class _FineWeights(torch.autograd.Function):
+    """(wg, wc, vb) of ``fpn_fine_level`` from out.weight, inner.weight, inner.bias: one single-workgroup launch each way
+    (as einsum / permute / reshape expressions: ~20 launches per step, three of them rocBLAS calls)."""
+
+    @staticmethod
+    def forward(ctx, wo, wi, bi):
+        wo_c, wi_c, bi_c = wo.detach().contiguous(), wi.detach().contiguous(), bi.detach().contiguous()
+        ctx.save_for_backward(wo_c, wi_c, bi_c)
+        ctx.set_materialize_grads(False)
+        return ops.fine_weights_fwd(wo_c, wi_c, bi_c)
+
+    @staticmethod
+    def backward(ctx, g_wg, g_wc, g_vb):
+        wo, wi, bi = ctx.saved_tensors
+
+        def c(g):
+            return None if g is None else g.contiguous()
+        if g_wg is None and g_wc is None and g_vb is None:
+            return None, None, None
+        return ops.fine_weights_bwd(wo, wi, bi, c(g_wg), c(g_wc), c(g_vb))
+
+
 def fpn_fine_level(c_low, f_coarse, inner, out):
     """out(F.interpolate(f_coarse, x2 bilinear, align_corners) + inner(c_low)) of the FPN's top-down path
     (models/mvs4net_utils.py:488-489) WITHOUT forming the 64-channel map at c_low's resolution (839 MB for ten 512x640
@@ -326,11 +411,9 @@ def fpn_fine_level(c_low, f_coarse, inner, out):
     = the gather-sum of a 1x1 conv of f_coarse (_FpnGather) + a 3x3 conv of c_low with the composed weights; the composed
     weights are differentiable functions of the parameters, so autograd carries the gradients back to ``out.weight``,
     ``inner.weight`` and ``inner.bias``.  Same re-association as the inference plan (conv_plan.FpnPlan)."""
-    wo = out.weight                                                       # [co, 64, 3, 3]
-    co = wo.shape[0]
-    wg = wo.permute(2, 3, 0, 1).reshape(9 * co, wo.shape[1], 1, 1)        # row = tap*co + co_idx
-    wc = torch.einsum("ocyx,ci->oiyx", wo, inner.weight[:, :, 0, 0])      # [co, cin, 3, 3]
-    vb = torch.einsum("ocyx,c->yxo", wo, inner.bias).reshape(9, co)
+    # wg [9co, 64, 1, 1] (row = tap*co + co_idx) = out.weight permuted; wc [co, cin, 3, 3] = out.weight x inner.weight;
+    # vb [9, co] = out.weight x inner.bias
+    wg, wc, vb = _FineWeights.apply(out.weight, inner.weight, inner.bias)
     H, W = c_low.shape[2], c_low.shape[3]
     P = _FpnGather.apply(f_coarse, wg, vb, H, W, out.weight)
     return conv_cl(c_low, wc, out.bias, out.stride, out.padding, skip=P, owner=(out.weight, "_fine_c"))
@@ -378,6 +461,8 @@ def batch_norm_cl(x, bn, relu=False, groups=1, skip=None):
         track = bn.track_running_stats
         if track and bn.momentum is None:
             raise NotImplementedError("batch_norm_cl: cumulative-average running statistics (momentum=None)")
+        if track:
+            CACHE.stat_writes += 1
         with torch.no_grad():
             pack = ops.bn_batch_stats(x, bn.weight, bn.bias, bn.running_mean if track else None,
                                       bn.running_var if track else None, bn.eps, bn.momentum or 0.0, groups,
@@ -408,3 +493,42 @@ def upsample2x_cl(x, mode):
     gather-form adjoint (no atomics)."""
     B, D, H, W, C = x.shape
     return _Upsample2xCL.apply(x.reshape(B * D, H, W, C), mode).reshape(B, D, 2 * H, 2 * W, C)
+
+
+class _UpCat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b)          # (shape donors; both are alive as other nodes' saved tensors anyway)
+        return ops.upcat(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        return ops.upcat(a, b, backward=g.contiguous())
+
+
+def upcat_cl(a, b):
+    """torch.cat([nearest x2 of a, b], -1) for channels-last maps a [NB,1,H/2,W/2,Ca], b [NB,1,H,W,Cb] -- the input of the
+    monocular head's 3x3 convolutions (models/mvs4net_utils.py:854-857) -- one launch forward, one backward."""
+    return _UpCat.apply(a, b)
+
+
+class _MonoDepth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, dmin, dmax):
+        dmin, dmax = dmin.detach().to(torch.float32).contiguous(), dmax.detach().to(torch.float32).contiguous()
+        depth, sig = ops.mono_depth_fwd(z.contiguous(), dmin, dmax)
+        ctx.save_for_backward(depth, sig, dmin, dmax)
+        return depth
+
+    @staticmethod
+    def backward(ctx, g):
+        depth, sig, dmin, dmax = ctx.saved_tensors
+        return ops.mono_depth_bwd(g.contiguous(), depth, sig, dmin, dmax), None, None
+
+
+def mono_depth_cl(z, d_min, d_max):
+    """1 / (1/d_max + (1/d_min - 1/d_max) * sigmoid(z)) per sample (models/mvs4net_utils.py:858-866), z of any shape
+    [B, ...]; one launch forward, one backward (as tensor expressions: ~13 forward and ~10 backward launches per stage)."""
+    return _MonoDepth.apply(z, d_min, d_max)

@@ -895,3 +895,143 @@ def test_fused_stage_selection_vs_autograd(D, inverse):
         note("fused_selection_D%d_%s" % (D, name), rel_l2=e)
         assert e <= 2e-6, (name, e)
     assert not res[1].requires_grad and res[0].requires_grad
+
+
+# ---- round 6: the training step's glue on fused kernels (csrc/train_glue.hip) ------------------------------------------
+def test_conv_cl_tap_adds_the_second_consumers_gradient_in_the_kernel():
+    """conv_cl(..., tap=True): y and an alias of x for x's other consumers; what flows back into the alias is added in the
+    input-gradient kernel's epilogue (no autograd accumulate launch).  Against the plain two-consumer graph, for a stride-1,
+    a stride-2 and a transposed layer."""
+    g = torch.Generator().manual_seed(3)
+    for cin, cout, k, s, p, tr, shape in [(16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1), False, (2, 3, 12, 20)),
+                                          (16, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), False, (2, 3, 12, 20)),
+                                          (8, 16, (1, 5, 5), (1, 2, 2), (0, 2, 2), False, (3, 1, 16, 24)),
+                                          (64, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 1, 9, 13)),
+                                          (32, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1), True, (1, 2, 6, 10))]:
+        B, D, H, W = shape
+        w = (0.2 * torch.randn((cin, cout) + k if tr else (cout, cin) + k, generator=g)).to(DEV)
+        x0 = torch.randn(B, D, H, W, cin, generator=g).to(DEV)
+        other = torch.randn(B, D, H, W, cin, generator=g).to(DEV)
+        res = []
+        for tap in (False, True):
+            x = x0.clone().requires_grad_(True)
+            wp = w.clone().requires_grad_(True)
+            xin = x * 1.0                                  # (a non-leaf, like an activation)
+            if tap:
+                y, xt = T.conv_cl(xin, wp, None, s, p, transposed=tr, tap=True)
+            else:
+                y, xt = T.conv_cl(xin, wp, None, s, p, transposed=tr), xin
+            (y.square().sum() + (xt * other).sum()).backward()
+            res.append((y.detach(), x.grad.clone(), wp.grad.clone()))
+        assert torch.equal(res[0][0], res[1][0])
+        scale = res[0][1].abs().max().item()
+        assert (res[0][1] - res[1][1]).abs().max().item() <= 1e-6 * scale, (cin, cout, k, s, tr)
+        assert torch.equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("lw,l1ot", [([1, 1, 1, 1], [0, 1]), ([0.5, 1.0, 1.5, 2.0], [0.3, 0.7])])
+def test_loss_total_chain_vs_tensor_form(lw, l1ot):
+    """MVS4net_loss's weighted total carried through the stages' fused kernels (mvster_stage_loss_fwd / _bwd) against the
+    reference's tensor expression  total += stage_lw * (l1ot_lw[0] * l1 + l1ot_lw[1] * ot)  (models/MVS4Net.py:151) on the
+    per-stage terms of ``stage_losses``: value and the gradients of every stage's attn_weight / mono_depth."""
+    from mvster_amd.loss import stage_losses
+    g = torch.Generator().manual_seed(11)
+    B = 2
+    inputs, gts, masks = {}, {}, {}
+    for si, (D, H, W) in enumerate([(8, 8, 10), (8, 16, 20), (4, 32, 40), (4, 64, 80)]):
+        key = "stage%d" % (si + 1)
+        inv = 1.0 / 900 + 2e-5 * (torch.arange(D).view(1, D, 1, 1) + 0.1 * torch.rand(B, D, H, W, generator=g))
+        hypo = (1.0 / inv).float().to(DEV)
+        gt = (1.0 / (1.0 / 900 + 2e-5 * (-1.0 + (D + 1) * torch.rand(B, H, W, generator=g)))).float()
+        mask = torch.rand(B, H, W, generator=g) > 0.3
+        gt[~mask] = 0.0
+        st = {"hypo_depth": hypo, "attn_weight": torch.softmax(3 * torch.randn(B, D, H, W, generator=g), 1).to(DEV)}
+        if si > 0:
+            st["mono_depth"] = (gt + 5 * torch.randn(B, H, W, generator=g)).float().to(DEV)
+        inputs[key], gts[key], masks[key] = st, gt.to(DEV), mask.float().to(DEV)
+    kw = dict(stage_lw=lw, l1ot_lw=l1ot, inverse_depth=True, ot_iter=10, ot_eps=1, ot_continous=False, mono=True)
+
+    def leaves():
+        out = {}
+        for k, st in inputs.items():
+            out[k] = {kk: (vv.clone().requires_grad_(True) if kk != "hypo_depth" else vv) for kk, vv in st.items()}
+        return out
+    a = leaves()
+    total, l1s, ots, rng = MVS4net_loss(a, gts, masks, **kw)
+    (3.0 * total).backward()
+    b = leaves()
+    want = torch.zeros((), device=DEV)
+    for si, k in enumerate(b):
+        l1, ot, _ = stage_losses(gts[k], b[k]["hypo_depth"], b[k]["attn_weight"], masks[k], b[k].get("mono_depth"), iters=10, eps=1,
+                                 inverse=True)
+        want = want + lw[si] * (l1ot[0] * l1 + l1ot[1] * ot)
+        assert abs(l1.item() - l1s[si].item()) <= 1e-6 * abs(l1.item()) and abs(ot.item() - ots[si].item()) <= 1e-6 * abs(ot.item())
+    (3.0 * want).backward()
+    assert abs(total.item() - want.item()) <= 2e-7 * abs(want.item()), (total.item(), want.item())
+    for k in a:
+        for kk in ("attn_weight", "mono_depth"):
+            if kk in a[k]:
+                ga, gb = a[k][kk].grad, b[k][kk].grad
+                if l1ot[0] == 0 and kk == "mono_depth":
+                    assert ga is None or ga.abs().max().item() == 0.0
+                    continue
+                assert (ga - gb).abs().max().item() <= 2e-6 * gb.abs().max().item(), (k, kk)
+
+
+def test_mono_depth_and_upcat_vs_tensor_form():
+    """The monocular head's fused pieces against the reference's expressions (models/mvs4net_utils.py:854-866):
+    cat(nearest x2, feature) and 1 / (1/d_max + (1/d_min - 1/d_max) * sigmoid(z)), values and gradients."""
+    g = torch.Generator().manual_seed(5)
+    a0 = torch.randn(3, 1, 6, 10, 16, generator=g).to(DEV)
+    b0 = torch.randn(3, 1, 12, 20, 8, generator=g).to(DEV)
+    wgt = torch.randn(3, 1, 12, 20, 24, generator=g).to(DEV)
+    res = []
+    for fused in (True, False):
+        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        if fused:
+            y = T.upcat_cl(a, b)
+        else:
+            up = F.interpolate(a[:, 0].permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1).unsqueeze(1)
+            y = torch.cat([up, b], -1)
+        (y * wgt).sum().backward()
+        res.append((y.detach(), a.grad, b.grad))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
+    assert (res[0][1] - res[1][1]).abs().max().item() <= 1e-6 * res[1][1].abs().max().item()
+    z0 = (2 * torch.randn(2, 24, 36, generator=g)).to(DEV)
+    dmin, dmax = torch.tensor([425.0, 500.0], device=DEV), torch.tensor([935.0, 1200.0], device=DEV)
+    wz = torch.randn(2, 24, 36, generator=g).to(DEV)
+    res = []
+    for fused in (True, False):
+        z = z0.clone().requires_grad_(True)
+        if fused:
+            d = T.mono_depth_cl(z, dmin, dmax)
+        else:
+            lo, hi = (1 / dmax)[:, None, None], (1 / dmin)[:, None, None]
+            d = 1 / (lo + (hi - lo) * torch.sigmoid(z))
+        (d * wz).sum().backward()
+        res.append((d.detach(), z.grad))
+    assert (res[0][0] - res[1][0]).abs().max().item() <= 2e-7 * res[1][0].abs().max().item()
+    assert (res[0][1] - res[1][1]).abs().max().item() <= 2e-6 * res[1][1].abs().max().item()
+
+
+def test_fine_weights_vs_tensor_form():
+    """Composed weights of the re-associated finest FPN level (mvster_fine_weights_fwd / _bwd) against the einsum form."""
+    g = torch.Generator().manual_seed(9)
+    wo0 = torch.randn(8, 64, 3, 3, generator=g).to(DEV)
+    wi0 = torch.randn(64, 8, 1, 1, generator=g).to(DEV)
+    bi0 = torch.randn(64, generator=g).to(DEV)
+    cw = [torch.randn(72, 64, 1, 1, generator=g).to(DEV), torch.randn(8, 8, 3, 3, generator=g).to(DEV), torch.randn(9, 8, generator=g).to(DEV)]
+    res = []
+    for fused in (True, False):
+        wo, wi, bi = (t.clone().requires_grad_(True) for t in (wo0, wi0, bi0))
+        if fused:
+            wg, wc, vb = T._FineWeights.apply(wo, wi, bi)
+        else:
+            wg = wo.permute(2, 3, 0, 1).reshape(72, 64, 1, 1)
+            wc = torch.einsum("ocyx,ci->oiyx", wo, wi[:, :, 0, 0])
+            vb = torch.einsum("ocyx,c->yxo", wo, bi).reshape(9, 8)
+        ((wg * cw[0]).sum() + (wc * cw[1]).sum() + (vb * cw[2]).sum()).backward()
+        res.append([wg.detach(), wc.detach(), vb.detach(), wo.grad, wi.grad, bi.grad])
+    for x, y in zip(*res):
+        assert x.shape == y.shape
+        assert (x - y).abs().max().item() <= 2e-5 * y.abs().max().item()
