@@ -228,6 +228,12 @@ int mvster_pack_conv_weights(const float* w, float* wpk, int cout, int cin, int 
 int mvster_pack_wino_weights(const float* w, float* wpk, int cout, int cin, int cin_pad, int kd, long s_n, long s_c, long s_z,
                              long s_y, long s_x, int flip, void* stream);
 
+/* The same for every record of a DEVICE table in ONE launch (the training step re-transforms the weights of all its
+ * Winograd layers after each optimizer update): 88-byte records {const float* w; float* wpk; long s_n, s_c, s_z, s_y, s_x;
+ * int cout, cin_raw, cin_pad, kd, flip, ntile, first_block, pad}, ntile = ceil(cout / 16), first_block = prefix sum of
+ * ceil(kd*16*cin_pad*ntile*16 / 256) over the earlier records, total_blocks = their sum. */
+int mvster_pack_wino_batch(const void* descs, int ndesc, int total_blocks, void* stream);
+
 /* The same refresh for a transposed layer (output-parity classes): w [cin, cout, kd, kh, kw] contiguous, ktot = kd*kh*kw
  * <= 27; class c packs the taps taps[c*27 .. c*27 + ntaps[c]) (flattened indices, input-offset order) at float offset
  * woff[c] of wpk. */
@@ -274,16 +280,18 @@ int mvster_conv_wgrad_finish(const float* partial, float* dw, int nblk, int ngrp
  *                gradients dbeta [C] = sum_g sum g_, dgamma [C] = sum_g sum g_*xh
  *   bwd_apply:   dx = scale * (g_ - sums[g][0]/rows - xh * sums[g][1]/rows),   g_ = gy * (y > 0), xh = (x - mean) * rstd;
  *                frozen = 1 (statistics are constants): dx = scale * g_
- * partial: [groups][mvster_bn_slots(rows, C, groups)][2][C] floats of scratch. */
+ * partial: [groups][mvster_bn_slots(rows, C, groups)][2][C] floats of scratch.  stats and bwd_reduce are ONE launch each:
+ * the last workgroup to arrive (ticket: one device int, 0 before the call and 0 again after it) adds the slots in a fixed
+ * order in fp64 and writes the results (slots published with write-through stores: no L2 write-back); groups*2C <= 2048. */
 int mvster_bn_relu_fwd(const float* x, const float* scale, const float* shift, const float* skip, float* y, long rows,
                        int C, int relu, int groups, void* stream);
 int mvster_bn_slots(long rows, int C, int groups);
 int mvster_bn_stats(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
-                    long* num_batches_tracked, float* partial, float* out, long rows, int C, int groups, float eps,
-                    float momentum, void* stream);
+                    long* num_batches_tracked, float* partial, float* out, int* ticket, long rows, int C, int groups,
+                    float eps, float momentum, void* stream);
 int mvster_bn_relu_bwd_reduce(const float* x, const float* gy, const float* scale, const float* shift, const float* mean,
-                              const float* rstd, float* partial, float* sums, float* dgamma, float* dbeta, long rows, int C,
-                              int relu, int groups, void* stream);
+                              const float* rstd, float* partial, float* sums, float* dgamma, float* dbeta, int* ticket,
+                              long rows, int C, int relu, int groups, void* stream);
 int mvster_bn_relu_bwd_apply(const float* x, const float* gy, const float* scale, const float* shift, const float* mean,
                              const float* rstd, const float* sums, float* dx, long rows, int C, int relu, int groups,
                              int frozen, void* stream);
@@ -372,11 +380,12 @@ int mvster_fine_weights_bwd(const float* wo, const float* wi, const float* bi, c
 /* Adam update (torch.optim.Adam semantics with L2 weight decay, no amsgrad; train_mvs4.py:367) of `count` fp32 tensors:
  * params / grads = HOST arrays of `count` device pointers, sizes / state_offs = host int arrays (elements; offsets of a
  * tensor's moments in the flat exp_avg / exp_avg_sq buffers).  step_cells [2] device floats: cell 0 = number of updates
- * done so far, + 1 afterwards (cell 1 scratch).  ceil(count / 128) launches (+ 1 when that is odd); the pointers travel as
+ * done so far, + 1 afterwards (cell 1 scratch); lr = one DEVICE float (a schedule reaches a captured step by rewriting
+ * it between replays).  ceil(count / 128) launches (+ 1 when that is odd); the pointers travel as
  * kernel arguments, so a captured step records them with the launch. */
 int mvster_fused_adam(const void* const* params, const void* const* grads, const int* sizes, const int* state_offs, int count,
-                      float* exp_avg, float* exp_avg_sq, float* step_cells, float lr, float beta1, float beta2, float eps,
-                      float weight_decay, void* stream);
+                      float* exp_avg, float* exp_avg_sq, float* step_cells, const float* lr, double beta1, double beta2,
+                      double eps, double weight_decay, void* stream);
 
 /* Batched gather, one launch: for every record r of the DEVICE table `descs` (32-byte records {const float* src; float* dst;
  * const int* idx; int n; int first_block}), dst[i] = idx[i] > 0 ? src[idx[i] - 1] : 0, i < n (n % 4 == 0); first_block =

@@ -43,14 +43,15 @@ SIGNATURES = {
     "mvster_fpn_tail_gather_bwd": [_f, _f, _i, _i, _i, _i, _i, _f],
     "mvster_pack_conv_weights": [_f, _f] + [_i] * 6 + [_l] * 5 + [_i, _f],
     "mvster_pack_wino_weights": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _l, _l, _i, _f],
+    "mvster_pack_wino_batch": [_f, _i, _i, _f],
     "mvster_pack_conv_weights_classes": [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f],
     "mvster_conv_wgrad": [_f, _f, _f] + [_i] * 20 + [_f],
     "mvster_conv_wgrad_slots": [_i] * 12,
     "mvster_bn_relu_fwd": [_f, _f, _f, _f, _f, _l, _i, _i, _i, _f],
     "mvster_conv_wgrad_finish": [_f, _f] + [_i] * 10 + [_f],
     "mvster_bn_slots": [_l, _i, _i],
-    "mvster_bn_stats": [_f] * 8 + [_l, _i, _i, _fl, _fl, _f],
-    "mvster_bn_relu_bwd_reduce": [_f] * 10 + [_l, _i, _i, _i, _f],
+    "mvster_bn_stats": [_f] * 9 + [_l, _i, _i, _fl, _fl, _f],
+    "mvster_bn_relu_bwd_reduce": [_f] * 11 + [_l, _i, _i, _i, _f],
     "mvster_bn_relu_bwd_apply": [_f] * 8 + [_l, _i, _i, _i, _i, _f],
     "mvster_upsample2x_cl_fwd": [_f, _f, _i, _i, _i, _i, _f],
     "mvster_upsample2x_cl_bwd": [_f, _f, _i, _i, _i, _i, _f],
@@ -67,7 +68,7 @@ SIGNATURES = {
     "mvster_upcat_bwd": [_f, _f, _f, _i, _i, _i, _i, _i, _f],
     "mvster_fine_weights_fwd": [_f] * 6 + [_i, _i, _i, _f],
     "mvster_fine_weights_bwd": [_f] * 9 + [_i, _i, _i, _f],
-    "mvster_fused_adam": [_f, _f, _f, _f, _i, _f, _f, _f, _fl, _fl, _fl, _fl, _fl, _f],
+    "mvster_fused_adam": [_f, _f, _f, _f, _i, _f, _f, _f, _f] + [ctypes.c_double] * 4 + [_f],
     "mvster_geo_filter": [_f] * 10 + [_i, _i, _i, _fl, _fl, _f],
     "mvster_mfma_probe": [_f, _f, _f, _f],
     "mvster_gather_batch": [_f, _i, _i, _f],

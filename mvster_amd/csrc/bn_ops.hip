@@ -1,17 +1,18 @@
 // Training-mode BatchNorm + ReLU on channels-last activations [rows, C] (C in {4,...,64}, multiple of 4):
 // the elementwise half of the reference's conv -> BatchNorm -> ReLU blocks (models/mvs4net_utils.py:116-123,
-// :224-251) under autograd.  HBM-bound streaming kernels; the batch statistics themselves come from the host
-// side (torch.var_mean, one pass).  Forward 1 read + 1 write; backward 4 reads + 1 write (PyTorch's autograd
-// over the unfused ops makes ~19 passes).
+// :224-251) under autograd.  HBM-bound streaming kernels.  Forward 2 reads + 1 write; backward 4 reads + 1 write
+// (PyTorch's autograd over the unfused ops makes ~19 passes).
 //   y  = relu(x * scale + shift)                  scale = gamma * rstd, shift = beta - mean * scale
 //   g  = gy * (y > 0)            xh = (x - mean) * rstd
 //   dbeta = sum g     dgamma = sum g * xh         dx = scale * (g - dbeta/N - xh * dgamma/N)
 // Every thread owns one float4 column group (blockDim*4 is a multiple of C), so per-channel sums stay in
-// registers along the grid-stride loop and are reduced once per workgroup through LDS into a per-workgroup
-// slot of `partial` [groups][nblk][2][C].  A small second kernel adds the slots in a fixed order and in fp64
-// (deterministic) and writes the finished statistics / sums.  (Finishing in the last workgroup of the first kernel
-// instead -- a ticket counter -- needs an agent-scope fence per workgroup, which on gfx950 writes the XCD's L2 back:
-// measured +5 ms per training step.)
+// registers along the grid-stride loop and are reduced once per workgroup (wave shuffles, then LDS) into a
+// per-workgroup slot of `partial` [groups][nblk][2][C].  The LAST workgroup to arrive (a ticket counter) adds the slots in
+// a fixed order and in fp64 (deterministic) and writes the finished statistics / sums: one launch per reduction.
+// Rounds 1-5 finished in a second launch (7 / 6 us each, 108 launches per training step), because the ticket form written
+// with __threadfence() costs an agent-scope release per workgroup, which on gfx950 writes the XCD's L2 back: +5 ms per
+// step.  The form here publishes the slots with write-through (sc1) stores and reads them with sc1 loads -- no L2
+// write-back, no L1 invalidate (MI355X_MICROARCH.md, "inter-workgroup visibility": sc1 stores and loads on both sides).
 #include "common.hpp"
 
 namespace {
@@ -22,6 +23,88 @@ __device__ __forceinline__ float bn_act(float x, float sc, float sh) { return fm
 // `cond ? g : 0.0f` on a just-loaded g into "g = 0; if (cond) {}" in the apply kernel (wrong code, caught by
 // tests/test_gpu_train.py::test_batch_norm_cl_matches_torch).
 __device__ __forceinline__ float relu_mask(int relu, float act) { return (relu == 0 || act > 0.0f) ? 1.0f : 0.0f; }
+
+// ---- one-launch reductions: write-through slots, ticket, last arriver finishes -----------------------------------------
+constexpr int kRedThreads = 1024;          // workgroup size of the two reduction kernels (<= 256 of them per launch)
+
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// True (in every thread) for the last workgroup of the grid to get here.  Every workgroup's st_agent stores issued before
+// the call are then visible to that workgroup's ld_agent loads.  The ticket is left at 0 for the next launch.
+__device__ __forceinline__ bool last_arriver(int* ticket, int total) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's write-through stores have completed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == total - 1;
+        if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
+// The eight per-thread sums of a reduction kernel (values 0-3: first slot row, 4-7: second) -> this workgroup's slot
+// [2][C]: lanes that own the same column group meet by wave shuffles (q = C/4 divides 64), the 16 waves through LDS.
+__device__ __forceinline__ void publish_slot(float (&v)[8], float* slot, int C, float (*red)[16][8]) {
+    const int q = C >> 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        for (int o = 32; o >= q; o >>= 1) v[j] += __shfl_down(v[j], o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < q) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave][lane][j] = v[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < q * 8) {
+        const int grp = threadIdx.x >> 3, val = threadIdx.x & 7;
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kRedThreads / 64; ++w) s += red[w][grp][val];
+        st_agent(slot + (val >> 2) * C + grp * 4 + (val & 3), s);
+    }
+}
+
+// Last workgroup: tot[g * 2C + col] (fp64, LDS) = the sum over the nblk slots of group g, for every group and column;
+// slots are walked in index order by a fixed number of lanes per column: deterministic.
+constexpr int kMaxPairs = 2048;            // groups * 2C the finishing workgroup holds (16 views x 64 channels)
+__device__ __forceinline__ void sum_slots(const float* __restrict__ partial, int nblk, int groups, int C, double* tot,
+                                          double* red) {
+    const int ncol = 2 * C, pairs = groups * ncol;
+    for (int base = 0; base < pairs; base += kRedThreads) {
+        const int np = pairs - base < kRedThreads ? pairs - base : kRedThreads;
+        int lanes = 1;
+        while (lanes * 2 * np <= kRedThreads) lanes *= 2;
+        const int pair = threadIdx.x % np, lane = threadIdx.x / np;
+        double s = 0.0;
+        if (lane < lanes) {
+            const int g = (base + pair) / ncol, col = (base + pair) - g * ncol;
+            const float* pg = partial + (long)g * nblk * ncol + col;
+            // (eight independent loads in flight per round: the slots were written through to memory, a load is ~1-2 us)
+            for (int n = lane; n < nblk; n += lanes * 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int m = n + u * lanes;
+                    t[u] = m < nblk ? ld_agent(pg + (long)m * ncol) : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += (double)t[u];
+            }
+        }
+        __syncthreads();
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = lanes >> 1; w > 0; w >>= 1) {
+            if (lane < w) red[threadIdx.x] += red[threadIdx.x + w * np];
+            __syncthreads();
+        }
+        if (lane == 0) tot[base + pair] = red[threadIdx.x];
+    }
+    __syncthreads();
+}
 
 // blockIdx.y = statistics group (the reference normalises every view's batch separately): group g owns rows
 // [g*rows, (g+1)*rows) of x and row g of the per-channel parameter arrays.
@@ -49,85 +132,48 @@ __global__ void __launch_bounds__(256) bn_relu_fwd_kernel(const float* __restric
     }
 }
 
-// Batch statistics, one pass: per (group, channel) sums of (x - p) and (x - p)^2 with the pivot p = the group's
-// first row (keeps the E[d^2] - E[d]^2 subtraction well conditioned whatever the channel's mean is).  Same thread
-// mapping and per-workgroup partial slots as the backward reduction.
-__global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__ x, float* __restrict__ partial, long n4, int C) {
-    __shared__ float red[256][8];
-    x += (long)blockIdx.y * n4 * 4;
-    partial += (long)blockIdx.y * gridDim.x * 2 * C;
-    const int q = C >> 2;
-    const long stride = (long)gridDim.x * 256;
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const int cg = (int)(i % q) * 4;
-    const f32x4 pv = ld4(x + cg);
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    for (; i < n4; i += stride) {
-        const f32x4 v = ld4(x + i * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float d = v[j] - pv[j];
-            s1[j] += d;
-            s2[j] = fmaf(d, d, s2[j]);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { red[threadIdx.x][j] = s1[j]; red[threadIdx.x][4 + j] = s2[j]; }
-    __syncthreads();
-    if (threadIdx.x < q * 8) {
-        const int grp = threadIdx.x >> 3, val = threadIdx.x & 7;
-        float s = 0.0f;
-        for (int t = grp; t < 256; t += q) s += red[t][val];
-        partial[((long)blockIdx.x * 2 + (val >> 2)) * C + grp * 4 + (val & 3)] = s;
-    }
-}
-
-// The finishing kernels: workgroup b owns channels 4b..4b+3 (8 columns: both slot rows), 128 threads per column
-// strided over the slots, fp64, LDS tree; the groups are walked one after the other so that whatever depends on their
-// order -- the running averages, the sums over the groups -- is formed in registers by the column's first thread.
-// (7 / 6 us per launch, 108 launches per training step.  Two rewrites -- 64 lanes per column meeting by shuffles and one
-// LDS pass for all groups; then every slot load of 8 groups issued up front, 32 per thread -- measured 8.5 / 7.6 and
-// 9.0 / 7.9 us: the slot loads are not what these launches wait for.)
-constexpr int kFinishLanes = 128;
-
-__device__ __forceinline__ double column_sum(const float* __restrict__ pg, int nblk, int C, double* red) {
-    const int col = threadIdx.x & 7, lane = threadIdx.x >> 3;
-    const int off = (col >> 2) * C + blockIdx.x * 4 + (col & 3);
-    double s = 0.0;
-    for (int n = lane; n < nblk; n += kFinishLanes) s += (double)pg[(long)n * 2 * C + off];
-    __syncthreads();                       // (red is reused from group to group)
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = kFinishLanes / 2; w > 0; w >>= 1) {
-        if (lane < w) red[threadIdx.x] += red[threadIdx.x + w * 8];
-        __syncthreads();
-    }
-    return red[col];                       // every thread gets its column's total
-}
-
-// Statistics: out [5][groups][C] = mean, biased variance, rstd, scale, shift; then the running-average updates of the
+// Batch statistics, one launch: per (group, channel) sums of (x - p) and (x - p)^2 with the pivot p = the group's
+// first row (keeps the E[d^2] - E[d]^2 subtraction well conditioned whatever the channel's mean is); the last workgroup
+// then writes out [5][groups][C] = mean, biased variance, rstd, scale, shift and applies the running-average updates of the
 // groups one after the other (what `groups` sequential module calls would do: momentum, unbiased variance) and
-// num_batches_tracked += groups.
-struct BnFinalizeArgs {
-    const float* partial; const float* x; const float* weight; const float* bias;
-    float* running_mean; float* running_var; long* num_batches_tracked; float* out;
-    long rows; int C, groups, nblk; float eps, momentum;
+// num_batches_tracked += groups.  blockIdx.y = statistics group.
+struct BnStatsArgs {
+    const float* x; const float* weight; const float* bias;
+    float* running_mean; float* running_var; long* num_batches_tracked; float* partial; float* out; int* ticket;
+    long rows, n4; int C, groups; float eps, momentum;
 };
 
-__global__ void __launch_bounds__(kFinishLanes * 8) bn_finalize_kernel(BnFinalizeArgs a) {
-    __shared__ double red[kFinishLanes * 8];
-    __shared__ double tot[8];
-    const int C = a.C, c = blockIdx.x * 4 + (threadIdx.x & 3);
-    const bool owner = threadIdx.x < 4, running = a.running_mean != nullptr;
-    const float unbias = (float)a.rows / (float)(a.rows > 1 ? a.rows - 1 : 1);
-    float rm = 0.0f, rv = 0.0f;
-    if (owner && running) { rm = a.running_mean[c]; rv = a.running_var[c]; }
-    for (int g = 0; g < a.groups; ++g) {
-        const double t = column_sum(a.partial + (long)g * a.nblk * 2 * C, a.nblk, C, red);
-        if (threadIdx.x < 8) tot[threadIdx.x] = t;
-        __syncthreads();
-        if (owner) {
-            const double m1 = tot[threadIdx.x] / (double)a.rows, m2 = tot[4 + threadIdx.x] / (double)a.rows;
+__global__ void __launch_bounds__(kRedThreads) bn_stats_kernel(BnStatsArgs a) {
+    __shared__ float red[kRedThreads / 64][16][8];
+    __shared__ double dred[kRedThreads];
+    __shared__ double tot[kMaxPairs];
+    const int C = a.C, q = C >> 2, nblk = gridDim.x;
+    const float* x = a.x + (long)blockIdx.y * a.n4 * 4;
+    const long stride = (long)nblk * kRedThreads;
+    long i = (long)blockIdx.x * kRedThreads + threadIdx.x;
+    const int cg = (int)(i % q) * 4;
+    const f32x4 pv = ld4(x + cg);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (; i < a.n4; i += stride) {
+        const f32x4 t = ld4(x + i * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = t[j] - pv[j];
+            v[j] += d;
+            v[4 + j] = fmaf(d, d, v[4 + j]);
+        }
+    }
+    publish_slot(v, a.partial + ((long)blockIdx.y * nblk + blockIdx.x) * 2 * C, C, red);
+    if (!last_arriver(a.ticket, nblk * a.groups)) return;
+    sum_slots(a.partial, nblk, a.groups, C, tot, dred);
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x;
+        const bool running = a.running_mean != nullptr;
+        const float unbias = (float)a.rows / (float)(a.rows > 1 ? a.rows - 1 : 1);
+        float rm = 0.0f, rv = 0.0f;
+        if (running) { rm = a.running_mean[c]; rv = a.running_var[c]; }
+        for (int g = 0; g < a.groups; ++g) {
+            const double m1 = tot[g * 2 * C + c] / (double)a.rows, m2 = tot[g * 2 * C + C + c] / (double)a.rows;
             const float mean = a.x[(long)g * a.rows * C + c] + (float)m1;
             float var = (float)(m2 - m1 * m1);
             var = var > 0.0f ? var : 0.0f;
@@ -139,63 +185,51 @@ __global__ void __launch_bounds__(kFinishLanes * 8) bn_finalize_kernel(BnFinaliz
             rm = (1.0f - a.momentum) * rm + a.momentum * mean;
             rv = (1.0f - a.momentum) * rv + a.momentum * (var * unbias);
         }
+        if (running) { a.running_mean[c] = rm; a.running_var[c] = rv; }
     }
-    if (owner && running) { a.running_mean[c] = rm; a.running_var[c] = rv; }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.num_batches_tracked) *a.num_batches_tracked += a.groups;
+    if (threadIdx.x == 0 && a.num_batches_tracked) *a.num_batches_tracked += a.groups;
 }
 
-// Backward sums: sums [groups][2][C] for the apply kernel and the parameter gradients summed over the groups,
-// dbeta [C] = sum_g sum g_, dgamma [C] = sum_g sum g_*xh.
-__global__ void __launch_bounds__(kFinishLanes * 8) bn_bwd_finish_kernel(const float* __restrict__ partial,
-                                                                         float* __restrict__ sums, float* __restrict__ dgamma,
-                                                                         float* __restrict__ dbeta, int C, int groups, int nblk) {
-    __shared__ double red[kFinishLanes * 8];
-    const int col = threadIdx.x & 7, c = blockIdx.x * 4 + (col & 3);
-    double total = 0.0;
-    for (int g = 0; g < groups; ++g) {
-        const double t = column_sum(partial + (long)g * nblk * 2 * C, nblk, C, red);
-        if (threadIdx.x < 8) sums[((long)g * 2 + (col >> 2)) * C + c] = (float)t;
-        total += t;
-    }
-    if (threadIdx.x < 4) dbeta[c] = (float)total;
-    else if (threadIdx.x < 8) dgamma[c] = (float)total;
-}
+// Backward sums, one launch: the last workgroup writes sums [groups][2][C] for the apply kernel and the parameter
+// gradients summed over the groups, dbeta [C] = sum_g sum g_, dgamma [C] = sum_g sum g_*xh.
+struct BnBwdReduceArgs {
+    const float* x; const float* gy; const float* scale; const float* shift; const float* mean; const float* rstd;
+    float* partial; float* sums; float* dgamma; float* dbeta; int* ticket;
+    long n4; int C, relu, groups;
+};
 
-__global__ void __launch_bounds__(256) bn_relu_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                                 const float* __restrict__ scale,
-                                                                 const float* __restrict__ shift,
-                                                                 const float* __restrict__ mean,
-                                                                 const float* __restrict__ rstd, float* __restrict__ partial,
-                                                                 long n4, int C, int relu) {
-    __shared__ float red[256][8];
-    x += (long)blockIdx.y * n4 * 4; gy += (long)blockIdx.y * n4 * 4;
-    scale += blockIdx.y * C; shift += blockIdx.y * C; mean += blockIdx.y * C; rstd += blockIdx.y * C;
-    partial += (long)blockIdx.y * gridDim.x * 2 * C;
-    const int q = C >> 2;
-    const long stride = (long)gridDim.x * 256;
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(kRedThreads) bn_relu_bwd_reduce_kernel(BnBwdReduceArgs a) {
+    __shared__ float red[kRedThreads / 64][16][8];
+    __shared__ double dred[kRedThreads];
+    __shared__ double tot[kMaxPairs];
+    const int C = a.C, q = C >> 2, nblk = gridDim.x, relu = a.relu;
+    const float* x = a.x + (long)blockIdx.y * a.n4 * 4;
+    const float* gy = a.gy + (long)blockIdx.y * a.n4 * 4;
+    const float *scale = a.scale + blockIdx.y * C, *shift = a.shift + blockIdx.y * C, *mean = a.mean + blockIdx.y * C,
+                *rstd = a.rstd + blockIdx.y * C;
+    const long stride = (long)nblk * kRedThreads;
+    long i = (long)blockIdx.x * kRedThreads + threadIdx.x;
     const int cg = (int)(i % q) * 4;
     const f32x4 sc = ld4(scale + cg), sh = ld4(shift + cg), mu = ld4(mean + cg), rs = ld4(rstd + cg);
-    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sgx[4] = {0.f, 0.f, 0.f, 0.f};
-    for (; i < n4; i += stride) {
-        const f32x4 v = ld4(x + i * 4), g4 = ld4(gy + i * 4);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (; i < a.n4; i += stride) {
+        const f32x4 t = ld4(x + i * 4), g4 = ld4(gy + i * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float g = g4[j] * relu_mask(relu, bn_act(v[j], sc[j], sh[j]));
-            sg[j] += g;
-            sgx[j] = fmaf(g, (v[j] - mu[j]) * rs[j], sgx[j]);
+            const float g = g4[j] * relu_mask(relu, bn_act(t[j], sc[j], sh[j]));
+            v[j] += g;
+            v[4 + j] = fmaf(g, (t[j] - mu[j]) * rs[j], v[4 + j]);
         }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { red[threadIdx.x][j] = sg[j]; red[threadIdx.x][4 + j] = sgx[j]; }
-    __syncthreads();
-    // thread t < q*8 sums one (column group, value) over the 256/q threads that share the column group
-    if (threadIdx.x < q * 8) {
-        const int grp = threadIdx.x >> 3, val = threadIdx.x & 7;
-        float s = 0.0f;
-        for (int t = grp; t < 256; t += q) s += red[t][val];
-        const int c = grp * 4 + (val & 3);
-        partial[((long)blockIdx.x * 2 + (val >> 2)) * C + c] = s;
+    publish_slot(v, a.partial + ((long)blockIdx.y * nblk + blockIdx.x) * 2 * C, C, red);
+    if (!last_arriver(a.ticket, nblk * a.groups)) return;
+    sum_slots(a.partial, nblk, a.groups, C, tot, dred);
+    for (int k = threadIdx.x; k < a.groups * 2 * C; k += kRedThreads) a.sums[k] = (float)tot[k];
+    if (threadIdx.x < 2 * C) {
+        double total = 0.0;
+        for (int g = 0; g < a.groups; ++g) total += tot[g * 2 * C + threadIdx.x];
+        if (threadIdx.x < C) a.dbeta[threadIdx.x] = (float)total;
+        else a.dgamma[threadIdx.x - C] = (float)total;
     }
 }
 
@@ -234,12 +268,12 @@ int check(long rows, int C) {
     return MVSTER_OK;
 }
 
-// Slots per group of `partial` for the two reductions: enough workgroups to stream at full rate, few enough that the
-// finishing kernel adds them up in a few microseconds.
+// Slots (= workgroups of 1024 threads) per group of `partial` for the two reductions: at most one workgroup per CU over
+// all groups (16 waves per CU stream at full rate, and the last arriver adds <= 256 slots).
 int slots_for(long rows, int C, int groups) {
     const long n4 = rows * (C / 4);
-    long n = (n4 + 255) / 256;
-    const long cap = groups > 1 ? 512 : 1024;
+    long n = (n4 + kRedThreads - 1) / kRedThreads;
+    const long cap = groups >= 256 ? 1 : 256 / groups;
     if (n > cap) n = cap;
     return (int)(n < 1 ? 1 : n);
 }
@@ -271,37 +305,35 @@ extern "C" int mvster_bn_slots(long rows, int C, int groups) {
 
 // out [5][groups][C] = mean, biased var, rstd, scale = gamma*rstd, shift = beta - mean*scale; running_mean / running_var
 // (optional, [C]) receive the `groups` exponential-average updates in group order (unbiased variance, torch semantics)
-// and num_batches_tracked (optional, int64 on the device) += groups.  Two launches.
+// and num_batches_tracked (optional, int64 on the device) += groups.  ticket: one int on the device, 0 before the call
+// and 0 again after it (the launch's arrival counter).  One launch; groups * C <= 1024.
 extern "C" int mvster_bn_stats(const float* x, const float* weight, const float* bias, float* running_mean,
-                               float* running_var, long* num_batches_tracked, float* partial, float* out, long rows, int C,
-                               int groups, float eps, float momentum, void* stream) {
-    if (!x || !weight || !bias || !partial || !out) return MVSTER_ERR_NULL;
+                               float* running_var, long* num_batches_tracked, float* partial, float* out, int* ticket,
+                               long rows, int C, int groups, float eps, float momentum, void* stream) {
+    if (!x || !weight || !bias || !partial || !out || !ticket) return MVSTER_ERR_NULL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MVSTER_ERR_NULL;
     if (int rc = check(rows, C)) return rc;
     if (groups < 1 || groups > 65535) return MVSTER_ERR_SHAPE;
+    if (groups * 2 * C > kMaxPairs) return MVSTER_ERR_UNSUPPORTED;
     const int nblk = slots_for(rows, C, groups);
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk, groups), dim3(256), 0, s, x, partial, rows * (C / 4), C);
-    BnFinalizeArgs a{partial, x, weight, bias, running_mean, running_var, num_batches_tracked, out,
-                     rows, C, groups, nblk, eps, momentum};
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 4), dim3(kFinishLanes * 8), 0, s, a);
+    BnStatsArgs a{x, weight, bias, running_mean, running_var, num_batches_tracked, partial, out, ticket,
+                  rows, rows * (C / 4), C, groups, eps, momentum};
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk, groups), dim3(kRedThreads), 0, (hipStream_t)stream, a);
     return mv_check_launch();
 }
 
-// sums [groups][2][C] (for bwd_apply), dgamma [C], dbeta [C]; partial as for mvster_bn_stats.  Two launches.
+// sums [groups][2][C] (for bwd_apply), dgamma [C], dbeta [C]; partial and ticket as for mvster_bn_stats.  One launch.
 extern "C" int mvster_bn_relu_bwd_reduce(const float* x, const float* gy, const float* scale, const float* shift,
                                          const float* mean, const float* rstd, float* partial, float* sums, float* dgamma,
-                                         float* dbeta, long rows, int C, int relu, int groups, void* stream) {
-    if (!x || !gy || !scale || !shift || !mean || !rstd || !partial || !sums || !dgamma || !dbeta) return MVSTER_ERR_NULL;
+                                         float* dbeta, int* ticket, long rows, int C, int relu, int groups, void* stream) {
+    if (!x || !gy || !scale || !shift || !mean || !rstd || !partial || !sums || !dgamma || !dbeta || !ticket)
+        return MVSTER_ERR_NULL;
     if (int rc = check(rows, C)) return rc;
     if (groups < 1 || groups > 65535) return MVSTER_ERR_SHAPE;
-    const long n4 = rows * (C / 4);
+    if (groups * 2 * C > kMaxPairs) return MVSTER_ERR_UNSUPPORTED;
     const int nblk = slots_for(rows, C, groups);
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(nblk, groups), dim3(256), 0, s, x, gy, scale, shift, mean, rstd, partial,
-                       n4, C, relu);
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(C / 4), dim3(kFinishLanes * 8), 0, s, partial, sums, dgamma, dbeta, C, groups,
-                       nblk);
+    BnBwdReduceArgs a{x, gy, scale, shift, mean, rstd, partial, sums, dgamma, dbeta, ticket, rows * (C / 4), C, relu, groups};
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(nblk, groups), dim3(kRedThreads), 0, (hipStream_t)stream, a);
     return mv_check_launch();
 }
 

@@ -850,10 +850,17 @@ int launch_wino_ring(const ConvArgs& a, hipStream_t s) {
 }
 
 // G g G^T for one (cout, cin) pair, G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]; one thread per packed element
-__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ wpk, int cout, int cin_raw, int cin, int kd, long s_n,
-                                 long s_c, long s_z, long s_y, long s_x, int flip, int ntile) {
+struct PackWinoDesc {          // 88 bytes; the batched form reads a device table of these
+    const float* w;
+    float* wpk;
+    long s_n, s_c, s_z, s_y, s_x;
+    int cout, cin_raw, cin, kd, flip, ntile;
+    int first_block, pad_;     // first_block: prefix sum of ceil(total / 256) over the records before this one
+};
+
+__device__ __forceinline__ void pack_wino_element(const PackWinoDesc& d, long idx) {
+    const int cin = d.cin, kd = d.kd, ntile = d.ntile, flip = d.flip;
     const long total = (long)kd * 16 * cin * ntile * 16;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     // packed fragment order [K step][N tile][lane][j]: K = (kz * 16 + point) * cin + ci, lane = (ci % 16 / 4) * 16 + (n % 16), j = ci % 4
     const int j = (int)(idx & 3), lanei = (int)((idx >> 2) & 63);
@@ -865,10 +872,10 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
     const int qz = k / cin, ci = k - qz * cin;
     const int kz = qz >> 4, q = qz & 15;
     float u = 0.f;
-    if (n < cout && ci < cin_raw) {
+    if (n < d.cout && ci < d.cin_raw) {
         const int xi = q >> 2, nu = q & 3;
         const float Gm[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
-        const float* g = w + n * s_n + ci * s_c + (flip ? kd - 1 - kz : kz) * s_z;
+        const float* g = d.w + n * d.s_n + ci * d.s_c + (flip ? kd - 1 - kz : kz) * d.s_z;
         float rowv[3];
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
@@ -876,13 +883,27 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
 #pragma unroll
             for (int y = 0; y < 3; ++y) {
                 const int yy = flip ? 2 - y : y, xx = flip ? 2 - x : x;
-                acc = fmaf(Gm[xi][y], g[yy * s_y + xx * s_x], acc);
+                acc = fmaf(Gm[xi][y], g[yy * d.s_y + xx * d.s_x], acc);
             }
             rowv[x] = acc;
         }
         u = fmaf(Gm[nu][0], rowv[0], fmaf(Gm[nu][1], rowv[1], Gm[nu][2] * rowv[2]));
     }
-    wpk[idx] = u;
+    d.wpk[idx] = u;
+}
+
+__global__ void pack_wino_kernel(PackWinoDesc d) { pack_wino_element(d, (long)blockIdx.x * blockDim.x + threadIdx.x); }
+
+// every record of a device table in ONE launch (the training step re-transforms the weights of all its Winograd layers,
+// forward and input-gradient forms, after each optimizer update: 44 launches of ~5 us as separate calls)
+__global__ void __launch_bounds__(256) pack_wino_batch_kernel(const PackWinoDesc* __restrict__ descs, int ndesc) {
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackWinoDesc d = descs[lo];
+    pack_wino_element(d, (long)((int)blockIdx.x - d.first_block) * 256 + threadIdx.x);
 }
 
 }  // namespace
@@ -937,7 +958,19 @@ extern "C" int mvster_pack_wino_weights(const float* w, float* wpk, int cout, in
     if (cout < 1 || cin_raw < 1 || cin_pad < cin_raw || cin_pad % 16 != 0 || (kd != 1 && kd != 3)) return MVSTER_ERR_SHAPE;
     const int ntile = (cout + 15) / 16;
     const long total = (long)kd * 16 * cin_pad * ntile * 16;
-    hipLaunchKernelGGL(mvconv::pack_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, wpk, cout,
-                       cin_raw, cin_pad, kd, s_n, s_c, s_z, s_y, s_x, flip, ntile);
+    mvconv::PackWinoDesc d{w, wpk, s_n, s_c, s_z, s_y, s_x, cout, cin_raw, cin_pad, kd, flip, ntile, 0, 0};
+    hipLaunchKernelGGL(mvconv::pack_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d);
+    return mv_check_launch();
+}
+
+// The same for every record of a DEVICE table in one launch: 88-byte records {const float* w; float* wpk; long s_n, s_c,
+// s_z, s_y, s_x; int cout, cin_raw, cin_pad, kd, flip, ntile, first_block, pad} with ntile = ceil(cout / 16) and
+// first_block = prefix sum of ceil(kd * 16 * cin_pad * ntile * 16 / 256); total_blocks = their sum.
+extern "C" int mvster_pack_wino_batch(const void* descs, int ndesc, int total_blocks, void* stream) {
+    if (!descs) return MVSTER_ERR_NULL;
+    if (ndesc < 1 || total_blocks < 1) return MVSTER_ERR_SHAPE;
+    static_assert(sizeof(mvconv::PackWinoDesc) == 88, "PackWinoDesc layout");
+    hipLaunchKernelGGL(mvconv::pack_wino_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const mvconv::PackWinoDesc*)descs, ndesc);
     return mv_check_launch();
 }

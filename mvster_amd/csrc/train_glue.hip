@@ -204,23 +204,23 @@ __global__ void __launch_bounds__(256) upcat_bwd_kernel(const float* __restrict_
 //   wc [CO, CI, 3,3] = sum_c wo[o,c,tap] wi[c,i]                             (the 3x3 conv of the fine trunk map)
 //   vb [9, CO]       = sum_c wo[o,c,tap] bi[c]                               (the gather-sum's per-tap bias terms)
 // and the adjoint: g_wo = g_wg (permuted) + sum_i g_wc wi + g_vb bi, g_wi [CM,CI] = sum_{o,tap} wo g_wc,
-// g_bi [CM] = sum_{o,tap} wo g_vb.  One workgroup; a few thousand multiply-adds.
+// g_bi [CM] = sum_{o,tap} wo g_vb.  A few workgroups; a few thousand multiply-adds each.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) fine_weights_fwd_kernel(const float* __restrict__ wo, const float* __restrict__ wi,
                                                                const float* __restrict__ bi, float* __restrict__ wg,
                                                                float* __restrict__ wc, float* __restrict__ vb, int CO, int CM,
                                                                int CI) {
-    for (int i = threadIdx.x; i < 9 * CO * CM; i += 256) {             // wg[(tap*CO + o)*CM + c]
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 9 * CO * CM; i += gridDim.x * 256) {             // wg[(tap*CO + o)*CM + c]
         const int c = i % CM, r = i / CM, o = r % CO, tap = r / CO;
         wg[i] = wo[(o * CM + c) * 9 + tap];
     }
-    for (int i = threadIdx.x; i < CO * CI * 9; i += 256) {             // wc[(o*CI + ci)*9 + tap]
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < CO * CI * 9; i += gridDim.x * 256) {             // wc[(o*CI + ci)*9 + tap]
         const int tap = i % 9, ci = (i / 9) % CI, o = i / (9 * CI);
         float s = 0.0f;
         for (int c = 0; c < CM; ++c) s = fmaf(wo[(o * CM + c) * 9 + tap], wi[c * CI + ci], s);
         wc[i] = s;
     }
-    for (int i = threadIdx.x; i < 9 * CO; i += 256) {                  // vb[tap*CO + o]
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 9 * CO; i += gridDim.x * 256) {                  // vb[tap*CO + o]
         const int o = i % CO, tap = i / CO;
         float s = 0.0f;
         for (int c = 0; c < CM; ++c) s = fmaf(wo[(o * CM + c) * 9 + tap], bi[c], s);
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(256) fine_weights_bwd_kernel(const float* __re
                                                                const float* __restrict__ g_wc, const float* __restrict__ g_vb,
                                                                float* __restrict__ g_wo, float* __restrict__ g_wi,
                                                                float* __restrict__ g_bi, int CO, int CM, int CI) {
-    for (int i = threadIdx.x; i < CO * CM * 9; i += 256) {             // g_wo[(o*CM + c)*9 + tap]
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < CO * CM * 9; i += gridDim.x * 256) {             // g_wo[(o*CM + c)*9 + tap]
         const int tap = i % 9, c = (i / 9) % CM, o = i / (9 * CM);
         float s = g_wg ? g_wg[((tap * CO + o)) * CM + c] : 0.0f;
         if (g_wc)
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(256) fine_weights_bwd_kernel(const float* __re
         if (g_vb) s = fmaf(g_vb[tap * CO + o], bi[c], s);
         g_wo[i] = s;
     }
-    for (int i = threadIdx.x; i < CM * CI; i += 256) {                 // g_wi[c*CI + ci]
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < CM * CI; i += gridDim.x * 256) {                 // g_wi[c*CI + ci]
         const int ci = i % CI, c = i / CI;
         float s = 0.0f;
         if (g_wc)
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) fine_weights_bwd_kernel(const float* __re
                 for (int tap = 0; tap < 9; ++tap) s = fmaf(wo[(o * CM + c) * 9 + tap], g_wc[(o * CI + ci) * 9 + tap], s);
         g_wi[i] = s;
     }
-    for (int c = threadIdx.x; c < CM; c += 256) {
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < CM; c += gridDim.x * 256) {
         float s = 0.0f;
         if (g_vb)
             for (int o = 0; o < CO; ++o)
@@ -280,8 +280,9 @@ struct AdamArgs {
 
 __global__ void __launch_bounds__(256) fused_adam_kernel(const AdamArgs a, float* __restrict__ exp_avg,
                                                          float* __restrict__ exp_avg_sq, const float* __restrict__ step_in,
-                                                         float* __restrict__ step_out, int bump, float lr, float beta1,
-                                                         float beta2, float eps, float weight_decay) {
+                                                         float* __restrict__ step_out, int bump,
+                                                         const float* __restrict__ lr_cell, double beta1, double beta2,
+                                                         double eps, double weight_decay) {
     int lo = 0, hi = a.count - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -290,22 +291,23 @@ __global__ void __launch_bounds__(256) fused_adam_kernel(const AdamArgs a, float
     const AdamTensor t = a.t[lo];
     const float step = step_in[0] + (bump ? 1.0f : 0.0f);
     if (blockIdx.x == 0 && threadIdx.x == 0) step_out[0] = step;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
+    // the scalars in double, like torch's fused kernel (its betas / eps / step size are doubles that promote the element math)
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const double step_size = (double)lr_cell[0] / bc1;
+    const double bc2_sqrt = sqrt(bc2);
     const int base = ((int)blockIdx.x - a.first_block[lo]) * 1024;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int i = base + j * 256 + threadIdx.x;
         if (i >= t.n) break;
-        float p = t.param[i], g = t.grad[i];
+        const float p = t.param[i];
+        float g = t.grad[i];
         float m = exp_avg[t.state_off + i], v = exp_avg_sq[t.state_off + i];
-        if (weight_decay != 0.0f) g = fmaf(p, weight_decay, g);
-        m = m + (g - m) * (1.0f - beta1);                       // lerp(m, g, 1 - beta1)
-        v = beta2 * v + (1.0f - beta2) * g * g;
-        const float denom = sqrtf(v) / bc2_sqrt + eps;
-        p -= step_size * m / denom;
-        t.param[i] = p;
+        if (weight_decay != 0.0) g = (float)((double)g + weight_decay * (double)p);
+        m = (float)((double)m + (1.0 - beta1) * ((double)g - (double)m));                 // lerp(m, g, 1 - beta1)
+        v = (float)(beta2 * (double)v + (1.0 - beta2) * (double)g * (double)g);
+        const double denom = (double)sqrtf(v) / bc2_sqrt + eps;
+        t.param[i] = (float)((double)p - step_size * (double)m / denom);
         exp_avg[t.state_off + i] = m;
         exp_avg_sq[t.state_off + i] = v;
     }
@@ -400,7 +402,7 @@ extern "C" int mvster_fine_weights_fwd(const float* wo, const float* wi, const f
                                        int CM, int CI, void* stream) {
     if (!wo || !wi || !bi || !wg || !wc || !vb) return MVSTER_ERR_NULL;
     if (CO <= 0 || CM <= 0 || CI <= 0) return MVSTER_ERR_SHAPE;
-    hipLaunchKernelGGL(fine_weights_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, wo, wi, bi, wg, wc, vb, CO, CM, CI);
+    hipLaunchKernelGGL(fine_weights_fwd_kernel, dim3((9 * CO * CM + 255) / 256), dim3(256), 0, (hipStream_t)stream, wo, wi, bi, wg, wc, vb, CO, CM, CI);
     return mv_check_launch();
 }
 
@@ -410,19 +412,20 @@ extern "C" int mvster_fine_weights_bwd(const float* wo, const float* wi, const f
                                        void* stream) {
     if (!wo || !wi || !bi || !g_wo || !g_wi || !g_bi) return MVSTER_ERR_NULL;
     if (CO <= 0 || CM <= 0 || CI <= 0) return MVSTER_ERR_SHAPE;
-    hipLaunchKernelGGL(fine_weights_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, wo, wi, bi, g_wg, g_wc, g_vb, g_wo,
+    hipLaunchKernelGGL(fine_weights_bwd_kernel, dim3((9 * CO * CM + 255) / 256), dim3(256), 0, (hipStream_t)stream, wo, wi, bi, g_wg, g_wc, g_vb, g_wo,
                        g_wi, g_bi, CO, CM, CI);
     return mv_check_launch();
 }
 
 // Adam update of `count` tensors: params / grads = arrays of `count` device pointers (host arrays), sizes / state_offs =
 // host int arrays (elements; offsets into exp_avg / exp_avg_sq).  step_cells [2] floats on the device: cell 0 holds the
-// number of updates done so far and holds it + 1 afterwards (cell 1 is scratch).  Launches of at most 128 tensors each;
+// number of updates done so far and holds it + 1 afterwards (cell 1 is scratch).  lr: one float ON THE DEVICE (a learning-
+// rate schedule then reaches a captured step: the host rewrites the cell between replays).  Launches of at most 128 tensors each;
 // with an odd number of launches a one-thread copy brings the count back to cell 0 -- callers see cell 0 only.
 extern "C" int mvster_fused_adam(const void* const* params, const void* const* grads, const int* sizes, const int* state_offs,
-                                 int count, float* exp_avg, float* exp_avg_sq, float* step_cells, float lr, float beta1,
-                                 float beta2, float eps, float weight_decay, void* stream) {
-    if (!params || !grads || !sizes || !state_offs || !exp_avg || !exp_avg_sq || !step_cells) return MVSTER_ERR_NULL;
+                                 int count, float* exp_avg, float* exp_avg_sq, float* step_cells, const float* lr, double beta1,
+                                 double beta2, double eps, double weight_decay, void* stream) {
+    if (!params || !grads || !sizes || !state_offs || !exp_avg || !exp_avg_sq || !step_cells || !lr) return MVSTER_ERR_NULL;
     if (count <= 0) return MVSTER_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int launches = (count + kAdamMaxTensors - 1) / kAdamMaxTensors;

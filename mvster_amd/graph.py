@@ -379,6 +379,9 @@ class GraphedTrainStep:
         if self.graph is None:
             self.loss = self._step()                   # (capture=False: the same sequence, eagerly)
             return self.loss
+        sync = getattr(self.optimizer, "sync_hyperparameters", None)
+        if sync is not None:
+            sync()                                     # (optim.FusedAdam: a scheduler's learning rate into the device cell)
         self.graph.replay()
         # the replayed optimizer update moved the parameters without touching their version counters: everything folded or
         # packed from them outside this graph (the eval plans, the cached training layers of an eager step) is stale now

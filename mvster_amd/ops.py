@@ -471,6 +471,19 @@ def _bn_slots(rows, C, groups):
     return n
 
 
+_TICKETS = {}
+
+
+def _ticket(dev):
+    """Address of a zero int32 on ``dev`` for a one-launch reduction's arrival counter (the kernel leaves it at zero).
+    Handed out round-robin from a pool: launches that could overlap (other streams) practically never share one."""
+    hit = _TICKETS.get(dev)
+    if hit is None:
+        hit = _TICKETS[dev] = [torch.zeros(4096, device=dev, dtype=torch.int32), 0]
+    hit[1] = (hit[1] + 1) % 4096
+    return hit[0].data_ptr() + 4 * hit[1]
+
+
 def bn_batch_stats(x, weight, bias, running_mean, running_var, eps, momentum, groups=1, num_batches_tracked=None):
     """-> pack [5, groups, C] = (mean, biased var, rstd, scale, shift); running_mean / running_var (or None) are
     updated in place, one exponential-average step per group, and num_batches_tracked (or None) += groups."""
@@ -486,7 +499,7 @@ def bn_batch_stats(x, weight, bias, running_mean, running_var, eps, momentum, gr
     if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
         raise RuntimeError("bn_batch_stats: num_batches_tracked must be an int64 tensor on the device")
     rc = lib.mvster_bn_stats(_ptr(x), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
-                             _ptr(num_batches_tracked), _ptr(partial), _ptr(pack), rows, C, int(groups),
+                             _ptr(num_batches_tracked), _ptr(partial), _ptr(pack), _ticket(x.device), rows, C, int(groups),
                              float(eps), float(momentum), _stream())
     _lib.check(rc, "bn_stats")
     return pack
@@ -526,7 +539,8 @@ def bn_relu_bwd(x, gy, scale, shift, mean, rstd, relu, groups=1, frozen=False):
     sums = torch.empty(groups, 2, C, device=x.device, dtype=torch.float32)
     dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
     rc = lib.mvster_bn_relu_bwd_reduce(_ptr(x), _ptr(gy), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(partial),
-                                       _ptr(sums), _ptr(dgb[0]), _ptr(dgb[1]), rows, C, int(relu), int(groups), _stream())
+                                       _ptr(sums), _ptr(dgb[0]), _ptr(dgb[1]), _ticket(x.device), rows, C, int(relu), int(groups),
+                                       _stream())
     _lib.check(rc, "bn_relu_bwd_reduce")
     dx = torch.empty_like(x)
     rc = lib.mvster_bn_relu_bwd_apply(_ptr(x), _ptr(gy), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(sums),

@@ -192,7 +192,25 @@ class _LayerCache:
             table[i] = (s_, d_, x_, n_, fb)
             fb += (n_ + 1023) // 1024
         descs = torch.from_numpy(table.view(np.uint8).copy()).to(dev)
-        return {"keys": keys, "descs": descs, "n": len(recs), "blocks": fb, "idx": keep, "wino": wino, "lib": _lib}
+        # the Winograd-transformed forms (arithmetic, not permutations): one table for mvster_pack_wino_batch
+        wdescs, wblocks = None, 0
+        if wino:
+            wt = np.zeros(len(wino), dtype=np.dtype([("w", "<u8"), ("wpk", "<u8"), ("s_n", "<i8"), ("s_c", "<i8"), ("s_z", "<i8"),
+                                                     ("s_y", "<i8"), ("s_x", "<i8"), ("cout", "<i4"), ("cin_raw", "<i4"),
+                                                     ("cin", "<i4"), ("kd", "<i4"), ("flip", "<i4"), ("ntile", "<i4"),
+                                                     ("fb", "<i4"), ("pad", "<i4")]))
+            assert wt.dtype.itemsize == 88
+            for i, (layer, weight, swap, flip) in enumerate(wino):
+                w = weight if weight.dim() == 5 else weight.unsqueeze(2)
+                st = w.stride()
+                s_n, s_c = (st[1], st[0]) if swap else (st[0], st[1])
+                ntile = (layer.cout + 15) // 16
+                wt[i] = (w.data_ptr(), layer.wpk_wino.data_ptr(), s_n, s_c, st[2], st[3], st[4], layer.cout, layer._cin_raw,
+                         layer.cin, layer.kernel[0], int(flip), ntile, wblocks, 0)
+                wblocks += (layer.kernel[0] * 16 * layer.cin * ntile * 16 + 255) // 256
+            wdescs = torch.from_numpy(wt.view(np.uint8).copy()).to(dev)
+        return {"keys": keys, "descs": descs, "n": len(recs), "blocks": fb, "idx": keep, "wino": wino, "lib": _lib,
+                "wino_descs": wdescs, "wino_blocks": wblocks}
 
     def run_batch(self, b):
         """Refresh every form recorded in ``b`` from its parameter (one launch + the Winograd transforms) and let ``get``
@@ -202,9 +220,9 @@ class _LayerCache:
         self._batch = b
         rc = b["lib"].load().mvster_gather_batch(b["descs"].data_ptr(), b["n"], b["blocks"], ops._stream())
         b["lib"].check(rc, "gather_batch")
-        for layer, weight, swap, flip in b["wino"]:
-            w = weight if weight.dim() == 5 else weight.unsqueeze(2)
-            layer._pack_wino(w, swap, flip)
+        if b["wino_descs"] is not None:
+            rc = b["lib"].load().mvster_pack_wino_batch(b["wino_descs"].data_ptr(), len(b["wino"]), b["wino_blocks"], ops._stream())
+            b["lib"].check(rc, "pack_wino_batch")
         self._batch_active = True
 
     def end_batch(self):

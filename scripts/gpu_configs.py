@@ -71,7 +71,11 @@ def train(H, W, N, B, steps=5, graph=False, coherent=False):
     losses = []
     if graph:
         from mvster_amd.graph import GraphedTrainStep
-        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, capturable=True, fused=FUSED_ADAM)
+        if os.environ.get("MVSTER_TORCH_ADAM") is None:
+            from mvster_amd.optim import FusedAdam
+            opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+        else:
+            opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, capturable=True, fused=FUSED_ADAM)
 
         def loss_fn(o, g_, m_):
             return MVS4net_loss(o, g_, m_, stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10, ot_eps=1,

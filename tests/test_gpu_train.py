@@ -1035,3 +1035,48 @@ def test_fine_weights_vs_tensor_form():
     for x, y in zip(*res):
         assert x.shape == y.shape
         assert (x - y).abs().max().item() <= 2e-5 * y.abs().max().item()
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_fused_adam_follows_torch_adam(wd):
+    """mvster_amd.optim.FusedAdam against torch.optim.Adam(fused=True) on ~300 tensors of mixed sizes (three launches of <= 128 tensors +
+    the counter's move back): parameters and moments after 5 steps with a learning-rate change in between, and a
+    state_dict round trip into torch.optim.Adam and back."""
+    from mvster_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(1)
+    shapes = [(8, 3, 3, 3), (8,), (64, 64, 3, 3), (1,), (5, 7), (1025,), (4096, 3)] * 43
+    base = [torch.randn(s, generator=g) for s in shapes]
+    pa = [torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+    pb = [torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+    oa = FusedAdam(pa, lr=1e-2, weight_decay=wd)
+    # (the reference: torch's own fused kernel -- with weight decay and tiny gradients the FIRST update is lr * sign(g + wd p),
+    #  which the single-tensor and the fused torch implementations themselves round differently at the 1e-5 level)
+    ob = torch.optim.Adam(pb, lr=1e-2, weight_decay=wd, fused=True)
+    for it in range(5):
+        grads = [torch.randn(s, generator=g).to(DEV) * (10.0 ** (it - 2)) for s in shapes]
+        for o, ps in ((oa, pa), (ob, pb)):
+            for p, gr in zip(ps, grads):
+                p.grad = gr.clone()
+            if it == 3:
+                o.param_groups[0]["lr"] = 3e-3
+            o.step()
+    worst = max(((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item() for a, b in zip(pa, pb))
+    assert worst <= 2e-6, worst
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert float(sa["state"][0]["step"]) == 5.0 == float(sb["state"][0]["step"])
+    for k in (0, 5, 300):
+        for name in ("exp_avg", "exp_avg_sq"):
+            x, y = sa["state"][k][name], sb["state"][k][name]
+            assert (x - y).abs().max().item() <= 2e-6 * y.abs().max().item() + 1e-30
+    # torch's state into a fresh FusedAdam, one more step on both
+    pc = [torch.nn.Parameter(p.detach().clone()) for p in pb]
+    oc = FusedAdam(pc, lr=3e-3, weight_decay=wd)
+    oc.load_state_dict(ob.state_dict())
+    grads = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    for o, ps in ((oc, pc), (ob, pb)):
+        for p, gr in zip(ps, grads):
+            p.grad = gr.clone()
+        o.step()
+    worst = max(((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item() for a, b in zip(pc, pb))
+    assert worst <= 2e-6, worst
+    assert float(oc.state_dict()["state"][0]["step"]) == 6.0
