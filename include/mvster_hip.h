@@ -90,6 +90,21 @@ int mvster_warp_agg_bwd(const float* ref_feat, const float* src_feat, const floa
 int mvster_warp_agg_bwd_scratch(int B, int NV, int C, int G, int D, int h, int w, int attn_fuse_d, long* window_floats,
                                 long* origin_ints);
 
+/* mvster_warp_agg_bwd with the source-view gradient accumulated by a SORTED SCATTER instead of scatter windows + global
+ * atomics (the adjoint of F.grid_sample in homo_warping, models/mvs4net_utils.py:13-59): the (pixel, hypothesis, view)
+ * samples are counting-sorted by 32x32 source tile (count, prefix sums, 48-byte records appended per touched tile), then one
+ * workgroup per (batch, view, 8-channel block, tile) accumulates its records in a 64-bit fixed-point LDS window and writes
+ * the tile with plain stores.  Bit-reproducible, independent of the smoothness of the depth maps; grad_src needs NO zero
+ * fill (every texel is written exactly once).  Same arguments as mvster_warp_agg_bwd except the scratch: rec (*rec_floats
+ * floats: the worst case of 4 records per sample and channel block) and ints (*ints ints) as sized by the _scratch query.
+ * MVSTER_ERR_UNSUPPORTED (from both) for source maps of more than 2048 tiles or 8190 texels a side: use mvster_warp_agg_bwd. */
+int mvster_warp_agg_bwd_sorted_scratch(int B, int NV, int C, int D, int h, int w, int Hs, int Ws, long* rec_floats, long* ints);
+int mvster_warp_agg_bwd_sorted(const float* ref_feat, const float* src_feat, const float* rt, const float* hypo,
+                               const float* out, const float* wsum, const float* grad_out, float* grad_ref, float* grad_src,
+                               float* rec, int* ints, int B, int NV, int C, int G, int D, int h, int w, int Hs, int Ws,
+                               long ref_batch_stride, long src_view_stride, long src_batch_stride, int group_cor,
+                               int attn_fuse_d, float attn_temp, void* stream);
+
 /* depth_values [B,ndv] (columns 0 and ndv-1 used) -> out [B,D,h,w].
  * inverse=1: models/mvs4net_utils.py:71-77 (init_inverse_range); inverse=0: :61-69 (init_range). */
 int mvster_init_range(const float* depth_values, int ndv, float* out, int B, int D, int h, int w, int inverse,

@@ -25,6 +25,8 @@ SIGNATURES = {
     "mvster_warp_agg_fwd_sched": [_f] * 6 + [_i, _f, _f, _f] + [_i] * 9 + [_l] * 3 + [_i, _fl, _i, _f],
     "mvster_warp_agg_bwd": [_f] * 11 + [_i] * 9 + [_l] * 3 + [_i, _i, _fl, _f],
     "mvster_warp_agg_bwd_scratch": [_i] * 8 + [_f, _f],
+    "mvster_warp_agg_bwd_sorted_scratch": [_i] * 8 + [_f, _f],
+    "mvster_warp_agg_bwd_sorted": [_f] * 11 + [_i] * 9 + [_l] * 3 + [_i, _i, _fl, _f],
     "mvster_init_range": [_f, _i, _f, _i, _i, _i, _i, _i, _f],
     "mvster_schedule_inverse_range": [_f, _f, _f, _i, _i, _i, _i, _f],
     "mvster_schedule_range": [_f, _f, _f, _i, _i, _i, _i, _f],

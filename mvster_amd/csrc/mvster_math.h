@@ -221,6 +221,22 @@ MV_HD Taps make_taps(float sx, float sy, int Hs, int Ws) {
     return t;
 }
 
+// The east / south fractions make_taps() forms its weights from, and the weights rebuilt from them (same operations,
+// same bits): what the sorted scatter of the warp backward stores per sample instead of four weights.
+MV_HD void tap_fractions(float sx, float sy, int Hs, int Ws, float& wx1, float& wy1) {
+    float cx = fmaxf(fminf(sx, (float)(Ws + 4)), -4.0f);
+    float cy = fmaxf(fminf(sy, (float)(Hs + 4)), -4.0f);
+    wx1 = sub_rn(cx, floorf(cx));
+    wy1 = sub_rn(cy, floorf(cy));
+}
+MV_HD void tap_weights(float wx1, float wy1, float& nw, float& ne, float& sw, float& se) {
+    float wx0 = sub_rn(1.0f, wx1), wy0 = sub_rn(1.0f, wy1);
+    nw = mul_rn(wy0, wx0);
+    ne = mul_rn(wy0, wx1);
+    sw = mul_rn(wy1, wx0);
+    se = mul_rn(wy1, wx1);
+}
+
 // Branch-free form for the kernels: out-of-bounds taps get weight 0 and a clamped (always
 // readable) address instead of a predicated load.  0 * finite == 0, so the blend is the
 // same value as with a zero-padded tap.

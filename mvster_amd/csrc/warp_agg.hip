@@ -1063,7 +1063,13 @@ __device__ __forceinline__ FixScale make_fix_scale(const float* maxima, int G, i
     if (!(bound < INFINITY)) { f.s = 0.0f; f.inv = __builtin_nanf(""); }
     return f;
 }
-__device__ __forceinline__ void fix_add(u64* p, float v, float s) { atomicAdd(p, (u64)__float2ll_rn(v * s)); }
+// round-to-nearest-even float -> 64-bit integer for |t| < 2^51 in four instructions (the library conversion takes ~12): adding
+// 1.5 * 2^52 in double leaves round(t) in the low mantissa bits, two's complement included
+__device__ __forceinline__ u64 fix_cvt(float t) {
+    const double d = (double)t + 6755399441055744.0;
+    return (u64)(__double_as_longlong(d) - 0x4338000000000000LL);
+}
+__device__ __forceinline__ void fix_add(u64* p, float v, float s) { atomicAdd(p, fix_cvt(v * s)); }
 __device__ __forceinline__ float fix_get(u64 v, float inv) { return (float)(long long)v * inv; }
 
 // max |x| of up to three arrays in one launch: workgroups [first[k], first[k+1]) reduce x[k] (n[k] floats, 16-byte aligned)
@@ -1158,7 +1164,59 @@ struct WarpAggBwdArgs {
     float* windows;
     int* win_org;
     const float* maxima;    // {max |grad_out|, max |ref|, max |src|} (device; written just before this launch)
+    // sorted scatter (mvster_warp_agg_bwd_sorted; REC instances of warp_agg_bwd_kernel): see the section below
+    const int* rec_offset;  // [B*NV*ntiles + 1] exclusive prefix sums of the tiles' record counts
+    int* rec_cursor;        // [B*NV*ntiles] running cursors (zero before the launch)
+    float* rec;             // the records, kRecWords floats each
+    int tiles_x, tiles_y;   // source tiles of kRecTile x kRecTile texels
 };
+
+// ------------------------------------------------------------------------------------------
+// Sorted scatter of the source-view gradient (the adjoint of grid_sample, mvs4net_utils.py:13-59) WITHOUT global atomics.
+// A (pixel, hypothesis, view) sample adds w_tap * dw[c] to four source texels.  With unrelated hypotheses on neighbouring
+// pixels (random-winner depth maps) those texels are spread over hundreds of pixels of an epipolar line: the scatter
+// windows above catch little and the rest are random-address global atomics, which the chip retires at ~370 G adds/s
+// whatever the kernel does (0.92 ms for the 335 M adds of the full-resolution stage).  Here the samples are counting-sorted
+// by SOURCE tile instead:
+//   K0 warp_bwd_count_kernel   projects every sample and counts, per (batch, view, 32x32 source tile), the samples with a
+//                              weighted tap in the tile (a sample on a tile border counts in up to four tiles)
+//   K-scan                     exclusive prefix sums of the counts
+//   K1 warp_agg_bwd_kernel<.., REC = true>   the backward's arithmetic as before, but instead of scattering it appends a
+//                              48-byte record {corner, tap mask, east / south fractions, dw[8]} per 8-channel block to the
+//                              list of every tile the sample touches (slots reserved per workgroup: one returning global
+//                              atomic per touched tile and view, not per sample)
+//   K2 warp_bwd_accum_kernel   one workgroup per (batch, view, channel block, tile): accumulates the tile's records in a
+//                              64-bit fixed-point LDS window (integer adds: the order of the records does not matter) and
+//                              writes the tile with plain coalesced stores -- every texel of grad_src exactly once, so
+//                              the buffer needs no zero fill either.
+// Deterministic by construction and independent of how smooth the depth maps are.
+// ------------------------------------------------------------------------------------------
+constexpr int kRecTile = 32, kRecShift = 5;
+constexpr int kRecWords = 12;            // {packed corner + mask, wx1, wy1, 0}, dw[0..3], dw[4..7]
+constexpr int kRecMaxTiles = 2048;       // source tiles per map the workgroups' LDS histograms hold (2048 x 1024 texels)
+
+// bit k set: tap k carries weight (k = 0 nw (x0, y0), 1 ne (x0+1, y0), 2 sw (x0, y0+1), 3 se); t after clamp_taps()
+__device__ __forceinline__ unsigned tap_mask(const mv::Taps& t) {
+    return (t.nw != 0.0f ? 1u : 0u) | (t.ne != 0.0f ? 2u : 0u) | (t.sw != 0.0f ? 4u : 0u) | (t.se != 0.0f ? 8u : 0u);
+}
+
+// The tiles that hold a weighted tap of the sample: tile[k] = tile of tap k, or -1 where the tap carries no weight or an
+// earlier tap already named the tile (statically indexed throughout: no compaction, nothing for the compiler to spill).
+struct SampleTiles {
+    int tile[4];
+};
+
+__device__ __forceinline__ SampleTiles sample_tiles(const mv::Taps& t, unsigned mask, int tiles_x) {
+    SampleTiles s;
+    const int tx0 = t.x0 >> kRecShift, tx1 = (t.x0 + 1) >> kRecShift;
+    const int ty0 = t.y0 >> kRecShift, ty1 = (t.y0 + 1) >> kRecShift;
+    const int id0 = ty0 * tiles_x + tx0, id1 = ty0 * tiles_x + tx1, id2 = ty1 * tiles_x + tx0, id3 = ty1 * tiles_x + tx1;
+    s.tile[0] = (mask & 1u) ? id0 : -1;
+    s.tile[1] = ((mask & 2u) && id1 != s.tile[0]) ? id1 : -1;
+    s.tile[2] = ((mask & 4u) && id2 != s.tile[0] && id2 != s.tile[1]) ? id2 : -1;
+    s.tile[3] = ((mask & 8u) && id3 != s.tile[0] && id3 != s.tile[1] && id3 != s.tile[2]) ? id3 : -1;
+    return s;
+}
 
 // Scatter window: the source-view gradient of one workgroup (64 reference pixels of a row x all depths) and
 // one view lands on a compact patch of the source map (a few rows around an epipolar segment), so it is
@@ -1247,7 +1305,8 @@ constexpr int kWinX = 96, kWinY = 6;
 static const bool g_bwd_no_tiles = MV_PROBE_ENV("MVSTER_BWD_NO_TILES") != nullptr;   // experiment switch
 [[maybe_unused]] static const bool g_pix = MV_PROBE_ENV("MVSTER_PIX") != nullptr;   // experiment switch: pixel-major kernel at the fine stages
 
-template <int C, int G, bool GROUP, int DMAX>
+// REC: the sorted-scatter form (see above) -- no scatter window, no tap queues; pass 2 appends records instead.
+template <int C, int G, bool GROUP, int DMAX, bool REC = false>
 __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs ba) {
     const WarpAggArgs& a = ba.f;
     constexpr int CG = C / G;
@@ -1257,9 +1316,11 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
     __shared__ float sc[2][DMAX][64];
     __shared__ float sd[2][DMAX][64];
     __shared__ u64 gref[C][64];
-    __shared__ u64 win[8][kWinY][kWinX];
+    __shared__ u64 win[REC ? 1 : 8][REC ? 1 : kWinY][REC ? 1 : kWinX];
     __shared__ int worg[2][2];
-    __shared__ TapQueue tapq[DMAX];          // one per wavefront
+    __shared__ TapQueue tapq[REC ? 1 : DMAX];          // one per wavefront
+    __shared__ int lcount[REC ? kRecMaxTiles : 1];     // REC: this workgroup's samples per source tile (one view at a time)
+    __shared__ int lbase[REC ? kRecMaxTiles : 1];      //      and the first list position reserved for them
     const FixScale fx = make_fix_scale(ba.maxima, G, a.D, CG, GROUP, a.fuse_d != 0, a.attn_temp);
 
     const int tx = threadIdx.x;
@@ -1292,7 +1353,17 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
         if (GO_REG) go[g] = gv;
     }
     for (int i = tid; i < C * 64; i += nthr) (&gref[0][0])[i] = 0;
-    for (int i = tid; i < 8 * kWinY * kWinX; i += nthr) (&win[0][0][0])[i] = 0;
+    // narrow maps: this thread's share of the reference gradient is summed over the views in registers (integers: the same
+    // bits as adding every view's term to LDS) and lands in LDS once
+    constexpr bool GREF_REG = C <= 16;
+    u64 gacc[GREF_REG ? C : 1];
+#pragma unroll
+    for (int c = 0; c < (GREF_REG ? C : 1); ++c) gacc[c] = 0;
+    if (!REC)
+        for (int i = tid; i < 8 * kWinY * kWinX; i += nthr) (&win[0][0][0])[i] = 0;
+    const int ntiles = REC ? ba.tiles_x * ba.tiles_y : 0;
+    if (REC)
+        for (int i = tid; i < ntiles; i += nthr) lcount[i] = 0;
     __syncthreads();
 
     for (int v = 0; v < a.NV; ++v) {
@@ -1313,8 +1384,24 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
         const long o10 = ((long)tc.yb * a.Ws + tc.xa) * C, o11 = ((long)tc.yb * a.Ws + tc.xb) * C;
         const float* sp = a.src + voff;
         float* gsp = ba.grad_src + voff;
+        // REC: the tiles this sample's weighted taps fall into, its tap mask and fractions (the record's header)
+        unsigned tmask = 0;
+        SampleTiles stl;
+        stl.tile[0] = stl.tile[1] = stl.tile[2] = stl.tile[3] = -1;
+        int li[4] = {0, 0, 0, 0};
+        float wx1 = 0.0f, wy1 = 0.0f;
+        if (REC) {
+            tmask = valid ? tap_mask(t) : 0u;
+            stl = sample_tiles(t, tmask, ba.tiles_x);
+            mv::tap_fractions(sx, sy, a.Hs, a.Ws, wx1, wy1);
+        }
 
         // pass 1: score (same arithmetic and order as the forward) and gdot = sum_g go[g] * cor[g]
+        // (the warped feature of every channel stays in registers for pass 2 where the register file has room: with
+        //  unrelated hypotheses on neighbouring pixels the taps are 32-byte gathers that miss L2, and the second gather
+        //  round was half of this kernel's memory time)
+        constexpr bool KEEP_WV = C <= 32;
+        float wvk[KEEP_WV ? C : 1];
         float score = 0.0f, gdot = 0.0f, part = 0.0f;
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
@@ -1329,6 +1416,7 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
                 for (int j = 0; j < 4; ++j) {
                     const int c = cb * 8 + c0 + j;
                     const float wv = mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
+                    if (KEEP_WV) wvk[KEEP_WV ? c : 0] = wv;
                     if (GROUP) {
                         const float pr = mv::mul_rn(wv, R[j]);
                         part = (c % CG == 0) ? pr : mv::add_rn(part, pr);
@@ -1350,8 +1438,14 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
         sc[v & 1][d][tx] = score;
         if (tid == 0) { worg[v & 1][0] = 0x7fffffff; worg[v & 1][1] = 0x7fffffff; }
         __syncthreads();
+        if (REC) {
+            // position of this sample among the workgroup's samples of each tile it touches
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2)
+                if (stl.tile[k2] >= 0) li[k2] = atomicAdd(&lcount[stl.tile[k2]], 1);
+        }
         // window origin = smallest tap coordinates of the taps that carry weight (one LDS atomic per wave)
-        {
+        if (!REC) {
             const bool any = valid && (t.nw != 0.0f || t.ne != 0.0f || t.sw != 0.0f || t.se != 0.0f);
             int mnx = any ? tc.xa : 0x7fffffff, mny = any ? tc.ya : 0x7fffffff;
 #pragma unroll
@@ -1389,6 +1483,27 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
             for (int j = 0; j < a.D; ++j) dws += sd[v & 1][j][tx];
             dscore = dws * invW * wgt * ((d == dstar ? 1.0f : 0.0f) - sig);
         }
+        long slot0[4] = {0, 0, 0, 0};
+        int cstride[4] = {0, 0, 0, 0};
+        if (REC) {
+            // reserve list space for the workgroup's samples: ONE returning global atomic per touched tile
+            const long g0 = ((long)b * a.NV + v) * ntiles;
+            for (int i = tid; i < ntiles; i += nthr) {
+                const int c = lcount[i];
+                if (c) {
+                    lbase[i] = atomicAdd(ba.rec_cursor + g0 + i, c);
+                    lcount[i] = 0;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2)
+                if (stl.tile[k2] >= 0) {
+                    const int off = ba.rec_offset[g0 + stl.tile[k2]];
+                    cstride[k2] = ba.rec_offset[g0 + stl.tile[k2] + 1] - off;
+                    slot0[k2] = (long)off * NB + lbase[stl.tile[k2]] + li[k2];
+                }
+        }
         const int wx0 = worg[v & 1][0], wy0 = worg[v & 1][1];
         // window coordinates of the four taps (negative / too large = outside -> global atomics)
         TapPlace tp;
@@ -1410,15 +1525,18 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
 #pragma unroll
                 for (int c0 = 0; c0 < 8; c0 += 4) {
                     const f32x4 R = ld4(rp + cbase + c0);
-                    const f32x4 A = ld4(sp + o00 + cbase + c0), Bq = ld4(sp + o01 + cbase + c0);
-                    const f32x4 Cq = ld4(sp + o10 + cbase + c0), Dq = ld4(sp + o11 + cbase + c0);
+                    f32x4 A = {0.f, 0.f, 0.f, 0.f}, Bq = A, Cq = A, Dq = A;
+                    if (!KEEP_WV) {
+                        A = ld4(sp + o00 + cbase + c0); Bq = ld4(sp + o01 + cbase + c0);
+                        Cq = ld4(sp + o10 + cbase + c0); Dq = ld4(sp + o11 + cbase + c0);
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int cl = c0 + j;               // channel within the pass
                         const int c = cbase + cl;
                         const float gv = GO_REG ? go[GO_REG ? (GROUP ? c / CG : c) : 0] : gq[c0 / 4][j];
                         const float dcor = fmaf(gv * invW, wgt, dscore);   // direct + through the softmax
-                        const float wv = mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
+                        const float wv = KEEP_WV ? wvk[KEEP_WV ? c : 0] : mv::blend(t, A[j], Bq[j], Cq[j], Dq[j]);
                         float dref;
                         if (GROUP) {
                             dw8[cl] = dcor * (1.0f / CG) * R[j];
@@ -1428,9 +1546,23 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
                             dref = 2.0f * df * dcor;
                             dw8[cl] = -dref;
                         }
-                        fix_add(&gref[c][tx], dref, fx.s);
+                        if (GREF_REG) gacc[GREF_REG ? c : 0] += fix_cvt(dref * fx.s);
+                        else fix_add(&gref[c][tx], dref, fx.s);
                     }
                 }
+            }
+            if (REC) {
+                // one 48-byte record per touched tile into the list of (batch, view, tile), channel block cb
+                const float hdr = __int_as_float((int)((unsigned)(t.x0 + 1) | ((unsigned)(t.y0 + 1) << 13) | (tmask << 26)));
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2)
+                    if (stl.tile[k2] >= 0) {
+                        float* r = ba.rec + (slot0[k2] + (long)cb * cstride[k2]) * kRecWords;
+                        st4(r, f32x4{hdr, wx1, wy1, 0.0f});
+                        st4(r + 4, f32x4{dw8[0], dw8[1], dw8[2], dw8[3]});
+                        st4(r + 8, f32x4{dw8[4], dw8[5], dw8[6], dw8[7]});
+                    }
+                continue;
             }
             scatter_taps(&win[0][0][0], kWinY * kWinX, kWinX, tapq[d], gsp, valid, t, tp, cbase, dw8, fx.s);
             __syncthreads();
@@ -1465,6 +1597,11 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
             __syncthreads();
         }
     }
+    if (GREF_REG) {
+#pragma unroll
+        for (int c = 0; c < (GREF_REG ? C : 1); ++c) atomicAdd(&gref[c][tx], gacc[c]);
+    }
+    if (REC || GREF_REG) __syncthreads();      // (the window form's last flush ends with a barrier, before these adds)
     // every reference pixel of this workgroup is complete: plain coalesced stores
     float* grp = ba.grad_ref + (long)b * a.ref_bs + (long)p0 * C;
     const int npix = min(64, hw - p0);
@@ -1756,6 +1893,128 @@ int launch_gather(const WarpAggBwdArgs& ba, int nblk, hipStream_t stream) {
     return mv_check_launch();
 }
 
+// ---- sorted scatter: K0 (count), scan, K2 (accumulate) ---------------------------------------------------------------
+// K0: thread = (pixel, hypothesis) of batch item blockIdx.y, all views; per view an LDS histogram over the source tiles,
+// flushed with one global atomic per touched tile.
+__global__ void __launch_bounds__(256) warp_bwd_count_kernel(WarpAggArgs a, int* __restrict__ count, int tiles_x, int tiles_y) {
+    __shared__ int lcount[kRecMaxTiles];
+    const int ntiles = tiles_x * tiles_y;
+    const int b = blockIdx.y;
+    const long hw = (long)a.h * a.w;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;            // = pixel * D + d
+    const bool valid = i < hw * a.D;
+    const long pc = valid ? i / a.D : hw - 1;
+    const int d = valid ? (int)(i - pc * a.D) : 0;
+    const int y = (int)(pc / a.w), x = (int)(pc - (long)y * a.w);
+    const float depth = a.hypo[((long)b * a.D + d) * hw + pc];
+    for (int t = threadIdx.x; t < ntiles; t += 256) lcount[t] = 0;
+    __syncthreads();
+    for (int v = 0; v < a.NV; ++v) {
+        mv::RT m;
+        const float* r = a.rt + ((long)b * a.NV + v) * 12;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) m.r[k] = r[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) m.t[k] = r[9 + k];
+        float sx, sy;
+        mv::project(m, (float)x, (float)y, depth, a.Hs, a.Ws, sx, sy);
+        mv::Taps t = mv::make_taps(sx, sy, a.Hs, a.Ws);
+        mv::clamp_taps(t, a.Hs, a.Ws);
+        const SampleTiles stl = sample_tiles(t, valid ? tap_mask(t) : 0u, tiles_x);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (stl.tile[k] >= 0) atomicAdd(&lcount[stl.tile[k]], 1);
+        __syncthreads();
+        int* gc = count + ((long)b * a.NV + v) * ntiles;
+        for (int tl = threadIdx.x; tl < ntiles; tl += 256) {
+            const int c = lcount[tl];
+            if (c) {
+                atomicAdd(gc + tl, c);
+                lcount[tl] = 0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) warp_bwd_zero_kernel(int* __restrict__ a, long na, int* __restrict__ b, long nb) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < na) a[i] = 0;
+    if (i < nb) b[i] = 0;
+}
+
+// offset[0..n] = exclusive prefix sums of count[0..n) (offset[n] = total); one workgroup
+__global__ void __launch_bounds__(1024) warp_bwd_scan_kernel(const int* __restrict__ count, int* __restrict__ offset, int n) {
+    __shared__ int part[1024];
+    const int chunk = (n + 1023) / 1024;
+    const int lo = threadIdx.x * chunk, hi = min(lo + chunk, n);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += count[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - s;                                 // exclusive
+    for (int i = lo; i < hi; ++i) {
+        offset[i] = run;
+        run += count[i];
+    }
+    if (threadIdx.x == 1023) offset[n] = part[1023];
+}
+
+struct WarpBwdAccumArgs {
+    const float* rec; const int* offset; const float* maxima; float* grad_src;
+    long src_vs, src_bs;
+    int NV, NB, C, Hs, Ws, tiles_x, tiles_y, G, D, CG, group, fuse;
+    float attn_temp;
+};
+
+// K2: workgroup = (tile, view * NB + channel block, batch); lane = record.  The window is channel-major ([8] planes of
+// 32 x 32 u64): the lanes of an atomic instruction hit one plane at (practically) random texels.
+__global__ void __launch_bounds__(256) warp_bwd_accum_kernel(WarpBwdAccumArgs a) {
+    __shared__ u64 win[8][kRecTile * kRecTile];
+    const FixScale fx = make_fix_scale(a.maxima, a.G, a.D, a.CG, a.group != 0, a.fuse != 0, a.attn_temp);
+    const int tile = blockIdx.x, v = blockIdx.y / a.NB, cb = blockIdx.y - v * a.NB, b = blockIdx.z;
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const int tile_y = tile / a.tiles_x, tile_x = tile - tile_y * a.tiles_x;
+    for (int i = threadIdx.x; i < 8 * kRecTile * kRecTile; i += 256) (&win[0][0])[i] = 0;
+    __syncthreads();
+    const long g0 = ((long)b * a.NV + v) * ntiles + tile;
+    const int off = a.offset[g0], cnt = a.offset[g0 + 1] - off;
+    const float* base = a.rec + ((long)off * a.NB + (long)cb * cnt) * kRecWords;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const float* r = base + (long)i * kRecWords;
+        const f32x4 h = ld4(r), d0 = ld4(r + 4), d1 = ld4(r + 8);
+        const unsigned pk = (unsigned)__float_as_int(h[0]);
+        const int x0 = (int)(pk & 0x1fffu) - 1, y0 = (int)((pk >> 13) & 0x1fffu) - 1;
+        const unsigned mask = pk >> 26;
+        float wt[4];
+        mv::tap_weights(h[1], h[2], wt[0], wt[1], wt[2], wt[3]);
+        const float dw[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int tx = x0 + (k & 1), ty = y0 + (k >> 1);
+            if (((mask >> k) & 1u) && (tx >> kRecShift) == tile_x && (ty >> kRecShift) == tile_y) {
+                const int idx = (ty & (kRecTile - 1)) * kRecTile + (tx & (kRecTile - 1));
+#pragma unroll
+                for (int c = 0; c < 8; ++c) fix_add(&win[c][idx], wt[k] * dw[c], fx.s);
+            }
+        }
+    }
+    __syncthreads();
+    // the tile's texels, every one exactly once: plain stores, channel-fastest (32 contiguous bytes per texel and block)
+    float* gsp = a.grad_src + (long)v * a.src_vs + (long)b * a.src_bs;
+    for (int i = threadIdx.x; i < 8 * kRecTile * kRecTile; i += 256) {
+        const int c = i & 7, tex = i >> 3;
+        const int ty = tile_y * kRecTile + (tex >> kRecShift), tx = tile_x * kRecTile + (tex & (kRecTile - 1));
+        if (ty < a.Hs && tx < a.Ws) gsp[((long)ty * a.Ws + tx) * a.C + cb * 8 + c] = fix_get(win[c][tex], fx.inv);
+    }
+}
+
 constexpr int kTileR = 4;     // reference rows per workgroup of the tile kernel
 
 // which first-pass kernel a configuration takes, its workgroups per batch item and its window height
@@ -1797,6 +2056,23 @@ int launch_bwd(const WarpAggBwdArgs& ba, hipStream_t stream) {
     }
     if (int rc = mv_check_launch()) return rc;
     return ba.windows ? launch_gather<kWinY, kWinX, C / 8>(ba, nblk, stream) : MVSTER_OK;
+}
+
+// K1 of the sorted scatter: the row kernel's REC instance (all channel counts; the 2-D tile kernel's advantage was its
+// shared scatter window, which this form does not have)
+template <int C, int G, bool GROUP>
+int launch_bwd_rec(const WarpAggBwdArgs& ba, hipStream_t stream) {
+    const WarpAggArgs& a = ba.f;
+    dim3 block(64, a.D);
+    dim3 grid((a.h * a.w + 63) / 64, a.B);
+    if (a.D <= 8) {
+        MV_NOTE_KERNEL("warp_agg_bwd_kernel<%d, %d, %s, 8, true>", C, G, GROUP ? "true" : "false");
+        hipLaunchKernelGGL((warp_agg_bwd_kernel<C, G, GROUP, 8, true>), grid, block, 0, stream, ba);
+    } else {
+        MV_NOTE_KERNEL("warp_agg_bwd_kernel<%d, %d, %s, %d, true>", C, G, GROUP ? "true" : "false", kMaxD);
+        hipLaunchKernelGGL((warp_agg_bwd_kernel<C, G, GROUP, kMaxD, true>), grid, block, 0, stream, ba);
+    }
+    return mv_check_launch();
 }
 
 }  // namespace
@@ -1940,7 +2216,8 @@ extern "C" int mvster_warp_agg_bwd(const float* ref_feat, const float* src_feat,
         long nf = 0, ni = 0;
         mvster_warp_agg_bwd_scratch(B, NV, C, G, D, h, w, attn_fuse_d, &nf, &ni);
         float* mx = reinterpret_cast<float*>(win_org + (ni - 4));
-        if (hipMemsetAsync(mx, 0, 16, s) != hipSuccess) return MVSTER_ERR_LAUNCH;
+        // (zeroed by a kernel, not a memset node: see mvster_warp_agg_bwd_sorted)
+        hipLaunchKernelGGL(warp_bwd_zero_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<int*>(mx), 4L, reinterpret_cast<int*>(mx), 0L);
         const long n_go = (long)B * D * h * w * G, n_ref = (long)h * w * C, n_src = (long)Hs * Ws * C;
         if (ref_batch_stride == n_ref && src_batch_stride == n_src && src_view_stride == n_src * B) {
             const float* xs[3] = {grad_out, ref_feat, src_feat};
@@ -1977,4 +2254,104 @@ extern "C" int mvster_warp_agg_bwd(const float* ref_feat, const float* src_feat,
     MV_CASE(64, 64, false)
 #undef MV_CASE
     return MVSTER_ERR_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// mvster_warp_agg_bwd with the source-view gradient accumulated by the SORTED SCATTER (see the section above the kernels):
+// no global atomics, bit-reproducible, independent of the smoothness of the depth maps, and grad_src needs no zero fill
+// (every texel is written exactly once).  Scratch: rec = *rec_floats floats (the worst case: every sample on a tile corner,
+// 4 records per sample and 8-channel block; typically 1.07 are used), ints = *ints ints (tile counts, cursors, offsets and
+// the operand maxima of the fixed-point scale).  MVSTER_ERR_UNSUPPORTED for source maps of more than 2048 tiles of 32 x 32
+// texels or beyond 8190 texels a side: the caller then takes mvster_warp_agg_bwd.
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int mvster_warp_agg_bwd_sorted_scratch(int B, int NV, int C, int D, int h, int w, int Hs, int Ws, long* rec_floats,
+                                                 long* ints) {
+    if (!rec_floats || !ints) return MVSTER_ERR_NULL;
+    if (B <= 0 || NV <= 0 || C <= 0 || C % 8 || D <= 0 || h <= 0 || w <= 0 || Hs <= 0 || Ws <= 0) return MVSTER_ERR_SHAPE;
+    const long tiles_x = (Ws + kRecTile - 1) / kRecTile, tiles_y = (Hs + kRecTile - 1) / kRecTile;
+    if (tiles_x * tiles_y > kRecMaxTiles || Hs > 8190 || Ws > 8190) return MVSTER_ERR_UNSUPPORTED;
+    const long n = (long)B * NV * tiles_x * tiles_y;
+    const long samples = (long)B * h * w * D * NV;
+    if (samples * 4 >= (1L << 31)) return MVSTER_ERR_UNSUPPORTED;          // (list positions are 32-bit)
+    *rec_floats = samples * 4 * (C / 8) * kRecWords;
+    *ints = 3 * n + 1 + 4;
+    return MVSTER_OK;
+}
+
+extern "C" int mvster_warp_agg_bwd_sorted(const float* ref_feat, const float* src_feat, const float* rt, const float* hypo,
+                                          const float* out, const float* wsum, const float* grad_out, float* grad_ref,
+                                          float* grad_src, float* rec, int* ints, int B, int NV, int C, int G, int D, int h,
+                                          int w, int Hs, int Ws, long ref_batch_stride, long src_view_stride,
+                                          long src_batch_stride, int group_cor, int attn_fuse_d, float attn_temp, void* stream) {
+    if (!ref_feat || !src_feat || !rt || !hypo || !out || !wsum || !grad_out || !grad_ref || !grad_src || !rec || !ints)
+        return MVSTER_ERR_NULL;
+    if (B <= 0 || NV <= 0 || D <= 0 || D > kMaxD || h <= 0 || w <= 0 || Hs <= 0 || Ws <= 0) return MVSTER_ERR_SHAPE;
+    if (!group_cor && G != C) return MVSTER_ERR_SHAPE;
+    long nf = 0, ni = 0;
+    if (int rc = mvster_warp_agg_bwd_sorted_scratch(B, NV, C, D, h, w, Hs, Ws, &nf, &ni)) return rc;
+    const int tiles_x = (Ws + kRecTile - 1) / kRecTile, tiles_y = (Hs + kRecTile - 1) / kRecTile;
+    const long n = (long)B * NV * tiles_x * tiles_y;
+    int* count = ints;
+    int* cursor = ints + n;
+    int* offset = ints + 2 * n;
+    float* mx = reinterpret_cast<float*>(ints + 3 * n + 1);
+    WarpAggBwdArgs ba;
+    WarpAggArgs& a = ba.f;
+    a.ref = ref_feat; a.src = src_feat; a.rt = rt; a.hypo = hypo; a.out = nullptr; a.wsum_out = nullptr;
+    a.ref_bs = ref_batch_stride; a.src_vs = src_view_stride; a.src_bs = src_batch_stride;
+    a.B = B; a.NV = NV; a.D = D; a.h = h; a.w = w; a.Hs = Hs; a.Ws = Ws;
+    a.attn_temp = attn_temp; a.sqrt_c = sqrtf((float)C); a.fuse_d = attn_fuse_d;
+    ba.fwd_out = out; ba.wsum = wsum; ba.grad_out = grad_out; ba.grad_ref = grad_ref; ba.grad_src = grad_src;
+    ba.windows = nullptr; ba.win_org = nullptr; ba.maxima = mx;
+    ba.rec_offset = offset; ba.rec_cursor = cursor; ba.rec = rec; ba.tiles_x = tiles_x; ba.tiles_y = tiles_y;
+    hipStream_t s = (hipStream_t)stream;
+    // counts, cursors and the operand maxima start at zero: a kernel of our own, not hipMemsetAsync -- inside a captured
+    // training step the memset node was seen to race with the kernels around it (garbage counts -> a memory fault on a
+    // later replay); kernel nodes of one stream are strictly ordered
+    hipLaunchKernelGGL(warp_bwd_zero_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, s, ints, 2 * n,
+                       reinterpret_cast<int*>(mx), 4L);
+    {
+        const long n_go = (long)B * D * h * w * G, n_ref = (long)h * w * C, n_src = (long)Hs * Ws * C;
+        if (ref_batch_stride == n_ref && src_batch_stride == n_src && src_view_stride == n_src * B) {
+            const float* xs[3] = {grad_out, ref_feat, src_feat};
+            const long ns[3] = {n_go, n_ref * B, n_src * B * NV};
+            launch_absmax(xs, ns, 3, mx, s);
+        } else {
+            launch_absmax(&grad_out, &n_go, 1, mx, s);
+            for (int bb = 0; bb < B; ++bb) {
+                const float* p = ref_feat + (long)bb * ref_batch_stride;
+                launch_absmax(&p, &n_ref, 1, mx + 1, s);
+            }
+            for (int v = 0; v < NV; ++v)
+                for (int bb = 0; bb < B; ++bb) {
+                    const float* p = src_feat + (long)v * src_view_stride + (long)bb * src_batch_stride;
+                    launch_absmax(&p, &n_src, 1, mx + 2, s);
+                }
+        }
+    }
+    const long per_item = (long)h * w * D;
+    hipLaunchKernelGGL(warp_bwd_count_kernel, dim3((unsigned)((per_item + 255) / 256), B), dim3(256), 0, s, a, count, tiles_x,
+                       tiles_y);
+    hipLaunchKernelGGL(warp_bwd_scan_kernel, dim3(1), dim3(1024), 0, s, count, offset, (int)n);
+    int rc = MVSTER_ERR_UNSUPPORTED;
+#define MV_CASE(CC, GG, GR) \
+    if (C == CC && G == GG && (group_cor != 0) == GR) rc = launch_bwd_rec<CC, GG, GR>(ba, s);
+    MV_CASE(64, 8, true)
+    MV_CASE(32, 8, true)
+    MV_CASE(16, 4, true)
+    MV_CASE(8, 4, true)
+    MV_CASE(16, 8, true)
+    MV_CASE(8, 8, true)
+    MV_CASE(64, 4, true)
+    MV_CASE(32, 4, true)
+    MV_CASE(8, 8, false)
+    MV_CASE(16, 16, false)
+    MV_CASE(32, 32, false)
+    MV_CASE(64, 64, false)
+#undef MV_CASE
+    if (rc) return rc;
+    WarpBwdAccumArgs k2{rec, offset, mx, grad_src, src_view_stride, src_batch_stride, NV, C / 8, C, Hs, Ws, tiles_x, tiles_y,
+                        G, D, C / G, group_cor ? 1 : 0, attn_fuse_d ? 1 : 0, attn_temp};
+    hipLaunchKernelGGL(warp_bwd_accum_kernel, dim3(tiles_x * tiles_y, NV * (C / 8), B), dim3(256), 0, s, k2);
+    return mv_check_launch();
 }

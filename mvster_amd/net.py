@@ -60,8 +60,11 @@ class _WarpAggPyr(torch.autograd.Function):
         else:
             g_pyr = torch.empty_like(pyr)
             g_ref, g_src = _WarpAggPyr._parts(g_pyr, B)
-            g_src.zero_()                                            # the source gradient is scattered with atomics
             ref_cl, src_cl = _WarpAggPyr._parts(pyr, B)
+            n_src, _, hs, ws, c_ = src_cl.shape
+            if not (ops.SORTED_SCATTER and ops.warp_agg_bwd_sorted_scratch(B, n_src, c_, hypo.shape[1], hypo.shape[2],
+                                                                           hypo.shape[3], hs, ws) is not None):
+                g_src.zero_()                                        # (window form: the source gradient is scattered with atomics)
             ops.warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad.contiguous(), G, group_cor, attn_fuse_d,
                                 attn_temp, into=(g_ref, g_src))
         if grad_ref_maps is not None:

@@ -158,15 +158,34 @@ def warp_agg_fwd_sched_cl(ref_cl, src_cl, rt, G, D, attn_fuse_d=True, attn_temp=
     return out, hypo
 
 
+# warp backward: counting-sort the samples by source tile (False / MVSTER_NO_SORTED_SCATTER: scatter windows + atomics)
+SORTED_SCATTER = __import__("os").environ.get("MVSTER_NO_SORTED_SCATTER") is None
+
+
+def warp_agg_bwd_sorted_scratch(B, NV, C, D, h, w, Hs, Ws):
+    """(record floats, ints) of scratch ``mvster_warp_agg_bwd_sorted`` needs, or None where it does not apply (source maps
+    of more than 2048 tiles of 32 x 32 texels)."""
+    import ctypes
+    nf, ni = ctypes.c_long(0), ctypes.c_long(0)
+    rc = _lib.load().mvster_warp_agg_bwd_sorted_scratch(B, NV, C, D, h, w, Hs, Ws, ctypes.addressof(nf), ctypes.addressof(ni))
+    if rc == -3:
+        return None
+    _lib.check(rc, "warp_agg_bwd_sorted_scratch")
+    return nf.value, ni.value
+
+
 def warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad_out, G, group_cor=True, attn_fuse_d=True, attn_temp=2.0,
-                    deterministic=None, into=None):
+                    deterministic=None, into=None, sorted_scatter=None):
     """Gradients of warp_agg_fwd_cl w.r.t. ref_cl and src_cl.  Inside a workgroup the gradients accumulate in 64-bit
     fixed-point LDS counters (integer atomics: 30x cheaper than ds_add_f32 on gfx950, and associative).
     ``deterministic`` (default: off, unless the environment sets MVSTER_BWD_DETERMINISTIC): the workgroups' scatter
     windows are stored densely and summed by a gather pass in fixed order instead of being flushed with global fp32
     atomics, which makes the source gradient bit-reproducible for every tap that falls inside a window (about 20 %
     slower on smooth depth maps, several times slower when neighbouring pixels' hypotheses are unrelated).
-    ``into`` = (g_ref, g_src): write into these contiguous buffers instead of allocating; g_src must come zeroed."""
+    ``into`` = (g_ref, g_src): write into these contiguous buffers instead of allocating; g_src must come zeroed -- except
+    with ``sorted_scatter`` (default ``ops.SORTED_SCATTER``; ``mvster_warp_agg_bwd_sorted``: the samples counting-sorted
+    by source tile, no global atomics, bit-reproducible, every texel of g_src written exactly once), which ignores what
+    the buffer holds.  Where the sorted form does not apply (huge source maps) the call takes the window form."""
     import ctypes
     import os
     grad_out = grad_out.contiguous()
@@ -177,6 +196,23 @@ def warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo, out, wsum, grad_out, G, group_cor=
     NV, _, Hs, Ws, _ = src_cl.shape
     D = hypo.shape[1]
     lib = _lib.load()
+    if sorted_scatter is None:
+        sorted_scatter = SORTED_SCATTER
+    scratch = warp_agg_bwd_sorted_scratch(B, NV, C, D, h, w, Hs, Ws) if sorted_scatter else None
+    if scratch is not None:
+        g_ref, g_src = (torch.empty_like(ref_cl), torch.empty_like(src_cl)) if into is None else into
+        if g_ref.shape != ref_cl.shape or g_src.shape != src_cl.shape:
+            raise ValueError("warp_agg_bwd: `into` buffers must have the shapes of ref_cl and src_cl")
+        _chk(g_ref, "warp_agg_bwd:into[0]")
+        _chk(g_src, "warp_agg_bwd:into[1]")
+        rec = torch.empty(scratch[0], device=ref_cl.device, dtype=torch.float32)
+        ints = torch.empty(scratch[1], device=ref_cl.device, dtype=torch.int32)
+        rc = lib.mvster_warp_agg_bwd_sorted(_ptr(ref_cl), _ptr(src_cl), _ptr(rt), _ptr(hypo), _ptr(out), _ptr(wsum),
+                                            _ptr(grad_out), _ptr(g_ref), _ptr(g_src), _ptr(rec), _ptr(ints), B, NV, C, G, D, h,
+                                            w, Hs, Ws, h * w * C, B * Hs * Ws * C, Hs * Ws * C, int(group_cor),
+                                            int(attn_fuse_d), float(attn_temp), _stream())
+        _lib.check(rc, "warp_agg_bwd_sorted")
+        return g_ref, g_src
     if into is None:
         g_ref = torch.empty_like(ref_cl)
         g_src = torch.zeros_like(src_cl)

@@ -1028,16 +1028,20 @@ def test_warp_agg_backward_vs_autograd(C, G, D, group_cor, fuse):
     e_fwd = (out.permute(0, 4, 1, 2, 3).cpu() - cor.detach()).abs().max().item() / max(cor.abs().max().item(), 1.0)
     scale = max(f.grad.abs().max().item() for f in feats)
     assert e_fwd <= 1e-4                        # (the forward has its own tests; measured 3e-6 .. 5e-5 here)
-    for det in (True, False):                   # dense windows + gather pass / windows flushed with global atomics
+    # sorted scatter (the default: samples counting-sorted by source tile, no global atomics; written into a buffer full of
+    # garbage: every texel is stored, none accumulated) / dense windows + gather pass / windows flushed with global atomics
+    for form in ("sorted", "gather", "atomic"):
+        into = None
+        if form == "sorted":
+            into = (torch.full_like(ref_cl, float("nan")), torch.full_like(src_cl, float("nan")))
         g_ref, g_src = ops.warp_agg_bwd_cl(ref_cl, src_cl, rt, hypo.to(DEV), out, wsum,
                                            gout.permute(0, 2, 3, 4, 1).contiguous().to(DEV), Gk, group_cor, fuse, 2.0,
-                                           deterministic=det)
+                                           deterministic=form == "gather", sorted_scatter=form == "sorted", into=into)
         e_ref = (g_ref.permute(0, 3, 1, 2).cpu() - feats[0].grad).abs().max().item() / scale
         e_src = max((g_src[v].permute(0, 3, 1, 2).cpu() - feats[v + 1].grad).abs().max().item() for v in range(N - 1)) / scale
-        note("warp_agg_bwd_C%d_G%d_D%d_%s_%s_%s" % (C, G, D, "group" if group_cor else "sqdiff", "fuse" if fuse else "nofuse",
-                                                    "gather" if det else "atomic"),
+        note("warp_agg_bwd_C%d_G%d_D%d_%s_%s_%s" % (C, G, D, "group" if group_cor else "sqdiff", "fuse" if fuse else "nofuse", form),
              fwd_rel=e_fwd, ref_rel=e_ref, src_rel=e_src, grad_absmax=scale)
-        assert e_ref <= 1e-4 and e_src <= 1e-4, det
+        assert e_ref <= 1e-4 and e_src <= 1e-4, form
 
 
 @pytest.mark.parametrize("C,G,D,h,w", [(8, 4, 4, 64, 160), (16, 4, 4, 32, 80), (32, 8, 8, 16, 70)])
@@ -1056,15 +1060,50 @@ def test_warp_agg_backward_is_reproducible(C, G, D, h, w):
                                                           + 0.0005 * torch.rand(B, D, h, w))).contiguous().to(DEV)
     out, wsum = ops.warp_agg_fwd_cl(ref, src, rt, hypo, G, True, True, 2.0, want_wsum=True)
     gout = torch.randn_like(out)
-    a = ops.warp_agg_bwd_cl(ref, src, rt, hypo, out, wsum, gout, G, True, True, 2.0, deterministic=True)
-    b = ops.warp_agg_bwd_cl(ref, src, rt, hypo, out, wsum, gout, G, True, True, 2.0, deterministic=True)
+    a = ops.warp_agg_bwd_cl(ref, src, rt, hypo, out, wsum, gout, G, True, True, 2.0, deterministic=True, sorted_scatter=False)
+    b = ops.warp_agg_bwd_cl(ref, src, rt, hypo, out, wsum, gout, G, True, True, 2.0, deterministic=True, sorted_scatter=False)
     assert torch.equal(a[0], b[0]), "reference gradient"
     assert torch.equal(a[1], b[1]), "source gradient (gather pass)"
-    c = ops.warp_agg_bwd_cl(ref, src, rt, hypo, out, wsum, gout, G, True, True, 2.0, deterministic=False)
+    c = ops.warp_agg_bwd_cl(ref, src, rt, hypo, out, wsum, gout, G, True, True, 2.0, deterministic=False, sorted_scatter=False)
     assert torch.equal(a[0], c[0])
     scale = c[1].abs().max().item()
     err = (a[1] - c[1]).abs().max().item() / scale
     note("warp_agg_bwd_gather_vs_atomic_C%d" % C, rel=err)
+    assert err <= 1e-5
+    # the sorted scatter: integer accumulation per source tile -- the same bits on every run whatever order the records land in
+    s1 = ops.warp_agg_bwd_cl(ref, src, rt, hypo, out, wsum, gout, G, True, True, 2.0, sorted_scatter=True)
+    s2 = ops.warp_agg_bwd_cl(ref, src, rt, hypo, out, wsum, gout, G, True, True, 2.0, sorted_scatter=True)
+    assert torch.equal(s1[0], s2[0]) and torch.equal(s1[1], s2[1]), "sorted scatter"
+    assert torch.equal(s1[0], a[0])
+    err = (s1[1] - a[1]).abs().max().item() / scale
+    note("warp_agg_bwd_sorted_vs_gather_C%d" % C, rel=err)
+    assert err <= 1e-5
+
+
+@pytest.mark.parametrize("C,G,D,h,w", [(8, 4, 4, 64, 160), (64, 8, 8, 16, 40)])
+def test_warp_agg_backward_sorted_scatter_random_winners(C, G, D, h, w):
+    """The regime the sorted scatter is for: every pixel's hypotheses anywhere in the depth range, unrelated to its
+    neighbours' (what a cascade with random weights hands from stage to stage), rotated cameras.  Reproducible to the bit, and
+    equal to the window / atomic form to rounding."""
+    torch.manual_seed(C + w)
+    B, N = 2, 4
+    _, proj, dv = make_inputs(N, h * 8, w * 8, seed=5, batch=B)
+    rt = ops.relative_projection(proj["stage1"].to(DEV))
+    ref = torch.randn(B, h, w, C, device=DEV)
+    src = torch.randn(N - 1, B, h, w, C, device=DEV)
+    full = O.init_inverse_range(dv, 48, h, w)
+    pick = torch.randint(0, 48 - D, (B, 1, h, w))
+    hypo = torch.gather(full, 1, pick + torch.arange(D).view(1, D, 1, 1)).contiguous().to(DEV)
+    out, wsum = ops.warp_agg_fwd_cl(ref, src, rt, hypo, G, True, True, 2.0, want_wsum=True)
+    gout = torch.randn_like(out)
+    s1 = ops.warp_agg_bwd_cl(ref, src, rt, hypo, out, wsum, gout, G, True, True, 2.0, sorted_scatter=True)
+    s2 = ops.warp_agg_bwd_cl(ref, src, rt, hypo, out, wsum, gout, G, True, True, 2.0, sorted_scatter=True)
+    assert torch.equal(s1[0], s2[0]) and torch.equal(s1[1], s2[1])
+    c = ops.warp_agg_bwd_cl(ref, src, rt, hypo, out, wsum, gout, G, True, True, 2.0, sorted_scatter=False)
+    assert torch.equal(s1[0], c[0])
+    scale = c[1].abs().max().item()
+    err = (s1[1] - c[1]).abs().max().item() / scale
+    note("warp_agg_bwd_sorted_vs_atomic_random_C%d" % C, rel=err)
     assert err <= 1e-5
 
 
