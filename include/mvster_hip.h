@@ -279,6 +279,12 @@ int mvster_conv_wgrad_slots(int CI, int CO, int kd, int kh, int kw, int sd, int 
 int mvster_conv_wgrad_finish(const float* partial, float* dw, int nblk, int ngrp, int cop, int width, int ntaps, int cip,
                              int co_lim, int ci_lim, int swap, int flip, void* stream);
 
+/* `count` finishes in ceil(count / 56) launches: recs = HOST array of 56-byte records {const float* partial; float* dw; int
+ * nblk, ngrp, cop, width, ntaps, cip, co_lim, ci_lim, swap, flip} -- the arguments of mvster_conv_wgrad_finish.  The
+ * training step defers the finishes of all its layers to the end of the backward pass (nothing reads a weight gradient
+ * before) and issues them together. */
+int mvster_conv_wgrad_finish_batch(const void* recs, int count, void* stream);
+
 /* Training-mode BatchNorm + ReLU on channels-last activations (C a power of two, 4..64): the elementwise half of the
  * reference's conv -> BatchNorm -> ReLU blocks (models/mvs4net_utils.py:116-123, :224-251) and its autograd.
  * x [groups*rows, C]: `groups` independent statistics groups of `rows` rows each (the reference normalises every
@@ -310,6 +316,11 @@ int mvster_bn_relu_bwd_reduce(const float* x, const float* gy, const float* scal
 int mvster_bn_relu_bwd_apply(const float* x, const float* gy, const float* scale, const float* shift, const float* mean,
                              const float* rstd, const float* sums, float* dx, long rows, int C, int relu, int groups,
                              int frozen, void* stream);
+
+/* out [C] = column sums of the channels-last x [rows, C], C in {4, 8, 16, 32, 64}: the bias gradient of the reference's
+ * convolutions with bias (sum of the output gradient over every voxel; FPN laterals models/mvs4net_utils.py:485-487,
+ * monocular heads :846-848).  partial: mvster_bn_slots(rows, C, 1) * 2 * C floats, ticket as above.  One launch. */
+int mvster_col_sum(const float* x, float* partial, float* out, int* ticket, long rows, int C, void* stream);
 
 /* Bilinear x2 up-sampling (align_corners=True) of a channels-last map, in [B,h,w,C] -> out [B,2h,2w,C], and its
  * adjoint gout [B,2h,2w,C] -> gin [B,h,w,C] as a gather (no atomics): the FPN top-down path in training

@@ -52,6 +52,8 @@ SIGNATURES = {
     "mvster_bn_relu_fwd": [_f, _f, _f, _f, _f, _l, _i, _i, _i, _f],
     "mvster_conv_wgrad_finish": [_f, _f] + [_i] * 10 + [_f],
     "mvster_bn_slots": [_l, _i, _i],
+    "mvster_col_sum": [_f, _f, _f, _f, _l, _i, _f],
+    "mvster_conv_wgrad_finish_batch": [_f, _i, _f],
     "mvster_bn_stats": [_f] * 9 + [_l, _i, _i, _fl, _fl, _f],
     "mvster_bn_relu_bwd_reduce": [_f] * 11 + [_l, _i, _i, _i, _f],
     "mvster_bn_relu_bwd_apply": [_f] * 8 + [_l, _i, _i, _i, _i, _f],

@@ -233,6 +233,39 @@ __global__ void __launch_bounds__(kRedThreads) bn_relu_bwd_reduce_kernel(BnBwdRe
     }
 }
 
+// Column sums of a channels-last tensor [rows, C] -> out [C] (the bias gradient of a convolution, sum of gy over every
+// voxel): the reductions' machinery with one statistics group, one launch, deterministic.
+struct ColSumArgs {
+    const float* x; float* partial; float* out; int* ticket;
+    long n4; int C;
+};
+
+__global__ void __launch_bounds__(kRedThreads) col_sum_kernel(ColSumArgs a) {
+    __shared__ float red[kRedThreads / 64][16][8];
+    __shared__ double dred[kRedThreads];
+    __shared__ double tot[2 * 64];
+    const int C = a.C, q = C >> 2, nblk = gridDim.x;
+    const long stride = (long)nblk * kRedThreads;
+    long i = (long)blockIdx.x * kRedThreads + threadIdx.x;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // two rows in flight per thread (second accumulator row: slot row 1, added to row 0 by the finishing workgroup)
+    for (; i + stride < a.n4; i += 2 * stride) {
+        const f32x4 t0 = ld4(a.x + i * 4), t1 = ld4(a.x + (i + stride) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += t0[j]; v[4 + j] += t1[j]; }
+    }
+    if (i < a.n4) {
+        const f32x4 t0 = ld4(a.x + i * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += t0[j];
+    }
+    (void)q;
+    publish_slot(v, a.partial + (long)blockIdx.x * 2 * C, C, red);
+    if (!last_arriver(a.ticket, nblk)) return;
+    sum_slots(a.partial, nblk, 1, C, tot, dred);
+    if (threadIdx.x < C) a.out[threadIdx.x] = (float)(tot[threadIdx.x] + tot[C + threadIdx.x]);
+}
+
 __global__ void __launch_bounds__(256) bn_relu_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ shift,
@@ -348,5 +381,16 @@ extern "C" int mvster_bn_relu_bwd_apply(const float* x, const float* gy, const f
     const long n4 = rows * (C / 4);
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(blocks_for(n4), groups), dim3(256), 0, (hipStream_t)stream, x, gy, scale,
                        shift, mean, rstd, sums, dx, n4, C, relu, frozen ? 0.0f : 1.0f / (float)rows);
+    return mv_check_launch();
+}
+
+// out [C] = column sums of x [rows, C] (C in {4, 8, 16, 32, 64}); partial: mvster_bn_slots(rows, C, 1) * 2 * C floats of
+// scratch, ticket as for mvster_bn_stats.  The bias gradient of the reference's convolutions with bias (FPN laterals,
+// monocular heads: models/mvs4net_utils.py:485-487, :846-848).  One launch.
+extern "C" int mvster_col_sum(const float* x, float* partial, float* out, int* ticket, long rows, int C, void* stream) {
+    if (!x || !partial || !out || !ticket) return MVSTER_ERR_NULL;
+    if (int rc = check(rows, C)) return rc;
+    ColSumArgs a{x, partial, out, ticket, rows * (C / 4), C};
+    hipLaunchKernelGGL(col_sum_kernel, dim3(slots_for(rows, C, 1)), dim3(kRedThreads), 0, (hipStream_t)stream, a);
     return mv_check_launch();
 }

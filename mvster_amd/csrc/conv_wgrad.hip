@@ -464,11 +464,11 @@ struct FinishArgs {
     int nblk, ngrp, cop, width, ntaps, cip, co_lim, ci_lim, swap, flip;
 };
 
-__global__ void __launch_bounds__(1024) conv_wgrad_finish_kernel(FinishArgs a) {
+__device__ __forceinline__ void finish_block(const FinishArgs& a, long block) {
     __shared__ float red[16][64];
     const int el = threadIdx.x & 63, lane = threadIdx.x >> 6;
     const long E = (long)a.ngrp * a.cop * a.width;
-    const long e = (long)blockIdx.x * 64 + el;
+    const long e = block * 64 + el;
     float s = 0.0f;
     if (e < E) {
         // eight slots in flight per thread (the loads are issued clamped and masked afterwards: one dependent load after
@@ -498,6 +498,27 @@ __global__ void __launch_bounds__(1024) conv_wgrad_finish_kernel(FinishArgs a) {
     if (a.flip) tap = a.ntaps - 1 - tap;
     const long o = a.swap ? ((long)ci * a.co_lim + row) * a.ntaps + tap : ((long)row * a.ci_lim + ci) * a.ntaps + tap;
     a.dw[o] = s;
+}
+
+__global__ void __launch_bounds__(1024) conv_wgrad_finish_kernel(FinishArgs a) { finish_block(a, blockIdx.x); }
+
+// Every pending finish of a training step in one launch: the weight gradients are read by nobody before the backward
+// pass is over (no hook-driven reducer: see train_ops.deferred_wgrad_finish), so the 64 finishing launches of 5 us become
+// one or two.  The records travel as kernel arguments (the partial buffers are fresh allocations every step).
+constexpr int kFinishBatch = 56;       // (56-byte records + a 4-byte block offset each: the argument block stays under 4 KB)
+struct FinishBatchArgs {
+    FinishArgs a[kFinishBatch];
+    int first_block[kFinishBatch];
+    int count;
+};
+
+__global__ void __launch_bounds__(1024) conv_wgrad_finish_batch_kernel(FinishBatchArgs b) {
+    int lo = 0, hi = b.count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (b.first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    finish_block(b.a[lo], (long)((int)blockIdx.x - b.first_block[lo]));
 }
 
 }  // namespace
@@ -571,5 +592,38 @@ extern "C" int mvster_conv_wgrad_finish(const float* partial, float* dw, int nbl
     FinishArgs a{partial, dw, nblk, ngrp, cop, width, ntaps, cip, co_lim, ci_lim, swap, flip};
     const long E = (long)ngrp * cop * width;
     hipLaunchKernelGGL(conv_wgrad_finish_kernel, dim3((unsigned)((E + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, a);
+    return mv_check_launch();
+}
+
+// `count` finishes in ceil(count / 56) launches: recs = HOST array of 56-byte records {const float* partial; float* dw; int
+// nblk, ngrp, cop, width, ntaps, cip, co_lim, ci_lim, swap, flip} (the arguments of mvster_conv_wgrad_finish, same checks).
+extern "C" int mvster_conv_wgrad_finish_batch(const void* recs, int count, void* stream) {
+    if (!recs) return MVSTER_ERR_NULL;
+    if (count <= 0) return MVSTER_ERR_SHAPE;
+    static_assert(sizeof(FinishArgs) == 56, "FinishArgs layout");
+    const FinishArgs* r = static_cast<const FinishArgs*>(recs);
+    for (int i = 0; i < count; ++i) {
+        const FinishArgs& a = r[i];
+        if (!a.partial || !a.dw) return MVSTER_ERR_NULL;
+        if (a.nblk <= 0 || a.ngrp <= 0 || a.cop <= 0 || a.width <= 0 || a.ntaps <= 0 || a.co_lim <= 0 || a.ci_lim <= 0 ||
+            a.co_lim > a.cop)
+            return MVSTER_ERR_SHAPE;
+        if (a.cip != 0 && a.cip != 4 && a.cip != 8) return MVSTER_ERR_UNSUPPORTED;
+        if (a.cip ? (a.width != 16 || a.ci_lim > a.cip || (long)a.ngrp * (16 / a.cip) < a.ntaps)
+                  : (a.ci_lim > a.width || a.ngrp != a.ntaps))
+            return MVSTER_ERR_SHAPE;
+    }
+    for (int i0 = 0; i0 < count; i0 += kFinishBatch) {
+        FinishBatchArgs b;
+        b.count = 0;
+        long blocks = 0;
+        for (int i = i0; i < count && b.count < kFinishBatch; ++i) {
+            b.a[b.count] = r[i];
+            b.first_block[b.count] = (int)blocks;
+            blocks += ((long)r[i].ngrp * r[i].cop * r[i].width + 63) / 64;
+            ++b.count;
+        }
+        hipLaunchKernelGGL(conv_wgrad_finish_batch_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, b);
+    }
     return mv_check_launch();
 }

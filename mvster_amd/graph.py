@@ -355,7 +355,11 @@ class GraphedTrainStep:
             out = self.model(self.imgs, self.proj, self.depth_values)
             res = self.loss_fn(out, self.gt, self.mask)
             loss = res[0] if isinstance(res, (tuple, list)) else res
-            loss.backward()
+            # (nothing reads a weight gradient before the backward pass is over -- the bucketed all-reduce and the optimizer
+            #  come after it -- so the 64 finishing launches of the weight-gradient kernels are issued as one)
+            from .train_ops import deferred_wgrad_finish
+            with deferred_wgrad_finish():
+                loss.backward()
         finally:
             if batched:
                 self._cache.end_batch()

@@ -435,12 +435,14 @@ def _wgrad_tiles(c):
     return 4 if t == 3 else t
 
 
-def conv_wgrad(x_cl, gy_cl, kernel, stride, padding, co_keep=None, ci_keep=None, mirrored=False):
+def conv_wgrad(x_cl, gy_cl, kernel, stride, padding, co_keep=None, ci_keep=None, mirrored=False, may_defer=False):
     """Weight gradient of the channels-last convolution y = conv(x; W[CO,CI,kd,kh,kw], stride, padding):
     x_cl [B,Di,Hi,Wi,CI], gy_cl [B,Do,Ho,Wo,CO] -> dW [co_keep,ci_keep,kd,kh,kw] (the leading channels; default all).
     With the roles of x and gy swapped it is the gradient of a ConvTranspose weight [cin,cout,...].  ``mirrored``: return
     dW with the taps mirrored and the two channel axes exchanged, [ci_keep,co_keep,kd,kh,kw] (the narrow-output form of
-    train_ops).  Two launches: the slot kernel and the finish.  Autograd of models/mvs4net_utils.py:116-123 etc."""
+    train_ops).  Two launches: the slot kernel and the finish.  ``may_defer``: inside ``train_ops.deferred_wgrad_finish`` the
+    finish is left to the batched launch at the end of the backward pass and dW is NOT valid before -- only for gradients
+    of leaf parameters, which nothing reads during the pass.  Autograd of models/mvs4net_utils.py:116-123 etc."""
     _chk(x_cl, "conv_wgrad:x")
     _chk(gy_cl, "conv_wgrad:gy")
     B, Di, Hi, Wi, CI = x_cl.shape
@@ -479,10 +481,55 @@ def conv_wgrad(x_cl, gy_cl, kernel, stride, padding, co_keep=None, ci_keep=None,
         raise RuntimeError("conv_wgrad: cannot keep more channels than the tensors have")
     dw = torch.empty((ci_keep, co_keep, kd, kh, kw) if mirrored else (co_keep, ci_keep, kd, kh, kw), device=x_cl.device,
                      dtype=torch.float32)
+    if WGRAD_PENDING is not None and may_defer:
+        # deferred: the caller (train_ops.deferred_wgrad_finish) issues every finish of the backward pass in one launch
+        WGRAD_PENDING.append((partial, dw, (nblk, ngrp, cop, width, ntaps, cip if packed else 0, co_keep, ci_keep, int(mirrored),
+                                            int(mirrored))))
+        # (an alias, not `dw` itself: autograd's AccumulateGrad adopts an incoming gradient only when nobody else holds
+        #  the tensor object -- otherwise it stores a CLONE, i.e. a copy of the not yet finished buffer)
+        return dw.view(dw.shape)
     rc = lib.mvster_conv_wgrad_finish(_ptr(partial), _ptr(dw), nblk, ngrp, cop, width, ntaps, cip if packed else 0,
                                       co_keep, ci_keep, int(mirrored), int(mirrored), _stream())
     _lib.check(rc, "conv_wgrad_finish")
     return dw
+
+
+WGRAD_PENDING = None          # a list while weight-gradient finishes are being deferred (train_ops.deferred_wgrad_finish)
+
+
+def conv_wgrad_flush():
+    """Issue the deferred finishes (``WGRAD_PENDING``) as one batched launch per 56 layers and empty the list."""
+    import ctypes
+    pend = WGRAD_PENDING
+    if not pend:
+        return
+
+    class Rec(ctypes.Structure):
+        _fields_ = [("partial", ctypes.c_void_p), ("dw", ctypes.c_void_p)] + [(n, ctypes.c_int) for n in
+                   ("nblk", "ngrp", "cop", "width", "ntaps", "cip", "co_lim", "ci_lim", "swap", "flip")]
+    arr = (Rec * len(pend))()
+    for r, (partial, dw, ints) in zip(arr, pend):
+        r.partial, r.dw = partial.data_ptr(), dw.data_ptr()
+        (r.nblk, r.ngrp, r.cop, r.width, r.ntaps, r.cip, r.co_lim, r.ci_lim, r.swap, r.flip) = ints
+    rc = _lib.load().mvster_conv_wgrad_finish_batch(ctypes.cast(arr, ctypes.c_void_p), len(pend), _stream())
+    _lib.check(rc, "conv_wgrad_finish_batch")
+    pend.clear()
+
+
+def col_sum(x):
+    """Sum of a channels-last tensor [..., C] over everything but the channels -> [C]; one launch, deterministic (a
+    convolution's bias gradient).  C in {4, 8, 16, 32, 64}."""
+    _chk(x, "col_sum")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    nblk = _bn_slots(rows, C, 1)
+    if nblk <= 0:
+        raise RuntimeError("col_sum: unsupported channel count %d" % C)
+    partial = torch.empty(nblk, 2, C, device=x.device, dtype=torch.float32)
+    out = torch.empty(C, device=x.device, dtype=torch.float32)
+    rc = _lib.load().mvster_col_sum(_ptr(x), _ptr(partial), _ptr(out), _ticket(x.device), rows, C, _stream())
+    _lib.check(rc, "col_sum")
+    return out
 
 
 _WGRAD_SLOTS = {}

@@ -313,19 +313,22 @@ class _ConvCL(torch.autograd.Function):
         elif gtap is not None:
             gx = gtap
         if ctx.needs_input_grad[1]:
+            # (a derived weight -- the finest FPN level's composed 3x3 -- hands its gradient on inside this backward pass)
+            leaf = own is None and weight.is_leaf
             if transposed:
-                gw = ops.conv_wgrad(gyp, xp, kernel, stride, padding, co_keep=cin, ci_keep=co)   # [cin, cout, k]
+                gw = ops.conv_wgrad(gyp, xp, kernel, stride, padding, co_keep=cin, ci_keep=co, may_defer=leaf)   # [cin, cout, k]
             elif stride == (1, 1, 1) and co <= 8 < xp.shape[-1] and kernel != (1, 1, 1):
                 # narrow OUTPUT side: the mirrored sum  dW[co][ci][t] = sum_q x[q][ci] * gy[q + p - t][co]  has gy as the
                 # shifted tensor, so the tap-packed kernel applies with the roles swapped (taps and padding mirrored)
                 mirror = tuple(k - 1 - p for k, p in zip(kernel, padding))
-                gw = ops.conv_wgrad(gyp, xp, kernel, stride, mirror, co_keep=cin, ci_keep=co, mirrored=True)
+                gw = ops.conv_wgrad(gyp, xp, kernel, stride, mirror, co_keep=cin, ci_keep=co, mirrored=True, may_defer=leaf)
             else:
-                gw = ops.conv_wgrad(xp, gyp, kernel, stride, padding, co_keep=co, ci_keep=cin)   # [cout, cin, k]
+                gw = ops.conv_wgrad(xp, gyp, kernel, stride, padding, co_keep=co, ci_keep=cin, may_defer=leaf)   # [cout, cin, k]
             if weight.dim() == 4:
                 gw = gw.squeeze(2)
         if bias is not None and ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 1, 2, 3))
+            # (the padded gradient where the head has a single output channel: the kernel sums 4 / 8 / ... / 64 columns)
+            gb = ops.col_sum(gyp)[:co] if co_p in (4, 8, 16, 32, 64) and gy.numel() else gy.sum((0, 1, 2, 3))
         gskip = None
         if ctx.has_skip[0]:
             gskip = gy
@@ -550,3 +553,24 @@ def mono_depth_cl(z, d_min, d_max):
     """1 / (1/d_max + (1/d_min - 1/d_max) * sigmoid(z)) per sample (models/mvs4net_utils.py:858-866), z of any shape
     [B, ...]; one launch forward, one backward (as tensor expressions: ~13 forward and ~10 backward launches per stage)."""
     return _MonoDepth.apply(z, d_min, d_max)
+
+
+class deferred_wgrad_finish:
+    """Context manager around a backward pass whose weight gradients nobody reads before it ends (no hook-driven reducer
+    such as DistributedDataParallel's): the convolutions' weight-gradient kernels leave their partial sums, and ONE batched
+    launch finishes all of them on exit (64 finishing launches of 5 us per training step otherwise).  ``GraphedTrainStep``
+    wraps its backward in it; plain ``loss.backward()`` finishes every layer on the spot."""
+
+    def __enter__(self):
+        if ops.WGRAD_PENDING is not None:
+            raise RuntimeError("deferred_wgrad_finish does not nest")
+        ops.WGRAD_PENDING = []
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        try:
+            if exc_type is None:
+                ops.conv_wgrad_flush()
+        finally:
+            ops.WGRAD_PENDING = None
+        return False
