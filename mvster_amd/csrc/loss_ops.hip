@@ -142,12 +142,155 @@ __global__ void __launch_bounds__(128) sinkhorn_kernel(const float* __restrict__
     for (int i = 0; i < D; ++i) jp[i * HW] = db[i] / (pred[i] + 1e-12f);
 }
 
+// The discrete form with the constant cost factored out of the exponentials: K_ij = |i - j| / eps does not depend on the
+// pixel, so  LSE_i(K_ij + u_i) = m + log sum_i E_ij exp(u_i - m)  with E_k = exp(k / eps) (D constants) and m = max_i u_i
+// (any shift is exact in exact arithmetic; 1 <= the sum <= D exp((D-1)/eps)).  D exponentials per update instead of D^2;
+// the reverse sweep uses the same factorisation for its softmax matrices (exp(K_ij + v_j + u_i - b_i) is
+// E_ij exp(v_j - m) / sum_j' E_ij' exp(v_j' - m) because u_i = b_i - LSE_j(K_ij + v_j)).  16 instead of 96 exponentials per
+// iteration at D = 4, 32 instead of 384 at D = 8; same mathematics, results within rounding of the form above.
+template <int D>
+__global__ void __launch_bounds__(128) sinkhorn_fast_kernel(const float* __restrict__ attn, const float* __restrict__ hypo,
+                                                            const float* __restrict__ gt, float* __restrict__ loss_pix,
+                                                            float* __restrict__ jac, int B, long HW, int iters, float inv_eps) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (long)B * HW) return;
+    const long b = p / HW, q = p - b * HW;
+    const float* ap = attn + b * D * HW + q;
+    const float* hp = hypo + b * D * HW + q;
+    const float g = gt[p];
+    float pred[D], bl[D], a[D], Ek[D];
+    int nearest = 0;
+    float best = 0.0f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        pred[i] = ap[i * HW];
+        bl[i] = logf(pred[i] + 1e-12f);
+        const float dist = fabsf(hp[i * HW] - g);
+        if (i == 0 || dist < best) { best = dist; nearest = i; }      // first minimum, like torch.min
+        Ek[i] = expf((float)i * inv_eps);
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) a[j] = logf((j == nearest ? 1.0f : 0.0f) + 1e-12f);
+#define MV_E(i, j) Ek[(i) > (j) ? (i) - (j) : (j) - (i)]
+    float uh[kMaxIters][D], vh[kMaxIters][D];      // potentials after every iteration (reverse sweep)
+    float u[D], v[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) u[i] = 0.0f;
+    for (int t = 0; t < iters; ++t) {
+        float m = u[0], e[D];
+#pragma unroll
+        for (int i = 1; i < D; ++i) m = fmaxf(m, u[i]);
+#pragma unroll
+        for (int i = 0; i < D; ++i) e[i] = expf(u[i] - m);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) sum = fmaf(MV_E(i, j), e[i], sum);
+            v[j] = a[j] - (m + logf(sum));
+        }
+        m = v[0];
+#pragma unroll
+        for (int j = 1; j < D; ++j) m = fmaxf(m, v[j]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) e[j] = expf(v[j] - m);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) sum = fmaf(MV_E(i, j), e[j], sum);
+            u[i] = bl[i] - (m + logf(sum));
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) { uh[t][i] = u[i]; vh[t][i] = v[i]; }
+    }
+    if (iters == 0) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) v[j] = 0.0f;
+    }
+    // loss and the gradients of the final plan (D^2 exponentials, once)
+    float loss = 0.0f, du[D], dv[D], db[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { du[i] = 0.0f; db[i] = 0.0f; dv[i] = 0.0f; }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const float c = fabsf((float)(i - j));
+            const float pc = expf(c * inv_eps + u[i] + v[j]) * c;
+            loss += pc;
+            du[i] += pc;
+            dv[j] += pc;
+        }
+    loss_pix[p] = loss;
+    // reverse sweep
+    for (int t = iters - 1; t >= 0; --t) {
+        float e[D], den[D];
+        // u_i = b_i - LSE_j(K_ij + v_j): softmax_ij = E_ij exp(v_j - m) / sum_j' E_ij' exp(v_j' - m)
+        float m = vh[t][0];
+#pragma unroll
+        for (int j = 1; j < D; ++j) m = fmaxf(m, vh[t][j]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) e[j] = expf(vh[t][j] - m);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) sum = fmaf(MV_E(i, j), e[j], sum);
+            den[i] = du[i] / sum;
+            db[i] += du[i];
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) acc = fmaf(den[i], MV_E(i, j), acc);
+            dv[j] -= acc * e[j];
+        }
+        // v_j = a_j - LSE_i(K_ij + u'_i), u' the previous iterate: softmax_ij = E_ij exp(u'_i - m) / sum_i' E_i'j exp(u'_i' - m)
+        float up[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) up[i] = t > 0 ? uh[t - 1][i] : 0.0f;
+        m = up[0];
+#pragma unroll
+        for (int i = 1; i < D; ++i) m = fmaxf(m, up[i]);
+#pragma unroll
+        for (int i = 0; i < D; ++i) e[i] = expf(up[i] - m);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) sum = fmaf(MV_E(i, j), e[i], sum);
+            den[j] = dv[j] / sum;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) acc = fmaf(den[j], MV_E(i, j), acc);
+            du[i] = -acc * e[i];
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) dv[j] = 0.0f;
+    }
+#undef MV_E
+    float* jp = jac + b * D * HW + q;
+#pragma unroll
+    for (int i = 0; i < D; ++i) jp[i * HW] = db[i] / (pred[i] + 1e-12f);
+}
+
 template <bool CONT>
 int launch_sinkhorn(const float* attn, const float* hypo, const float* gt, const float* mask, float* loss_pix, float* jac,
                     int B, int D, long HW, int iters, float eps, hipStream_t s) {
     const long n = (long)B * HW;
     dim3 grid((unsigned)((n + 127) / 128)), block(128);
     const float inv_eps = 1.0f / eps;
+    if constexpr (!CONT) {
+        // the shipped stage widths on the factored form (D exponentials per update); others on the general kernel
+#define MV_F(D_) if (D == D_) { hipLaunchKernelGGL((sinkhorn_fast_kernel<D_>), grid, block, 0, s, attn, hypo, gt, loss_pix, jac, B, HW, iters, inv_eps); return mv_check_launch(); }
+        MV_F(4) MV_F(8)
+#undef MV_F
+    }
 #define MV_S(D_) if (D == D_) { hipLaunchKernelGGL((sinkhorn_kernel<D_, CONT>), grid, block, 0, s, attn, hypo, gt, mask, loss_pix, jac, B, HW, iters, inv_eps); return mv_check_launch(); }
     if (!CONT) { MV_S(2) }
     MV_S(3) MV_S(4) MV_S(5) MV_S(6) MV_S(7) MV_S(8)
