@@ -348,7 +348,12 @@ def api_call_measure(args, model, dev, seed, shard):
       ..._eager               the same with ``model.graph_cache = False`` (every call issues its launches: the round-4 API path)
       ..._synced              a device synchronisation after every call (the reference's loop reads the outputs back per sample)
       ..._tocuda              the samples start in host memory and go through the reference's ``tocuda`` (utils.py:59-67:
-                              ``.to(torch.device("cuda"))`` per tensor, pageable memory, default DataLoader) before each call"""
+                              ``.to(torch.device("cuda"))`` per tensor, pageable memory, default DataLoader) before each call
+      with_outputs_to_host    device-resident samples, and every call followed by the reference's ``tensor2numpy(outputs)``
+                              (utils.py:50-57, test_mvs4.py:208: ``.detach().cpu().numpy().copy()`` of every tensor of the
+                              nested dict, 47 MB per 512x640 depth map, the last stage's twice) -- the D2H leg of the loop
+      ..._packed              the same through ``mvster_amd.graph.outputs_to_numpy`` (one copy through a pinned buffer)
+      ..._packed_needed_keys  ... keeping only what ``save_depth`` reads (depth + photometric_confidence, 6.5 MB)"""
     from mvster_amd.synthetic import make_inputs
     pool_n = 4
     host = [make_inputs(nviews=args.views, H=args.height, W=args.width, seed=seed + 31 * k, batch=args.batch) for k in range(pool_n)]
@@ -370,6 +375,22 @@ def api_call_measure(args, model, dev, seed, shard):
         cnt[0] += 1
         keep[0] = model([i.to(dev) for i in im], {k: v.to(dev) for k, v in pr.items()}, d.to(dev))
 
+    def call_to_host():
+        call()
+        o = keep[0]
+        keep[0] = {k: ({k2: v2.detach().cpu().numpy().copy() for k2, v2 in v.items()} if isinstance(v, dict)
+                       else v.detach().cpu().numpy().copy()) for k, v in o.items()}
+
+    def call_to_host_packed():
+        from mvster_amd.graph import outputs_to_numpy
+        call()
+        keep[0] = outputs_to_numpy(keep[0])
+
+    def call_to_host_needed():
+        from mvster_amd.graph import outputs_to_numpy
+        call()
+        keep[0] = outputs_to_numpy(keep[0], keys=("depth", "photometric_confidence"))
+
     def run(fn, warm):
         for _ in range(warm):
             fn()
@@ -383,6 +404,11 @@ def api_call_measure(args, model, dev, seed, shard):
     out["synced_every_call"] = run(call_synced, 2)
     out["from_host_tocuda"] = run(call_tocuda, 2)
     out["from_host_tocuda"]["h2d_MB_per_call"] = round(sum(i.numel() for i in host[0][0]) * 4 / 1e6, 2)
+    out["with_outputs_to_host"] = run(call_to_host, 2)
+    o = keep[0]
+    out["with_outputs_to_host"]["d2h_MB_per_call"] = round(sum(a.nbytes for k, v in o.items() for a in (v.values() if isinstance(v, dict) else [v])) / 1e6, 2)
+    out["with_outputs_to_host_packed"] = run(call_to_host_packed, 2)
+    out["with_outputs_to_host_packed_needed_keys"] = run(call_to_host_needed, 2)
     stats1 = dict(model._fwd_cache.stats)
     out["cache"] = {k: stats1[k] - stats0[k] for k in stats1}
     # one replayed call against the eager forward on the same sample: the cache must not change a bit

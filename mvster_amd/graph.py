@@ -51,6 +51,64 @@ def _is_dense(t):
     return True
 
 
+_HOST_STAGING = {}
+
+
+def outputs_to_numpy(outputs, keys=None):
+    """The reference's ``tensor2numpy(outputs)`` (utils.py:50-57; test_mvs4.py:208) for the dict ``MVS4net`` returns, with
+    ONE device -> host copy where that is possible: a ``ForwardCache`` call hands out all its tensors as views of one
+    fresh device buffer, which goes through one pinned staging buffer (kept per size) instead of ~40 blocking pageable
+    copies of 0.3-10 MB (the flattened last-stage entries are the same tensors as ``stage4``'s: the reference's recursion
+    copies them twice).  ``keys``: keep only these entries per stage (e.g. ``("depth", "photometric_confidence")`` -- all
+    ``save_depth`` reads, test_mvs4.py:213-264: 6.5 of the 47 MB per 512x640 depth map).  Returns freshly allocated numpy
+    arrays in the reference's structure.  Anything else (eager results, other devices) falls back to per-tensor copies."""
+    import numpy as np
+
+    def want(k):
+        return keys is None or k in keys
+    flat = []
+    for k, v in outputs.items():
+        if isinstance(v, dict):
+            flat += [((k, k2), t) for k2, t in v.items() if want(k2) and torch.is_tensor(t)]
+        elif torch.is_tensor(v) and want(k):
+            flat.append(((k,), v))
+    out = {}
+
+    def put(path, arr):
+        if len(path) == 1:
+            out[path[0]] = arr
+        else:
+            out.setdefault(path[0], {})[path[1]] = arr
+    tensors = [t for _, t in flat]
+    one = (len(tensors) > 0 and all(t.is_cuda and t.dtype == torch.float32 for t in tensors)
+           and len({t.untyped_storage().data_ptr() for t in tensors}) == 1)
+    if not one:
+        for path, t in flat:
+            put(path, t.detach().cpu().numpy().copy())
+        return out
+    st = tensors[0].untyped_storage()
+    n = st.nbytes() // 4
+    dev_flat = torch.empty(0, dtype=torch.float32, device=tensors[0].device).set_(st, 0, (n,), (1,))
+    # only the span the wanted tensors cover
+    lo = min(t.storage_offset() for t in tensors)
+    hi = max(t.storage_offset() + (0 if t.numel() == 0 else 1 + sum((sz - 1) * sd for sz, sd in zip(t.shape, t.stride()))) for t in tensors)
+    stage = _HOST_STAGING.get(n)
+    if stage is None:
+        if len(_HOST_STAGING) > 4:
+            _HOST_STAGING.clear()
+        stage = _HOST_STAGING[n] = torch.empty(n, dtype=torch.float32).pin_memory()
+    stage[lo:hi].copy_(dev_flat[lo:hi], non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    seen = {}
+    for path, t in flat:
+        key = (t.storage_offset(), tuple(t.shape), tuple(t.stride()))
+        arr = seen.get(key)
+        if arr is None:
+            arr = seen[key] = np.array(stage.as_strided(t.shape, t.stride(), t.storage_offset()).numpy(), copy=True)
+        put(path, arr)
+    return out
+
+
 class _CachedForward:
     """One captured eval forward of a ``ForwardCache``: static inputs (views of one flat buffer), the graph, the static
     outputs and the recipe that clones them into one fresh allocation per call."""

@@ -35,6 +35,28 @@ def test_train_mode_protocol_two_ranks():
     assert line["mode"] == "train" and line["n_gpus"] == 2 and line["ranks_seen"] == 2
     assert abs(line["param_digest_spread"]) <= 1e-9
     assert line["value"] > 0
+    # every rank's own rate in rank order, also in training mode (the driver's scaling run reads it)
+    assert line["rank_order"] == [0, 1] and len(line["per_rank_value"]) == 2 and min(line["per_rank_value"]) > 0
+
+
+def test_train_mode_under_the_drivers_launcher_two_ranks():
+    """The driver's own launch line -- python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1
+    ... bench.py --gpus 2 -- through the training protocol: one JSON line from rank 0, two per-rank values."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--stub", "--mode", "train",
+                        "--gpus", "2", "--steps", "5", "--warmup", "2"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["mode"] == "train" and line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert line["rank_order"] == [0, 1] and len(line["per_rank_value"]) == 2 and min(line["per_rank_value"]) > 0
+    assert abs(line["param_digest_spread"]) <= 1e-9
 
 
 def test_four_ranks_train_protocol():

@@ -535,6 +535,56 @@ def test_forward_graph_cache_follows_weight_updates_shapes_and_mode_changes(ship
     assert torch.equal(m(*a)["stage4"]["attn_weight"], before)
 
 
+def test_forward_graph_cache_sees_batchnorm_statistics_moved_by_a_training_forward(shipped_cfg, checkpoint):
+    """The native BatchNorm writes its running statistics through raw pointers (no ``_version`` bump): a train-mode forward
+    WITHOUT an optimizer step (BatchNorm re-calibration, a frozen-backbone fine-tune, a no_grad forward in training mode)
+    must still send the next eval call back to fresh plans instead of replaying the graph folded from the old statistics."""
+    m = MVS4net(**shipped_cfg)
+    m.load_state_dict(checkpoint, strict=True)
+    m.to(DEV).eval()
+    a = to_dev(*make_inputs(nviews=3, H=64, W=128, seed=7, batch=2))
+    m(*a)
+    before = m(*a)["stage4"]["attn_weight"].clone()
+    assert m._fwd_cache.stats["captured"] == 1
+    rm0 = m.feature.conv0[0].bn.running_mean.clone()
+    m.train()
+    with torch.no_grad():
+        m(*a)                                                        # moves the running statistics, nothing else
+    m.eval()
+    assert not torch.equal(rm0, m.feature.conv0[0].bn.running_mean)
+    got = m(*a)["stage4"]["attn_weight"]
+    want = m.forward_eager(*a)["stage4"]["attn_weight"]
+    assert torch.equal(got, want) and not torch.equal(got, before)
+    assert torch.equal(m(*a)["stage4"]["attn_weight"], want) and m._fwd_cache.stats["captured"] == 2
+
+
+def test_outputs_to_numpy_equals_tensor2numpy(shipped_cfg, checkpoint):
+    """graph.outputs_to_numpy -- the reference's tensor2numpy(outputs) (utils.py:50-57) with one device -> host copy for a
+    graph-cache result -- returns the same arrays, in the reference's structure, freshly allocated; ``keys`` keeps a subset."""
+    from mvster_amd.graph import outputs_to_numpy
+    m = MVS4net(**shipped_cfg)
+    m.load_state_dict(checkpoint, strict=True)
+    m.to(DEV).eval()
+    a = to_dev(*make_inputs(nviews=3, H=64, W=128, seed=9))
+    for call in range(3):                                            # eager result, captured, replayed
+        o = m(*a)
+        want = {k: ({k2: v2.detach().cpu().numpy().copy() for k2, v2 in v.items()} if isinstance(v, dict) else v.detach().cpu().numpy().copy())
+                for k, v in o.items()}
+        got = outputs_to_numpy(o)
+        assert list(got.keys()) == list(want.keys())
+        for k, v in want.items():
+            if isinstance(v, dict):
+                assert list(got[k].keys()) == list(v.keys())
+                for k2, w2 in v.items():
+                    assert got[k][k2].shape == w2.shape and np.array_equal(got[k][k2], w2), (call, k, k2)
+            else:
+                assert got[k].shape == v.shape and np.array_equal(got[k], v), (call, k)
+        sub = outputs_to_numpy(o, keys=("depth", "photometric_confidence"))
+        assert sorted(sub["stage2"].keys()) == ["depth", "photometric_confidence"] and np.array_equal(sub["depth"], want["depth"])
+    second = outputs_to_numpy(m(*a))
+    assert second["depth"] is not got["depth"] and np.array_equal(second["depth"], got["depth"])     # not the staging buffer
+
+
 def test_fused_hypothesis_scheduling_gives_the_same_forward(shipped_cfg, checkpoint):
     """``MVS4net.fuse_hypotheses`` (off by default: measured slower): every stage's hypotheses computed inside the warp launch
     (mvster_warp_agg_fwd_sched) -- the same forward, bit for bit, eager and through the graph cache (the switch is part of
