@@ -341,6 +341,11 @@ class GraphedTrainStep:
     returns the scalar to minimise first, like ``MVS4net_loss``.
     """
 
+    # HIP streams the postponed weight-gradient kernels are spread over (train_ops.deferred_wgrad_finish).  Measured on the
+    # config-4 step: 1 stream 13.25 ms, 2 13.12, 4 13.61, 8 14.62 -- the weight-gradient kernels are persistent grids that fill
+    # the chip, so they gain little from running beside each other and every extra branch of the captured graph costs
+    wgrad_streams = 2
+
     def __init__(self, model, optimizer, loss_fn, imgs, proj_matrices, depth_values, depth_gt_ms, mask_ms, warmup=3,
                  grad_sync=None, capture=True):
         """``capture=False``: the same object without the hipGraph -- every call runs the identical sequence (static input
@@ -416,7 +421,7 @@ class GraphedTrainStep:
             # (nothing reads a weight gradient before the backward pass is over -- the bucketed all-reduce and the optimizer
             #  come after it -- so the 64 finishing launches of the weight-gradient kernels are issued as one)
             from .train_ops import deferred_wgrad_finish
-            with deferred_wgrad_finish():
+            with deferred_wgrad_finish(streams=self.wgrad_streams):
                 loss.backward()
         finally:
             if batched:

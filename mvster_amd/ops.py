@@ -435,14 +435,22 @@ def _wgrad_tiles(c):
     return 4 if t == 3 else t
 
 
-def conv_wgrad(x_cl, gy_cl, kernel, stride, padding, co_keep=None, ci_keep=None, mirrored=False, may_defer=False):
+def conv_wgrad_shape(x_cl, gy_cl, kernel, co_keep=None, ci_keep=None, mirrored=False):
+    """Shape of what ``conv_wgrad`` returns for these arguments."""
+    co_keep = gy_cl.shape[-1] if co_keep is None else co_keep
+    ci_keep = x_cl.shape[-1] if ci_keep is None else ci_keep
+    return ((ci_keep, co_keep) if mirrored else (co_keep, ci_keep)) + tuple(kernel)
+
+
+def conv_wgrad(x_cl, gy_cl, kernel, stride, padding, co_keep=None, ci_keep=None, mirrored=False, may_defer=False, dw=None):
     """Weight gradient of the channels-last convolution y = conv(x; W[CO,CI,kd,kh,kw], stride, padding):
     x_cl [B,Di,Hi,Wi,CI], gy_cl [B,Do,Ho,Wo,CO] -> dW [co_keep,ci_keep,kd,kh,kw] (the leading channels; default all).
     With the roles of x and gy swapped it is the gradient of a ConvTranspose weight [cin,cout,...].  ``mirrored``: return
     dW with the taps mirrored and the two channel axes exchanged, [ci_keep,co_keep,kd,kh,kw] (the narrow-output form of
     train_ops).  Two launches: the slot kernel and the finish.  ``may_defer``: inside ``train_ops.deferred_wgrad_finish`` the
     finish is left to the batched launch at the end of the backward pass and dW is NOT valid before -- only for gradients
-    of leaf parameters, which nothing reads during the pass.  Autograd of models/mvs4net_utils.py:116-123 etc."""
+    of leaf parameters, which nothing reads during the pass.  ``dw``: write into this tensor instead of allocating.
+    Autograd of models/mvs4net_utils.py:116-123 etc."""
     _chk(x_cl, "conv_wgrad:x")
     _chk(gy_cl, "conv_wgrad:gy")
     B, Di, Hi, Wi, CI = x_cl.shape
@@ -479,8 +487,11 @@ def conv_wgrad(x_cl, gy_cl, kernel, stride, padding, co_keep=None, ci_keep=None,
     ci_keep = CI if ci_keep is None else ci_keep
     if co_keep > CO or ci_keep > CI:
         raise RuntimeError("conv_wgrad: cannot keep more channels than the tensors have")
-    dw = torch.empty((ci_keep, co_keep, kd, kh, kw) if mirrored else (co_keep, ci_keep, kd, kh, kw), device=x_cl.device,
-                     dtype=torch.float32)
+    shape = (ci_keep, co_keep, kd, kh, kw) if mirrored else (co_keep, ci_keep, kd, kh, kw)
+    if dw is None:
+        dw = torch.empty(shape, device=x_cl.device, dtype=torch.float32)
+    elif tuple(dw.shape) != shape or not dw.is_contiguous() or dw.dtype != torch.float32:
+        raise RuntimeError("conv_wgrad: `dw` must be a contiguous float32 tensor of shape %s" % (shape,))
     if WGRAD_PENDING is not None and may_defer:
         # deferred: the caller (train_ops.deferred_wgrad_finish) issues every finish of the backward pass in one launch
         WGRAD_PENDING.append((partial, dw, (nblk, ngrp, cop, width, ntaps, cip if packed else 0, co_keep, ci_keep, int(mirrored),

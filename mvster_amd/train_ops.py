@@ -316,14 +316,25 @@ class _ConvCL(torch.autograd.Function):
             # (a derived weight -- the finest FPN level's composed 3x3 -- hands its gradient on inside this backward pass)
             leaf = own is None and weight.is_leaf
             if transposed:
-                gw = ops.conv_wgrad(gyp, xp, kernel, stride, padding, co_keep=cin, ci_keep=co, may_defer=leaf)   # [cin, cout, k]
+                wargs = (gyp, xp, kernel, stride, padding)                                   # -> [cin, cout, k]
+                wkw = dict(co_keep=cin, ci_keep=co)
             elif stride == (1, 1, 1) and co <= 8 < xp.shape[-1] and kernel != (1, 1, 1):
                 # narrow OUTPUT side: the mirrored sum  dW[co][ci][t] = sum_q x[q][ci] * gy[q + p - t][co]  has gy as the
                 # shifted tensor, so the tap-packed kernel applies with the roles swapped (taps and padding mirrored)
                 mirror = tuple(k - 1 - p for k, p in zip(kernel, padding))
-                gw = ops.conv_wgrad(gyp, xp, kernel, stride, mirror, co_keep=cin, ci_keep=co, mirrored=True, may_defer=leaf)
+                wargs = (gyp, xp, kernel, stride, mirror)
+                wkw = dict(co_keep=cin, ci_keep=co, mirrored=True)
             else:
-                gw = ops.conv_wgrad(xp, gyp, kernel, stride, padding, co_keep=co, ci_keep=cin, may_defer=leaf)   # [cout, cin, k]
+                wargs = (xp, gyp, kernel, stride, padding)                                   # -> [cout, cin, k]
+                wkw = dict(co_keep=co, ci_keep=cin)
+            if leaf and _WGRAD_JOBS is not None:
+                # deferred_wgrad_finish: nothing reads this gradient before the backward pass is over, so the kernel itself
+                # waits for the end of the pass and runs there beside the other layers' (see the context manager)
+                dw = torch.empty(ops.conv_wgrad_shape(wargs[0], wargs[1], kernel, **wkw), device=gy.device, dtype=torch.float32)
+                _WGRAD_JOBS.append((wargs, wkw, dw))
+                gw = dw.view(dw.shape)           # (an alias: AccumulateGrad adopts a tensor only if nobody else holds it)
+            else:
+                gw = ops.conv_wgrad(*wargs, **wkw)
             if weight.dim() == 4:
                 gw = gw.squeeze(2)
         if bias is not None and ctx.needs_input_grad[2]:
@@ -555,22 +566,56 @@ def mono_depth_cl(z, d_min, d_max):
     return _MonoDepth.apply(z, d_min, d_max)
 
 
+_WGRAD_JOBS = None           # a list while deferred_wgrad_finish is active: (args, kwargs, dw) of the postponed kernels
+_WGRAD_STREAMS = {}
+
+
 class deferred_wgrad_finish:
     """Context manager around a backward pass whose weight gradients nobody reads before it ends (no hook-driven reducer
-    such as DistributedDataParallel's): the convolutions' weight-gradient kernels leave their partial sums, and ONE batched
-    launch finishes all of them on exit (64 finishing launches of 5 us per training step otherwise).  ``GraphedTrainStep``
-    wraps its backward in it; plain ``loss.backward()`` finishes every layer on the spot."""
+    such as DistributedDataParallel's; ``GraphedTrainStep`` wraps its backward in it).  The weight-gradient kernels of leaf
+    parameters are not launched where autograd reaches them but on exit, round-robin over ``streams`` HIP streams forked
+    from the current one and joined back: most of the 64 launches are small, latency-bound layers of the coarse stages,
+    which then run beside each other instead of one after the other inside the backward chain; every stream finishes its
+    layers' partial sums with ONE batched launch (64 finishing launches of 5 us otherwise).  The activations and output
+    gradients the kernels read are kept alive until the join.  Plain ``loss.backward()`` outside the context runs every
+    layer on the spot."""
+
+    def __init__(self, streams=2):
+        self.nstreams = max(1, int(streams))
 
     def __enter__(self):
-        if ops.WGRAD_PENDING is not None:
+        global _WGRAD_JOBS
+        if _WGRAD_JOBS is not None:
             raise RuntimeError("deferred_wgrad_finish does not nest")
-        ops.WGRAD_PENDING = []
+        _WGRAD_JOBS = []
         return self
 
     def __exit__(self, exc_type, exc, tb):
+        global _WGRAD_JOBS
+        jobs, _WGRAD_JOBS = _WGRAD_JOBS, None
+        if exc_type is not None or not jobs:
+            return False
+        dev = jobs[0][2].device
+        main = torch.cuda.current_stream(dev)
+        pool = _WGRAD_STREAMS.setdefault(dev, [])
+        while len(pool) < self.nstreams:
+            pool.append(torch.cuda.Stream(device=dev))
+        side = pool[:self.nstreams]
+        pend = [[] for _ in side]
         try:
-            if exc_type is None:
-                ops.conv_wgrad_flush()
+            for s_ in side:
+                s_.wait_stream(main)                                     # fork: every input of the jobs is ready
+            for i, (wargs, wkw, dw) in enumerate(jobs):
+                k = i % len(side)
+                ops.WGRAD_PENDING = pend[k]
+                with torch.cuda.stream(side[k]):
+                    ops.conv_wgrad(*wargs, may_defer=True, dw=dw, **wkw)
+            for k, s_ in enumerate(side):
+                ops.WGRAD_PENDING = pend[k]
+                with torch.cuda.stream(s_):
+                    ops.conv_wgrad_flush()
         finally:
             ops.WGRAD_PENDING = None
+            for s_ in side:
+                main.wait_stream(s_)                                     # join (the inputs are released after it)
         return False
