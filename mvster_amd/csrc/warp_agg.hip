@@ -1168,7 +1168,7 @@ struct WarpAggBwdArgs {
     const int* rec_offset;  // [B*NV*ntiles + 1] exclusive prefix sums of the tiles' record counts
     int* rec_cursor;        // [B*NV*ntiles] running cursors (zero before the launch)
     float* rec;             // the records, kRecWords floats each
-    int tiles_x, tiles_y;   // source tiles of kRecTile x kRecTile texels
+    int tiles_x, tiles_y;   // source tiles of kRecTileX x kRecTileY texels
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1191,9 +1191,9 @@ struct WarpAggBwdArgs {
 //                              the buffer needs no zero fill either.
 // Deterministic by construction and independent of how smooth the depth maps are.
 // ------------------------------------------------------------------------------------------
-constexpr int kRecTile = 32, kRecShift = 5;
+constexpr int kRecTileX = 32, kRecShiftX = 5, kRecTileY = 16, kRecShiftY = 4;     // source tile: 32 x 16 texels
 constexpr int kRecWords = 12;            // {packed corner + mask, wx1, wy1, 0}, dw[0..3], dw[4..7]
-constexpr int kRecMaxTiles = 2048;       // source tiles per map the workgroups' LDS histograms hold (2048 x 1024 texels)
+constexpr int kRecMaxTiles = 4096;       // source tiles per map the workgroups' LDS histograms hold (4096 x 512 texels)
 
 // bit k set: tap k carries weight (k = 0 nw (x0, y0), 1 ne (x0+1, y0), 2 sw (x0, y0+1), 3 se); t after clamp_taps()
 __device__ __forceinline__ unsigned tap_mask(const mv::Taps& t) {
@@ -1208,8 +1208,8 @@ struct SampleTiles {
 
 __device__ __forceinline__ SampleTiles sample_tiles(const mv::Taps& t, unsigned mask, int tiles_x) {
     SampleTiles s;
-    const int tx0 = t.x0 >> kRecShift, tx1 = (t.x0 + 1) >> kRecShift;
-    const int ty0 = t.y0 >> kRecShift, ty1 = (t.y0 + 1) >> kRecShift;
+    const int tx0 = t.x0 >> kRecShiftX, tx1 = (t.x0 + 1) >> kRecShiftX;
+    const int ty0 = t.y0 >> kRecShiftY, ty1 = (t.y0 + 1) >> kRecShiftY;
     const int id0 = ty0 * tiles_x + tx0, id1 = ty0 * tiles_x + tx1, id2 = ty1 * tiles_x + tx0, id3 = ty1 * tiles_x + tx1;
     s.tile[0] = (mask & 1u) ? id0 : -1;
     s.tile[1] = ((mask & 2u) && id1 != s.tile[0]) ? id1 : -1;
@@ -1976,12 +1976,12 @@ struct WarpBwdAccumArgs {
 // K2: workgroup = (tile, view * NB + channel block, batch); lane = record.  The window is channel-major ([8] planes of
 // 32 x 32 u64): the lanes of an atomic instruction hit one plane at (practically) random texels.
 __global__ void __launch_bounds__(256) warp_bwd_accum_kernel(WarpBwdAccumArgs a) {
-    __shared__ u64 win[8][kRecTile * kRecTile];
+    __shared__ u64 win[8][kRecTileX * kRecTileY];
     const FixScale fx = make_fix_scale(a.maxima, a.G, a.D, a.CG, a.group != 0, a.fuse != 0, a.attn_temp);
     const int tile = blockIdx.x, v = blockIdx.y / a.NB, cb = blockIdx.y - v * a.NB, b = blockIdx.z;
     const int ntiles = a.tiles_x * a.tiles_y;
     const int tile_y = tile / a.tiles_x, tile_x = tile - tile_y * a.tiles_x;
-    for (int i = threadIdx.x; i < 8 * kRecTile * kRecTile; i += 256) (&win[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < 8 * kRecTileX * kRecTileY; i += 256) (&win[0][0])[i] = 0;
     __syncthreads();
     const long g0 = ((long)b * a.NV + v) * ntiles + tile;
     const int off = a.offset[g0], cnt = a.offset[g0 + 1] - off;
@@ -1998,8 +1998,8 @@ __global__ void __launch_bounds__(256) warp_bwd_accum_kernel(WarpBwdAccumArgs a)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int tx = x0 + (k & 1), ty = y0 + (k >> 1);
-            if (((mask >> k) & 1u) && (tx >> kRecShift) == tile_x && (ty >> kRecShift) == tile_y) {
-                const int idx = (ty & (kRecTile - 1)) * kRecTile + (tx & (kRecTile - 1));
+            if (((mask >> k) & 1u) && (tx >> kRecShiftX) == tile_x && (ty >> kRecShiftY) == tile_y) {
+                const int idx = (ty & (kRecTileY - 1)) * kRecTileX + (tx & (kRecTileX - 1));
 #pragma unroll
                 for (int c = 0; c < 8; ++c) fix_add(&win[c][idx], wt[k] * dw[c], fx.s);
             }
@@ -2008,9 +2008,9 @@ __global__ void __launch_bounds__(256) warp_bwd_accum_kernel(WarpBwdAccumArgs a)
     __syncthreads();
     // the tile's texels, every one exactly once: plain stores, channel-fastest (32 contiguous bytes per texel and block)
     float* gsp = a.grad_src + (long)v * a.src_vs + (long)b * a.src_bs;
-    for (int i = threadIdx.x; i < 8 * kRecTile * kRecTile; i += 256) {
+    for (int i = threadIdx.x; i < 8 * kRecTileX * kRecTileY; i += 256) {
         const int c = i & 7, tex = i >> 3;
-        const int ty = tile_y * kRecTile + (tex >> kRecShift), tx = tile_x * kRecTile + (tex & (kRecTile - 1));
+        const int ty = tile_y * kRecTileY + (tex >> kRecShiftX), tx = tile_x * kRecTileX + (tex & (kRecTileX - 1));
         if (ty < a.Hs && tx < a.Ws) gsp[((long)ty * a.Ws + tx) * a.C + cb * 8 + c] = fix_get(win[c][tex], fx.inv);
     }
 }
@@ -2268,7 +2268,7 @@ extern "C" int mvster_warp_agg_bwd_sorted_scratch(int B, int NV, int C, int D, i
                                                  long* ints) {
     if (!rec_floats || !ints) return MVSTER_ERR_NULL;
     if (B <= 0 || NV <= 0 || C <= 0 || C % 8 || D <= 0 || h <= 0 || w <= 0 || Hs <= 0 || Ws <= 0) return MVSTER_ERR_SHAPE;
-    const long tiles_x = (Ws + kRecTile - 1) / kRecTile, tiles_y = (Hs + kRecTile - 1) / kRecTile;
+    const long tiles_x = (Ws + kRecTileX - 1) / kRecTileX, tiles_y = (Hs + kRecTileY - 1) / kRecTileY;
     if (tiles_x * tiles_y > kRecMaxTiles || Hs > 8190 || Ws > 8190) return MVSTER_ERR_UNSUPPORTED;
     const long n = (long)B * NV * tiles_x * tiles_y;
     const long samples = (long)B * h * w * D * NV;
@@ -2289,7 +2289,7 @@ extern "C" int mvster_warp_agg_bwd_sorted(const float* ref_feat, const float* sr
     if (!group_cor && G != C) return MVSTER_ERR_SHAPE;
     long nf = 0, ni = 0;
     if (int rc = mvster_warp_agg_bwd_sorted_scratch(B, NV, C, D, h, w, Hs, Ws, &nf, &ni)) return rc;
-    const int tiles_x = (Ws + kRecTile - 1) / kRecTile, tiles_y = (Hs + kRecTile - 1) / kRecTile;
+    const int tiles_x = (Ws + kRecTileX - 1) / kRecTileX, tiles_y = (Hs + kRecTileY - 1) / kRecTileY;
     const long n = (long)B * NV * tiles_x * tiles_y;
     int* count = ints;
     int* cursor = ints + n;

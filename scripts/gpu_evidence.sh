@@ -22,10 +22,14 @@ cp gpurun_out/prof/bench_under_rocprof.json $E/${TAG}_bench_under_rocprof.json
 python scripts/layer_table.py 2>&1 | grep -v amdgpu.ids > $E/${TAG}_layer_table.txt; tail -1 $E/${TAG}_layer_table.txt
 timeout 600 python bench.py --mode train --steps 20 --warmup 3 2>/dev/null > $E/${TAG}_train_bench.json; cut -c1-200 $E/${TAG}_train_bench.json
 timeout 600 python bench.py --mode train --steps 20 --warmup 3 --coherent 2>/dev/null > $E/${TAG}_train_bench_smooth_depth.json; cut -c1-200 $E/${TAG}_train_bench_smooth_depth.json
-TRAIN_STEPS=6 TRAIN_STEPS_SHORT=1 bash scripts/gpu_train_profile.sh > /dev/null 2>&1; cp gpurun_out/prof_train/train_kernel_stats.csv $E/${TAG}_train_kernel_stats.csv
-cp gpurun_out/prof_train/train_short_kernel_stats.csv $E/${TAG}_train_kernel_stats_short_run.csv
-# (train_steps.py runs two untimed steps first: 8 and 3 steps in the two profiles)
-python scripts/train_categories.py $E/${TAG}_train_kernel_stats.csv 8 $E/${TAG}_train_kernel_stats_short_run.csv 3 > $E/${TAG}_train_categories.txt; head -18 $E/${TAG}_train_categories.txt
+# training categories of the CAPTURED step (what the bench replays): 6 replays minus 1, kernel by kernel
+timeout 900 bash scripts/gpu_train_cat.sh evtrain > /dev/null 2>&1
+cp gpurun_out/evtrain/train_kernel_stats.csv $E/${TAG}_train_kernel_stats.csv
+cp gpurun_out/evtrain/train_kernel_stats_short_run.csv $E/${TAG}_train_kernel_stats_short_run.csv
+cp gpurun_out/evtrain/train_categories.txt $E/${TAG}_train_categories.txt; head -18 $E/${TAG}_train_categories.txt
+cp gpurun_out/evtrain/train_kernels.txt $E/${TAG}_train_kernels.txt
+timeout 600 bash scripts/gpu_warp_sorted.sh evwarp > /dev/null 2>&1; cp gpurun_out/evwarp/summary.txt $E/${TAG}_warp_bwd_sorted_vs_atomic.txt
+timeout 600 bash scripts/gpu_inflight_trace.sh > /dev/null 2>&1; cp gpurun_out/inflight/steady_state.txt $E/${TAG}_inflight_steady_state.txt
 bash scripts/gpu_tests.sh
 for f in kernels model train fusion; do cp gpurun_out/parity_$f.json $E/${TAG}_parity_$f.json 2>/dev/null; done
 cp gpurun_out/test_gpu_*.log $E/ 2>/dev/null
