@@ -82,16 +82,16 @@ __device__ __forceinline__ void sum_slots(const float* __restrict__ partial, int
         if (lane < lanes) {
             const int g = (base + pair) / ncol, col = (base + pair) - g * ncol;
             const float* pg = partial + (long)g * nblk * ncol + col;
-            // (eight independent loads in flight per round: the slots were written through to memory, a load is ~1-2 us)
-            for (int n = lane; n < nblk; n += lanes * 8) {
-                float t[8];
+            // (sixteen independent loads in flight per round: the slots were written through to memory, a load is ~1-2 us)
+            for (int n = lane; n < nblk; n += lanes * 16) {
+                float t[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const int m = n + u * lanes;
                     t[u] = m < nblk ? ld_agent(pg + (long)m * ncol) : 0.0f;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) s += (double)t[u];
+                for (int u = 0; u < 16; ++u) s += (double)t[u];
             }
         }
         __syncthreads();
@@ -305,7 +305,9 @@ int check(long rows, int C) {
 // all groups (16 waves per CU stream at full rate, and the last arriver adds <= 256 slots).
 int slots_for(long rows, int C, int groups) {
     const long n4 = rows * (C / 4);
-    long n = (n4 + kRedThreads - 1) / kRedThreads;
+    // (at least four grid-stride rounds per workgroup: the last arriver's tail grows with the slots -- 17.8 against 8.4 us
+    //  of streaming for a 10 MB, 64-channel tensor with 256 slots -- and a small tensor is latency-bound anyway)
+    long n = (n4 + 4 * kRedThreads - 1) / (4 * kRedThreads);
     const long cap = groups >= 256 ? 1 : 256 / groups;
     if (n > cap) n = cap;
     return (int)(n < 1 ? 1 : n);
