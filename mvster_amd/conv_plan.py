@@ -102,6 +102,13 @@ def tuned_choice(layer, B, Di, Hi, Wi, skip_mode):
     hit = _tuning().get(sig)
     if hit:
         return hit, "exact"
+    if skip_mode == SKIP_ADD:
+        # a same-shape skip only adds one read to the epilogue: where the table knows the layer without it (the training
+        # step's input-gradient layers that add a second consumer's gradient, train_ops.conv_cl(tap=True)), that choice
+        # beats the heuristics (a kernel form without the skip path answers "unsupported" and the caller falls back)
+        hit = _tuning().get(sig[:-1] + "0")
+        if hit:
+            return hit, "exact (without skip)"
     lst = _families().get((sig[:sig.index("_", sig.index("_s") + 1)], skip_mode))
     if lst:
         lv, ld, lb = math.log2(max(1, B * Di * Hi * Wi)), math.log2(max(1, Di)), math.log2(max(1, B))
