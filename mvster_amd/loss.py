@@ -108,6 +108,15 @@ def stage_losses(gt_depth, hypo_depth, attn_weight, mask, mono_depth=None, iters
     return l1, ot, ratio
 
 
+def stage_losses_total(gt_depth, hypo_depth, attn_weight, mask, mono_depth, total, iters, eps, continuous, inverse, w_l1, w_ot,
+                       w_stage):
+    """``stage_losses`` plus the running total of MVS4net_loss: -> (l1, ot, out_of_range_ratio, total + w_stage * (w_l1 * l1 +
+    w_ot * ot)) (models/MVS4Net.py:131-151), ``total`` None for the first stage.  One fused forward, one fused backward."""
+    _check_stage(attn_weight, iters, "MVS4net_loss")
+    return _StageLoss.apply(attn_weight, mono_depth, total, hypo_depth, gt_depth, mask, int(iters), float(eps), bool(continuous),
+                            bool(inverse), float(w_l1), float(w_ot), float(w_stage))
+
+
 def _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):
     """Per stage: (index, key, l1, ot, out_of_range_ratio, running total) -- the total of MVS4Net.py:151 is carried through
     the stages' fused kernels instead of ~5 scalar launches per stage."""
@@ -121,11 +130,9 @@ def _stage_terms(inputs, depth_gt_ms, mask_ms, kwargs):
     total = None
     for stage_idx, key in enumerate([k for k in inputs.keys() if "stage" in k]):
         st = inputs[key]
-        _check_stage(st["attn_weight"], ot_iter, "MVS4net_loss")
-        l1, ot, outside_ratio, total = _StageLoss.apply(
-            st["attn_weight"], st["mono_depth"] if mono and stage_idx != 0 else None, total, st["hypo_depth"], depth_gt_ms[key],
-            mask_ms[key], int(ot_iter), float(ot_eps), bool(ot_continous), bool(inverse), float(l1ot_lw[0]), float(l1ot_lw[1]),
-            float(stage_lw[stage_idx]))
+        l1, ot, outside_ratio, total = stage_losses_total(
+            depth_gt_ms[key], st["hypo_depth"], st["attn_weight"], mask_ms[key], st["mono_depth"] if mono and stage_idx != 0 else None,
+            total, ot_iter, ot_eps, ot_continous, inverse, l1ot_lw[0], l1ot_lw[1], stage_lw[stage_idx])
         yield stage_idx, key, l1, ot, outside_ratio, total
 
 

@@ -25,9 +25,17 @@ def oracle_stage_losses(gt, hypo, attn, mask, mono_depth=None, iters=3, eps=1, c
     return l1, sinkhorn(gt, hypo, attn, m, iters, eps, continuous)[1], oor[m].float().mean()
 
 
+def oracle_stage_losses_total(gt, hypo, attn, mask, mono_depth, total, iters, eps, continuous, inverse, w_l1, w_ot, w_stage):
+    """The product's fused per-stage call (terms + the weighted running total, models/MVS4Net.py:151) as tensor expressions."""
+    l1, ot, ratio = oracle_stage_losses(gt, hypo, attn, mask, mono_depth, iters, eps, continuous, inverse)
+    total = torch.zeros((), dtype=torch.float32, device=gt.device) if total is None else total
+    return l1, ot, ratio, total + w_stage * (w_l1 * l1 + w_ot * ot)
+
+
 @pytest.fixture
 def tensor_level_ot(monkeypatch):
     monkeypatch.setattr(L, "stage_losses", oracle_stage_losses)
+    monkeypatch.setattr(L, "stage_losses_total", oracle_stage_losses_total)
 
 
 def test_ot_term_has_no_cpu_fallback(golden):
