@@ -544,8 +544,10 @@ class ConvLayer:
         if (variant & 0xff) == 11:
             if self._b3_src is None or skip_mode == SKIP_UPSAMPLE_ADD or self.prob is not None:
                 raise RuntimeError("conv_b3: layer not eligible")
-            if self.wpk_b3 is None:
+            stamp = (self._b3_src._version, self._b3_src.data_ptr())
+            if self.wpk_b3 is None or getattr(self, "_b3_stamp", None) != stamp:     # (in-place weight updates re-split)
                 self.wpk_b3 = pack_b3(self._b3_src, self.cin, self.cout, self.kernel[0])
+                self._b3_stamp = stamp
             wpk, nt = self.wpk_b3, 1
         rc = _lib.load().mvster_conv_mfma(
             x.data_ptr(), wpk.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),

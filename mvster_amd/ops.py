@@ -85,6 +85,18 @@ def forward_prologue(imgs, proj_list, depth_values, D, h, w, inverse):
         raise RuntimeError("forward_prologue: expects at most 16 views of [B,3,H,W]")
     N = len(imgs)
     dev = imgs[0].device
+    # (raw pointers go to the kernel: every shape it derives addresses from is checked here)
+    for i, im in enumerate(imgs):
+        if tuple(im.shape) != (B, 3, H, W) or im.device != dev:
+            raise RuntimeError("forward_prologue: imgs[%d] is %s on %s, expected [%d,3,%d,%d] on %s"
+                               % (i, tuple(im.shape), im.device, B, H, W, dev))
+    for k, pm in enumerate(pms):
+        if tuple(pm.shape) != (B, N, 2, 4, 4) or pm.device != dev:
+            raise RuntimeError("forward_prologue: proj_list[%d] is %s, expected [%d,%d,2,4,4]" % (k, tuple(pm.shape), B, N))
+    if dv.dim() != 2 or dv.shape[0] != B or dv.shape[1] < 2 or dv.device != dev:
+        raise RuntimeError("forward_prologue: depth_values is %s, expected [%d, >= 2]" % (tuple(dv.shape), B))
+    if D < 1 or h < 1 or w < 1:
+        raise RuntimeError("forward_prologue: bad hypothesis volume %dx%dx%d" % (D, h, w))
     packed = torch.empty(N * B, 1, H, W, 4, device=dev, dtype=torch.float32)
     rt = torch.empty(len(pms), B, N - 1, 12, device=dev, dtype=torch.float32)
     hypo = torch.empty(B, D, h, w, device=dev, dtype=torch.float32)
@@ -351,6 +363,12 @@ def upsample_bilinear_multi(xs, H, W):
     if not 1 <= len(xs) <= 8:
         raise RuntimeError("upsample_bilinear_multi: 1..8 maps per launch")
     B = xs[0].shape[0]
+    for i, x in enumerate(xs):
+        if x.dim() != 3 or x.shape[0] != B or x.device != xs[0].device or x.shape[1] < 1 or x.shape[2] < 1:
+            raise RuntimeError("upsample_bilinear_multi: map %d is %s on %s, expected [%d,h,w] on %s"
+                               % (i, tuple(x.shape), x.device, B, xs[0].device))
+    if H < 1 or W < 1:
+        raise RuntimeError("upsample_bilinear_multi: bad output size %dx%d" % (H, W))
     outs = [torch.empty(B, H, W, device=x.device, dtype=torch.float32) for x in xs]
     n = len(xs)
     ip = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])
