@@ -122,6 +122,7 @@ FUSE_TAIL = True                # finest FPN level: lateral step + gather-sum in
 FUSE_SELECT = True              # reg2d conv11 + prob + selection in one launch (tests set it to False for the two-launch form)
 LDS_BUDGET = 12 * 256 * 16      # bytes of staged patch the LDS variant accepts (conv_mfma.hip kMaxStage)
 FORCE_VARIANT = None            # None = choose per layer; 0 / 1 pin the kernel variant (experiments, tests)
+TPERS16_MIN_VOXELS = 40960      # 16 -> 8 transposed layers take the persistent MFMA kernel from this many input voxels
 NARROW_MIN_VOXELS = 64 * 256    # untuned narrow layers take the MFMA kernel from this many output voxels (one 8 x 32 tile per CU)
 
 
@@ -479,6 +480,12 @@ class ConvLayer:
                     variant = 3                     # (an older library loaded through MVSTER_LIB for an A/B run)
             if self.w_deconv is not None and skip_mode in (SKIP_NONE, SKIP_ADD) and FORCE_VARIANT in (None, 4):
                 variant = 4
+                if (FORCE_VARIANT is None and self.prob is None and self.cin == 16 and self.cout == 8
+                        and B * Di * Hi * Wi >= TPERS16_MIN_VOXELS):
+                    # 16 -> 8 transposed 3x3 stride 2 without the fused head (the training step's conv11 and the input
+                    # gradient of conv1): the persistent MFMA kernel of the wider transposed layers, 41 against 55 us at
+                    # 2 x 4 x 256 x 320, 15 against 22 at 2 x 4 x 128 x 160 (the VALU kernel is instruction-bound there)
+                    variant, mt, nt = 5, 2, 1
             g = (np.asarray(arr, dtype=np.int32), mt, nt, (B, DoF, HoF, WoF), variant)
             self._geom_cache[key] = g
         return g

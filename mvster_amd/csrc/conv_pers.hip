@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(512) conv_pers8_kernel(ConvArgs a, PersArgs p)
 
 // ------------------------------------------------------------------------------------------------------------------
 // Transposed 1x3x3 stride (1,2,2) convolutions (reg2d's conv7 / conv9: 64 -> 32, 32 -> 16, with the U-Net skip added at the
-// output resolution).  The direct kernel runs them as four output-parity classes, each a 1-, 2-, 2- or 4-tap stride-1
+// output resolution; since round 6 also 16 -> 8, the last transposed layer and the stride-2 layers' input gradient in training).  The direct kernel runs them as four output-parity classes, each a 1-, 2-, 2- or 4-tap stride-1
 // convolution over the input lattice in its own set of workgroups: 2 to 8 K steps per workgroup tile -- all prologue, no
 // steady state (16-25 us at stage 4 against 4-8 us of HBM / MFMA time).  Here a persistent workgroup stages a 4 x 32 input
 // tile (+ one halo row and column: the taps reach i and i + 1) once and computes ALL FOUR classes from it, 18 K steps per
@@ -657,6 +657,9 @@ __global__ void __launch_bounds__(512) conv_tpers_kernel(ConvArgs a, PersArgs p)
         for (int mt = 0; mt < MT; ++mt) {
             const int y = here.ty0 + (orc[mt] & 255), x = here.tx0 + (orc[mt] >> 8);
             oval[mt] = y < a.Ho && x < a.Wo;
+            // (a layer with 8 output channels -- reg2d's last transposed layer in training -- fills half an N tile: the
+            //  lanes of channels 8..15 store nothing)
+            oval[mt] = oval[mt] && nt0 * 16 + lq * 4 < a.cout;
             obase[mt] = (unsigned)(((((here.b * a.DoF + here.zo) * a.HoF + 2 * y) * a.WoF + 2 * x) * a.cout + nt0 * 16 + lq * 4)) * 4u;
         }
         int wbase = 0;
@@ -1368,12 +1371,13 @@ int dispatch_pp(const ConvArgs& a, int mt, int nt, hipStream_t s) {
 // or 1 x 5 x 5 with "same" padding geometry handled by the generic bounds checks, stride 1 or 2 in-plane.
 int dispatch_pers(const ConvArgs& a, int mt, int nt, int wpc, hipStream_t s) {
     if (a.nclass == 4 && a.osd == 1 && a.osh == 2 && a.osw == 2 && a.sd == 1 && a.sh == 1 && a.sw == 1 && a.skip_mode <= 1 &&
-        !a.prob_w && a.cout % 16 == 0 && (a.cin == 32 || a.cin == 64) && mt == 2 && nt == 1) {
+        !a.prob_w && (a.cout % 16 == 0 || a.cout == 8) && (a.cin == 16 || a.cin == 32 || a.cin == 64) && mt == 2 && nt == 1) {
         // transposed 1x3x3 stride (1,2,2): the classes must be the 1 / 2 / 2 / 4-tap ones in (py, px) order, unpadded
         for (int c = 0; c < 4; ++c)
             if (a.kd[c] != 1 || a.kh[c] != (c >> 1) + 1 || a.kw[c] != (c & 1) + 1 || a.pd[c] || a.ph[c] || a.pw[c] || a.od[c] ||
                 a.oh[c] != (c >> 1) || a.ow[c] != (c & 1) || a.nsteps[c] != a.kh[c] * a.kw[c] * (a.cin / 16))
                 return MVSTER_ERR_UNSUPPORTED;
+        if (a.cin == 16) return a.skip_mode == 1 ? launch_tpers<1, true>(a, wpc, s) : launch_tpers<1, false>(a, wpc, s);
         if (a.cin == 32) return a.skip_mode == 1 ? launch_tpers<2, true>(a, wpc, s) : launch_tpers<2, false>(a, wpc, s);
         return a.skip_mode == 1 ? launch_tpers<4, true>(a, wpc, s) : launch_tpers<4, false>(a, wpc, s);
     }
