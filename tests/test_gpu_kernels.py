@@ -934,7 +934,8 @@ def test_fpn_tail_gather():
         assert err <= 1e-5 * want.abs().max().item()
 
 
-@pytest.mark.parametrize("NB,H,W,CO,pitch", [(2, 12, 20, 8, 80), (1, 64, 34, 8, 72), (1, 8, 8, 16, 144), (1, 18, 70, 8, 80)])
+@pytest.mark.parametrize("NB,H,W,CO,pitch", [(2, 12, 20, 8, 80), (1, 64, 34, 8, 72), (1, 8, 8, 16, 144), (1, 18, 70, 8, 80),
+                                             (2, 32, 128, 8, 80), (1, 44, 132, 8, 80), (2, 70, 200, 8, 72)])   # (LDS-tiled form)
 def test_fpn_tail_gather_adjoint(NB, H, W, CO, pitch):
     """mvster_fpn_tail_gather_bwd against autograd through the PyTorch restatement of the gather."""
     from tests.conv_emulator import fpn_tail_gather_reference
