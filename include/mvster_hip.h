@@ -322,6 +322,19 @@ int mvster_bn_relu_bwd_apply(const float* x, const float* gy, const float* scale
  * monocular heads :846-848).  partial: mvster_bn_slots(rows, C, 1) * 2 * C floats, ticket as above.  One launch. */
 int mvster_col_sum(const float* x, float* partial, float* out, int* ticket, long rows, int C, void* stream);
 
+/* The same BatchNorm passes for SMALL tensors in one launch each way (most layers of the step: coarse stages, deep U-Net
+ * levels): a thread keeps its <= 8 (backward: 4) float4 of x (and gy) in registers across the reduction, the last workgroup
+ * to arrive finishes and publishes the statistics and releases the others, which spin on a flag -- a grid barrier among at
+ * most 128 resident workgroups.  fwd_fused = mvster_bn_stats + mvster_bn_relu_fwd (same `out`, same running updates);
+ * bwd_fused = mvster_bn_relu_bwd_reduce + _apply (pack = the forward's `out`).  partial: groups * 128 * 2 * C floats; sync: 3
+ * device ints, zero before and after.  mvster_bn_fused_ok(rows, C, groups, backward) says whether a tensor fits (16 / 8 MB). */
+int mvster_bn_fused_ok(long rows, int C, int groups, int backward);
+int mvster_bn_fwd_fused(const float* x, const float* skip, float* y, const float* weight, const float* bias, float* running_mean,
+                        float* running_var, long* num_batches_tracked, float* partial, float* out, int* sync, long rows, int C,
+                        int relu, int groups, float eps, float momentum, void* stream);
+int mvster_bn_bwd_fused(const float* x, const float* gy, const float* pack, float* partial, float* sums, float* dgamma,
+                        float* dbeta, float* dx, int* sync, long rows, int C, int relu, int groups, void* stream);
+
 /* Bilinear x2 up-sampling (align_corners=True) of a channels-last map, in [B,h,w,C] -> out [B,2h,2w,C], and its
  * adjoint gout [B,2h,2w,C] -> gin [B,h,w,C] as a gather (no atomics): the FPN top-down path in training
  * (models/mvs4net_utils.py:488-496 under autograd).  C % 4 == 0. */

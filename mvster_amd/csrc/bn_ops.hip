@@ -295,6 +295,220 @@ __global__ void __launch_bounds__(256) bn_relu_bwd_apply_kernel(const float* __r
     }
 }
 
+// ---- small tensors: statistics + apply in ONE launch (forward), reduce + apply in ONE launch (backward) -------------------
+// Most BatchNorm layers of the step are small (coarse cascade stages, deep U-Net levels): two dependent launches each way
+// cost more in latency than in bytes.  Here a thread keeps its R float4 of x (and gy) in registers across the reduction: the
+// workgroups publish their slots, the last arriver finishes the statistics and publishes them (write-through) and raises a
+// flag the others spin on (one lane per workgroup, s_sleep) -- a grid barrier, safe because the grid is at most
+// kFusedMaxWG workgroups of 1024 threads (every one resident on its own CU) -- then everybody applies from registers.
+// One read of x instead of two (three of x / gy instead of four in the backward).  sync = {arrivals, flag, departures}, all
+// zero before the launch; the last workgroup to LEAVE zeroes them again.
+constexpr int kFusedMaxWG = 128;
+
+__device__ __forceinline__ int ld_agent_i(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent_i(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// arrive; true (in every thread) for the last workgroup, which must call grid_release() after publishing its results
+__device__ __forceinline__ bool grid_arrive(int* sync, int total) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1;
+    __syncthreads();
+    return s_last != 0;
+}
+__device__ __forceinline__ void grid_release(int* sync) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's write-through result stores have completed
+    __syncthreads();
+    if (threadIdx.x == 0) st_agent_i(sync + 1, 1);
+}
+__device__ __forceinline__ void grid_wait(int* sync) {
+    if (threadIdx.x == 0)
+        while (ld_agent_i(sync + 1) == 0) __builtin_amdgcn_s_sleep(2);
+    __syncthreads();
+}
+__device__ __forceinline__ void grid_depart(int* sync, int total) {
+    __syncthreads();
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+        st_agent_i(sync, 0);
+        st_agent_i(sync + 1, 0);
+        st_agent_i(sync + 2, 0);
+    }
+}
+
+struct BnFusedFwdArgs {
+    const float* x; const float* skip; float* y; const float* weight; const float* bias;
+    float* running_mean; float* running_var; long* num_batches_tracked; float* partial; float* out; int* sync;
+    long rows, n4; int C, groups, relu; float eps, momentum;
+};
+
+template <int R>
+__global__ void __launch_bounds__(kRedThreads) bn_fused_fwd_kernel(BnFusedFwdArgs a) {
+    __shared__ float red[kRedThreads / 64][16][8];
+    __shared__ double dred[kRedThreads];
+    __shared__ double tot[kMaxPairs];
+    const int C = a.C, q = C >> 2, nblk = gridDim.x, g = blockIdx.y, total = nblk * a.groups;
+    const float* x = a.x + (long)g * a.n4 * 4;
+    const long stride = (long)nblk * kRedThreads;
+    const long i0 = (long)blockIdx.x * kRedThreads + threadIdx.x;
+    const int cg = (int)(i0 % q) * 4;
+    const f32x4 pv = ld4(x + cg);
+    f32x4 xr[R];
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const long i = i0 + j * stride;
+        xr[j] = i < a.n4 ? ld4(x + i * 4) : pv;               // (the pivot adds nothing to the sums)
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d = xr[j][k] - pv[k];
+            v[k] += d;
+            v[4 + k] = fmaf(d, d, v[4 + k]);
+        }
+    publish_slot(v, a.partial + ((long)g * nblk + blockIdx.x) * 2 * C, C, red);
+    const long gs = (long)a.groups * C;
+    if (grid_arrive(a.sync, total)) {
+        sum_slots(a.partial, nblk, a.groups, C, tot, dred);
+        if (threadIdx.x < C) {
+            const int c = threadIdx.x;
+            const bool running = a.running_mean != nullptr;
+            const float unbias = (float)a.rows / (float)(a.rows > 1 ? a.rows - 1 : 1);
+            float rm = 0.0f, rv = 0.0f;
+            if (running) { rm = a.running_mean[c]; rv = a.running_var[c]; }
+            for (int gg = 0; gg < a.groups; ++gg) {
+                const double m1 = tot[gg * 2 * C + c] / (double)a.rows, m2 = tot[gg * 2 * C + C + c] / (double)a.rows;
+                const float mean = a.x[(long)gg * a.rows * C + c] + (float)m1;
+                float var = (float)(m2 - m1 * m1);
+                var = var > 0.0f ? var : 0.0f;
+                const float rstd = 1.0f / sqrtf(var + a.eps);
+                const float scale = a.weight[c] * rstd;
+                float* o = a.out + (long)gg * C + c;
+                st_agent(o, mean); st_agent(o + gs, var); st_agent(o + 2 * gs, rstd); st_agent(o + 3 * gs, scale);
+                st_agent(o + 4 * gs, a.bias[c] - mean * scale);
+                rm = (1.0f - a.momentum) * rm + a.momentum * mean;
+                rv = (1.0f - a.momentum) * rv + a.momentum * (var * unbias);
+            }
+            if (running) { a.running_mean[c] = rm; a.running_var[c] = rv; }
+        }
+        if (threadIdx.x == 0 && a.num_batches_tracked) *a.num_batches_tracked += a.groups;
+        grid_release(a.sync);
+    } else {
+        grid_wait(a.sync);
+    }
+    float sc[4], sh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sc[k] = ld_agent(a.out + 3 * gs + (long)g * C + cg + k);
+        sh[k] = ld_agent(a.out + 4 * gs + (long)g * C + cg + k);
+    }
+    float* y = a.y + (long)g * a.n4 * 4;
+    const float* skip = a.skip ? a.skip + (long)g * a.n4 * 4 : nullptr;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const long i = i0 + j * stride;
+        if (i < a.n4) {
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float t = bn_act(xr[j][k], sc[k], sh[k]);
+                o[k] = a.relu ? fmaxf(t, 0.0f) : t;
+            }
+            if (skip) o += ld4(skip + i * 4);
+            st4(y + i * 4, o);
+        }
+    }
+    grid_depart(a.sync, total);
+}
+
+struct BnFusedBwdArgs {
+    const float* x; const float* gy; const float* pack; float* partial; float* sums; float* dgamma; float* dbeta; float* dx;
+    int* sync; long rows, n4; int C, groups, relu;
+};
+
+template <int R>
+__global__ void __launch_bounds__(kRedThreads) bn_fused_bwd_kernel(BnFusedBwdArgs a) {
+    __shared__ float red[kRedThreads / 64][16][8];
+    __shared__ double dred[kRedThreads];
+    __shared__ double tot[kMaxPairs];
+    const int C = a.C, q = C >> 2, nblk = gridDim.x, g = blockIdx.y, total = nblk * a.groups, relu = a.relu;
+    const long gs = (long)a.groups * C;
+    const float* x = a.x + (long)g * a.n4 * 4;
+    const float* gy = a.gy + (long)g * a.n4 * 4;
+    const long stride = (long)nblk * kRedThreads;
+    const long i0 = (long)blockIdx.x * kRedThreads + threadIdx.x;
+    const int cg = (int)(i0 % q) * 4;
+    const f32x4 mu = ld4(a.pack + (long)g * C + cg), rs = ld4(a.pack + 2 * gs + (long)g * C + cg);
+    const f32x4 sc = ld4(a.pack + 3 * gs + (long)g * C + cg), sh = ld4(a.pack + 4 * gs + (long)g * C + cg);
+    f32x4 gr[R], xh[R];                                           // g = gy * mask, xh = (x - mean) * rstd
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const long i = i0 + j * stride;
+        const bool ok = i < a.n4;
+        const f32x4 t = ok ? ld4(x + i * 4) : mu, g4 = ok ? ld4(gy + i * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            gr[j][k] = g4[k] * relu_mask(relu, bn_act(t[k], sc[k], sh[k]));
+            xh[j][k] = (t[k] - mu[k]) * rs[k];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] += gr[j][k];
+            v[4 + k] = fmaf(gr[j][k], xh[j][k], v[4 + k]);
+        }
+    publish_slot(v, a.partial + ((long)g * nblk + blockIdx.x) * 2 * C, C, red);
+    if (grid_arrive(a.sync, total)) {
+        sum_slots(a.partial, nblk, a.groups, C, tot, dred);
+        for (int k = threadIdx.x; k < a.groups * 2 * C; k += kRedThreads) st_agent(a.sums + k, (float)tot[k]);
+        if (threadIdx.x < 2 * C) {
+            double t2 = 0.0;
+            for (int gg = 0; gg < a.groups; ++gg) t2 += tot[gg * 2 * C + threadIdx.x];
+            if (threadIdx.x < C) a.dbeta[threadIdx.x] = (float)t2;
+            else a.dgamma[threadIdx.x - C] = (float)t2;
+        }
+        grid_release(a.sync);
+    } else {
+        grid_wait(a.sync);
+    }
+    const float inv_n = 1.0f / (float)a.rows;
+    float s0[4], s1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        s0[k] = ld_agent(a.sums + (long)g * 2 * C + cg + k);
+        s1[k] = ld_agent(a.sums + (long)g * 2 * C + C + cg + k);
+    }
+    float* dx = a.dx + (long)g * a.n4 * 4;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const long i = i0 + j * stride;
+        if (i < a.n4) {
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = sc[k] * (gr[j][k] - s0[k] * inv_n - xh[j][k] * s1[k] * inv_n);
+            st4(dx + i * 4, o);
+        }
+    }
+    grid_depart(a.sync, total);
+}
+
+// float4 per thread (R) and workgroups per group for the fused forms, or R = 0 where the tensor does not fit the resident grid
+int fused_plan(long rows, int C, int groups, int rmax, int& nblk) {
+    const long n4 = rows * (C / 4);
+    if (groups < 1 || groups > kFusedMaxWG || groups * 2 * C > kMaxPairs) return 0;
+    const int cap = kFusedMaxWG / groups;
+    for (int r = 2; r <= rmax; r *= 2) {
+        const long n = (n4 + (long)kRedThreads * r - 1) / ((long)kRedThreads * r);
+        if (n <= cap) { nblk = (int)(n < 1 ? 1 : n); return r; }
+    }
+    return 0;
+}
+
 int check(long rows, int C) {
     if (rows <= 0) return MVSTER_ERR_SHAPE;
     if (C < 4 || C > 64 || (C & (C - 1)) != 0) return MVSTER_ERR_UNSUPPORTED;
@@ -394,5 +608,54 @@ extern "C" int mvster_col_sum(const float* x, float* partial, float* out, int* t
     if (int rc = check(rows, C)) return rc;
     ColSumArgs a{x, partial, out, ticket, rows * (C / 4), C};
     hipLaunchKernelGGL(col_sum_kernel, dim3(slots_for(rows, C, 1)), dim3(kRedThreads), 0, (hipStream_t)stream, a);
+    return mv_check_launch();
+}
+
+// Whether mvster_bn_fwd_fused (backward = 0) / mvster_bn_bwd_fused (backward = 1) take a tensor of `groups` x `rows` x C: the
+// grid must be resident as a whole (<= 128 workgroups of 1024 threads, <= 8 / 4 float4 of x (and gy) per thread: 16 / 8 MB;
+// twice that spills registers at 1024 threads per workgroup).
+extern "C" int mvster_bn_fused_ok(long rows, int C, int groups, int backward) {
+    if (check(rows, C)) return 0;
+    int nblk = 0;
+    return fused_plan(rows, C, groups, backward ? 4 : 8, nblk) ? 1 : 0;
+}
+
+// Training-mode BatchNorm (+ ReLU, + skip) of a SMALL tensor in one launch: what mvster_bn_stats + mvster_bn_relu_fwd do in
+// two (same statistics pack `out` [5][groups][C], same running-average updates).  partial: groups * 128 * 2 * C floats of
+// scratch; sync: 3 ints on the device, zero before the call and zero again after it.  MVSTER_ERR_UNSUPPORTED where
+// mvster_bn_fused_ok says no.
+extern "C" int mvster_bn_fwd_fused(const float* x, const float* skip, float* y, const float* weight, const float* bias,
+                                   float* running_mean, float* running_var, long* num_batches_tracked, float* partial, float* out,
+                                   int* sync, long rows, int C, int relu, int groups, float eps, float momentum, void* stream) {
+    if (!x || !y || !weight || !bias || !partial || !out || !sync) return MVSTER_ERR_NULL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return MVSTER_ERR_NULL;
+    if (int rc = check(rows, C)) return rc;
+    int nblk = 0;
+    const int r = fused_plan(rows, C, groups, 8, nblk);
+    if (!r) return MVSTER_ERR_UNSUPPORTED;
+    BnFusedFwdArgs a{x, skip, y, weight, bias, running_mean, running_var, num_batches_tracked, partial, out, sync,
+                     rows, rows * (C / 4), C, groups, relu, eps, momentum};
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(nblk, groups), block(kRedThreads);
+    if (r == 2) hipLaunchKernelGGL(bn_fused_fwd_kernel<2>, grid, block, 0, s, a);
+    else if (r == 4) hipLaunchKernelGGL(bn_fused_fwd_kernel<4>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(bn_fused_fwd_kernel<8>, grid, block, 0, s, a);
+    return mv_check_launch();
+}
+
+// Its backward in one launch (mvster_bn_relu_bwd_reduce + mvster_bn_relu_bwd_apply): pack = the forward's `out`; sums
+// [groups][2][C] scratch; dgamma, dbeta [C]; dx like x.
+extern "C" int mvster_bn_bwd_fused(const float* x, const float* gy, const float* pack, float* partial, float* sums, float* dgamma,
+                                   float* dbeta, float* dx, int* sync, long rows, int C, int relu, int groups, void* stream) {
+    if (!x || !gy || !pack || !partial || !sums || !dgamma || !dbeta || !dx || !sync) return MVSTER_ERR_NULL;
+    if (int rc = check(rows, C)) return rc;
+    int nblk = 0;
+    const int r = fused_plan(rows, C, groups, 4, nblk);
+    if (!r) return MVSTER_ERR_UNSUPPORTED;
+    BnFusedBwdArgs a{x, gy, pack, partial, sums, dgamma, dbeta, dx, sync, rows, rows * (C / 4), C, groups, relu};
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(nblk, groups), block(kRedThreads);
+    if (r == 2) hipLaunchKernelGGL(bn_fused_bwd_kernel<2>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(bn_fused_bwd_kernel<4>, grid, block, 0, s, a);
     return mv_check_launch();
 }

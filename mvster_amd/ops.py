@@ -587,13 +587,67 @@ _TICKETS = {}
 
 
 def _ticket(dev):
-    """Address of a zero int32 on ``dev`` for a one-launch reduction's arrival counter (the kernel leaves it at zero).
-    Handed out round-robin from a pool: launches that could overlap (other streams) practically never share one."""
+    """Address of four zero int32s on ``dev`` for a one-launch reduction's arrival counter / a fused pass's grid barrier
+    (the kernels leave them at zero).  Handed out round-robin from a pool: launches that could overlap (other streams)
+    practically never share one."""
     hit = _TICKETS.get(dev)
     if hit is None:
-        hit = _TICKETS[dev] = [torch.zeros(4096, device=dev, dtype=torch.int32), 0]
+        hit = _TICKETS[dev] = [torch.zeros(4 * 4096, device=dev, dtype=torch.int32), 0]
     hit[1] = (hit[1] + 1) % 4096
-    return hit[0].data_ptr() + 4 * hit[1]
+    return hit[0].data_ptr() + 16 * hit[1]
+
+
+_BN_FUSED_OK = {}
+# Small tensors: BatchNorm statistics + apply (reduce + apply) in ONE launch with a resident-grid barrier.  OFF: measured on
+# the config-4 step it takes 62 launches away (216 -> 154) and saves nothing -- 12.92 against 12.88 ms: the barrier is ~6
+# dependent memory round trips (slot drain, ticket, slot loads, statistics publish, flag poll, statistics loads), 13 us
+# for a tensor the two launches handle in 10 + 5 (profiles/r06_*bn_fused_ab.txt).  Kept behind this switch with its tests.
+BN_FUSED = False
+
+
+def bn_fused_ok(rows, C, groups, backward):
+    key = (rows, C, groups, backward)
+    ok = _BN_FUSED_OK.get(key)
+    if ok is None:
+        ok = _BN_FUSED_OK[key] = bool(_lib.load().mvster_bn_fused_ok(rows, C, groups, int(backward)))
+    return ok and BN_FUSED
+
+
+def bn_fwd_fused(x, weight, bias, running_mean, running_var, eps, momentum, relu, groups=1, num_batches_tracked=None, skip=None):
+    """``bn_batch_stats`` + ``bn_relu_fwd`` of a small tensor in ONE launch -> (y, pack)."""
+    _chk(x, "bn_fwd_fused:x")
+    _chk(skip, "bn_fwd_fused:skip")
+    C = x.shape[-1]
+    rows = x.numel() // C // groups
+    if skip is not None and tuple(skip.shape) != tuple(x.shape):
+        raise RuntimeError("bn_fwd_fused: skip must have the shape of x")
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
+        raise RuntimeError("bn_fwd_fused: num_batches_tracked must be an int64 tensor on the device")
+    partial = torch.empty(groups, 128, 2, C, device=x.device, dtype=torch.float32)
+    pack = torch.empty(5, groups, C, device=x.device, dtype=torch.float32)
+    y = torch.empty_like(x)
+    rc = _lib.load().mvster_bn_fwd_fused(_ptr(x), _ptr(skip), _ptr(y), _ptr(weight), _ptr(bias), _ptr(running_mean),
+                                         _ptr(running_var), _ptr(num_batches_tracked), _ptr(partial), _ptr(pack),
+                                         _ticket(x.device), rows, C, int(relu), int(groups), float(eps), float(momentum), _stream())
+    _lib.check(rc, "bn_fwd_fused")
+    return y, pack
+
+
+def bn_bwd_fused(x, gy, pack, relu, groups=1):
+    """``bn_relu_bwd`` of a small tensor in ONE launch -> (dx, dbeta, dgamma)."""
+    _chk(x, "bn_bwd_fused:x")
+    _chk(gy, "bn_bwd_fused:gy")
+    _chk(pack, "bn_bwd_fused:pack")
+    C = x.shape[-1]
+    rows = x.numel() // C // groups
+    partial = torch.empty(groups, 128, 2, C, device=x.device, dtype=torch.float32)
+    sums = torch.empty(groups, 2, C, device=x.device, dtype=torch.float32)
+    dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    rc = _lib.load().mvster_bn_bwd_fused(_ptr(x), _ptr(gy), _ptr(pack), _ptr(partial), _ptr(sums), _ptr(dgb[0]), _ptr(dgb[1]),
+                                         _ptr(dx), _ticket(x.device), rows, C, int(relu), int(groups), _stream())
+    _lib.check(rc, "bn_bwd_fused")
+    return dx, dgb[1], dgb[0]
 
 
 def bn_batch_stats(x, weight, bias, running_mean, running_var, eps, momentum, groups=1, num_batches_tracked=None):

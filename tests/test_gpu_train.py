@@ -1080,3 +1080,41 @@ def test_fused_adam_follows_torch_adam(wd):
     worst = max(((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item() for a, b in zip(pc, pb))
     assert worst <= 2e-6, worst
     assert float(oc.state_dict()["state"][0]["step"]) == 6.0
+
+
+@pytest.mark.parametrize("shape,groups,relu,with_skip", [((2, 8, 8, 10, 64), 1, True, True), ((2, 4, 64, 80, 16), 1, True, False),
+                                                         ((10, 1, 64, 80, 64), 5, True, False), ((6, 1, 100, 128, 16), 3, False, True),
+                                                         ((2, 8, 64, 80, 8), 1, True, False)])
+def test_batch_norm_cl_fused_small_tensor_form(monkeypatch, shape, groups, relu, with_skip):
+    """ops.BN_FUSED (off by default: measured no faster): statistics + apply and reduce + apply of a small tensor in one launch
+    each with a resident-grid barrier -- the same output, running statistics and gradients as the two-launch forms (the
+    reductions are summed in another order: agreement to rounding), and the barrier's counters are left at zero."""
+    C = shape[-1]
+    g = torch.Generator().manual_seed(C + groups)
+    x0 = (torch.randn(shape, generator=g) * 2 + 0.5).to(DEV)
+    skip0 = torch.randn(shape, generator=g).to(DEV) if with_skip else None
+    gout = torch.randn(shape, generator=g).to(DEV)
+    res = []
+    for fused in (False, True):
+        monkeypatch.setattr(ops, "BN_FUSED", fused)
+        bn = (torch.nn.BatchNorm3d(C) if shape[1] > 1 else torch.nn.BatchNorm3d(C)).to(DEV).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C))
+            bn.bias.copy_(torch.linspace(-0.2, 0.2, C))
+        x = x0.clone().requires_grad_(True)
+        sk = skip0.clone().requires_grad_(True) if with_skip else None
+        for _ in range(2):                                   # twice: the barrier's counters must come back to zero
+            y = T.batch_norm_cl(x, bn, relu=relu, groups=groups, skip=sk)
+        (y * gout).sum().backward()
+        res.append((y.detach(), x.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone(),
+                    int(bn.num_batches_tracked), None if sk is None else sk.grad))
+    a, b = res
+    assert a[6] == b[6] == 2 * groups
+    for i, tol in ((0, 2e-6), (1, 2e-5), (2, 2e-5), (3, 2e-5), (4, 2e-6), (5, 2e-6)):
+        scale = a[i].abs().max().item() + 1e-30
+        assert (a[i] - b[i]).abs().max().item() <= tol * scale, (i, (a[i] - b[i]).abs().max().item(), scale)
+    if with_skip:
+        assert torch.equal(a[7], b[7])
+    tk = ops._TICKETS[DEV][0] if DEV in ops._TICKETS else None
+    torch.cuda.synchronize()
+    assert tk is None or int(tk.abs().sum()) == 0
