@@ -322,6 +322,19 @@ int mvster_bn_relu_bwd_apply(const float* x, const float* gy, const float* scale
  * monocular heads :846-848).  partial: mvster_bn_slots(rows, C, 1) * 2 * C floats, ticket as above.  One launch. */
 int mvster_col_sum(const float* x, float* partial, float* out, int* ticket, long rows, int C, void* stream);
 
+/* Training-mode BatchNorm as the step runs it since round 6: TWO launches per pass without a serial tail -- the reduction
+ * kernel only writes its per-workgroup slots, the apply kernel's workgroups sum them in their prologue (every workgroup its
+ * group's, in the same fixed order, fp64), one extra workgroup does the running-average updates (forward) / the parameter
+ * gradients (backward).  train_fwd = mvster_bn_stats + mvster_bn_relu_fwd (same `out` pack [5][groups][C], same running
+ * updates); train_bwd = mvster_bn_relu_bwd_reduce + _apply (pack = the forward's `out`).  partial: groups *
+ * mvster_bn_train_slots(rows, C, groups) * 2 * C floats.  models/mvs4net_utils.py:116-123, :224-251 under autograd. */
+int mvster_bn_train_slots(long rows, int C, int groups);
+int mvster_bn_train_fwd(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
+                        long* num_batches_tracked, const float* skip, float* partial, float* y, float* out, long rows, int C,
+                        int relu, int groups, float eps, float momentum, void* stream);
+int mvster_bn_train_bwd(const float* x, const float* gy, const float* pack, float* partial, float* dgamma, float* dbeta, float* dx,
+                        long rows, int C, int relu, int groups, void* stream);
+
 /* The same BatchNorm passes for SMALL tensors in one launch each way (most layers of the step: coarse stages, deep U-Net
  * levels): a thread keeps its <= 8 (backward: 4) float4 of x (and gy) in registers across the reduction, the last workgroup
  * to arrive finishes and publishes the statistics and releases the others, which spin on a flag -- a grid barrier among at

@@ -53,6 +53,9 @@ SIGNATURES = {
     "mvster_conv_wgrad_finish": [_f, _f] + [_i] * 10 + [_f],
     "mvster_bn_slots": [_l, _i, _i],
     "mvster_col_sum": [_f, _f, _f, _f, _l, _i, _f],
+    "mvster_bn_train_slots": [_l, _i, _i],
+    "mvster_bn_train_fwd": [_f] * 10 + [_l, _i, _i, _i, _fl, _fl, _f],
+    "mvster_bn_train_bwd": [_f] * 7 + [_l, _i, _i, _i, _f],
     "mvster_bn_fused_ok": [_l, _i, _i, _i],
     "mvster_bn_fwd_fused": [_f] * 11 + [_l, _i, _i, _i, _fl, _fl, _f],
     "mvster_bn_bwd_fused": [_f] * 9 + [_l, _i, _i, _i, _f],

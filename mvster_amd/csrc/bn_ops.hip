@@ -47,6 +47,7 @@ __device__ __forceinline__ bool last_arriver(int* ticket, int total) {
 
 // The eight per-thread sums of a reduction kernel (values 0-3: first slot row, 4-7: second) -> this workgroup's slot
 // [2][C]: lanes that own the same column group meet by wave shuffles (q = C/4 divides 64), the 16 waves through LDS.
+template <bool AGENT = true>
 __device__ __forceinline__ void publish_slot(float (&v)[8], float* slot, int C, float (*red)[16][8]) {
     const int q = C >> 2;
 #pragma unroll
@@ -63,13 +64,16 @@ __device__ __forceinline__ void publish_slot(float (&v)[8], float* slot, int C, 
         float s = 0.0f;
 #pragma unroll
         for (int w = 0; w < kRedThreads / 64; ++w) s += red[w][grp][val];
-        st_agent(slot + (val >> 2) * C + grp * 4 + (val & 3), s);
+        // (AGENT: read by another workgroup of the SAME launch -> write-through; otherwise by the next launch -> plain)
+        if (AGENT) st_agent(slot + (val >> 2) * C + grp * 4 + (val & 3), s);
+        else slot[(val >> 2) * C + grp * 4 + (val & 3)] = s;
     }
 }
 
 // Last workgroup: tot[g * 2C + col] (fp64, LDS) = the sum over the nblk slots of group g, for every group and column;
 // slots are walked in index order by a fixed number of lanes per column: deterministic.
 constexpr int kMaxPairs = 2048;            // groups * 2C the finishing workgroup holds (16 views x 64 channels)
+template <bool AGENT = true>
 __device__ __forceinline__ void sum_slots(const float* __restrict__ partial, int nblk, int groups, int C, double* tot,
                                           double* red) {
     const int ncol = 2 * C, pairs = groups * ncol;
@@ -88,7 +92,7 @@ __device__ __forceinline__ void sum_slots(const float* __restrict__ partial, int
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const int m = n + u * lanes;
-                    t[u] = m < nblk ? ld_agent(pg + (long)m * ncol) : 0.0f;
+                    t[u] = m < nblk ? (AGENT ? ld_agent(pg + (long)m * ncol) : pg[(long)m * ncol]) : 0.0f;
                 }
 #pragma unroll
                 for (int u = 0; u < 16; ++u) s += (double)t[u];
@@ -97,11 +101,12 @@ __device__ __forceinline__ void sum_slots(const float* __restrict__ partial, int
         __syncthreads();
         red[threadIdx.x] = s;
         __syncthreads();
-        for (int w = lanes >> 1; w > 0; w >>= 1) {
-            if (lane < w) red[threadIdx.x] += red[threadIdx.x + w * np];
-            __syncthreads();
+        // (the column's first thread adds its <= 64 lane sums in order: two barriers instead of a tree's seven)
+        if (lane == 0) {
+            double t = red[pair];
+            for (int l = 1; l < lanes; ++l) t += red[l * np + pair];
+            tot[base + pair] = t;
         }
-        if (lane == 0) tot[base + pair] = red[threadIdx.x];
     }
     __syncthreads();
 }
@@ -290,6 +295,199 @@ __global__ void __launch_bounds__(256) bn_relu_bwd_apply_kernel(const float* __r
             const float g = g4[j] * relu_mask(relu, bn_act(v[j], sc[j], sh[j]));
             const float xh = (v[j] - mu[j]) * rs[j];
             o[j] = sc[j] * (g - s0[j] * inv_n - xh * s1[j] * inv_n);
+        }
+        st4(dx + i * 4, o);
+    }
+}
+
+// ---- the training passes without a serial tail: slots in one launch, their sum in the NEXT launch's prologue --------------
+// The one-launch reductions above end in a tail only the last workgroup runs -- store drain, ticket, one or two rounds of
+// memory-latency loads of the written-through slots, an LDS tree, the finalize: 8-10 us per launch, 108 launches per step,
+// more than the streaming of most layers.  Here the reduction kernels just write their slots (plain stores: the next
+// launch finds them in L2) and the APPLY kernels sum them in their prologue -- every workgroup its own group's, in the same
+// fixed order (deterministic, every workgroup gets the same bits), ~2 us, all workgroups at once.  One extra workgroup per
+// launch does what needs all groups in order: the running averages (forward), the parameter gradients (backward).
+struct BnSlotsArgs {
+    const float* x; const float* gy; const float* pack; float* partial;
+    long n4; int C, groups, relu;
+};
+
+// forward statistics slots: sums of (x - pivot), (x - pivot)^2 (pivot = the group's first row)
+__global__ void __launch_bounds__(kRedThreads) bn_stats_slots_kernel(BnSlotsArgs a) {
+    __shared__ float red[kRedThreads / 64][16][8];
+    const int C = a.C, q = C >> 2, nblk = gridDim.x;
+    const float* x = a.x + (long)blockIdx.y * a.n4 * 4;
+    const long stride = (long)nblk * kRedThreads;
+    long i = (long)blockIdx.x * kRedThreads + threadIdx.x;
+    const int cg = (int)(i % q) * 4;
+    const f32x4 pv = ld4(x + cg);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (; i < a.n4; i += stride) {
+        const f32x4 t = ld4(x + i * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = t[j] - pv[j];
+            v[j] += d;
+            v[4 + j] = fmaf(d, d, v[4 + j]);
+        }
+    }
+    publish_slot<false>(v, a.partial + ((long)blockIdx.y * nblk + blockIdx.x) * 2 * C, C, red);
+}
+
+// backward slots: sums of g = gy * (y > 0) and g * xh
+__global__ void __launch_bounds__(kRedThreads) bn_bwd_slots_kernel(BnSlotsArgs a) {
+    __shared__ float red[kRedThreads / 64][16][8];
+    const int C = a.C, q = C >> 2, nblk = gridDim.x, relu = a.relu, g = blockIdx.y;
+    const long gs = (long)a.groups * C;
+    const float* x = a.x + (long)g * a.n4 * 4;
+    const float* gy = a.gy + (long)g * a.n4 * 4;
+    const long stride = (long)nblk * kRedThreads;
+    long i = (long)blockIdx.x * kRedThreads + threadIdx.x;
+    const int cg = (int)(i % q) * 4;
+    const f32x4 mu = ld4(a.pack + (long)g * C + cg), rs = ld4(a.pack + 2 * gs + (long)g * C + cg);
+    const f32x4 sc = ld4(a.pack + 3 * gs + (long)g * C + cg), sh = ld4(a.pack + 4 * gs + (long)g * C + cg);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (; i < a.n4; i += stride) {
+        const f32x4 t = ld4(x + i * 4), g4 = ld4(gy + i * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gg = g4[j] * relu_mask(relu, bn_act(t[j], sc[j], sh[j]));
+            v[j] += gg;
+            v[4 + j] = fmaf(gg, (t[j] - mu[j]) * rs[j], v[4 + j]);
+        }
+    }
+    publish_slot<false>(v, a.partial + ((long)g * nblk + blockIdx.x) * 2 * C, C, red);
+}
+
+struct BnTrainFwdArgs {
+    const float* x; const float* partial; const float* weight; const float* bias; const float* skip;
+    float* running_mean; float* running_var; long* num_batches_tracked; float* y; float* out;
+    long rows, n4; int C, groups, relu, nslots; float eps, momentum;
+};
+
+// mean / biased variance of (group gg, channel c) from the summed slots
+__device__ __forceinline__ void bn_moments(const double* tot, int C, int c, long rows, float pivot, float& mean, float& var) {
+    const double m1 = tot[c] / (double)rows, m2 = tot[C + c] / (double)rows;
+    mean = pivot + (float)m1;
+    var = (float)(m2 - m1 * m1);
+    var = var > 0.0f ? var : 0.0f;
+}
+
+// grid (apply blocks + 1, groups): block (last, 0) applies the running-average updates of all groups in order (what `groups`
+// sequential module calls would do) and counts the batches; the others finish THEIR group's statistics and stream.
+__global__ void __launch_bounds__(kRedThreads) bn_train_fwd_kernel(BnTrainFwdArgs a) {
+    __shared__ double dred[kRedThreads];
+    __shared__ double tot[kMaxPairs];
+    __shared__ float scl[64], shl[64];
+    const int C = a.C, g = blockIdx.y, nblk = gridDim.x - 1;
+    if ((int)blockIdx.x == nblk) {
+        if (g != 0 || (!a.running_mean && !a.num_batches_tracked)) return;
+        sum_slots<false>(a.partial, a.nslots, a.groups, C, tot, dred);
+        if (threadIdx.x < C && a.running_mean) {
+            const int c = threadIdx.x;
+            const float unbias = (float)a.rows / (float)(a.rows > 1 ? a.rows - 1 : 1);
+            float rm = a.running_mean[c], rv = a.running_var[c];
+            for (int gg = 0; gg < a.groups; ++gg) {
+                float mean, var;
+                bn_moments(tot + gg * 2 * C, C, c, a.rows, a.x[(long)gg * a.rows * C + c], mean, var);
+                rm = (1.0f - a.momentum) * rm + a.momentum * mean;
+                rv = (1.0f - a.momentum) * rv + a.momentum * (var * unbias);
+            }
+            a.running_mean[c] = rm; a.running_var[c] = rv;
+        }
+        if (threadIdx.x == 0 && a.num_batches_tracked) *a.num_batches_tracked += a.groups;
+        return;
+    }
+    // (the first streaming loads are issued before the prologue: for most layers that is all a thread reads)
+    const long ifirst = (long)blockIdx.x * kRedThreads + threadIdx.x;
+    const f32x4 vfirst = ifirst < a.n4 ? ld4(a.x + (long)g * a.n4 * 4 + ifirst * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    sum_slots<false>(a.partial + (long)g * a.nslots * 2 * C, a.nslots, 1, C, tot, dred);
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x;
+        float mean, var;
+        bn_moments(tot, C, c, a.rows, a.x[(long)g * a.rows * C + c], mean, var);
+        const float rstd = 1.0f / sqrtf(var + a.eps);
+        const float scale = a.weight[c] * rstd, shift = a.bias[c] - mean * scale;
+        scl[c] = scale; shl[c] = shift;
+        if (blockIdx.x == 0) {
+            float* o = a.out + (long)g * C + c;
+            const long gs = (long)a.groups * C;
+            o[0] = mean; o[gs] = var; o[2 * gs] = rstd; o[3 * gs] = scale; o[4 * gs] = shift;
+        }
+    }
+    __syncthreads();
+    const int q = C >> 2;
+    const float* x = a.x + (long)g * a.n4 * 4;
+    float* y = a.y + (long)g * a.n4 * 4;
+    const float* skip = a.skip ? a.skip + (long)g * a.n4 * 4 : nullptr;
+    const long stride = (long)nblk * kRedThreads;
+    long i = (long)blockIdx.x * kRedThreads + threadIdx.x;
+    const int cg = (int)(i % q) * 4;
+    const f32x4 sc = {scl[cg], scl[cg + 1], scl[cg + 2], scl[cg + 3]}, sh = {shl[cg], shl[cg + 1], shl[cg + 2], shl[cg + 3]};
+    for (; i < a.n4; i += stride) {
+        const f32x4 v = i == ifirst ? vfirst : ld4(x + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = bn_act(v[j], sc[j], sh[j]);
+            o[j] = a.relu ? fmaxf(t, 0.0f) : t;
+        }
+        if (skip) o += ld4(skip + i * 4);
+        st4(y + i * 4, o);
+    }
+}
+
+struct BnTrainBwdArgs {
+    const float* x; const float* gy; const float* pack; const float* partial; float* dgamma; float* dbeta; float* dx;
+    long rows, n4; int C, groups, relu, nslots;
+};
+
+// grid (apply blocks + 1, groups): block (last, 0) writes dgamma / dbeta (sums over the groups); the others sum THEIR group's
+// slots and stream dx = scale * (g - sum_g / n - xh * sum_gxh / n).
+__global__ void __launch_bounds__(kRedThreads) bn_train_bwd_kernel(BnTrainBwdArgs a) {
+    __shared__ double dred[kRedThreads];
+    __shared__ double tot[kMaxPairs];
+    __shared__ float s0l[64], s1l[64];
+    const int C = a.C, g = blockIdx.y, nblk = gridDim.x - 1, relu = a.relu;
+    if ((int)blockIdx.x == nblk) {
+        if (g != 0) return;
+        sum_slots<false>(a.partial, a.nslots, a.groups, C, tot, dred);
+        if (threadIdx.x < 2 * C) {
+            double t2 = 0.0;
+            for (int gg = 0; gg < a.groups; ++gg) t2 += tot[gg * 2 * C + threadIdx.x];
+            if (threadIdx.x < C) a.dbeta[threadIdx.x] = (float)t2;
+            else a.dgamma[threadIdx.x - C] = (float)t2;
+        }
+        return;
+    }
+    const long ifirst = (long)blockIdx.x * kRedThreads + threadIdx.x;
+    const bool hasfirst = ifirst < a.n4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 vfirst = hasfirst ? ld4(a.x + (long)g * a.n4 * 4 + ifirst * 4) : zero4;
+    const f32x4 gfirst = hasfirst ? ld4(a.gy + (long)g * a.n4 * 4 + ifirst * 4) : zero4;
+    sum_slots<false>(a.partial + (long)g * a.nslots * 2 * C, a.nslots, 1, C, tot, dred);
+    if (threadIdx.x < C) { s0l[threadIdx.x] = (float)tot[threadIdx.x]; s1l[threadIdx.x] = (float)tot[C + threadIdx.x]; }
+    __syncthreads();
+    const int q = C >> 2;
+    const long gs = (long)a.groups * C;
+    const float* x = a.x + (long)g * a.n4 * 4;
+    const float* gy = a.gy + (long)g * a.n4 * 4;
+    float* dx = a.dx + (long)g * a.n4 * 4;
+    const long stride = (long)nblk * kRedThreads;
+    long i = (long)blockIdx.x * kRedThreads + threadIdx.x;
+    const int cg = (int)(i % q) * 4;
+    const f32x4 mu = ld4(a.pack + (long)g * C + cg), rs = ld4(a.pack + 2 * gs + (long)g * C + cg);
+    const f32x4 sc = ld4(a.pack + 3 * gs + (long)g * C + cg), sh = ld4(a.pack + 4 * gs + (long)g * C + cg);
+    const f32x4 s0 = {s0l[cg], s0l[cg + 1], s0l[cg + 2], s0l[cg + 3]}, s1 = {s1l[cg], s1l[cg + 1], s1l[cg + 2], s1l[cg + 3]};
+    const float inv_n = 1.0f / (float)a.rows;
+    for (; i < a.n4; i += stride) {
+        const f32x4 v = i == ifirst ? vfirst : ld4(x + i * 4), g4 = i == ifirst ? gfirst : ld4(gy + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gg = g4[j] * relu_mask(relu, bn_act(v[j], sc[j], sh[j]));
+            const float xh = (v[j] - mu[j]) * rs[j];
+            o[j] = sc[j] * (gg - s0[j] * inv_n - xh * s1[j] * inv_n);
         }
         st4(dx + i * 4, o);
     }
@@ -527,6 +725,26 @@ int slots_for(long rows, int C, int groups) {
     return (int)(n < 1 ? 1 : n);
 }
 
+int train_apply_blocks(long rows, int C, int groups);
+
+// Slots of the tail-less training passes: every apply workgroup sums all of its group's slots, 2C columns each, so wide
+// tensors get fewer (<= 8 loads per thread of the 1024: 64 slots at 64 channels, 128 at 32, 256 below)
+int train_slots_for(long rows, int C, int groups) {
+    int n = slots_for(rows, C, groups);               // (at most one per CU: with 512 slots at 8 channels the apply kernels'
+                                                      //  prologues cost more than the streaming gains, 2.41 against 2.32 ms)
+    const int cap = 4096 / C;
+    return n > cap ? cap : n;
+}
+
+// Streaming workgroups (1024 threads) of the tail-less apply kernels: two per CU for the large tensors
+int train_apply_blocks(long rows, int C, int groups) {
+    const long n4 = rows * (C / 4);
+    long n = (n4 + 4 * kRedThreads - 1) / (4 * kRedThreads);
+    const long cap = groups >= 512 ? 1 : 512 / groups;
+    if (n > cap) n = cap;
+    return (int)(n < 1 ? 1 : n);
+}
+
 int blocks_for(long n4) {
     const long want = (n4 + 255) / 256;
     return (int)(want < 2048 ? want : 2048);
@@ -657,5 +875,50 @@ extern "C" int mvster_bn_bwd_fused(const float* x, const float* gy, const float*
     dim3 grid(nblk, groups), block(kRedThreads);
     if (r == 2) hipLaunchKernelGGL(bn_fused_bwd_kernel<2>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(bn_fused_bwd_kernel<4>, grid, block, 0, s, a);
+    return mv_check_launch();
+}
+
+// slots per group of `partial` for mvster_bn_train_fwd / _bwd (0: unsupported channel count)
+extern "C" int mvster_bn_train_slots(long rows, int C, int groups) {
+    if (check(rows, C) || groups < 1 || groups > 65535) return 0;
+    return train_slots_for(rows, C, groups);
+}
+
+// Training-mode BatchNorm (+ ReLU, + skip) as TWO launches without a serial tail: the statistics slots, then the apply kernel
+// whose workgroups sum the slots in their prologue (see the kernels).  Same results as mvster_bn_stats + mvster_bn_relu_fwd
+// (same slot sums, same fp64 finish, same running-average updates); out = the statistics pack [5][groups][C].  partial:
+// groups * mvster_bn_train_slots(rows, C, groups) * 2 * C floats.
+extern "C" int mvster_bn_train_fwd(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
+                                   long* num_batches_tracked, const float* skip, float* partial, float* y, float* out, long rows,
+                                   int C, int relu, int groups, float eps, float momentum, void* stream) {
+    if (!x || !weight || !bias || !partial || !y || !out) return MVSTER_ERR_NULL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return MVSTER_ERR_NULL;
+    if (int rc = check(rows, C)) return rc;
+    if (groups < 1 || groups > 65535 || groups * 2 * C > kMaxPairs) return groups < 1 ? MVSTER_ERR_SHAPE : MVSTER_ERR_UNSUPPORTED;
+    const long n4 = rows * (C / 4);
+    const int nslots = train_slots_for(rows, C, groups), napply = train_apply_blocks(rows, C, groups);
+    hipStream_t s = (hipStream_t)stream;
+    BnSlotsArgs sa{x, nullptr, nullptr, partial, n4, C, groups, relu};
+    hipLaunchKernelGGL(bn_stats_slots_kernel, dim3(nslots, groups), dim3(kRedThreads), 0, s, sa);
+    BnTrainFwdArgs a{x, partial, weight, bias, skip, running_mean, running_var, num_batches_tracked, y, out,
+                     rows, n4, C, groups, relu, nslots, eps, momentum};
+    hipLaunchKernelGGL(bn_train_fwd_kernel, dim3(napply + 1, groups), dim3(kRedThreads), 0, s, a);
+    return mv_check_launch();
+}
+
+// Its backward, two launches: the slots of sum g / sum g*xh, then dx with the sums formed in the prologue; pack = the
+// forward's `out`; dgamma, dbeta [C] (summed over the groups).
+extern "C" int mvster_bn_train_bwd(const float* x, const float* gy, const float* pack, float* partial, float* dgamma,
+                                   float* dbeta, float* dx, long rows, int C, int relu, int groups, void* stream) {
+    if (!x || !gy || !pack || !partial || !dgamma || !dbeta || !dx) return MVSTER_ERR_NULL;
+    if (int rc = check(rows, C)) return rc;
+    if (groups < 1 || groups > 65535 || groups * 2 * C > kMaxPairs) return groups < 1 ? MVSTER_ERR_SHAPE : MVSTER_ERR_UNSUPPORTED;
+    const long n4 = rows * (C / 4);
+    const int nslots = train_slots_for(rows, C, groups), napply = train_apply_blocks(rows, C, groups);
+    hipStream_t s = (hipStream_t)stream;
+    BnSlotsArgs sa{x, gy, pack, partial, n4, C, groups, relu};
+    hipLaunchKernelGGL(bn_bwd_slots_kernel, dim3(nslots, groups), dim3(kRedThreads), 0, s, sa);
+    BnTrainBwdArgs a{x, gy, pack, partial, dgamma, dbeta, dx, rows, n4, C, groups, relu, nslots};
+    hipLaunchKernelGGL(bn_train_bwd_kernel, dim3(napply + 1, groups), dim3(kRedThreads), 0, s, a);
     return mv_check_launch();
 }

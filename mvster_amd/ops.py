@@ -583,6 +583,17 @@ def _bn_slots(rows, C, groups):
     return n
 
 
+_BN_TRAIN_SLOTS = {}
+
+
+def _bn_train_slots(rows, C, groups):
+    key = (rows, C, groups)
+    n = _BN_TRAIN_SLOTS.get(key)
+    if n is None:
+        n = _BN_TRAIN_SLOTS[key] = _lib.load().mvster_bn_train_slots(rows, C, groups)
+    return n
+
+
 _TICKETS = {}
 
 
@@ -611,6 +622,52 @@ def bn_fused_ok(rows, C, groups, backward):
     if ok is None:
         ok = _BN_FUSED_OK[key] = bool(_lib.load().mvster_bn_fused_ok(rows, C, groups, int(backward)))
     return ok and BN_FUSED
+
+
+BN_TAILLESS = True            # training BatchNorm: slot sums in the apply kernels' prologue (False: last-arriver reductions)
+
+
+def bn_train_fwd(x, weight, bias, running_mean, running_var, eps, momentum, relu, groups=1, num_batches_tracked=None, skip=None):
+    """Training-mode BatchNorm (+ ReLU, + skip): slots, then apply with the statistics finished in its prologue -> (y, pack);
+    the running statistics / counter are updated in place like ``bn_batch_stats``."""
+    _chk(x, "bn_train_fwd:x")
+    _chk(skip, "bn_train_fwd:skip")
+    C = x.shape[-1]
+    rows = x.numel() // C // groups
+    if skip is not None and tuple(skip.shape) != tuple(x.shape):
+        raise RuntimeError("bn_train_fwd: skip must have the shape of x")
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
+        raise RuntimeError("bn_train_fwd: num_batches_tracked must be an int64 tensor on the device")
+    nblk = _bn_train_slots(rows, C, groups)
+    if nblk <= 0:
+        raise RuntimeError("bn_train_fwd: unsupported channel count %d" % C)
+    partial = torch.empty(groups, nblk, 2, C, device=x.device, dtype=torch.float32)
+    pack = torch.empty(5, groups, C, device=x.device, dtype=torch.float32)
+    y = torch.empty_like(x)
+    rc = _lib.load().mvster_bn_train_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                         _ptr(num_batches_tracked), _ptr(skip), _ptr(partial), _ptr(y), _ptr(pack), rows, C,
+                                         int(relu), int(groups), float(eps), float(momentum), _stream())
+    _lib.check(rc, "bn_train_fwd")
+    return y, pack
+
+
+def bn_train_bwd(x, gy, pack, relu, groups=1):
+    """Backward of ``bn_train_fwd`` -> (dx, dbeta, dgamma): slots, then dx with the sums formed in its prologue."""
+    _chk(x, "bn_train_bwd:x")
+    _chk(gy, "bn_train_bwd:gy")
+    _chk(pack, "bn_train_bwd:pack")
+    C = x.shape[-1]
+    rows = x.numel() // C // groups
+    nblk = _bn_train_slots(rows, C, groups)
+    if nblk <= 0:
+        raise RuntimeError("bn_train_bwd: unsupported channel count %d" % C)
+    partial = torch.empty(groups, nblk, 2, C, device=x.device, dtype=torch.float32)
+    dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    rc = _lib.load().mvster_bn_train_bwd(_ptr(x), _ptr(gy), _ptr(pack), _ptr(partial), _ptr(dgb[0]), _ptr(dgb[1]), _ptr(dx), rows,
+                                         C, int(relu), int(groups), _stream())
+    _lib.check(rc, "bn_train_bwd")
+    return dx, dgb[1], dgb[0]
 
 
 def bn_fwd_fused(x, weight, bias, running_mean, running_var, eps, momentum, relu, groups=1, num_batches_tracked=None, skip=None):

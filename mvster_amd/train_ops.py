@@ -470,6 +470,8 @@ class _BnReluCL(torch.autograd.Function):
         C = x.shape[-1]
         if not frozen and ops.bn_fused_ok(x.numel() // C // groups, C, groups, True):
             dx, dbeta, dgamma = ops.bn_bwd_fused(x, gy, pack, relu, groups)          # (small tensor: one launch)
+        elif not frozen and ops.BN_TAILLESS:
+            dx, dbeta, dgamma = ops.bn_train_bwd(x, gy, pack, relu, groups)          # (slot sums in the apply kernel's prologue)
         else:
             dx, dbeta, dgamma = ops.bn_relu_bwd(x, gy, pack[3], pack[4], pack[0], pack[2], relu, groups, frozen)
         gskip = gy if has_skip else None          # the skip connection's gradient is the output gradient itself
@@ -477,13 +479,16 @@ class _BnReluCL(torch.autograd.Function):
 
 
 class _BnFusedCL(torch.autograd.Function):
-    """Training-mode relu(BatchNorm(x)) (+ skip) of a small tensor: statistics, running-average updates and the apply in one
-    launch (``mvster_bn_fwd_fused``); the backward is ``_BnReluCL``'s (one launch where the tensor is small enough)."""
+    """Training-mode relu(BatchNorm(x)) (+ skip) with the statistics finished INSIDE the forward op: ``mvster_bn_train_fwd``
+    (slots, then the apply kernel sums them in its prologue) or, behind ``ops.BN_FUSED``, ``mvster_bn_fwd_fused`` (a small
+    tensor in one launch); the backward is ``_BnReluCL``'s, which picks the matching form."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, nbt, eps, momentum, relu, groups, skip=None):
-        y, pack = ops.bn_fwd_fused(x, weight.detach(), bias.detach(), running_mean, running_var, eps, momentum, relu, groups,
-                                   num_batches_tracked=nbt, skip=None if skip is None else skip.contiguous())
+        C = x.shape[-1]
+        fn = ops.bn_fwd_fused if ops.bn_fused_ok(x.numel() // C // groups, C, groups, False) else ops.bn_train_fwd
+        y, pack = fn(x, weight.detach(), bias.detach(), running_mean, running_var, eps, momentum, relu, groups,
+                     num_batches_tracked=nbt, skip=None if skip is None else skip.contiguous())
         ctx.save_for_backward(x, pack)
         ctx.cfg = (relu, groups, False, skip is not None)
         return y
@@ -517,8 +522,8 @@ def batch_norm_cl(x, bn, relu=False, groups=1, skip=None):
             raise NotImplementedError("batch_norm_cl: cumulative-average running statistics (momentum=None)")
         if track:
             CACHE.stat_writes += 1
-        if ops.bn_fused_ok(x.numel() // C // groups, C, groups, False):
-            # small tensor: statistics + apply in ONE launch (x stays in registers across a resident-grid barrier)
+        if ops.BN_TAILLESS or ops.bn_fused_ok(x.numel() // C // groups, C, groups, False):
+            # statistics slots + apply with the finish in its prologue (or, behind ops.BN_FUSED, a small tensor in ONE launch)
             return _BnFusedCL.apply(x, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
                                     bn.num_batches_tracked if track else None, bn.eps, bn.momentum or 0.0, relu, groups, skip)
         with torch.no_grad():
