@@ -1083,10 +1083,9 @@ struct AbsMaxArgs {
 };
 constexpr int kAbsMaxBlocks = 1536;
 
-__global__ void __launch_bounds__(256) absmax_kernel(AbsMaxArgs a, float* __restrict__ out) {
+__device__ __forceinline__ void absmax_block(const AbsMaxArgs& a, float* __restrict__ out, int b) {
     __shared__ float wave_max[4];
     __shared__ int wave_bad[4];
-    const int b = blockIdx.x;
     const int k = (b >= a.first[1] ? 1 : 0) + (b >= a.first[2] ? 1 : 0);
     const float* __restrict__ x = a.x[k];
     const long n = a.n[k];
@@ -1130,8 +1129,10 @@ __global__ void __launch_bounds__(256) absmax_kernel(AbsMaxArgs a, float* __rest
     }
 }
 
-// workgroups in proportion to the arrays' sizes (they finish together), each array at least one
-void launch_absmax(const float* const* x, const long* n, int count, float* out, hipStream_t s) {
+__global__ void __launch_bounds__(256) absmax_kernel(AbsMaxArgs a, float* __restrict__ out) { absmax_block(a, out, blockIdx.x); }
+
+// the workgroup layout of launch_absmax, for kernels that carry the reduction beside other work
+static AbsMaxArgs absmax_args(const float* const* x, const long* n, int count) {
     AbsMaxArgs a;
     long total = 0;
     for (int k = 0; k < count; ++k) total += n[k];
@@ -1147,6 +1148,12 @@ void launch_absmax(const float* const* x, const long* n, int count, float* out, 
         }
         a.first[k + 1] = a.first[k] + (int)nb;
     }
+    return a;
+}
+
+// workgroups in proportion to the arrays' sizes (they finish together), each array at least one
+void launch_absmax(const float* const* x, const long* n, int count, float* out, hipStream_t s) {
+    const AbsMaxArgs a = absmax_args(x, n, count);
     // (unused entries own no workgroups: first[k] == first[k+1] == gridDim.x, never selected)
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)a.first[3]), dim3(256), 0, s, a, out);
 }
@@ -1896,12 +1903,12 @@ int launch_gather(const WarpAggBwdArgs& ba, int nblk, hipStream_t stream) {
 // ---- sorted scatter: K0 (count), scan, K2 (accumulate) ---------------------------------------------------------------
 // K0: thread = (pixel, hypothesis) of batch item blockIdx.y, all views; per view an LDS histogram over the source tiles,
 // flushed with one global atomic per touched tile.
-__global__ void __launch_bounds__(256) warp_bwd_count_kernel(WarpAggArgs a, int* __restrict__ count, int tiles_x, int tiles_y) {
+__device__ __forceinline__ void warp_bwd_count_block(const WarpAggArgs& a, int* __restrict__ count, int tiles_x, int tiles_y,
+                                                     int bx, int b) {
     __shared__ int lcount[kRecMaxTiles];
     const int ntiles = tiles_x * tiles_y;
-    const int b = blockIdx.y;
     const long hw = (long)a.h * a.w;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;            // = pixel * D + d
+    const long i = (long)bx * 256 + threadIdx.x;                    // = pixel * D + d
     const bool valid = i < hw * a.D;
     const long pc = valid ? i / a.D : hw - 1;
     const int d = valid ? (int)(i - pc * a.D) : 0;
@@ -1941,6 +1948,23 @@ __global__ void __launch_bounds__(256) warp_bwd_zero_kernel(int* __restrict__ a,
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < na) a[i] = 0;
     if (i < nb) b[i] = 0;
+}
+
+__global__ void __launch_bounds__(256) warp_bwd_count_kernel(WarpAggArgs a, int* __restrict__ count, int tiles_x, int tiles_y) {
+    warp_bwd_count_block(a, count, tiles_x, tiles_y, blockIdx.x, blockIdx.y);
+}
+
+// The counting pass and the operand maxima of the fixed-point scale in ONE launch: they are independent, one is bound by
+// instructions and the other by memory, and each alone leaves most of the chip idle for part of its time.  Workgroups
+// [0, nabs) reduce the maxima, the rest count (per_b workgroups per batch item).
+__global__ void __launch_bounds__(256) warp_bwd_prep_kernel(WarpAggArgs a, int* __restrict__ count, int tiles_x, int tiles_y,
+                                                            AbsMaxArgs am, float* __restrict__ maxima, int nabs, int per_b) {
+    if ((int)blockIdx.x < nabs) {
+        absmax_block(am, maxima, blockIdx.x);
+        return;
+    }
+    const int r = (int)blockIdx.x - nabs;
+    warp_bwd_count_block(a, count, tiles_x, tiles_y, r % per_b, r / per_b);
 }
 
 // offset[0..n] = exclusive prefix sums of count[0..n) (offset[n] = total); one workgroup
@@ -2310,12 +2334,18 @@ extern "C" int mvster_warp_agg_bwd_sorted(const float* ref_feat, const float* sr
     // later replay); kernel nodes of one stream are strictly ordered
     hipLaunchKernelGGL(warp_bwd_zero_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, s, ints, 2 * n,
                        reinterpret_cast<int*>(mx), 4L);
+    const long per_item = (long)h * w * D;
+    const long per_b = (per_item + 255) / 256;
     {
         const long n_go = (long)B * D * h * w * G, n_ref = (long)h * w * C, n_src = (long)Hs * Ws * C;
-        if (ref_batch_stride == n_ref && src_batch_stride == n_src && src_view_stride == n_src * B) {
+        if (ref_batch_stride == n_ref && src_batch_stride == n_src && src_view_stride == n_src * B &&
+            per_b * B < (1L << 30)) {
+            // (contiguous operands: the maxima and the counting pass share a launch)
             const float* xs[3] = {grad_out, ref_feat, src_feat};
             const long ns[3] = {n_go, n_ref * B, n_src * B * NV};
-            launch_absmax(xs, ns, 3, mx, s);
+            const AbsMaxArgs am = absmax_args(xs, ns, 3);
+            hipLaunchKernelGGL(warp_bwd_prep_kernel, dim3((unsigned)(am.first[3] + per_b * B)), dim3(256), 0, s, a, count, tiles_x,
+                               tiles_y, am, mx, am.first[3], (int)per_b);
         } else {
             launch_absmax(&grad_out, &n_go, 1, mx, s);
             for (int bb = 0; bb < B; ++bb) {
@@ -2327,11 +2357,9 @@ extern "C" int mvster_warp_agg_bwd_sorted(const float* ref_feat, const float* sr
                     const float* p = src_feat + (long)v * src_view_stride + (long)bb * src_batch_stride;
                     launch_absmax(&p, &n_src, 1, mx + 2, s);
                 }
+            hipLaunchKernelGGL(warp_bwd_count_kernel, dim3((unsigned)per_b, B), dim3(256), 0, s, a, count, tiles_x, tiles_y);
         }
     }
-    const long per_item = (long)h * w * D;
-    hipLaunchKernelGGL(warp_bwd_count_kernel, dim3((unsigned)((per_item + 255) / 256), B), dim3(256), 0, s, a, count, tiles_x,
-                       tiles_y);
     hipLaunchKernelGGL(warp_bwd_scan_kernel, dim3(1), dim3(1024), 0, s, count, offset, (int)n);
     int rc = MVSTER_ERR_UNSUPPORTED;
 #define MV_CASE(CC, GG, GR) \
