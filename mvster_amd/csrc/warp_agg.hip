@@ -1330,6 +1330,7 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
     __shared__ int lbase[REC ? kRecMaxTiles : 1];      //      and the first list position reserved for them
     const FixScale fx = make_fix_scale(ba.maxima, G, a.D, CG, GROUP, a.fuse_d != 0, a.attn_temp);
 
+    const mv::GridNorm gn = mv::make_grid_norm(a.Hs, a.Ws);
     const int tx = threadIdx.x;
     const int d = threadIdx.y;
     const int tid = d * 64 + tx;
@@ -1383,7 +1384,7 @@ __global__ void __launch_bounds__(64 * DMAX) warp_agg_bwd_kernel(WarpAggBwdArgs 
             for (int i = 0; i < 3; ++i) m.t[i] = r[9 + i];
         }
         float sx, sy;
-        mv::project(m, (float)x, (float)y, depth, a.Hs, a.Ws, sx, sy);
+        mv::project(m, (float)x, (float)y, depth, gn, sx, sy);      // (shared reciprocals: the forward kernels' form)
         mv::Taps t = mv::make_taps(sx, sy, a.Hs, a.Ws);
         const mv::TapsClamped tc = mv::clamp_taps(t, a.Hs, a.Ws);
         const long voff = (long)v * a.src_vs + (long)b * a.src_bs;
@@ -1909,6 +1910,7 @@ __device__ __forceinline__ void warp_bwd_count_block(const WarpAggArgs& a, int* 
     const int ntiles = tiles_x * tiles_y;
     const long hw = (long)a.h * a.w;
     const long i = (long)bx * 256 + threadIdx.x;                    // = pixel * D + d
+    const mv::GridNorm gn = mv::make_grid_norm(a.Hs, a.Ws);
     const bool valid = i < hw * a.D;
     const long pc = valid ? i / a.D : hw - 1;
     const int d = valid ? (int)(i - pc * a.D) : 0;
@@ -1924,7 +1926,7 @@ __device__ __forceinline__ void warp_bwd_count_block(const WarpAggArgs& a, int* 
 #pragma unroll
         for (int k = 0; k < 3; ++k) m.t[k] = r[9 + k];
         float sx, sy;
-        mv::project(m, (float)x, (float)y, depth, a.Hs, a.Ws, sx, sy);
+        mv::project(m, (float)x, (float)y, depth, gn, sx, sy);      // (shared reciprocals: the forward kernels' form)
         mv::Taps t = mv::make_taps(sx, sy, a.Hs, a.Ws);
         mv::clamp_taps(t, a.Hs, a.Ws);
         const SampleTiles stl = sample_tiles(t, valid ? tap_mask(t) : 0u, tiles_x);
