@@ -181,25 +181,25 @@ __global__ void __launch_bounds__(128) sinkhorn_fast_kernel(const float* __restr
 #pragma unroll
         for (int i = 1; i < D; ++i) m = fmaxf(m, u[i]);
 #pragma unroll
-        for (int i = 0; i < D; ++i) e[i] = expf(u[i] - m);
+        for (int i = 0; i < D; ++i) e[i] = __expf(u[i] - m);
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             float sum = 0.0f;
 #pragma unroll
             for (int i = 0; i < D; ++i) sum = fmaf(MV_E(i, j), e[i], sum);
-            v[j] = a[j] - (m + logf(sum));
+            v[j] = a[j] - (m + __logf(sum));
         }
         m = v[0];
 #pragma unroll
         for (int j = 1; j < D; ++j) m = fmaxf(m, v[j]);
 #pragma unroll
-        for (int j = 0; j < D; ++j) e[j] = expf(v[j] - m);
+        for (int j = 0; j < D; ++j) e[j] = __expf(v[j] - m);
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             float sum = 0.0f;
 #pragma unroll
             for (int j = 0; j < D; ++j) sum = fmaf(MV_E(i, j), e[j], sum);
-            u[i] = bl[i] - (m + logf(sum));
+            u[i] = bl[i] - (m + __logf(sum));
         }
 #pragma unroll
         for (int i = 0; i < D; ++i) { uh[t][i] = u[i]; vh[t][i] = v[i]; }
@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(128) sinkhorn_fast_kernel(const float* __restr
 #pragma unroll
         for (int j = 1; j < D; ++j) m = fmaxf(m, vh[t][j]);
 #pragma unroll
-        for (int j = 0; j < D; ++j) e[j] = expf(vh[t][j] - m);
+        for (int j = 0; j < D; ++j) e[j] = __expf(vh[t][j] - m);
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             float sum = 0.0f;
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(128) sinkhorn_fast_kernel(const float* __restr
 #pragma unroll
         for (int i = 1; i < D; ++i) m = fmaxf(m, up[i]);
 #pragma unroll
-        for (int i = 0; i < D; ++i) e[i] = expf(up[i] - m);
+        for (int i = 0; i < D; ++i) e[i] = __expf(up[i] - m);
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             float sum = 0.0f;
