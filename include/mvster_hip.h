@@ -268,7 +268,8 @@ int mvster_conv_wgrad(const float* x, const float* gy, float* partial, int nblk,
                       int pw, int packed, void* stream);
 
 /* Slot count (`nblk`) to give `partial` for a layer: > 0 where the persistent weight-gradient kernel applies (3x3 / 3x3x3,
- * stride 1, 16 / 32 / 64 channels on both sides: it fills exactly its workgroup count of slots), 0 = caller's choice. */
+ * stride 1, 16 / 32 / 64 channels on both sides: it fills exactly its workgroup count of slots) and for the 5x5 stride-2
+ * layers (one resident round of workgroups), 0 = caller's choice.  The caller may use fewer slots, never more. */
 int mvster_conv_wgrad_slots(int CI, int CO, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int packed);
 
 /* Finish of the weight gradient: adds the nblk slots (fixed order) and writes dW in the parameter's layout in one launch.

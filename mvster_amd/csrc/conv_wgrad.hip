@@ -392,7 +392,21 @@ int launch_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, hipStream_t
     const size_t lds = sizeof(float) * ((size_t)kXC * PA + (size_t)TY * XB * PB);
     // (layers that need more -- stride-2 3x3 from 32 channels, 3x3 from 64 -- were measured no faster here with the limit
     //  raised to 128 KB, one workgroup per CU, than on the per-tap kernels below: 105 vs 47+ us, 642 vs 588 us)
-    if (lds > 64 * 1024 || a.sw > wgrad_stride_bound(TY)) return MVSTER_ERR_UNSUPPORTED;   // (prefetch register budget)
+    // The 5x5 stride-2 layers of the FPN (16 -> 32, 32 -> 64) need 65.4 KB: two workgroups per CU still fit the 160 KB.
+    static const bool big5 = MV_PROBE_ENV("MVSTER_WGRAD_NO_BIG5") == nullptr;
+    const size_t limit = (TY == 5 && PCB == 0 && big5) ? 80 * 1024 : 64 * 1024;
+    if (lds > limit || a.sw > wgrad_stride_bound(TY)) return MVSTER_ERR_UNSUPPORTED;   // (prefetch register budget)
+    if (lds > 64 * 1024) {
+        static unsigned long allowed = 0;                          // per kernel and per device ordinal
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MVSTER_ERR_UNSUPPORTED;
+        if (!((allowed >> dev) & 1ul)) {
+            if (hipFuncSetAttribute((const void*)conv_wgrad_lds_kernel<MT, NT, TY, KW, PCB>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+                return MVSTER_ERR_UNSUPPORTED;
+            allowed |= 1ul << dev;
+        }
+    }
     const int mgroups = cot / MT, ngroups = PCB > 0 ? 1 : cit / NT;
     MV_NOTE_KERNEL("conv_wgrad_lds_kernel<%d, %d, %d, %d, %d>", MT, NT, TY, KW, PCB);
     hipLaunchKernelGGL((conv_wgrad_lds_kernel<MT, NT, TY, KW, PCB>), dim3(nblk, mgroups * ngroups), dim3(256), lds, s, a, mgroups);
@@ -572,7 +586,15 @@ extern "C" int mvster_conv_wgrad(const float* x, const float* gy, float* partial
 // (more slots would only be zero-filled and re-read by the finish), else 0 = the caller's own rule.
 extern "C" int mvster_conv_wgrad_slots(int CI, int CO, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
                                        int packed) {
-    if (packed || CI <= 0 || CO <= 0) return 0;
+    if (CI <= 0 || CO <= 0) return 0;
+    // The 5x5 stride-2 layers of the FPN on the LDS kernel: one resident round of workgroups (two per CU; measured 8 -> 16
+    // 108 -> 99 us at 512 slots, 16 -> 32 127 -> 102 us at 256, 32 -> 64 145 -> 130 us at 64 -- the tail round of a
+    // larger grid costs more than the parallelism gives).
+    if (kd == 1 && kh == 5 && kw == 5 && sw == 2 && sh == 2 && !(CI & 3) && !(CO & 3)) {
+        const int groups = packed ? 1 : ((CO + 15) / 16) * ((CI + 15) / 16);
+        if (groups <= 8) return 512 / groups;
+    }
+    if (packed) return 0;
     WgradArgs a{};
     a.CI = CI; a.CO = CO; a.kd = kd; a.kh = kh; a.kw = kw; a.sd = sd; a.sh = sh; a.sw = sw; a.pd = pd; a.ph = ph; a.pw = pw;
     const int cot = (CO + 15) / 16 == 3 ? 4 : (CO + 15) / 16, cit = (CI + 15) / 16 == 3 ? 4 : (CI + 15) / 16;

@@ -108,7 +108,7 @@ def forward_prologue(imgs, proj_list, depth_values, D, h, w, inverse):
     return packed, rt, hypo
 
 
-WGRAD_MAX_SLOTS = 1024        # weight-gradient partial-sum slots per launch (a module attribute: experiments set it)
+WGRAD_MAX_SLOTS = 2048        # weight-gradient partial-sum slots per launch (a module attribute: experiments set it)
 
 
 def to_channels_last(feat_nchw):
@@ -495,7 +495,7 @@ def conv_wgrad(x_cl, gy_cl, kernel, stride, padding, co_keep=None, ci_keep=None,
     lib = _lib.load()
     pers = _wgrad_pers_slots(lib, CI, CO, kernel, stride, padding, packed)
     if pers > 0:
-        nblk = min(nblk, pers)            # the persistent kernel fills one slot per workgroup (conv_wgrad_pers.hip)
+        nblk = min(nblk, pers)            # the persistent kernel fills one slot per workgroup; 5x5 s2: one resident round
     partial = torch.empty(nblk, ngrp, cop, width, device=x_cl.device, dtype=torch.float32)
     rc = lib.mvster_conv_wgrad(_ptr(x_cl), _ptr(gy_cl), _ptr(partial), nblk, B, Di, Hi, Wi, CI, Do, Ho, Wo, CO,
                                kd, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
