@@ -228,10 +228,13 @@ __host__ __device__ constexpr int wg_pitch(int c, int s) {
     return p;
 }
 
-// largest x stride the prefetch registers are sized for: the 3x3x3 layers (TY = 9) are all stride 1
-__host__ __device__ constexpr int wgrad_stride_bound(int ty) { return ty == 9 ? 1 : 2; }
-
-template <int MT, int NT, int TY, int KW, int PCB>
+// Round 6: the x stride is a template parameter (1 or 2), so the staged-patch geometry (XB, PB) and with it every LDS
+// offset of the MFMA phase is an instruction immediate, and everything about a staging slot that does not change from
+// one chunk to the next (its global offset inside the unit, its LDS address, its patch row / column) is formed once per
+// thread.  Before, the index arithmetic of the three staging lambdas and of the operand addresses -- runtime divisions by
+// XB, the (row -> b, z, y) decode on the vector unit, a select per B operand -- was ~235 VALU instructions per wave and
+// chunk beside 20 MFMAs on the narrow layers: 1 800 cycles per chunk and SIMD where the matrix pipe needs 640.
+template <int MT, int NT, int TY, int KW, int PCB, int SW>
 __global__ void __launch_bounds__(256) conv_wgrad_lds_kernel(WgradArgs a, int mgroups) {
     constexpr int TAPS = TY * KW;
     constexpr bool PACKED = PCB > 0;
@@ -239,13 +242,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_lds_kernel(WgradArgs a, int mg
     constexpr int NG = PACKED ? (TAPS + TPN - 1) / TPN : TAPS;      // N-tile groups per (mt, nt)
     constexpr int NTT = PACKED ? 1 : NT;
     constexpr int NACC = MT * NTT * NG;
+    constexpr int PA = wg_pitch(MT * 16, 1);
+    constexpr int CBB = PACKED ? PCB : NT * 16;                      // B channels staged per pixel
+    constexpr int PB = wg_pitch(CBB, SW);
+    constexpr int XB = (kXC - 1) * SW + KW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int PA = wg_pitch(MT * 16, 1);
-    const int CBB = PACKED ? PCB : NT * 16;                          // B channels staged per pixel
-    const int PB = wg_pitch(CBB, a.sw);
-    const int XB = (kXC - 1) * a.sw + KW;
-    float* As = lds;                                                 // [kXC][PA]
-    float* Bs = lds + kXC * PA;                                      // [TY][XB][PB]
+    float* const As = lds;                                           // [kXC][PA]
+    float* const Bs = lds + kXC * PA;                                // [TY][XB][PB]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, k = lane >> 4;
@@ -255,77 +258,142 @@ __global__ void __launch_bounds__(256) conv_wgrad_lds_kernel(WgradArgs a, int mg
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
 
-    // per-lane LDS offsets of the B operand (the taps of a packed tile differ per lane)
-    int boff[NG];
-    bool bval[NG];
+    // MFMA operands of this lane: K step ks = wave + 4 it of a chunk = output columns ks*4 + k; the `it` part is an immediate.
+    // A packed tile's lanes take different taps (r / PCB); a tap past the last one reads the last one's values -- its columns
+    // of `partial` are dropped by the finish kernel.
+    const float* const Ab = As + (wave * 4 + k) * PA + r;
+    const float* const Bb = Bs + (wave * 4 + k) * SW * PB + (PACKED ? 0 : r);
+    const float* bpk[PACKED ? NG : 1];
+    if (PACKED) {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int tap = PACKED ? g * TPN + r / PCB : g;
-        const int tapc = tap < TAPS ? tap : TAPS - 1;
-        const int ty = tapc / KW, kx = tapc - ty * KW;
-        boff[g] = (ty * XB + kx) * PB + (PACKED ? r % PCB : 0);
-        bval[g] = tap < TAPS && (!PACKED || (r % PCB) < a.CI);
+        for (int g = 0; g < NG; ++g) {
+            const int tap = min(g * TPN + r / (PACKED ? PCB : 1), TAPS - 1);
+            const int ty = tap / KW, kx = tap - ty * KW;
+            bpk[g] = Bb + (ty * XB + kx) * PB + r % (PACKED ? PCB : 1);
+        }
     }
 
     const int nrows = a.B * a.Do * a.Ho;
     const int nchunks = (a.Wo + kXC - 1) / kXC;
-    constexpr int qa = MT * 4, qb = (PACKED ? PCB : NT * 16) / 4;    // float4 per staged pixel
+    constexpr int qa = MT * 4, qb = CBB / 4;                         // float4 per staged pixel
     // A staging unit = one chunk of one output row.  Units are register-double-buffered: the global loads of unit u+1
     // are issued before the MFMAs of unit u and written to LDS after them (measured over the 64 weight gradients of a
     // config-4 step: 5.26 -> 4.40 ms; the 27-tap layers gain too, although the nine staged rows cost them 40 registers).
     constexpr int NA = (kXC * qa + 255) / 256;
-    constexpr int NBX = (TY * (63 * wgrad_stride_bound(TY) + KW) * qb + 255) / 256;
+    constexpr int nb4 = TY * XB * qb;                                // float4 of the B patch
+    constexpr int NBX = (nb4 + 255) / 256;
     f32x4v ra[NA], rb[NBX];
-    const int nb4 = TY * XB * qb;                                    // float4 of the B patch (<= NBX * 256)
-    const int my_rows = blockIdx.x < nrows ? (nrows - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const int nunits = my_rows * nchunks;
-    auto unit_row = [&](int u) { return blockIdx.x + (u / nchunks) * gridDim.x; };
-    auto load_a = [&](int row, int x1, int idx) {
+    // per staging slot, once: byte offset inside the unit (from the unit's first gy column / first patch pixel), LDS
+    // address, and for the bounds tests the chunk column (A; 255 = no such slot) or column | 1 << (8 + patch row) (B)
+    unsigned a_g[NA], a_px[NA], b_g[NBX], b_pos[NBX];
+    float* a_s[NA];
+    float* b_s[NBX];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int idx = threadIdx.x + i * 256;
         const int px = idx / qa, q = idx - px * qa;
         const int c = m0 + q * 4;
-        f32x4v v = {0.f, 0.f, 0.f, 0.f};
-        if (idx < kXC * qa && x1 + px < a.Wo && c < a.CO)
-            v = *reinterpret_cast<const f32x4v*>(a.gy + ((long)row * a.Wo + (x1 + px)) * a.CO + c);
-        return v;
-    };
-    auto load_b = [&](int row, int x1, int idx) {
-        const int yo = row % a.Ho, t = row / a.Ho;
-        const int zo = t % a.Do, b = t / a.Do;
-        const int q = idx % qb;
-        const int rest = idx / qb;
+        const bool ok = idx < kXC * qa && c < a.CO;
+        a_g[i] = (unsigned)(px * a.CO + c) * 4u;
+        a_px[i] = ok ? (unsigned)px : 255u;
+        a_s[i] = As + px * PA + q * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < NBX; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const int q = idx % qb, rest = idx / qb;
         const int px = rest % XB, ty = rest / XB;
         const int kz = ty / a.kh, ky = ty - kz * a.kh;
-        const int iz = zo * a.sd - a.pd + kz, iy = yo * a.sh - a.ph + ky, ix = x1 * a.sw - a.pw + px;
         const int c = n0 + q * 4;
-        f32x4v v = {0.f, 0.f, 0.f, 0.f};
-        if (idx < nb4 && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi && c < a.CI)
-            v = *reinterpret_cast<const f32x4v*>(a.x + ((((long)b * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.CI + c);
-        return v;
+        const bool ok = idx < nb4 && c < a.CI;
+        b_g[i] = (unsigned)(((kz * a.Hi + ky) * a.Wi + px) * a.CI + c) * 4u;
+        b_pos[i] = ok ? (unsigned)px | (1u << (8 + ty)) : 0u;
+        b_s[i] = Bs + (ty * XB + px) * PB + q * 4;
+    }
+    // this workgroup's units: rows blockIdx.x, + gridDim.x, ...; all of it wave-uniform and stepped, not divided
+    struct Unit {
+        int chunk, b, zo, yo;
+        long row;
     };
-    auto store_a = [&](int idx, const f32x4v& v) {
-        const int px = idx / qa, q = idx - px * qa;
-        if (idx < kXC * qa) *reinterpret_cast<f32x4v*>(As + px * PA + q * 4) = v;
+    Unit nu;
+    nu.chunk = 0;
+    nu.row = blockIdx.x;
+    {
+        const int yo = (int)(nu.row % a.Ho), t = (int)(nu.row / a.Ho);
+        nu.yo = yo;
+        nu.zo = t % a.Do;
+        nu.b = t / a.Do;
+    }
+    auto advance = [&](Unit& u) {
+        if (++u.chunk < nchunks) return;
+        u.chunk = 0;
+        u.row += gridDim.x;
+        u.yo += (int)gridDim.x;
+        while (u.yo >= a.Ho) {
+            u.yo -= a.Ho;
+            if (++u.zo == a.Do) {
+                u.zo = 0;
+                ++u.b;
+            }
+        }
     };
-    auto store_b = [&](int idx, const f32x4v& v) {
-        const int q = idx % qb;
-        const int rest = idx / qb;
-        const int px = rest % XB, ty = rest / XB;
-        if (idx < nb4) *reinterpret_cast<f32x4v*>(Bs + (ty * XB + px) * PB + q * 4) = v;
+    auto fetch = [&](const Unit& u) {
+        const int x1 = u.chunk * kXC;
+        const int iz0 = u.zo * a.sd - a.pd, iy0 = u.yo * a.sh - a.ph, ix0 = x1 * SW - a.pw;
+        // buffer descriptors at the unit's origin (the B origin may lie in front of the tensor: only lanes whose pixel is
+        // inside the volume use it); 0xFFFFFFF0 is out of range -> zeros
+        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.gy + (u.row * a.Wo + x1) * a.CO), (short)0, (int)0xFFFFFF00u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.x + ((((long)u.b * a.Di + iz0) * a.Hi + iy0) * a.Wi + ix0) * a.CI), (short)0, (int)0xFFFFFF00u,
+            0x00020000);
+        const unsigned rem = (unsigned)min(a.Wo - x1, kXC);
+        unsigned rowmask = 0;                                        // bit 8 + ty: patch row ty lies inside the volume
+        int kz = 0, ky = 0;
+#pragma unroll
+        for (int ty = 0; ty < TY; ++ty) {
+            if ((unsigned)(iz0 + kz) < (unsigned)a.Di && (unsigned)(iy0 + ky) < (unsigned)a.Hi) rowmask |= 1u << (8 + ty);
+            if (++ky == a.kh) {
+                ky = 0;
+                ++kz;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const unsigned off = a_px[i] < rem ? a_g[i] : 0xFFFFFFF0u;
+            ra[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(ars, off, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < NBX; ++i) {
+            const bool ok = (b_pos[i] & rowmask) != 0 && (unsigned)(ix0 + (int)(b_pos[i] & 255u)) < (unsigned)a.Wi;
+            const unsigned off = ok ? b_g[i] : 0xFFFFFFF0u;
+            rb[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(brs, off, 0, 0));
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            if ((i + 1) * 256 <= kXC * qa || threadIdx.x + i * 256 < kXC * qa) *reinterpret_cast<f32x4v*>(a_s[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NBX; ++i)
+            if ((i + 1) * 256 <= nb4 || threadIdx.x + i * 256 < nb4) *reinterpret_cast<f32x4v*>(b_s[i]) = rb[i];
     };
     auto compute = [&]() {
-        // K steps of this wave: four output columns each
-        for (int ks = wave; ks < kXC / 4; ks += 4) {
-            const int px = ks * 4 + k;
+#pragma unroll
+        for (int it = 0; it < kXC / 16; ++it) {
             float av[MT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) av[i] = As[px * PA + i * 16 + r];
-            const float* bp = Bs + px * a.sw * PB + (PACKED ? 0 : r);
+            for (int i = 0; i < MT; ++i) av[i] = Ab[it * 16 * PA + i * 16];
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
 #pragma unroll
                 for (int j = 0; j < NTT; ++j) {
-                    float bv = bp[boff[g] + j * 16];
-                    if (PACKED) bv = bval[g] ? bv : 0.0f;
+                    float bv;
+                    if (PACKED) {
+                        bv = bpk[PACKED ? g : 0][it * 16 * SW * PB];
+                    } else {
+                        bv = Bb[it * 16 * SW * PB + ((g / KW) * XB + g % KW) * PB + j * 16];
+                    }
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
                         acc[(i * NTT + j) * NG + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[(i * NTT + j) * NG + g], 0, 0, 0);
@@ -333,23 +401,19 @@ __global__ void __launch_bounds__(256) conv_wgrad_lds_kernel(WgradArgs a, int mg
             }
         }
     };
-    auto fetch = [&](int u) {
-        const int row = unit_row(u), x1 = (u % nchunks) * kXC;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = load_a(row, x1, threadIdx.x + i * 256);
-#pragma unroll
-        for (int i = 0; i < NBX; ++i) rb[i] = load_b(row, x1, threadIdx.x + i * 256);
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) store_a(threadIdx.x + i * 256, ra[i]);
-#pragma unroll
-        for (int i = 0; i < NBX; ++i) store_b(threadIdx.x + i * 256, rb[i]);
-    };
-    if (nunits > 0) { fetch(0); commit(); }
+    const int my_rows = blockIdx.x < nrows ? (nrows - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int nunits = my_rows * nchunks;
+    if (nunits > 0) {
+        fetch(nu);
+        advance(nu);
+        commit();
+    }
     __syncthreads();
     for (int u = 0; u < nunits; ++u) {
-        if (u + 1 < nunits) fetch(u + 1);
+        if (u + 1 < nunits) {
+            fetch(nu);
+            advance(nu);
+        }
         compute();
         __syncthreads();                                             // this unit's readers are done
         if (u + 1 < nunits) commit();
@@ -385,32 +449,42 @@ __global__ void __launch_bounds__(256) conv_wgrad_lds_kernel(WgradArgs a, int mg
             }
 }
 
-template <int MT, int NT, int TY, int KW, int PCB>
-int launch_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, hipStream_t s) {
-    const int PA = wg_pitch(MT * 16, 1), PB = wg_pitch(PCB > 0 ? PCB : NT * 16, a.sw);
-    const int XB = (kXC - 1) * a.sw + KW;
-    const size_t lds = sizeof(float) * ((size_t)kXC * PA + (size_t)TY * XB * PB);
-    // (layers that need more -- stride-2 3x3 from 32 channels, 3x3 from 64 -- were measured no faster here with the limit
-    //  raised to 128 KB, one workgroup per CU, than on the per-tap kernels below: 105 vs 47+ us, 642 vs 588 us)
+template <int MT, int NT, int TY, int KW, int PCB, int SW>
+int launch_wgrad_lds_sw(const WgradArgs& a, int nblk, int cot, int cit, hipStream_t s) {
+    constexpr int PA = wg_pitch(MT * 16, 1), PB = wg_pitch(PCB > 0 ? PCB : NT * 16, SW);
+    constexpr int XB = (kXC - 1) * SW + KW;
+    constexpr size_t lds = sizeof(float) * ((size_t)kXC * PA + (size_t)TY * XB * PB);
+    // (layers that need more than 64 KB -- stride-2 3x3 from 32 channels, 3x3 from 64 -- were measured no faster here with the
+    //  limit raised to 128 KB, one workgroup per CU, than on the per-tap kernels below: 105 vs 47+ us, 642 vs 588 us.)
     // The 5x5 stride-2 layers of the FPN (16 -> 32, 32 -> 64) need 65.4 KB: two workgroups per CU still fit the 160 KB.
     static const bool big5 = MV_PROBE_ENV("MVSTER_WGRAD_NO_BIG5") == nullptr;
     const size_t limit = (TY == 5 && PCB == 0 && big5) ? 80 * 1024 : 64 * 1024;
-    if (lds > limit || a.sw > wgrad_stride_bound(TY)) return MVSTER_ERR_UNSUPPORTED;   // (prefetch register budget)
+    if (lds > limit) return MVSTER_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
         static unsigned long allowed = 0;                          // per kernel and per device ordinal
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MVSTER_ERR_UNSUPPORTED;
         if (!((allowed >> dev) & 1ul)) {
-            if (hipFuncSetAttribute((const void*)conv_wgrad_lds_kernel<MT, NT, TY, KW, PCB>,
+            if (hipFuncSetAttribute((const void*)conv_wgrad_lds_kernel<MT, NT, TY, KW, PCB, SW>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
                 return MVSTER_ERR_UNSUPPORTED;
             allowed |= 1ul << dev;
         }
     }
     const int mgroups = cot / MT, ngroups = PCB > 0 ? 1 : cit / NT;
-    MV_NOTE_KERNEL("conv_wgrad_lds_kernel<%d, %d, %d, %d, %d>", MT, NT, TY, KW, PCB);
-    hipLaunchKernelGGL((conv_wgrad_lds_kernel<MT, NT, TY, KW, PCB>), dim3(nblk, mgroups * ngroups), dim3(256), lds, s, a, mgroups);
+    MV_NOTE_KERNEL("conv_wgrad_lds_kernel<%d, %d, %d, %d, %d, %d>", MT, NT, TY, KW, PCB, SW);
+    hipLaunchKernelGGL((conv_wgrad_lds_kernel<MT, NT, TY, KW, PCB, SW>), dim3(nblk, mgroups * ngroups), dim3(256), lds, s, a, mgroups);
     return mv_check_launch();
+}
+
+// x stride 1, and 2 for the 3x3 / 5x5 layers (the only strided ones of the network)
+template <int MT, int NT, int TY, int KW, int PCB>
+int launch_wgrad_lds(const WgradArgs& a, int nblk, int cot, int cit, hipStream_t s) {
+    if (a.sw == 1) return launch_wgrad_lds_sw<MT, NT, TY, KW, PCB, 1>(a, nblk, cot, cit, s);
+    if constexpr ((TY == 3 || TY == 5) && KW == TY) {
+        if (a.sw == 2) return launch_wgrad_lds_sw<MT, NT, TY, KW, PCB, 2>(a, nblk, cot, cit, s);
+    }
+    return MVSTER_ERR_UNSUPPORTED;
 }
 
 // Accumulator tiles (MT * NT * tap groups) a wavefront may hold.  Small tiles win: the staging of a chunk is not
