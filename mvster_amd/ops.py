@@ -491,7 +491,9 @@ def conv_wgrad(x_cl, gy_cl, kernel, stride, padding, co_keep=None, ci_keep=None,
     # workgroups = slots of `partial` (added in a fixed order by the finish kernel: deterministic).  Measured on the
     # config-4 step: 1024 slots 26.0 ms, 512 26.4 ms, 256 27.9 ms -- the kernels want the parallelism more than the
     # reduction minds the size.
-    nblk = max(1, min((rows + 3) // 4, (32 << 20) // slot_bytes, WGRAD_MAX_SLOTS))
+    # (at least two workgroups per CU where the layer has the rows for it: the small full-resolution layers -- the depth
+    #  head's 4 -> 32 at [2, 256, 320] ran on 128 workgroups, 69 us for 0.4 GFLOP)
+    nblk = max(1, min(max((rows + 3) // 4, min(rows, 512)), (32 << 20) // slot_bytes, WGRAD_MAX_SLOTS))
     lib = _lib.load()
     pers = _wgrad_pers_slots(lib, CI, CO, kernel, stride, padding, packed)
     if pers > 0:
