@@ -849,6 +849,391 @@ int launch_wino_ring(const ConvArgs& a, hipStream_t s) {
     return mv_check_launch();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Pair form of the 3x3x3 layers (round 6, review item 4: "transform each input slice once").  The ring kernel above walks
+// (output slice z, depth tap kz, chunk): input slice z + kz - 1 is fetched and transformed once per (z, kz) -- three times.
+// Walking the input slices once needs three live accumulator sets (192 registers beside V's 64 and the weight read-ahead:
+// does not fit at two waves per SIMD, scripts/probes/wino_once_regs.hip).  TWO sets fit -- the register budget of MODE 2,
+// with the second output SLICE where MODE 2 holds the second N tile: a tile is the output slices (2 zp, 2 zp + 1) of an
+// 8 x 32 window and its steps walk the four input slices 2 zp - 1 .. 2 zp + 2 (window index kz = 0..3) x chunks; the slice of
+// window index kz feeds set 0 (output 2 zp) through depth tap kz and set 1 (output 2 zp + 1) through tap kz - 1.  Four fetches
+// and transforms per two output slices instead of six (D = 4 with its padding: six instead of ten), and 128 MFMAs behind the
+// inner transforms instead of 64.  Per output element the (depth tap, chunk) summation order is the ring kernel's: results are
+// bit-identical to it.  Frame = MODE 0 / 2 of the ring kernel: waves 0-3 compute (one N tile, blockIdx.y picks it), waves 4-7
+// issue the DMA; 16-channel inputs keep their three weight blocks resident, 32-channel inputs stream two blocks per step.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NCH, bool SKIP>
+__global__ void __launch_bounds__(512) conv_wino_pair_kernel(ConvArgs a, PersArgs p) {
+    using G = RingGeom;
+    constexpr int KD = 3, NS = 2;
+    constexpr int TY = G::TY, PLANE = G::PLANE, NBLK = G::NBLK, RS = G::ROWSLOTS, SLICE = G::SLICE;
+    constexpr int NLW = 4;                                  // loading waves
+    constexpr int NIW = (NBLK + NLW / 2 - 1) / (NLW / 2);  // slice DMA instructions per loading wave and step
+    constexpr int CIN = NCH * 16;
+    constexpr int UBLK = 16 * 64;                           // float4 of one weight block: (depth tap, chunk) of one N tile
+    constexpr bool URES = KD * NCH <= 3;                    // every block of the workgroup's N tile stays in LDS
+    constexpr int UST = URES ? UBLK : NS * UBLK;            // float4 per weight slot
+    constexpr int USLOTS = URES ? KD * NCH : 2;
+    constexpr int NUW = NS * 16 / NLW;                      // weight DMA instructions per loading wave and step (streamed form)
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    f32x4v* const ring = reinterpret_cast<f32x4v*>(lds_raw);              // 4 patch slices
+    f32x4v* const uring = ring + 4 * SLICE;
+    f32x4v* const scratch = uring + USLOTS * UST;                         // 64 float4: surplus DMA slots
+
+    const int lane = threadIdx.x & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = wave8 >> 2, wave = wave8 & 3;
+    const int lm = lane & 15, lq = lane >> 4;
+    const int nt0 = blockIdx.y;
+    const long wstep = (long)a.ntile_total * 256;          // floats per K step (16 channels) of the packed weights
+    const int dop = a.Do >> 1;                              // output slice pairs
+    auto in_rsrc = [&](int k) -> __amdgpu_buffer_rsrc_t {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in) - 256 * k, (short)0, (int)(a.in_bytes + 1024u * k), 0x00020000);
+    };
+    auto w_rsrc = [&](int k) -> __amdgpu_buffer_rsrc_t {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpk) - 256 * k, (short)0,
+                                                 (int)(KD * 16 * NCH * wstep * 4 + 1024 * k), 0x00020000);
+    };
+    const int lpl = wave / (NLW / 2), lblk0 = (wave % (NLW / 2)) * NIW;   // a loading wave's plane and first block
+    auto decode_piece = [&](int n, int ln, unsigned& db, int& dp) {
+        const int blk = lblk0 + n;
+        const int s = blk * 64 + ln;
+        const int q1 = s & 1;
+        int t = s >> 1;
+        const int xh = t % G::PWH;
+        t /= G::PWH;
+        const int py = t >> 1, px = 2 * xh + (t & 1);
+        const bool valid = blk < NBLK && py < G::PH;
+        dp = px | (py << 8);
+        db = valid ? (unsigned)((py * a.Wi + px) * (CIN * 4) + (lpl * 8 + q1 * 4) * 4) : 0x80000000u;
+    };
+    auto decode_tile = [&](unsigned tile) -> TilePos {
+        TilePos t;
+        auto div = [&](unsigned n, int k) -> unsigned { return ((__umulhi(n, p.mul[k]) >> p.shr[k]) & ~p.one[k]) | (n & p.one[k]); };
+        unsigned q = div(tile, 0);
+        t.tx0 = (int)(tile - q * p.tiles_x) * 32;
+        unsigned q2 = div(q, 1);
+        t.ty0 = (int)(q - q2 * p.tiles_y) * TY;
+        const unsigned q3 = div(q2, 2);                     // (the host formed this divisor from Do / 2)
+        t.zo = (int)(q2 - q3 * (unsigned)dop);              // pair index
+        t.b = (int)q3;
+        return t;
+    };
+    const unsigned nwg = gridDim.x;
+    // a step = (window slice kz = 0..3, chunk c); window slices outside the volume have no step
+    auto first_step = [&](unsigned tile) -> RingStep {
+        RingStep st;
+        st.tile = tile;
+        st.live = tile < p.ntiles;
+        st.pos = decode_tile(st.live ? tile : 0u);
+        st.kz = max(0, 1 - 2 * st.pos.zo);
+        st.kz_hi = min(4, a.Di - 2 * st.pos.zo + 1);
+        st.c = 0;
+        return st;
+    };
+    auto is_last = [&](const RingStep& st) -> bool { return st.c == NCH - 1 && st.kz == st.kz_hi - 1; };
+    auto next_step = [&](const RingStep& st) -> RingStep {
+        if (!st.live) return st;
+        if (is_last(st)) return first_step(st.tile + nwg);
+        RingStep n = st;
+        if (++n.c == NCH) {
+            n.c = 0;
+            ++n.kz;
+        }
+        return n;
+    };
+    struct SliceReq {
+        unsigned origin, wi;
+        int iy0, ix0;
+        bool interior;
+        f32x4v* dst0;
+    };
+    auto slice_req = [&](const RingStep& st, int slot) -> SliceReq {
+        SliceReq r;
+        const int iz = 2 * st.pos.zo + st.kz - 1;
+        r.iy0 = st.pos.ty0 - a.ph[0];
+        r.ix0 = st.pos.tx0 - a.pw[0];
+        r.origin = (unsigned)(((((st.pos.b * a.Di + iz) * a.Hi + r.iy0) * a.Wi + r.ix0) * CIN + st.c * 16) * 4);
+        r.wi = st.live ? (unsigned)a.Wi : 0u;
+        r.interior = st.live && r.iy0 >= 0 && r.ix0 >= 0 && r.iy0 + G::PH <= a.Hi && r.ix0 + 2 * G::PWH <= a.Wi;
+        r.dst0 = ring + slot * SLICE;
+        return r;
+    };
+    auto slice_piece = [&](const SliceReq& r, int n, unsigned db, int dp) {
+        constexpr int IMM[4] = {0, 1024, 2048, 3072};
+        const bool real = lblk0 + n < NBLK;
+        f32x4v* const dst = (NIW * (NLW / 2) == NBLK || n + 1 < NIW || real) ? r.dst0 + lpl * PLANE + (lblk0 + (n & ~3)) * 64
+                                                                             : scratch - (n & 3) * 64;
+        const __amdgpu_buffer_rsrc_t rs = in_rsrc(n & 3);
+        if (r.interior) {
+            const unsigned so = r.origin;
+            switch (n & 3) {
+                case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, db, so, IMM[0], 0); break;
+                case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, db, so, IMM[1], 0); break;
+                case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, db, so, IMM[2], 0); break;
+                default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, db, so, IMM[3], 0); break;
+            }
+        } else {
+            const int ix = r.ix0 + (dp & 255), iy = r.iy0 + (dp >> 8);
+            const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < r.wi;
+            const unsigned off = ok ? db + r.origin : 0x80000000u;
+            switch (n & 3) {
+                case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, off, 0, IMM[0], 0); break;
+                case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, off, 0, IMM[1], 0); break;
+                case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, off, 0, IMM[2], 0); break;
+                default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, off, 0, IMM[3], 0); break;
+            }
+        }
+    };
+    // one kilobyte of a weight block: transform point q of (depth tap kz, chunk c), to `dst` (+ the immediate of piece m & 3)
+    const unsigned wlane = lane * 16;
+    auto weight_piece = [&](int kz, int c, int q, f32x4v* dst, int m) {
+        const unsigned so = (unsigned)((((long)(kz * 16 + q) * NCH + c) * wstep + (long)nt0 * 256) * 4);
+        const __amdgpu_buffer_rsrc_t rs = w_rsrc(m & 3);
+        switch (m & 3) {
+            case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, wlane, so, 0, 0); break;
+            case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, wlane, so, 1024, 0); break;
+            case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, wlane, so, 2048, 0); break;
+            default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, wlane, so, 3072, 0); break;
+        }
+    };
+    // streamed weights of one step: slot = [set][point][lane]; this wave's NUW kilobytes are consecutive and belong to ONE set
+    // (set s takes depth tap kz - s; a set without a tap in this step fetches nothing)
+    auto weight_step = [&](const RingStep& st, int slot) {
+        const int set = (wave * NUW) >> 4, q0 = (wave * NUW) & 15;
+        const int kz = st.kz - set;
+        if (!st.live || kz < 0 || kz >= KD) return;
+        f32x4v* const dst0 = uring + slot * UST + wave * NUW * 64;
+#pragma unroll
+        for (int m = 0; m < NUW; ++m) weight_piece(kz, st.c, q0 + m, dst0 + (m & ~3) * 64, m);
+    };
+
+    RingStep s0 = first_step(xcd_remap(blockIdx.x, nwg));
+    RingStep s1 = next_step(s0), s2 = next_step(s1), s3 = next_step(s2);
+    if (half == 1) {
+        // ---- loading waves: the first three slices and the first weights, then one request set per step
+        unsigned dbl[NIW];
+        int dpl[NIW];
+#pragma unroll
+        for (int n = 0; n < NIW; ++n) decode_piece(n, lane, dbl[n], dpl[n]);
+        const RingStep* const first[3] = {&s0, &s1, &s2};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const SliceReq r = slice_req(*first[k], k);
+#pragma unroll
+            for (int n = 0; n < NIW; ++n) slice_piece(r, n, dbl[n], dpl[n]);
+        }
+        if (URES) {
+#pragma unroll
+            for (int kz = 0; kz < KD; ++kz)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)         // 16 points over four waves
+                        weight_piece(kz, c, wave * 4 + m, uring + (kz * NCH + c) * UBLK + wave * 4 * 64, m);
+        } else {
+            weight_step(s0, 0);
+        }
+        __syncthreads();        // (waits for everything requested so far)
+        for (int g = 0; s0.live; ++g) {
+            if (!URES) weight_step(s1, (g + 1) & 1);
+            const SliceReq sr = slice_req(s3, (g + 3) & 3);
+#pragma unroll
+            for (int n = 0; n < NIW; ++n) slice_piece(sr, n, dbl[n], dpl[n]);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            s0 = s1;
+            s1 = s2;
+            s2 = s3;
+            s3 = next_step(s3);
+        }
+        return;
+    }
+    __syncthreads();
+
+    // ---- compute waves ------------------------------------------------------------------------------------------------
+    const int n0 = nt0 * 16 + lq * 4;
+    const f32x4v scv = *reinterpret_cast<const f32x4v*>(a.scale + n0);
+    const f32x4v shv = *reinterpret_cast<const f32x4v*>(a.shift + n0);
+    const int abase = 2 * wave * RS + 2 * lm + (lq >> 1) * PLANE + (lq & 1);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t skip_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(SKIP ? a.skip : a.in), (short)0, SKIP ? (int)p.out_bytes : 0, 0x00020000);
+    const unsigned obase = (unsigned)((2 * wave * a.Wo + 2 * lm) * a.cout + nt0 * 16 + lq * 4) * 4u;
+    const unsigned opix = (unsigned)a.cout * 4u, orow = (unsigned)a.Wo * opix;
+    const unsigned oslice = (unsigned)a.Ho * orow;
+    const float floor_v = a.relu ? 0.0f : -__builtin_inff();
+
+    Q4 d[4][4], V[4][4];
+    auto read_block = [&](int slot) {
+        const f32x4v* patch = ring + slot * SLICE + abase;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const f32x4v v = patch[r * RS + (x & 1) * (G::PWH * 2) + (x >> 1) * 2];
+                d[r][x] = {{v[0], v[1]}, {v[2], v[3]}};
+            }
+    };
+    auto transform_block = [&]() {       // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const Q4 t0 = d[0][x] - d[2][x], t1 = d[1][x] + d[2][x], t2 = d[2][x] - d[1][x], t3 = d[1][x] - d[3][x];
+            d[0][x] = t0;
+            d[1][x] = t1;
+            d[2][x] = t2;
+            d[3][x] = t3;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            V[r][0] = d[r][0] - d[r][2];
+            V[r][1] = d[r][1] + d[r][2];
+            V[r][2] = d[r][2] - d[r][1];
+            V[r][3] = d[r][1] - d[r][3];
+        }
+    };
+    f32x4v acc[16][NS];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int st = 0; st < NS; ++st) acc[q][st] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    read_block(0);
+    transform_block();
+
+    for (int g = 0; s0.live; ++g) {
+        const bool last = is_last(s0);
+        // weight blocks of this step's sets: resident [tap][chunk] or this step's slot [set]
+        const f32x4v* const u0 = uring + (URES ? (min(s0.kz, KD - 1) * NCH + s0.c) * UBLK : (g & 1) * UST) + lane;
+        const f32x4v* const u1 = uring + (URES ? (max(s0.kz - 1, 0) * NCH + s0.c) * UBLK : (g & 1) * UST + UBLK) + lane;
+        __builtin_amdgcn_sched_barrier(0);
+        // One set after the other, each behind ONE wave-uniform branch: a set without a depth tap in this step (the window's
+        // first slice has none for set 1, its last none for set 0) is skipped.  Weights are read one group of four transform
+        // points ahead.  (Three copies of a two-set phase, or branches around groups of MFMAs, made the allocator spill.)
+        auto set_phase = [&](auto st_c, const f32x4v* us) {
+            constexpr int ST = decltype(st_c)::value;
+            f32x4v ub[2][4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) ub[0][qq] = us[qq * 64];
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                if (grp < 3) {
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) ub[(grp + 1) & 1][qq] = us[((grp + 1) * 4 + qq) * 64];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        acc[grp * 4 + qq][ST] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[grp & 1][qq][j], elem(V[grp][qq], j),
+                                                                                     acc[grp * 4 + qq][ST], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (s0.kz < KD) set_phase(std::integral_constant<int, 0>{}, u0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s0.kz > 0) set_phase(std::integral_constant<int, 1>{}, u1);
+        __builtin_amdgcn_sched_barrier(0);
+        // (the packed additions are inline assembly: MFMA results reach them only behind these wait states, and the
+        //  transform below overwrites MFMA source registers)
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (last) {
+            const TilePos& here = s0.pos;
+            const unsigned oorigin = (unsigned)((((here.b * a.Do + 2 * here.zo) * a.Ho + here.ty0) * a.Wo + here.tx0) * a.cout) * 4u;
+            unsigned ooff[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bool ok = here.ty0 + 2 * wave + i < a.Ho && here.tx0 + 2 * lm + j < a.Wo;
+                    ooff[i][j] = ok ? obase + oorigin + i * orow + j * opix : 0x80000000u;
+                }
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                f32x4v skv[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const unsigned so = st * oslice;
+                        skv[i][j] = SKIP ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, ooff[i][j], so, 0))
+                                         : (f32x4v){0.f, 0.f, 0.f, 0.f};
+                    }
+                // Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; fused epilogue on the 2x2 pixels x 4 channels of this lane
+                Q4 m[16], t[2][4];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) m[q] = {{acc[q][st][0], acc[q][st][1]}, {acc[q][st][2], acc[q][st][3]}};
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    t[0][x] = m[0 + x] + m[4 + x] + m[8 + x];
+                    t[1][x] = m[4 + x] - (m[8 + x] + m[12 + x]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    Q4 y[2];
+                    y[0] = t[i][0] + t[i][1] + t[i][2];
+                    y[1] = t[i][1] - (t[i][2] + t[i][3]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4v v = {y[j].lo[0], y[j].lo[1], y[j].hi[0], y[j].hi[1]};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = fmaxf(fmaf(v[e], scv[e], shv[e]), floor_v);
+                            if (SKIP) v[e] += skv[i][j][e];
+                        }
+                        const unsigned so = st * oslice;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, ooff[i][j], so, MV_STORE_AUX);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int st = 0; st < NS; ++st) acc[q][st] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        read_block((g + 1) & 3);
+        transform_block();                // d (step g+1) -> V
+        __builtin_amdgcn_sched_barrier(0);
+        // everyone is done with slice g and weight slot g & 1
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        s0 = s1;
+        s1 = s2;
+        s2 = s3;
+        s3 = next_step(s3);
+    }
+}
+
+template <int NCH, bool SKIP>
+int launch_wino_pair(const ConvArgs& a, hipStream_t s) {
+    using G = RingGeom;
+    constexpr int KD = 3;
+    constexpr bool URES = KD * NCH <= 3;
+    constexpr int USLOTS = URES ? KD * NCH : 2, UST = (URES ? 1 : 2) * 16 * 64;
+    const size_t lds = (size_t)(4 * G::SLICE + USLOTS * UST + 64) * 16;
+    if (lds > 160 * 1024 || (a.Do & 1) || a.Do != a.Di) return MVSTER_ERR_UNSUPPORTED;
+    auto kern = conv_wino_pair_kernel<NCH, SKIP>;
+    static unsigned long attr_done = 0;
+    if (!allow_big_lds(reinterpret_cast<const void*>(kern), attr_done)) return MVSTER_ERR_LAUNCH;
+    const int ncu = num_cus();
+    if (ncu <= 0) return MVSTER_ERR_LAUNCH;
+    ConvArgs pairs = a;                                    // tiles = (b, slice PAIR, 8 x 32 window)
+    pairs.Do = a.Do / 2;
+    PersArgs p;
+    if (!fill_pers_args(pairs, G::TY, p)) return MVSTER_ERR_UNSUPPORTED;
+    if ((long)KD * 16 * NCH * a.ntile_total * 1024 >= (1L << 31)) return MVSTER_ERR_UNSUPPORTED;
+    const long ntiles = p.ntiles;
+    const int ny = a.ntile_total;
+    long gmax = (long)ncu / ny;                            // one workgroup per CU (LDS)
+    if (gmax < 1) gmax = 1;
+    const long rounds = (ntiles + gmax - 1) / gmax;       // equal shares
+    const long gx = (ntiles + rounds - 1) / rounds;
+    MV_NOTE_KERNEL("conv_wino_pair_kernel<%d, %s>", NCH, SKIP ? "true" : "false");
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, ny, 1), dim3(512), lds, s, a, p);
+    return mv_check_launch();
+}
+
 // G g G^T for one (cout, cin) pair, G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]; one thread per packed element
 struct PackWinoDesc {          // 88 bytes; the batched form reads a device table of these
     const float* w;
@@ -921,6 +1306,12 @@ int dispatch_wino(const ConvArgs& a, int nt, int wpc, bool ring, hipStream_t s) 
     if (ring) {
         // nt = 1: waves 4-7 only issue the DMA (mode 0); nt = 2: the two halves of the workgroup compute one N tile each
         // (mode 1), or with wpc = 1 the compute waves hold both and waves 4-7 load (mode 2)
+        if (nt == 1 && wpc == 3) {                         // pair form: two output slices per tile (kd == 3, 16 / 32 channels in)
+            if (kd != 3) return MVSTER_ERR_UNSUPPORTED;
+            if (nch == 1) return a.skip_mode == 1 ? launch_wino_pair<1, true>(a, s) : launch_wino_pair<1, false>(a, s);
+            if (nch == 2) return a.skip_mode == 1 ? launch_wino_pair<2, true>(a, s) : launch_wino_pair<2, false>(a, s);
+            return MVSTER_ERR_UNSUPPORTED;
+        }
         const int mode = nt == 1 ? 0 : (wpc == 1 ? 2 : 1);
 #define MV_R(MODE_, NCH_, KD_)                                                                      \
     if (mode == MODE_ && nch == NCH_ && kd == KD_)                                                  \
