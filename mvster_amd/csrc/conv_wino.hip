@@ -1155,8 +1155,8 @@ __global__ void __launch_bounds__(512) conv_wino_pair_kernel(ConvArgs a, PersArg
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const unsigned so = st * oslice;
-                        skv[i][j] = SKIP ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, ooff[i][j], so, 0))
+                        const unsigned vo = ooff[i][j] + st * oslice;
+                        skv[i][j] = SKIP ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(skip_rsrc, vo, 0, 0))
                                          : (f32x4v){0.f, 0.f, 0.f, 0.f};
                     }
                 // Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; fused epilogue on the 2x2 pixels x 4 channels of this lane
@@ -1181,8 +1181,12 @@ __global__ void __launch_bounds__(512) conv_wino_pair_kernel(ConvArgs a, PersArg
                             v[e] = fmaxf(fmaf(v[e], scv[e], shv[e]), floor_v);
                             if (SKIP) v[e] += skv[i][j][e];
                         }
-                        const unsigned so = st * oslice;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, ooff[i][j], so, MV_STORE_AUX);
+                        // (the slice offset goes into the VECTOR offset: with an SGPR soffset hipcc 7.2 puts the next output's
+                        //  v_fma right behind the store -- LLVM's hazard recogniser only separates a > 64-bit store from a VALU
+                        //  write of its data registers when soffset is NOT a register -- and gfx950 then stores the new value in
+                        //  the last lanes of the second dword: one wrong element in 128, found by the bit-equality check)
+                        const unsigned vo = ooff[i][j] + st * oslice;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, vo, 0, MV_STORE_AUX);
                     }
                 }
             }

@@ -806,6 +806,31 @@ def test_winograd_conv_against_fp64_and_direct(cin, cout, kd, nt, variant, shape
          direct_err_over_max=(direct.double() - ref).abs().max().item() / scale)
 
 
+@pytest.mark.parametrize("cin,shape", [(16, (1, 4, 38, 70)), (16, (2, 2, 9, 40)), (16, (1, 6, 8, 32)), (16, (3, 4, 13, 63)),
+                                       (32, (1, 8, 16, 20)), (32, (1, 4, 38, 70)), (32, (2, 2, 8, 40)), (32, (1, 6, 8, 32))])
+@pytest.mark.parametrize("with_skip", [False, True])
+def test_winograd_pair_form_is_the_ring_kernel_bit_for_bit(cin, shape, with_skip):
+    """conv_wino_pair_kernel (variant word 9 | 3 << 8, nt = 1): two output slices per tile, each input slice of the
+    four-slice window fetched and transformed once for both.  Per output element the (depth tap, chunk) order is the ring
+    kernel's, so the results are equal bit for bit -- ragged windows, first / last pairs (padded depth taps skipped), several
+    tiles per workgroup, with and without the epilogue's skip.  (Measured no faster than the ring kernel: DESIGN.md 8.6; the
+    plan does not pick it.)"""
+    from mvster_amd import _lib
+    g = torch.Generator().manual_seed(cin + shape[3])
+    w = (torch.randn(cin, cin, 3, 3, 3, generator=g) * 0.1).to(DEV)
+    layer = cp.ConvLayer(w, False, (1, 1, 1), (1, 1, 1), relu=not with_skip)
+    layer.scale.copy_(torch.rand(layer.scale.shape, generator=g) + 0.5)
+    layer.shift.copy_(torch.randn(layer.shift.shape, generator=g) * 0.1)
+    x = torch.randn(*shape, cin, generator=g).to(DEV)
+    skip = torch.randn(*shape, cin, generator=g).to(DEV) if with_skip else None
+    sm = cp.SKIP_ADD if with_skip else cp.SKIP_NONE
+    want = layer(x, skip=skip, skip_mode=sm, tiles=(2, 1, 9))
+    assert _lib.last_kernel().startswith("conv_wino_ring_kernel<")
+    got = layer(x, skip=skip, skip_mode=sm, tiles=(2, 1, 9 | (3 << 8)))
+    assert _lib.last_kernel().startswith("conv_wino_pair_kernel<"), _lib.last_kernel()
+    assert torch.equal(got, want), (got - want).abs().max().item()
+
+
 def test_untuned_shapes_pick_winograd_when_the_map_is_large_enough():
     """A shape the measured table has never seen: the plan's rule sends eligible layers with enough 8 x 32 tiles to the
     Winograd kernels and leaves small maps on the direct / split-K kernels; either way the result is the direct kernel's
