@@ -37,16 +37,19 @@ namespace {
 using mvconv::f32x4v;
 using mvconv::lds_void;
 
-constexpr int kXC = 64;            // output columns per unit
-constexpr int kXBP = 80;           // staged input columns per row: 66 needed, five 16-pixel pieces
-
-template <int MT, int NT, int KD, int R>
+// XC = output columns per unit (a multiple of 16): 64, or 80 / 48 / 32 where the map's width leaves a 64-column grid mostly
+// empty (W = 80: two chunks of 64 are 38 % zero columns -- MFMAs on zeros; one chunk of 80 has none).  The staged input rows
+// are XC + 16 columns (XC + 2 needed, in 16-pixel pieces).
+template <int MT, int NT, int KD, int R, int XC>
 __global__ void __launch_bounds__(512) conv_wgrad_pers_kernel(WgradArgs a, int mgroups, int nblk, unsigned x_bytes, unsigned gy_bytes, int dbg) {
     constexpr int TAPS = KD * 9;
+    constexpr int kXC = XC, kXBP = XC + 16;
+    constexpr int PA = XC / 16, PB = kXBP / 16;             // 16-pixel pieces per staged gy / input row
+    static_assert(XC % 16 == 0 && (R * (XC / 4)) % 4 == 0, "whole pieces, and the four compute waves split the K steps evenly");
     constexpr int RB = R + 2;                               // input rows per depth slice
     constexpr int APL = R * kXC * 4, BPL = KD * RB * kXBP * 4;            // float4 per plane
     constexpr int BUF = MT * APL + NT * BPL;                // float4 per buffer
-    constexpr int NPA = MT * R * (kXC / 16), NPB = NT * KD * RB * (kXBP / 16);
+    constexpr int NPA = MT * R * PA, NPB = NT * KD * RB * PB;
     constexpr int NPW = (NPA + NPB + 3) / 4;                // DMA pieces per wave and unit
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     f32x4v* const lds = reinterpret_cast<f32x4v*>(lds_raw);
@@ -92,7 +95,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_pers_kernel(WgradArgs a, int m
                 f32x4v* dst = scratch;
                 bool is_a = false;
                 if (i < NPA) {
-                    const int plane = i / (R * 4), rem = i - plane * (R * 4), rr = rem >> 2, pb = rem & 3;
+                    const int plane = i / (R * PA), rem = i - plane * (R * PA), rr = rem / PA, pb = rem - rr * PA;
                     const int xo = x1 + pb * 16 + lp, y = yo + rr;
                     const bool ok = xo < a.Wo && y < a.Ho;
                     const unsigned o = (unsigned)(((((b * a.Do + zo) * a.Ho + y) * a.Wo + xo) * a.CO + m0 + plane * 16 + lq * 4) * 4);
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_pers_kernel(WgradArgs a, int m
                     is_a = true;
                 } else if (i < NPA + NPB) {
                     const int j = i - NPA;
-                    const int plane = j / (KD * RB * 5), rem = j - plane * (KD * RB * 5), row = rem / 5, pb = rem - row * 5;
+                    const int plane = j / (KD * RB * PB), rem = j - plane * (KD * RB * PB), row = rem / PB, pb = rem - row * PB;
                     const int kz = row / RB, ry = row - kz * RB;
                     const int p = pb * 16 + lp;
                     const int ix = x1 - a.pw + p, iy = yo - a.ph + ry, iz = zo - a.pd + kz;
@@ -214,12 +217,12 @@ __global__ void __launch_bounds__(512) conv_wgrad_pers_kernel(WgradArgs a, int m
     }
 }
 
-template <int MT, int NT, int KD, int R>
+template <int MT, int NT, int KD, int R, int XC>
 int launch_wgrad_pers(const WgradArgs& a, int nblk, int cot, int cit, hipStream_t s) {
     constexpr int RB = R + 2;
-    const size_t lds = (size_t)(2 * (MT * R * kXC * 4 + NT * KD * RB * kXBP * 4) + 64) * 16;     // (the reduction reuses it)
-    if (lds > 160 * 1024) return MVSTER_ERR_UNSUPPORTED;
-    auto kern = conv_wgrad_pers_kernel<MT, NT, KD, R>;
+    constexpr size_t lds = (size_t)(2 * (MT * R * XC * 4 + NT * KD * RB * (XC + 16) * 4) + 64) * 16;     // (the reduction reuses it)
+    static_assert(lds <= 160 * 1024, "two unit buffers fit the LDS");
+    auto kern = conv_wgrad_pers_kernel<MT, NT, KD, R, XC>;
     static unsigned long attr_done = 0;
     if (lds > 64 * 1024 && !mvconv::allow_big_lds(reinterpret_cast<const void*>(kern), attr_done)) return MVSTER_ERR_LAUNCH;
     const int ncu = mvconv::num_cus();
@@ -232,7 +235,7 @@ int launch_wgrad_pers(const WgradArgs& a, int nblk, int cot, int cit, hipStream_
     int active = ncu / (mgroups * ngroups);                // one workgroup (8 waves, most of the LDS) per CU: wgrad_pers_slots
     if (active < 1) active = 1;
     if (active > nblk) active = nblk;
-    MV_NOTE_KERNEL("conv_wgrad_pers_kernel<%d, %d, %d, %d>", MT, NT, KD, R);
+    MV_NOTE_KERNEL("conv_wgrad_pers_kernel<%d, %d, %d, %d, %d>", MT, NT, KD, R, XC);
     static const int dbg = MV_PROBE_ENV("MVSTER_WGRAD_DBG") ? atoi(MV_PROBE_ENV("MVSTER_WGRAD_DBG")) : 0;     // timing experiments only
     hipLaunchKernelGGL(kern, dim3(active, mgroups * ngroups), dim3(512), lds, s, a, mgroups, nblk, (unsigned)x_bytes, (unsigned)gy_bytes, dbg);
     return mv_check_launch();
@@ -265,16 +268,20 @@ int try_wgrad_pers(const WgradArgs& a, int nblk, int cot, int cit, hipStream_t s
         (a.CI & 15) || a.CO > 64 || a.CI > 64 || a.CO == 48 || a.CI == 48)     // (48: the callers round 3 tiles up to 4, the planes here hold 16 * tiles channels)
         return MVSTER_ERR_UNSUPPORTED;
     if (!((a.kd == 1 && a.pd == 0) || (a.kd == 3 && a.pd == 1))) return MVSTER_ERR_UNSUPPORTED;
+    // columns per unit: the multiple of 16 that leaves the fewest empty columns on this width (ties: the wider unit)
+    const auto waste = [&](int xc) { return ((a.Wo + xc - 1) / xc) * xc - a.Wo; };
     if (a.kd == 1) {
-        // 9 taps: up to 2 x 2 channel tiles (36 accumulator tiles) per workgroup
+        // 9 taps: up to 2 x 2 channel tiles (36 accumulator tiles) per workgroup; units of 64 or 80 columns
         const int mt = cot >= 2 ? 2 : 1, nt = cit >= 2 ? 2 : 1;
-        if (mt == 1 && nt == 1) return launch_wgrad_pers<1, 1, 1, 4>(a, nblk, cot, cit, s);
-        if (mt == 2 && nt == 1) return launch_wgrad_pers<2, 1, 1, 4>(a, nblk, cot, cit, s);
-        if (mt == 1 && nt == 2) return launch_wgrad_pers<1, 2, 1, 4>(a, nblk, cot, cit, s);
-        return launch_wgrad_pers<2, 2, 1, 2>(a, nblk, cot, cit, s);
+        const bool wide = waste(80) < waste(64);
+        if (mt == 1 && nt == 1) return wide ? launch_wgrad_pers<1, 1, 1, 4, 80>(a, nblk, cot, cit, s) : launch_wgrad_pers<1, 1, 1, 4, 64>(a, nblk, cot, cit, s);
+        if (mt == 2 && nt == 1) return wide ? launch_wgrad_pers<2, 1, 1, 4, 80>(a, nblk, cot, cit, s) : launch_wgrad_pers<2, 1, 1, 4, 64>(a, nblk, cot, cit, s);
+        if (mt == 1 && nt == 2) return wide ? launch_wgrad_pers<1, 2, 1, 2, 80>(a, nblk, cot, cit, s) : launch_wgrad_pers<1, 2, 1, 4, 64>(a, nblk, cot, cit, s);
+        return wide ? launch_wgrad_pers<2, 2, 1, 2, 80>(a, nblk, cot, cit, s) : launch_wgrad_pers<2, 2, 1, 2, 64>(a, nblk, cot, cit, s);
     }
-    // 27 taps: one channel tile pair per workgroup
-    return launch_wgrad_pers<1, 1, 3, 2>(a, nblk, cot, cit, s);
+    // 27 taps: one channel tile pair per workgroup; units of 64 or 48 columns (80 does not fit the LDS twice)
+    if (waste(48) < waste(64)) return launch_wgrad_pers<1, 1, 3, 2, 48>(a, nblk, cot, cit, s);
+    return launch_wgrad_pers<1, 1, 3, 2, 64>(a, nblk, cot, cit, s);
 }
 
 }  // namespace mvwgrad
