@@ -605,6 +605,8 @@ def train_measure(args, rank, local_rank, world, steps, warmup, min_total_s=0.5)
     else:
         if getattr(args, "wgrad_streams", None):
             GraphedTrainStep.wgrad_streams = args.wgrad_streams
+        if getattr(args, "wgrad_overlap", None) is not None:
+            GraphedTrainStep.wgrad_overlap = bool(args.wgrad_overlap)
         graphed = GraphedTrainStep(model, opt, loss_fn, imgs, proj, dv, gt, mask, warmup=3, grad_sync=bucket)
         step = lambda: graphed()               # noqa: E731
 
@@ -724,6 +726,8 @@ def main():
                     help="eval mode, N = 1: skip the embedded training measurement (line['train']: ten captured steps of config 4)")
     ap.add_argument("--wgrad-streams", type=int, default=0,
                     help="train mode: streams the postponed weight-gradient kernels are spread over (0 = the default, 2)")
+    ap.add_argument("--wgrad-overlap", type=int, default=None,
+                    help="train mode: 1 = weight-gradient kernels beside the backward chain on one side stream, 0 = after it (default: the class attribute)")
     ap.add_argument("--torch-adam", action="store_true",
                     help="train mode: torch.optim.Adam(fused=True) instead of mvster_amd.optim.FusedAdam (A/B)")
     ap.add_argument("--mode", choices=("eval", "train"), default="eval",

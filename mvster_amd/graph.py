@@ -341,10 +341,13 @@ class GraphedTrainStep:
     returns the scalar to minimise first, like ``MVS4net_loss``.
     """
 
-    # HIP streams the postponed weight-gradient kernels are spread over (train_ops.deferred_wgrad_finish).  Measured on the
-    # config-4 step: 1 stream 13.25 ms, 2 13.12, 4 13.61, 8 14.62 -- the weight-gradient kernels are persistent grids that fill
-    # the chip, so they gain little from running beside each other and every extra branch of the captured graph costs
-    wgrad_streams = 2
+    # HIP streams the postponed weight-gradient kernels are spread over (train_ops.deferred_wgrad_finish).  They are persistent
+    # grids sized for an empty chip: beside each other (or beside the backward chain: wgrad_overlap) they lose more than the
+    # overlap gives.  Measured on the config-4 step at the end of round 6: 1 stream 11.85 ms, 2 11.95, 3 12.90, 4 14.13; on one
+    # side stream beside the backward chain instead of after it 12.69 (mid-round, before the kernels' rewrite: 13.25 / 13.12 /
+    # 13.61 for 1 / 2 / 4).
+    wgrad_streams = 1
+    wgrad_overlap = False           # True: the kernels run on one side stream beside the backward chain, not after it
 
     def __init__(self, model, optimizer, loss_fn, imgs, proj_matrices, depth_values, depth_gt_ms, mask_ms, warmup=3,
                  grad_sync=None, capture=True):
@@ -421,7 +424,7 @@ class GraphedTrainStep:
             # (nothing reads a weight gradient before the backward pass is over -- the bucketed all-reduce and the optimizer
             #  come after it -- so the 64 finishing launches of the weight-gradient kernels are issued as one)
             from .train_ops import deferred_wgrad_finish
-            with deferred_wgrad_finish(streams=self.wgrad_streams):
+            with deferred_wgrad_finish(streams=self.wgrad_streams, overlap=self.wgrad_overlap):
                 loss.backward()
         finally:
             if batched:

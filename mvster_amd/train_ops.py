@@ -332,6 +332,8 @@ class _ConvCL(torch.autograd.Function):
                 # waits for the end of the pass and runs there beside the other layers' (see the context manager)
                 dw = torch.empty(ops.conv_wgrad_shape(wargs[0], wargs[1], kernel, **wkw), device=gy.device, dtype=torch.float32)
                 _WGRAD_JOBS.append((wargs, wkw, dw))
+                if _WGRAD_EAGER is not None:
+                    _WGRAD_EAGER.launch(wargs, wkw, dw)
                 gw = dw.view(dw.shape)           # (an alias: AccumulateGrad adopts a tensor only if nobody else holds it)
             else:
                 gw = ops.conv_wgrad(*wargs, **wkw)
@@ -598,6 +600,7 @@ def mono_depth_cl(z, d_min, d_max):
 
 
 _WGRAD_JOBS = None           # a list while deferred_wgrad_finish is active: (args, kwargs, dw) of the postponed kernels
+_WGRAD_EAGER = None          # the active deferred_wgrad_finish(overlap=True): kernels go to its side stream where autograd reaches them
 _WGRAD_STREAMS = {}
 
 
@@ -611,23 +614,58 @@ class deferred_wgrad_finish:
     gradients the kernels read are kept alive until the join.  Plain ``loss.backward()`` outside the context runs every
     layer on the spot."""
 
-    def __init__(self, streams=2):
+    def __init__(self, streams=2, overlap=False):
         self.nstreams = max(1, int(streams))
+        self.overlap = bool(overlap)
+        self._side = None
+        self._pend = []
 
     def __enter__(self):
-        global _WGRAD_JOBS
+        global _WGRAD_JOBS, _WGRAD_EAGER
         if _WGRAD_JOBS is not None:
             raise RuntimeError("deferred_wgrad_finish does not nest")
         _WGRAD_JOBS = []
+        _WGRAD_EAGER = self if self.overlap else None
+        self._side, self._pend = None, []
         return self
 
+    def launch(self, wargs, wkw, dw):
+        """overlap=True: the kernel goes to ONE side stream the moment autograd reaches the layer (its inputs are ready on the
+        current stream) and runs beside the rest of the backward chain; the finishes stay batched at the end."""
+        dev = dw.device
+        main = torch.cuda.current_stream(dev)
+        if self._side is None:
+            pool = _WGRAD_STREAMS.setdefault(dev, [])
+            if not pool:
+                pool.append(torch.cuda.Stream(device=dev))
+            self._side = pool[0]
+        self._side.wait_stream(main)
+        prev = ops.WGRAD_PENDING
+        ops.WGRAD_PENDING = self._pend
+        try:
+            with torch.cuda.stream(self._side):
+                ops.conv_wgrad(*wargs, may_defer=True, dw=dw, **wkw)
+        finally:
+            ops.WGRAD_PENDING = prev
+
     def __exit__(self, exc_type, exc, tb):
-        global _WGRAD_JOBS
+        global _WGRAD_JOBS, _WGRAD_EAGER
         jobs, _WGRAD_JOBS = _WGRAD_JOBS, None
+        eager, _WGRAD_EAGER = _WGRAD_EAGER, None
         if exc_type is not None or not jobs:
             return False
         dev = jobs[0][2].device
         main = torch.cuda.current_stream(dev)
+        if eager is not None:
+            try:
+                ops.WGRAD_PENDING = self._pend
+                with torch.cuda.stream(self._side):
+                    ops.conv_wgrad_flush()
+            finally:
+                ops.WGRAD_PENDING = None
+                main.wait_stream(self._side)                             # join (the kernels' inputs are released after it)
+                self._pend = []
+            return False
         pool = _WGRAD_STREAMS.setdefault(dev, [])
         while len(pool) < self.nstreams:
             pool.append(torch.cuda.Stream(device=dev))

@@ -929,6 +929,40 @@ def test_conv_cl_tap_adds_the_second_consumers_gradient_in_the_kernel():
         assert torch.equal(res[0][2], res[1][2])
 
 
+def test_deferred_weight_gradients_equal_the_inline_ones():
+    """deferred_wgrad_finish: leaf-parameter weight-gradient kernels run at the end of the backward pass on side streams (one
+    batched finish per stream), or with overlap=True on one side stream where autograd reaches them.  Same kernels on the
+    same operands: every gradient equals the plain backward's bit for bit, for 1 / 2 / 3 streams and the overlap form."""
+    g = torch.Generator().manual_seed(5)
+    ws = [(0.2 * torch.randn(16, 8, 1, 3, 3, generator=g)).to(DEV), (0.2 * torch.randn(32, 16, 1, 5, 5, generator=g)).to(DEV),
+          (0.2 * torch.randn(32, 32, 3, 3, 3, generator=g)).to(DEV), (0.2 * torch.randn(16, 32, 1, 1, 1, generator=g)).to(DEV)]
+    x0 = torch.randn(2, 2, 24, 40, 8, generator=g).to(DEV)
+
+    def run(ctx):
+        params = [w.clone().requires_grad_(True) for w in ws]
+        x = x0.clone().requires_grad_(True)
+        y = T.conv_cl(x, params[0], None, 1, (0, 1, 1))
+        y = T.conv_cl(y, params[1], None, (1, 2, 2), (0, 2, 2))
+        y = T.conv_cl(y, params[2], None, 1, (1, 1, 1))
+        y = T.conv_cl(y, params[3], None, 1, 0)
+        loss = y.square().sum()
+        if ctx is None:
+            loss.backward()
+        else:
+            with ctx:
+                loss.backward()
+        torch.cuda.synchronize()
+        return [x.grad.clone()] + [p.grad.clone() for p in params]
+
+    want = run(None)
+    for ctx in (T.deferred_wgrad_finish(streams=1), T.deferred_wgrad_finish(streams=2), T.deferred_wgrad_finish(streams=3),
+                T.deferred_wgrad_finish(overlap=True)):
+        got = run(ctx)
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
+    assert T._WGRAD_JOBS is None and T._WGRAD_EAGER is None and ops.WGRAD_PENDING is None
+
+
 @pytest.mark.parametrize("lw,l1ot", [([1, 1, 1, 1], [0, 1]), ([0.5, 1.0, 1.5, 2.0], [0.3, 0.7])])
 def test_loss_total_chain_vs_tensor_form(lw, l1ot):
     """MVS4net_loss's weighted total carried through the stages' fused kernels (mvster_stage_loss_fwd / _bwd) against the
