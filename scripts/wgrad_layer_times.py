@@ -1,3 +1,5 @@
+"""Every weight-gradient call of one eager config-4 training step (512x640, 5 views, B = 2): kernel, time between HIP events,
+TFLOP/s on direct-form FLOPs; slowest first.  GPU only."""
 import sys
 sys.path.insert(0, '.')
 import torch

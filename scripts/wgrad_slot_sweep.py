@@ -1,3 +1,5 @@
+"""Weight-gradient time of the staged-kernel layers against the number of partial-sum slots (= workgroups) the caller gives
+them (ops.WGRAD_MAX_SLOTS): where one resident round of workgroups beats a larger grid.  GPU only."""
 import sys
 sys.path.insert(0, '.')
 import torch
