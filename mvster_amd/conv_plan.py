@@ -486,6 +486,13 @@ class ConvLayer:
                     # gradient of conv1): the persistent MFMA kernel of the wider transposed layers, 41 against 55 us at
                     # 2 x 4 x 256 x 320, 15 against 22 at 2 x 4 x 128 x 160 (the VALU kernel is instruction-bound there)
                     variant, mt, nt = 5, 2, 1
+            if (FORCE_VARIANT is None and self.transposed and self.kernel == (1, 5, 5) and self.stride == (1, 2, 2)
+                    and self.padding == (0, 2, 2) and self.cin in (16, 32) and self.prob is None
+                    and skip_mode in (SKIP_NONE, SKIP_ADD) and B * Di * Hi * Wi >= TPERS16_MIN_VOXELS):
+                # the input gradients of the FPN's 5x5 stride-2 convolutions (training): the persistent kernel's 1x5x5 form,
+                # bit-identical to the direct kernel the table's entries name; 16 -> 8 at [10, 256, 320] 200 -> 109 us,
+                # 32 -> 16 at [10, 128, 160] 113 -> 66 us (scripts/conv_tpers5_check.py)
+                variant, mt, nt = 5, 2, 1
             g = (np.asarray(arr, dtype=np.int32), mt, nt, (B, DoF, HoF, WoF), variant)
             self._geom_cache[key] = g
         return g

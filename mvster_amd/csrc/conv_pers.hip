@@ -539,15 +539,23 @@ __global__ void __launch_bounds__(512) conv_pers8_kernel(ConvArgs a, PersArgs p)
 // chunk set; the classes' packed weights (their own K order: bit-identical to the direct kernel) stay in LDS; four compute
 // waves (2 M tiles each), four loading waves.
 // ------------------------------------------------------------------------------------------------------------------
-template <int NCH, bool SKIP>
+// KS = 5 (round 6): the 1x5x5 stride (1,2,2) form -- the input gradients of the FPN's 5x5 stride-2 convolutions, which ran on the
+// direct kernel (16 -> 8 at [10, 256, 320]: 217 us for 65 us of HBM time).  The output parities take 3 / 2 taps per axis (classes of
+// 9 / 6 / 6 / 4 taps, the even ones padded by one): the tile is staged with a one-pixel ring, 6 x 34 input pixels, and an odd
+// class starts one row / column further in.
+template <int NCH, bool SKIP, int KS>
 __global__ void __launch_bounds__(512) conv_tpers_kernel(ConvArgs a, PersArgs p) {
+    static_assert(KS == 3 || KS == 5, "1x3x3 or 1x5x5, stride (1,2,2)");
     constexpr int MT = 2;                                   // (one N tile per workgroup: blockIdx.y)
-    using G = PersGeom<MT, 2, 1, 1>;                        // 5 x 33 input pixels per tile
+    constexpr bool K5 = KS == 5;
+    constexpr int KT = K5 ? 3 : 2;                          // most taps per axis of a class
+    constexpr int PADO = K5 ? 1 : 0;                        // the staged tile starts this far in front of the output tile's input pixel
+    using G = PersGeom<MT, KT, 1, 1>;                       // 5 x 33 (6 x 34) input pixels per tile
     constexpr int TY = G::TY, PW = G::PW, PLANE = G::PLANE, NBLK = G::NBLK, RS = G::ROWSLOTS;
     constexpr int BUF = NCH * 2 * PLANE;
     constexpr int NI = NCH * 2 * NBLK, NIW = (NI + 3) / 4;
     constexpr int CIN = NCH * 16;
-    // (K steps of all four classes: (1 + 2 + 2 + 4) taps x NCH chunks = 9 * NCH kilobytes of weights per N tile)
+    // (K steps of all four classes: (1 + 2 + 2 + 4) or (9 + 6 + 6 + 4) taps x NCH chunks = 9 (25) * NCH kilobytes of weights per N tile)
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     f32x4v* const lds = reinterpret_cast<f32x4v*>(lds_raw);
     f32x4v* const scratch = lds + 2 * BUF;
@@ -591,13 +599,14 @@ __global__ void __launch_bounds__(512) conv_tpers_kernel(ConvArgs a, PersArgs p)
             dbase[n] = valid ? (unsigned)((prow * a.Wi + px) * (CIN * 4) + (c * 16 + pl * 8 + q1 * 4) * 4) : 0x80000000u;
         }
         auto dma_tile = [&](const TilePos& t, int buf, bool live) {
-            const unsigned origin = (unsigned)((((t.b * a.Di + t.zo) * a.Hi + t.ty0) * a.Wi + t.tx0) * (CIN * 4));
+            // (the ring of the 5x5 form may put the origin in front of the tensor: 32-bit wrap-around, only in-image lanes use it)
+            const unsigned origin = (unsigned)((((t.b * a.Di + t.zo) * a.Hi + t.ty0 - PADO) * a.Wi + t.tx0 - PADO) * (CIN * 4));
             const unsigned wi = live ? (unsigned)a.Wi : 0u;
             f32x4v* const dst0 = lds + buf * BUF;
 #pragma unroll
             for (int n = 0; n < NIW; ++n) {
                 const int i = wave + 4 * n;
-                const int ix = t.tx0 + (dpos[n] & 255), iy = t.ty0 + (dpos[n] >> 8);
+                const int ix = t.tx0 - PADO + (dpos[n] & 255), iy = t.ty0 - PADO + (dpos[n] >> 8);
                 const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < wi;
                 const unsigned off = ok ? dbase[n] + origin : 0x80000000u;
                 f32x4v* const dst = (NI % 4 == 0 || n + 1 < NIW || i < NI) ? dst0 + (i / NBLK) * PLANE + (i % NBLK) * 64 : scratch;
@@ -666,7 +675,10 @@ __global__ void __launch_bounds__(512) conv_tpers_kernel(ConvArgs a, PersArgs p)
 #pragma unroll
         for (int cls = 0; cls < 4; ++cls) {
             const int py = cls >> 1, px = cls & 1;
-            const int kh = py + 1, kw = px + 1;               // taps of the class: input offsets 0..kh-1, 0..kw-1
+            // taps of the class, and the patch row / column of its first one: 3x3: 1 / 2 taps from the pixel itself; 5x5: 3 taps from
+            // the ring (even outputs) or 2 from the pixel (odd ones)
+            const int kh = K5 ? 3 - py : py + 1, kw = K5 ? 3 - px : px + 1;
+            const int cbase = K5 ? py * RS + px * 2 : 0;
             f32x4v acc[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
@@ -679,9 +691,9 @@ __global__ void __launch_bounds__(512) conv_tpers_kernel(ConvArgs a, PersArgs p)
             }
             // K order of the class's packed block: tap-major (dy, then dx), channel-minor
 #pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
+            for (int dy = 0; dy < KT; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
+                for (int dx = 0; dx < KT; ++dx) {
                     if (dy >= kh || dx >= kw) continue;
                     const int tap = dy * kw + dx;
 #pragma unroll
@@ -689,7 +701,7 @@ __global__ void __launch_bounds__(512) conv_tpers_kernel(ConvArgs a, PersArgs p)
                         const f32x4v w = wl[(wbase + tap * NCH + c) * 64 + lane];
                         f32x4v A[MT];
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) A[mt] = patch[abase[mt] + c * 2 * PLANE + dy * RS + dx * 2];
+                        for (int mt = 0; mt < MT; ++mt) A[mt] = patch[abase[mt] + c * 2 * PLANE + cbase + dy * RS + dx * 2];
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1201,12 +1213,12 @@ int launch_pers(const ConvArgs& a, int wpc, hipStream_t s) {
     return mv_check_launch();
 }
 
-template <int NCH, bool SKIP>
+template <int NCH, bool SKIP, int KS>
 int launch_tpers(const ConvArgs& a, int wpc, hipStream_t s) {
-    using G = PersGeom<2, 2, 1, 1>;
-    const size_t lds = (size_t)(2 * NCH * 2 * G::PLANE + 64 + 9 * NCH * 64) * 16;
+    using G = PersGeom<2, KS == 5 ? 3 : 2, 1, 1>;
+    const size_t lds = (size_t)(2 * NCH * 2 * G::PLANE + 64 + (KS == 5 ? 25 : 9) * NCH * 64) * 16;
     if (lds > 160 * 1024) return MVSTER_ERR_UNSUPPORTED;
-    auto kern = conv_tpers_kernel<NCH, SKIP>;
+    auto kern = conv_tpers_kernel<NCH, SKIP, KS>;
     static unsigned long attr_done = 0;
     if (lds > 64 * 1024 && !allow_big_lds(reinterpret_cast<const void*>(kern), attr_done)) return MVSTER_ERR_LAUNCH;
     const int ncu = num_cus();
@@ -1223,7 +1235,7 @@ int launch_tpers(const ConvArgs& a, int wpc, hipStream_t s) {
     if (gmax < 1) gmax = 1;
     const long rounds = (ntiles + gmax - 1) / gmax;
     const long gx = (ntiles + rounds - 1) / rounds;
-    MV_NOTE_KERNEL("conv_tpers_kernel<%d, %s>", NCH, SKIP ? "true" : "false");
+    MV_NOTE_KERNEL("conv_tpers_kernel<%d, %s, %d>", NCH, SKIP ? "true" : "false", KS);
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, a.ntile_total, 1), dim3(512), lds, s, a, p);
     return mv_check_launch();
 }
@@ -1372,14 +1384,24 @@ int dispatch_pp(const ConvArgs& a, int mt, int nt, hipStream_t s) {
 int dispatch_pers(const ConvArgs& a, int mt, int nt, int wpc, hipStream_t s) {
     if (a.nclass == 4 && a.osd == 1 && a.osh == 2 && a.osw == 2 && a.sd == 1 && a.sh == 1 && a.sw == 1 && a.skip_mode <= 1 &&
         !a.prob_w && (a.cout % 16 == 0 || a.cout == 8) && (a.cin == 16 || a.cin == 32 || a.cin == 64) && mt == 2 && nt == 1) {
-        // transposed 1x3x3 stride (1,2,2): the classes must be the 1 / 2 / 2 / 4-tap ones in (py, px) order, unpadded
-        for (int c = 0; c < 4; ++c)
-            if (a.kd[c] != 1 || a.kh[c] != (c >> 1) + 1 || a.kw[c] != (c & 1) + 1 || a.pd[c] || a.ph[c] || a.pw[c] || a.od[c] ||
-                a.oh[c] != (c >> 1) || a.ow[c] != (c & 1) || a.nsteps[c] != a.kh[c] * a.kw[c] * (a.cin / 16))
+        // transposed 1x3x3 stride (1,2,2): the classes must be the 1 / 2 / 2 / 4-tap ones in (py, px) order, unpadded;
+        // 1x5x5: the 9 / 6 / 6 / 4-tap ones, an even parity padded by one (16 / 32 input channels: 25 KB of weights per chunk)
+        const bool k5 = a.kh[0] == 3;
+        if (k5 && a.cin == 64) return MVSTER_ERR_UNSUPPORTED;
+        for (int c = 0; c < 4; ++c) {
+            const int py = c >> 1, px = c & 1;
+            const int kh = k5 ? 3 - py : py + 1, kw = k5 ? 3 - px : px + 1, ph = k5 ? 1 - py : 0, pw = k5 ? 1 - px : 0;
+            if (a.kd[c] != 1 || a.kh[c] != kh || a.kw[c] != kw || a.pd[c] || a.ph[c] != ph || a.pw[c] != pw || a.od[c] ||
+                a.oh[c] != py || a.ow[c] != px || a.nsteps[c] != kh * kw * (a.cin / 16))
                 return MVSTER_ERR_UNSUPPORTED;
-        if (a.cin == 16) return a.skip_mode == 1 ? launch_tpers<1, true>(a, wpc, s) : launch_tpers<1, false>(a, wpc, s);
-        if (a.cin == 32) return a.skip_mode == 1 ? launch_tpers<2, true>(a, wpc, s) : launch_tpers<2, false>(a, wpc, s);
-        return a.skip_mode == 1 ? launch_tpers<4, true>(a, wpc, s) : launch_tpers<4, false>(a, wpc, s);
+        }
+#define MV_TP(NCH_)                                                                                                   \
+    return k5 ? (a.skip_mode == 1 ? launch_tpers<NCH_, true, 5>(a, wpc, s) : launch_tpers<NCH_, false, 5>(a, wpc, s)) \
+              : (a.skip_mode == 1 ? launch_tpers<NCH_, true, 3>(a, wpc, s) : launch_tpers<NCH_, false, 3>(a, wpc, s));
+        if (a.cin == 16) { MV_TP(1) }
+        if (a.cin == 32) { MV_TP(2) }
+#undef MV_TP
+        return a.skip_mode == 1 ? launch_tpers<4, true, 3>(a, wpc, s) : launch_tpers<4, false, 3>(a, wpc, s);
     }
     if (a.nclass != 1 || a.osd != 1 || a.osh != 1 || a.osw != 1 || a.skip_mode > 1 || a.prob_w || a.cout % 16 != 0 ||
         a.sh != a.sw || a.kh[0] != a.kw[0] || a.ntile_total % nt != 0 || mt != 2)

@@ -705,6 +705,37 @@ def test_persistent_transposed_conv_bit_identical_to_direct(cin, cout, shape, wi
     assert _lib.last_kernel().startswith("conv_tpers_kernel<")
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(16, 8, (1, 1, 7, 33)), (16, 8, (2, 1, 12, 40)), (32, 16, (3, 1, 5, 70)),
+                                            (32, 16, (1, 2, 16, 32)), (16, 16, (2, 1, 9, 21)), (32, 32, (1, 1, 4, 64))])
+@pytest.mark.parametrize("with_skip", [False, True])
+def test_persistent_transposed_5x5_conv_bit_identical_to_direct(cin, cout, shape, with_skip):
+    """conv_tpers_kernel<., ., 5>: the transposed 1x5x5 stride-(1,2,2) layers (the input gradients of the FPN's 5x5 stride-2
+    convolutions; models/mvs4net_utils.py:430-446 in training) -- output-parity classes of 9 / 6 / 6 / 4 taps from one input
+    tile staged with a one-pixel ring, each in its packed K order: EQUAL to the direct kernel, ragged sizes, 8 output channels
+    (half an N tile), with and without a tensor added in the epilogue; and the plan picks it for maps of >= 40 960 voxels."""
+    from mvster_amd import _lib
+    g = torch.Generator().manual_seed(cin + cout + shape[3])
+    w = (torch.randn(cin, cout, 1, 5, 5, generator=g) * 0.1).to(DEV)
+    layer = cp.ConvLayer(w, True, (1, 2, 2), (0, 2, 2), relu=False)
+    layer.scale.copy_(torch.rand(layer.scale.shape, generator=g) + 0.5)
+    layer.shift.copy_(torch.randn(layer.shift.shape, generator=g) * 0.1)
+    x = torch.randn(*shape, cin, generator=g).to(DEV)
+    B, D, H, W = shape
+    skip = torch.randn(B, D, 2 * H, 2 * W, cout, generator=g).to(DEV) if with_skip else None
+    sm = cp.SKIP_ADD if with_skip else cp.SKIP_NONE
+    want = layer(x, skip=skip, skip_mode=sm, tiles=(1, 1, 0))
+    assert _lib.last_kernel().startswith("conv_mfma_kernel<")
+    for wpc in (0, 1, 2):
+        got = layer(x, skip=skip, skip_mode=sm, tiles=(2, 1, 5 | (wpc << 8)))
+        assert torch.equal(got, want), (wpc, (got - want).abs().max().item())
+    assert _lib.last_kernel().startswith("conv_tpers_kernel<") and _lib.last_kernel().endswith(", 5>")
+    if (cin, cout) == (16, 8) and not with_skip:
+        big = torch.randn(2, 1, 128, 160, cin, generator=g).to(DEV)
+        got = layer(big)
+        assert _lib.last_kernel().startswith("conv_tpers_kernel<"), _lib.last_kernel()
+        assert torch.equal(got, layer(big, tiles=(1, 1, 0)))
+
+
 @pytest.mark.parametrize("cin,cout,shape", [(32, 64, (2, 1, 18, 34)), (64, 64, (1, 1, 8, 66)), (32, 16, (3, 1, 4, 6)),
                                             (16, 64, (2, 1, 10, 38))])
 def test_persistent_1x1_with_upsample_add_bit_identical_to_direct(cin, cout, shape):
