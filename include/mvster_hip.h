@@ -181,6 +181,11 @@ int mvster_conv_small(const float* in, const float* w, const float* scale, const
 int mvster_conv_narrow(const float* in, const float* w, const float* scale, const float* shift, const float* skip,
                        float* out, int NB, int H, int W, int cin, int relu, int mt, int wpc, void* stream);
 
+/* The 8 -> 4 form of the same kernel (round 6): in [NB,H,W,8], w [3,3,8,8] with output columns 4..7 zero, scale / shift [8]
+ * -> out [NB,H,W,4]; no skip.  The input gradient of reg2d's conv0 in training (autograd of models/mvs4net_utils.py:875). */
+int mvster_conv_narrow4(const float* in, const float* w, const float* scale, const float* shift, float* out, int NB, int H,
+                        int W, int relu, int mt, int wpc, void* stream);
+
 /* ConvTranspose3d (1,3,3), stride (1,2,2), padding (0,1,1), output_padding (0,1,1) + BatchNorm scale/shift +
  * ReLU + skip add for (cin, cout) in {(16,8), (32,16)} on the VALU (the layers are HBM-bound).  in [NB,Hi,Wi,cin],
  * w [3,3,cin,cout], skip optional [NB,2Hi,2Wi,cout]; prob_w/prob_b optional (cout == 8): fuse the 1x1x1 head,

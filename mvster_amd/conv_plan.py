@@ -212,7 +212,7 @@ class ConvLayer:
         self._cin_raw = cin
         self.classes, self.woff = self._class_table()
         self.wpk = None
-        self.w_small = self.w_deconv = self.wpk_wino = self.wpk_b3 = self._b3_src = None
+        self.w_small = self.w_small4 = self.w_deconv = self.wpk_wino = self.wpk_b3 = self._b3_src = None
         self._pack(w)
         self.ntile_total = (cout + 15) // 16
         npad = self.ntile_total * 16
@@ -310,6 +310,14 @@ class ConvLayer:
             if self.cin != cin:
                 ws = torch.nn.functional.pad(ws, (0, 0, 0, self.cin - cin))
             self.w_small = ws.contiguous().to(dev)
+        # 8 -> 4 (the input gradient of reg2d's first layer): the narrow MFMA kernel's four-channel form, weights as [3,3,8,8]
+        # with zero output columns 4..7
+        self.w_small4 = None
+        if (not self.transposed and self.kernel == (1, 3, 3) and self.stride == (1, 1, 1) and self.padding == (0, 1, 1)
+                and cout == 4 and self.cin == 8):
+            ws = w[:, :, 0].permute(2, 3, 1, 0)                       # [3,3,cin,4]
+            ws = torch.nn.functional.pad(ws, (0, 4, 0, self.cin - cin))
+            self.w_small4 = ws.contiguous().to(dev)
         self._pack_wino(w)
         self._pack_b3(w)
 
@@ -372,6 +380,11 @@ class ConvLayer:
             if self.cin != self._cin_raw:
                 ws = torch.nn.functional.pad(ws, (0, 0, 0, self.cin - self._cin_raw))
             self.w_small.copy_(ws)
+        if getattr(self, "w_small4", None) is not None:
+            wv = w.transpose(0, 1) if swap else w
+            if flip:
+                wv = wv.flip(2, 3, 4)
+            self.w_small4[:, :, :self._cin_raw, :4].copy_(wv[:, :, 0].permute(2, 3, 1, 0))      # [3,3,cin,4]; the rest stays zero
 
     def _repack_classes_on_device(self, w):
         """Transposed layer: every output-parity class in one launch (tap lists and block offsets from the class table)."""
@@ -478,6 +491,9 @@ class ConvLayer:
                     variant, mt, nt = (10, 0, 0) if B * Do * Ho * Wo >= NARROW_MIN_VOXELS else (3, 0, 0)
                 if variant == 10 and not hasattr(_lib.load(), "mvster_conv_narrow"):
                     variant = 3                     # (an older library loaded through MVSTER_LIB for an A/B run)
+            if (getattr(self, "w_small4", None) is not None and skip_mode == SKIP_NONE and FORCE_VARIANT is None
+                    and self.prob is None and B * Do * Ho * Wo >= NARROW_MIN_VOXELS and hasattr(_lib.load(), "mvster_conv_narrow4")):
+                variant, mt, nt = 10, 0, 0          # (129 -> 60 us at [2, 4, 512, 640]: it ran on the direct kernel)
             if self.w_deconv is not None and skip_mode in (SKIP_NONE, SKIP_ADD) and FORCE_VARIANT in (None, 4):
                 variant = 4
                 if (FORCE_VARIANT is None and self.prob is None and self.cin == 16 and self.cout == 8
@@ -532,6 +548,14 @@ class ConvLayer:
             want = (oshape + (self.cout,)) if skip_mode == SKIP_ADD else (B, 1, oshape[2] // 2, oshape[3] // 2, self.cout)
             if tuple(skip.shape) != tuple(want):
                 raise RuntimeError("conv_mfma: skip shape %s, expected %s" % (tuple(skip.shape), tuple(want)))
+        if variant == 10 and self.w_small is None and getattr(self, "w_small4", None) is not None:
+            if skip is not None:
+                raise RuntimeError("conv_narrow4: the four-channel form has no skip path")
+            rc = _lib.load().mvster_conv_narrow4(
+                x.data_ptr(), self.w_small4.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), out.data_ptr(), B * Di, Hi, Wi,
+                int(self.relu), mt if mt in (2, 4) else 0, nt & 31, ops._stream())
+            _lib.check(rc, "conv_narrow4")
+            return out
         if variant == 10:
             if self.w_small is None or skip_mode == SKIP_UPSAMPLE_ADD:
                 raise RuntimeError("conv_narrow: layer not eligible")

@@ -53,8 +53,11 @@ struct NarrowGeom {
     static constexpr size_t LDS = (size_t)(R * STAGE + 64) * 16;
 };
 
-template <int CIN, int MT, int R, bool SKIP>
+// CO4: the layer has FOUR output channels (the input gradient of reg2d's first layer in training: 8 -> 4, the cost volume's
+// groups): w is padded to eight with zeros, the lanes of channels 4..7 store nothing and the output pitch is four.
+template <int CIN, int MT, int R, bool SKIP, bool CO4 = false>
 __global__ void __launch_bounds__(512) conv_narrow_kernel(NarrowArgs a) {
+    static_assert(!(CO4 && SKIP), "the four-channel form has no skip path");
     using G = NarrowGeom<CIN, MT, R, SKIP>;
     constexpr int Q = G::Q, TY = G::TY, PW = G::PW, NBLK = G::NBLK, NI = G::NI, NIW = G::NIW;
     constexpr int NKS = 3 * Q;                                 // K steps of 16: (tap pair x 8 channels) or (tap row x 4 channels)
@@ -217,7 +220,7 @@ __global__ void __launch_bounds__(512) conv_narrow_kernel(NarrowArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
-        const unsigned oorigin = (unsigned)((((nb * a.H + y0) * a.W) + x0) * 32);
+        const unsigned oorigin = (unsigned)((((nb * a.H + y0) * a.W) + x0) * (CO4 ? 16 : 32));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int row = wave * MT + mt;
@@ -228,8 +231,8 @@ __global__ void __launch_bounds__(512) conv_narrow_kernel(NarrowArgs a) {
                 if (a.relu) v[j] = fmaxf(v[j], 0.0f);
                 if (SKIP) v[j] += skv[mt][j];
             }
-            const bool ok = y0 + row < a.H && x0 + col < a.W;
-            const unsigned off = ok ? oorigin + (unsigned)(((row * a.W + col) * 8 + (lq & 1) * 4) * 4) : 0x80000000u;
+            const bool ok = y0 + row < a.H && x0 + col < a.W && !(CO4 && (lq & 1));
+            const unsigned off = ok ? oorigin + (unsigned)(((row * a.W + col) * (CO4 ? 4 : 8) + (lq & 1) * 4) * 4) : 0x80000000u;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, off, 0, MV_STORE_AUX);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): done reading this stage
@@ -237,10 +240,10 @@ __global__ void __launch_bounds__(512) conv_narrow_kernel(NarrowArgs a) {
     }
 }
 
-template <int CIN, int MT, int R, bool SKIP>
+template <int CIN, int MT, int R, bool SKIP, bool CO4 = false>
 int launch_narrow(NarrowArgs& a, int wpc, hipStream_t s) {
     using G = NarrowGeom<CIN, MT, R, SKIP>;
-    auto kern = conv_narrow_kernel<CIN, MT, R, SKIP>;
+    auto kern = conv_narrow_kernel<CIN, MT, R, SKIP, CO4>;
     static unsigned long attr_done = 0;
     if (G::LDS > 64 * 1024 && !mvconv::allow_big_lds(reinterpret_cast<const void*>(kern), attr_done)) return MVSTER_ERR_LAUNCH;
     const int ncu = mvconv::num_cus();
@@ -259,7 +262,11 @@ int launch_narrow(NarrowArgs& a, int wpc, hipStream_t s) {
     const long gmax = (long)ncu * per_cu;
     const long rounds = (ntiles + gmax - 1) / gmax;            // equal shares
     const long gx = (ntiles + rounds - 1) / rounds;
-    MV_NOTE_KERNEL("conv_narrow_kernel<%d, %d, %d, %s>", CIN, MT, R, SKIP ? "true" : "false");
+    if (CO4) {
+        MV_NOTE_KERNEL("conv_narrow_kernel<%d, %d, %d, false, true>", CIN, MT, R);
+    } else {
+        MV_NOTE_KERNEL("conv_narrow_kernel<%d, %d, %d, %s>", CIN, MT, R, SKIP ? "true" : "false");
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(512), G::LDS, s, a);
     return mv_check_launch();
 }
@@ -290,5 +297,25 @@ extern "C" int mvster_conv_narrow(const float* in, const float* w, const float* 
         if (mt == 2) return skip ? launch_narrow<4, 2, 4, true>(a, wpc, s) : launch_narrow<4, 2, 4, false>(a, wpc, s);
         if (mt == 4) return skip ? launch_narrow<4, 4, 4, true>(a, wpc, s) : launch_narrow<4, 4, 4, false>(a, wpc, s);
     }
+    return MVSTER_ERR_UNSUPPORTED;
+}
+
+// The 8 -> 4 form: in [NB,H,W,8], w [3][3][8][8] with output columns 4..7 zero, scale / shift [8] (entries 4..7 unused) ->
+// out [NB,H,W,4].  No skip.  The input gradient of reg2d's conv0 (models/mvs4net_utils.py:875) in training: the gradient of
+// the cost volume's four groups, which ran on the direct kernel (129 us at [2, 4, 512, 640] for 31 us of HBM time).
+extern "C" int mvster_conv_narrow4(const float* in, const float* w, const float* scale, const float* shift, float* out, int NB,
+                                   int H, int W, int relu, int mt, int wpc, void* stream) {
+    if (!in || !w || !scale || !shift || !out) return MVSTER_ERR_NULL;
+    if (NB <= 0 || H <= 0 || W <= 0) return MVSTER_ERR_SHAPE;
+    const long in_bytes = (long)NB * H * W * 32, out_bytes = (long)NB * H * W * 16;
+    if (in_bytes >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    NarrowArgs a;
+    a.in = in; a.w = w; a.scale = scale; a.shift = shift; a.skip = nullptr; a.out = out;
+    a.NB = NB; a.H = H; a.W = W; a.relu = relu;
+    a.in_bytes = (unsigned)in_bytes; a.out_bytes = (unsigned)out_bytes;
+    if (mt == 0) mt = (long)NB * H * W >= (1L << 20) ? 4 : 2;
+    hipStream_t s = (hipStream_t)stream;
+    if (mt == 2) return launch_narrow<8, 2, 4, false, true>(a, wpc, s);
+    if (mt == 4) return launch_narrow<8, 4, 3, false, true>(a, wpc, s);
     return MVSTER_ERR_UNSUPPORTED;
 }

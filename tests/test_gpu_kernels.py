@@ -465,6 +465,37 @@ def test_narrow_mfma_conv_against_fp64_and_valu(cin, shape):
     note("conv_narrow_mfma_%d_%s" % (cin, "x".join(map(str, shape))), err_over_max=worst)
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 8, 32), (2, 3, 21, 45), (1, 4, 37, 130), (1, 2, 5, 7), (2, 4, 128, 160)])
+def test_narrow_mfma_conv_four_output_channels(shape):
+    """The 8 -> 4 form of the shift-packed kernel (mvster_conv_narrow4: weights padded to eight output columns, the lanes of
+    channels 4..7 store nothing, output pitch four) -- the input gradient of reg2d's first layer in training, i.e. the gradient
+    of the cost volume's four groups: against an fp64 convolution and the direct kernel, both tile heights, ragged tiles; the
+    plan takes it from 16 384 voxels on; a weight refreshed in place (the training step's re-pack) is followed."""
+    from mvster_amd import _lib
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(H + W)
+    w = (torch.randn(4, 8, 1, 3, 3, generator=g) * 0.2).to(DEV)
+    x = torch.randn(B, D, H, W, 8, generator=g).to(DEV)
+    layer = cp.ConvLayer(w, False, (1, 1, 1), (0, 1, 1), relu=False)
+    assert layer.w_small4 is not None and layer.w_small is None
+    for rnd in range(2):
+        ref = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3).double(), w.double(), padding=(0, 1, 1)).permute(0, 2, 3, 4, 1)
+        scale = ref.abs().max().item()
+        direct = layer(x, tiles=(1, 1, 0))
+        assert _lib.last_kernel().startswith("conv_mfma_kernel<")
+        for mt in (2, 4):
+            got = layer(x, tiles=(mt, 1, 10))
+            assert _lib.last_kernel() == "conv_narrow_kernel<8, %d, %d, false, true>" % (mt, 4 if mt == 2 else 3), _lib.last_kernel()
+            assert got.shape == direct.shape == (B, D, H, W, 4)
+            assert (got.double() - ref).abs().max().item() < 2e-6 * scale
+            assert (got - direct).abs().max().item() < 2e-6 * scale
+        auto = layer(x)
+        assert _lib.last_kernel().startswith("conv_narrow_kernel<" if B * D * H * W >= cp.NARROW_MIN_VOXELS else "conv_mfma_kernel<")
+        assert (auto - direct).abs().max().item() < 2e-6 * scale
+        w.mul_(-0.5).add_(0.01)                       # the optimizer's in-place update, then the step's re-pack
+        layer.repack_on_device(w)
+
+
 @pytest.mark.parametrize("cin", [4, 8])
 def test_narrow_mfma_conv_non_finite_footprint(cin):
     """Pins the one documented divergence of the shift-packed MFMA kernel (variant 10, the default for narrow layers with
