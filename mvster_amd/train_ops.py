@@ -608,13 +608,15 @@ class deferred_wgrad_finish:
     """Context manager around a backward pass whose weight gradients nobody reads before it ends (no hook-driven reducer
     such as DistributedDataParallel's; ``GraphedTrainStep`` wraps its backward in it).  The weight-gradient kernels of leaf
     parameters are not launched where autograd reaches them but on exit, round-robin over ``streams`` HIP streams forked
-    from the current one and joined back: most of the 64 launches are small, latency-bound layers of the coarse stages,
-    which then run beside each other instead of one after the other inside the backward chain; every stream finishes its
-    layers' partial sums with ONE batched launch (64 finishing launches of 5 us otherwise).  The activations and output
+    from the current one and joined back; every stream finishes its layers' partial sums with ONE batched launch (64
+    finishing launches of 5 us otherwise).  ``overlap=True`` launches each kernel on one side stream where autograd reaches
+    its layer instead (beside the rest of the backward chain; the finishes stay batched at the end).  Measured on the
+    config-4 step: one stream after the chain is the fastest form -- the kernels are persistent grids sized
+    for an empty chip, and every cross-stream edge of the captured graph costs ~10 us.  The activations and output
     gradients the kernels read are kept alive until the join.  Plain ``loss.backward()`` outside the context runs every
     layer on the spot."""
 
-    def __init__(self, streams=2, overlap=False):
+    def __init__(self, streams=1, overlap=False):
         self.nstreams = max(1, int(streams))
         self.overlap = bool(overlap)
         self._side = None
