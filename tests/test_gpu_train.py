@@ -785,6 +785,30 @@ def test_graphed_step_gradients_equal_eager_gradients(monkeypatch):
     assert worst <= 1e-5, (worst_name, worst)
 
 
+def test_side_stream_stages_give_the_main_stream_step():
+    """MVS4net.train_side_stages: the coarse stages' forward (and, through autograd's stream rule, backward) on a side stream
+    launches the same kernels on the same operands in the same per-tensor order: loss, every stage output and every
+    gradient equal the single-stream step bit for bit -- one shared side stream and one stream per stage alike."""
+    build, loss_fn, (imgs, proj, dv, gt, mask) = _small_train_setup()
+    runs = []
+    for stages, separate in (((), False), ((0, 1, 2), False), ((0, 1, 2), True), ((1, 3), False)):
+        m = build()
+        m.train_side_stages, m.train_side_separate = stages, separate
+        out = m(imgs, proj, dv)
+        loss = loss_fn(out, gt, mask)[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.detach().clone(), [out["stage%d" % (s + 1)]["depth"].detach().clone() for s in range(4)],
+                     {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    want = runs[0]
+    for got in runs[1:]:
+        assert torch.equal(want[0], got[0])
+        assert all(torch.equal(a, b) for a, b in zip(want[1], got[1]))
+        assert want[2].keys() == got[2].keys()
+        for k in want[2]:
+            assert torch.equal(want[2][k], got[2][k]), k
+
+
 def test_eager_forward_after_graph_replays_sees_the_updated_weights():
     """Optimizer updates that run inside a hipGraph replay bump no version counter: the packed forms of the training layers
     (train_ops._LayerCache) and the folded eval plans would be stale for an eager forward that follows.  GraphedTrainStep
