@@ -186,6 +186,15 @@ int mvster_conv_narrow(const float* in, const float* w, const float* scale, cons
 int mvster_conv_narrow4(const float* in, const float* w, const float* scale, const float* shift, float* out, int NB, int H,
                         int W, int relu, int mt, int wpc, void* stream);
 
+/* FPN4.conv0 in ONE launch (round 6; models/mvs4net_utils.py:427-428: 3 -> 8 -> 8 channels, each conv3x3 + BatchNorm + ReLU):
+ * in [NB,H,W,4] (RGB0), w1 [3,3,4,8], w2 [3,3,8,8], scale / shift [8] each -> out [NB,H,W,8].  The 8-channel intermediate
+ * stays in LDS (14 x 64-pixel tiles, the first layer computed on the 16 x 66 halo tile, zero outside the image), so the pair
+ * moves 78 MB instead of 183 MB at 5 x 512 x 640.  Same result as two mvster_conv_narrow calls up to fp32 summation order.
+ * wpc: workgroups per CU (0 = default).  csrc/conv_narrow.hip. */
+int mvster_conv_narrow_pair(const float* in, const float* w1, const float* scale1, const float* shift1, const float* w2,
+                            const float* scale2, const float* shift2, float* out, int NB, int H, int W, int relu1, int relu2,
+                            int wpc, void* stream);
+
 /* ConvTranspose3d (1,3,3), stride (1,2,2), padding (0,1,1), output_padding (0,1,1) + BatchNorm scale/shift +
  * ReLU + skip add for (cin, cout) in {(16,8), (32,16)} on the VALU (the layers are HBM-bound).  in [NB,Hi,Wi,cin],
  * w [3,3,cin,cout], skip optional [NB,2Hi,2Wi,cout]; prob_w/prob_b optional (cout == 8): fuse the 1x1x1 head,

@@ -38,6 +38,7 @@ SIGNATURES = {
     "mvster_conv_small": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f],
     "mvster_conv_narrow": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f],
     "mvster_conv_narrow4": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f],
+    "mvster_conv_narrow_pair": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f],
     "mvster_deconv_select": [_f] * 14 + [_i] * 6 + [_fl, _f],
     "mvster_deconv_small": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f],
     "mvster_fpn_tail_gather": [_f, _f, _f, _f, _i, _i, _i, _i, _f],

@@ -123,6 +123,8 @@ FUSE_SELECT = True              # reg2d conv11 + prob + selection in one launch 
 LDS_BUDGET = 12 * 256 * 16      # bytes of staged patch the LDS variant accepts (conv_mfma.hip kMaxStage)
 FORCE_VARIANT = None            # None = choose per layer; 0 / 1 pin the kernel variant (experiments, tests)
 TPERS16_MIN_VOXELS = 40960      # 16 -> 8 transposed layers take the persistent MFMA kernel from this many input voxels
+FUSE_CONV0 = True               # FPN conv0[0] -> conv0[1] in one launch (FpnPlan._conv0)
+NARROW_PAIR_MIN_PIXELS = 512 * 14 * 64   # ... from two 14 x 64 tiles per CU (below: the two layers' own launches)
 NARROW_MIN_VOXELS = 64 * 256    # untuned narrow layers take the MFMA kernel from this many output voxels (one 8 x 32 tile per CU)
 
 
@@ -827,12 +829,28 @@ class FpnPlan:
 
     def trunk(self, x):
         """Bottom-up path + the first top-down map f1: what both branches below need."""
-        c0 = self._seq(self.conv0, x)
+        c0 = self._conv0(x)
         c1 = self._seq(self.conv1, c0)
         c2 = self._seq(self.conv2, c1)
         c3 = self._seq(self.conv3, c2)
         f1 = self.inner1(c2, skip=c3, skip_mode=SKIP_UPSAMPLE_ADD)
         return c0, c1, c3, f1
+
+    def _conv0(self, x):
+        """conv0[0] -> conv0[1] (3 -> 8 -> 8 at full resolution) in one launch, the intermediate in LDS (conv_narrow_pair_kernel:
+        78 instead of 183 MB of HBM traffic at 5 x 512 x 640); small maps and forced variants take the two layers' own launches."""
+        a, b = self.conv0
+        N, D, H, W, _ = x.shape
+        if (FUSE_CONV0 and FORCE_VARIANT is None and a.w_small is not None and b.w_small is not None and a.cin == 4 and b.cin == 8
+                and D == 1 and N * H * W >= NARROW_PAIR_MIN_PIXELS and x.is_cuda and a.w_small.device == x.device and x.is_contiguous() and x.dtype == torch.float32
+                and hasattr(_lib.load(), "mvster_conv_narrow_pair")):
+            out = torch.empty((N, 1, H, W, 8), device=x.device, dtype=torch.float32)
+            rc = _lib.load().mvster_conv_narrow_pair(
+                x.data_ptr(), a.w_small.data_ptr(), a.scale.data_ptr(), a.shift.data_ptr(), b.w_small.data_ptr(),
+                b.scale.data_ptr(), b.shift.data_ptr(), out.data_ptr(), N, H, W, int(a.relu), int(b.relu), 0, ops._stream())
+            _lib.check(rc, "conv_narrow_pair")
+            return out
+        return self._seq(self.conv0, x)
 
     def coarse(self, c3, f1):
         """Output convs of the two coarse levels: everything stages 1 and 2 need."""

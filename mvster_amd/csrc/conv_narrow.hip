@@ -271,6 +271,320 @@ int launch_narrow(NarrowArgs& a, int wpc, hipStream_t s) {
     return mv_check_launch();
 }
 
+
+// ---- conv0a -> conv0b of the FPN in ONE launch (round 6) ---------------------------------------------------------------
+// The two full-resolution layers of FPN4.conv0 (models/mvs4net_utils.py:427-428: 3 -> 8 -> 8, each conv + BatchNorm + ReLU,
+// eval statistics folded into scale / shift) as two launches write and re-read the 8-channel intermediate: 26 + 52 MB and
+// 52 + 52 MB at 5 x 512 x 640.  Here the intermediate lives in LDS: a workgroup computes the first layer on the
+// (TY + 2) x (TX + 2) halo tile (zero where the tile leaves the image: the second layer's padding) and the second layer from it,
+// 26 + 52 MB of HBM traffic in all.  Same MFMA packing as conv_narrow_kernel (N = 2 pixels x 8 channels) in both phases.
+//   tile 14 x 64 output pixels; mid tile 16 x 66 = per row two 32-pixel units + ONE pixel pair, and the 16 rows' extra pairs
+//   together are a 33rd unit (M index = row);  phase 1 = 33 units x 12 MFMAs, phase 2 = 28 units x 24: 1.19 MFMAs per output
+//   pixel against 1.125 for the two launches (the halo costs 6 %).
+//   LDS: ring of two input patches (18 x 68 pixels x 16 B, LDS-DMA by the four loading waves) + the mid tile (33 KB) = 74 KB,
+//   two workgroups per CU.  Two barriers per tile: patch landed / mid free, mid complete / patch free.
+// (probe build: bits of `dbg` knock out parts of the kernel for timing -- 1 / 2: the MFMAs of phase 1 / 2, 4: the output stores,
+//  8: the input loads, 16: every tile, 32: the epilogues, 64: the form without pinned instruction order; scripts/conv_narrow_pair_bench.py)
+#ifdef MVSTER_PROBES
+#define PAIR_DBG a.dbg
+#else
+#define PAIR_DBG 0
+#endif
+struct NarrowPairArgs {
+    const float* in;      // [NB, H, W, 4]
+    const float* w1;      // [3][3][4][8]
+    const float* scale1;  // [8]
+    const float* shift1;
+    const float* w2;      // [3][3][8][8]
+    const float* scale2;
+    const float* shift2;
+    float* out;           // [NB, H, W, 8]
+    int NB, H, W, relu1, relu2, dbg;
+    unsigned in_bytes, out_bytes, ntiles;
+    FastDiv tiles_x, tiles_y;
+};
+
+struct PairGeom {
+    static constexpr int TY = 14, TX = 64;
+    static constexpr int MH = TY + 2, MW = TX + 2;             // mid tile (first layer's outputs)
+    static constexpr int PH = TY + 4, PW = TX + 4;             // input patch
+    static constexpr int PSLOTS = PH * PW;                     // float4 slots (four channels per pixel)
+    static constexpr int NIW = ((PSLOTS + 63) / 64 + 3) / 4;   // DMA wave-instructions per loading wave
+    static constexpr int STAGE = NIW * 4 * 64;                 // slots of a ring stage (surplus slots included)
+    static constexpr int R = 2;
+    static constexpr int MID = MH * MW * 2;
+    static constexpr size_t LDS = (size_t)(R * STAGE + MID + 8) * 16;   // + scale / shift of both layers
+};
+
+template <int PIN>
+__global__ void __launch_bounds__(512, 4) conv_narrow_pair_kernel(NarrowPairArgs a) {
+    using G = PairGeom;
+    constexpr int TY = G::TY, PW = G::PW, MW = G::MW, NIW = G::NIW;
+    static_assert(G::MH == 16, "the extra pixel pairs of the mid tile's rows form exactly one 16-row MFMA unit");
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    f32x4v* const lds = reinterpret_cast<f32x4v*>(lds_raw);
+    f32x4v* const mid = lds + G::R * G::STAGE;
+
+    const int lane = threadIdx.x & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wave8 & 3;
+    const bool loader = wave8 >= 4;
+    const int lm = lane & 15, lq = lane >> 4;
+    const unsigned nwg = gridDim.x;
+    unsigned tile = xcd_remap(blockIdx.x, nwg);
+    if (PAIR_DBG & 16) tile = a.ntiles;
+
+    auto decode = [&](unsigned t, int& nb, int& y0, int& x0) {
+        unsigned txu, tyu;
+        nb = (int)fdivmod(fdivmod(t, a.tiles_x, txu), a.tiles_y, tyu);
+        y0 = (int)tyu * TY;
+        x0 = (int)txu * G::TX;
+    };
+
+    if (loader) {
+        const __amdgpu_buffer_rsrc_t in_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)a.in_bytes, 0x00020000);
+        unsigned dbase[NIW];
+        int dpos[NIW];                                          // column | row << 8; -1 = a surplus slot
+#pragma unroll
+        for (int n = 0; n < NIW; ++n) {
+            const int s = (wave + 4 * n) * 64 + lane;
+            const int prow = s / PW, pl = s - prow * PW;
+            dpos[n] = s < G::PSLOTS ? (pl | (prow << 8)) : -1;
+            dbase[n] = (unsigned)((prow * a.W + pl) * 16);
+        }
+        auto dma_tile = [&](unsigned t, int stage, bool live) {
+            int nb, y0, x0;
+            decode(t, nb, y0, x0);
+            const unsigned porigin = (unsigned)((((nb * a.H + y0 - 2) * a.W) + x0 - 2) * 16);   // (32-bit wrap-around on borders)
+            const unsigned wlim = live ? (unsigned)a.W : 0u;
+            f32x4v* const dst0 = lds + stage * G::STAGE;
+#pragma unroll
+            for (int n = 0; n < NIW; ++n) {
+                const int ix = x0 + (dpos[n] & 255) - 2, iy = y0 + (dpos[n] >> 8) - 2;
+                const bool ok = dpos[n] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < wlim && !(PAIR_DBG & 8);
+                const unsigned off = ok ? dbase[n] + porigin : 0x80000000u;
+                f32x4v* const dst = dst0 + (wave + 4 * n) * 64;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_void*)dst, 16, off, 0, 0, 0);
+            }
+        };
+        dma_tile(tile < a.ntiles ? tile : 0u, 0, tile < a.ntiles);
+        {
+            const unsigned t = tile + nwg;
+            dma_tile(t < a.ntiles ? t : 0u, 1, t < a.ntiles);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");          // the first patch has landed
+        int st = 0;
+        for (; tile < a.ntiles; tile += nwg) {
+            __builtin_amdgcn_s_barrier();                       // (1) patch of this tile visible
+            __builtin_amdgcn_s_barrier();                       // (2) phase 1 has read it: its stage is free
+            const unsigned t = tile + 2u * nwg;
+            dma_tile(t < a.ntiles ? t : 0u, st, t < a.ntiles);
+            st ^= 1;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");      // the next tile's patch has landed
+        }
+        return;
+    }
+
+    // ---- compute waves -------------------------------------------------------------------------------------------------
+    const int delta = lm >> 3, co = lm & 7;
+    // layer 1 (four input channels): K step s = tap row ky, K slot = (channel j, tap column kx' = lq)
+    f32x4v wf1[3];
+    const int p1 = 2 * lm + lq;                                 // operand slot of a unit's row: + tap row * PW
+    const int px1 = lm * PW + 64 + lq;                          // the extra unit: M index = mid row, pixel pair (64, 65)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int kx = lq - delta;
+        const bool nz = kx >= 0 && kx <= 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = a.w1[nz ? ((s * 3 + kx) * 4 + j) * 8 + co : 0];
+            wf1[s][j] = nz ? v : 0.0f;
+        }
+    }
+    // layer 2 (eight input channels): K step s = tap pair, K slot = (tap 2 s + (lq >> 1), channels (lq & 1) * 4 + j)
+    // (tap row = s >> 1, tap column kx' = 2 (s & 1) + (lq >> 1): two lane-dependent slots, the rest are immediates)
+    f32x4v wf2[6];
+    int p2[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int pxl = 2 * lm + 2 * e + (lq >> 1);
+        p2[e] = (pxl ^ ((pxl >> 3) & 1)) * 2 + (lq & 1);
+    }
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int t = 2 * s + (lq >> 1);
+        const int ky = t >> 2, kxp = t & 3, c0 = (lq & 1) * 4;
+        const int kx = kxp - delta;
+        const bool nz = kx >= 0 && kx <= 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = a.w2[nz ? ((ky * 3 + kx) * 8 + c0 + j) * 8 + co : 0];
+            wf2[s][j] = nz ? v : 0.0f;
+        }
+    }
+    // scale / shift of both layers wait in LDS (eight float4 slots behind the mid tile) and are read in the epilogues: held in
+    // registers they are 16 VGPRs too many for two workgroups per CU
+    f32x4v* const consts = mid + G::MID;
+    if (wave == 0 && lane < 32) {
+        const float* const src = lane < 8 ? a.scale1 : lane < 16 ? a.shift1 : lane < 24 ? a.scale2 : a.shift2;
+        reinterpret_cast<float*>(consts)[lane] = src[lane & 7];
+        __builtin_amdgcn_s_waitcnt(0xc07f);                     // (visible to the other waves after the first barrier)
+    }
+    const int hi = lq & 1;
+    // accumulators are D^T: lane (lm, lq) holds channels (lq & 1) * 4 .. + 3 of pixel 2 lm + (lq >> 1) of its unit
+    const int col = 2 * lm + (lq >> 1);
+    const int mcol = (col ^ ((col >> 3) & 1)) * 2 + (lq & 1);   // its slot in a mid row (pair swap of the 8-channel layout)
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (int)a.out_bytes, 0x00020000);
+    int st = 0;
+    for (; tile < a.ntiles; tile += nwg) {
+        int nb, y0, x0;
+        decode(tile, nb, y0, x0);
+        const f32x4v* const stage = lds + st * G::STAGE;
+        st ^= 1;
+        __builtin_amdgcn_s_barrier();                           // (1) patch landed; everyone is done with the old mid tile
+        // ---- phase 1: mid = ReLU(BN(conv(in))) on the halo tile, zero outside the image --------------------------------
+        {
+            auto finish1 = [&](f32x4v v, int mrow, int mpix, int slot) {
+                if (PAIR_DBG & 32) return;
+                const f32x4v sc = consts[hi], sh = consts[2 + hi];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = fmaf(v[j], sc[j], sh[j]);
+                    if (a.relu1) v[j] = fmaxf(v[j], 0.0f);
+                }
+                const bool in_img = (unsigned)(y0 - 1 + mrow) < (unsigned)a.H && (unsigned)(x0 - 1 + mpix) < (unsigned)a.W;
+                if (!in_img) v = (f32x4v){0.f, 0.f, 0.f, 0.f};
+                mid[mrow * MW * 2 + slot] = v;
+            };
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = wave * 4 + rr;
+                f32x4v A[2][3], acc[2];
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) A[m][s] = stage[(r + s) * PW + 32 * m + p1];
+                acc[0] = acc[1] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+                if (PIN) __builtin_amdgcn_sched_barrier(0);
+                if (!(PAIR_DBG & 1))
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[s][j], A[m][s][j], acc[m], 0, 0, 0);
+                        if (PIN) __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) finish1(acc[m], r, 32 * m + col, 64 * m + mcol);
+            }
+            if (wave == 0) {
+                f32x4v A[3], acc = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 3; ++s) A[s] = stage[s * PW + px1];
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[s][j], A[s][j], acc, 0, 0, 0);
+                // lane (lm, lq): channels (lq & 1) * 4 .. of pixel 64 + (lq >> 1) of mid row lm
+                finish1(acc, lm, 64 + (lq >> 1), (64 + (lq >> 1)) * 2 + (lq & 1));
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): mid written, patch read
+        __builtin_amdgcn_s_barrier();                           // (2)
+        // ---- phase 2: out = ReLU(BN(conv(mid))) ------------------------------------------------------------------------
+        {
+            const unsigned oorigin = (unsigned)((((nb * a.H + y0) * a.W) + x0) * 32);
+            auto finish2 = [&](f32x4v v, int u) {
+                if (PAIR_DBG & 32) return;
+                const int r = u >> 1, x = 32 * (u & 1) + col;
+                const f32x4v sc = consts[4 + hi], sh = consts[6 + hi];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = fmaf(v[j], sc[j], sh[j]);
+                    if (a.relu2) v[j] = fmaxf(v[j], 0.0f);
+                }
+                const bool ok = y0 + r < a.H && x0 + x < a.W;
+                const unsigned off = ok && !(PAIR_DBG & 4) ? oorigin + (unsigned)(((r * a.W + x) * 8 + (lq & 1) * 4) * 4) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, off, 0, MV_STORE_AUX);
+            };
+            const int u0 = wave * 7;                            // 28 units (row, half), seven per wave
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int ua = u0 + 2 * p, ub = ua + 1;
+                const int ba = ((ua >> 1) * MW + 32 * (ua & 1)) * 2, bb = ((ub >> 1) * MW + 32 * (ub & 1)) * 2;
+                f32x4v A[2][6], acc[2];
+#pragma unroll
+                for (int s = 0; s < 6; ++s) {
+                    A[0][s] = mid[ba + (s >> 1) * MW * 2 + p2[s & 1]];
+                    A[1][s] = mid[bb + (s >> 1) * MW * 2 + p2[s & 1]];
+                }
+                acc[0] = acc[1] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+                if (PIN) __builtin_amdgcn_sched_barrier(0);
+                if (!(PAIR_DBG & 2))
+#pragma unroll
+                for (int s = 0; s < 6; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf2[s][j], A[m][s][j], acc[m], 0, 0, 0);
+                        if (PIN) __builtin_amdgcn_sched_barrier(0);
+                    }
+                finish2(acc[0], ua);
+                finish2(acc[1], ub);
+            }
+            {
+                const int u = u0 + 6;
+                const int b = ((u >> 1) * MW + 32 * (u & 1)) * 2;
+                f32x4v A[6], acc = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 6; ++s) A[s] = mid[b + (s >> 1) * MW * 2 + p2[s & 1]];
+#pragma unroll
+                for (int s = 0; s < 6; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf2[s][j], A[s][j], acc, 0, 0, 0);
+                finish2(acc, u);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): done reading the mid tile
+    }
+}
+
+int launch_narrow_pair(NarrowPairArgs& a, int wpc, hipStream_t s) {
+    using G = PairGeom;
+#ifdef MVSTER_PROBES
+    auto kern = (a.dbg & 64) ? conv_narrow_pair_kernel<0> : conv_narrow_pair_kernel<1>;
+    static unsigned long attr_done0 = 0, attr_done1 = 0;
+    unsigned long& attr_done = (a.dbg & 64) ? attr_done0 : attr_done1;
+#else
+    auto kern = conv_narrow_pair_kernel<1>;
+    static unsigned long attr_done = 0;
+#endif
+    if (G::LDS > 64 * 1024 && !mvconv::allow_big_lds(reinterpret_cast<const void*>(kern), attr_done)) return MVSTER_ERR_LAUNCH;
+    const int ncu = mvconv::num_cus();
+    if (ncu <= 0) return MVSTER_ERR_LAUNCH;
+    const unsigned tx = (unsigned)((a.W + G::TX - 1) / G::TX), ty = (unsigned)((a.H + G::TY - 1) / G::TY);
+    const long ntiles = (long)tx * ty * a.NB;
+    if (ntiles >= (1L << 30)) return MVSTER_ERR_SHAPE;
+    a.ntiles = (unsigned)ntiles;
+    a.tiles_x = mv_fastdiv(tx);
+    a.tiles_y = mv_fastdiv(ty);
+    const int by_lds = (int)((160 * 1024) / G::LDS);
+    int per_cu = wpc > 0 ? wpc : 2;
+    if (per_cu > by_lds) per_cu = by_lds;
+    if (per_cu > 2) per_cu = 2;
+    if (per_cu < 1) per_cu = 1;
+    const long gmax = (long)ncu * per_cu;
+    const long rounds = (ntiles + gmax - 1) / gmax;            // equal shares
+    const long gx = (ntiles + rounds - 1) / rounds;
+    MV_NOTE_KERNEL("conv_narrow_pair_kernel");
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(512), G::LDS, s, a);
+    return mv_check_launch();
+}
+
 }  // namespace
 
 // in [NB,H,W,cin] channels-last (cin in {4, 8}), w [3][3][cin][8], scale / shift [8], skip [NB,H,W,8] or null ->
@@ -318,4 +632,22 @@ extern "C" int mvster_conv_narrow4(const float* in, const float* w, const float*
     if (mt == 2) return launch_narrow<8, 2, 4, false, true>(a, wpc, s);
     if (mt == 4) return launch_narrow<8, 4, 3, false, true>(a, wpc, s);
     return MVSTER_ERR_UNSUPPORTED;
+}
+
+// FPN4.conv0 in one launch (models/mvs4net_utils.py:427-428): in [NB,H,W,4] (RGB0) -> conv3x3 (w1 [3][3][4][8]) * scale1 +
+// shift1, ReLU if relu1 -> conv3x3 (w2 [3][3][8][8]) * scale2 + shift2, ReLU if relu2 -> out [NB,H,W,8].  The 8-channel
+// intermediate never reaches HBM.  wpc: workgroups per CU (0 = default, 2).
+extern "C" int mvster_conv_narrow_pair(const float* in, const float* w1, const float* scale1, const float* shift1,
+                                       const float* w2, const float* scale2, const float* shift2, float* out, int NB, int H,
+                                       int W, int relu1, int relu2, int wpc, void* stream) {
+    if (!in || !w1 || !scale1 || !shift1 || !w2 || !scale2 || !shift2 || !out) return MVSTER_ERR_NULL;
+    if (NB <= 0 || H <= 0 || W <= 0) return MVSTER_ERR_SHAPE;
+    const long in_bytes = (long)NB * H * W * 16, out_bytes = (long)NB * H * W * 32;
+    if (out_bytes >= (1L << 31)) return MVSTER_ERR_SHAPE;
+    NarrowPairArgs a;
+    a.in = in; a.w1 = w1; a.scale1 = scale1; a.shift1 = shift1; a.w2 = w2; a.scale2 = scale2; a.shift2 = shift2; a.out = out;
+    a.NB = NB; a.H = H; a.W = W; a.relu1 = relu1; a.relu2 = relu2;
+    a.in_bytes = (unsigned)in_bytes; a.out_bytes = (unsigned)out_bytes;
+    a.dbg = wpc >> 4;                                           // (read by the probe build only)
+    return launch_narrow_pair(a, wpc & 15, (hipStream_t)stream);
 }

@@ -465,6 +465,58 @@ def test_narrow_mfma_conv_against_fp64_and_valu(cin, shape):
     note("conv_narrow_mfma_%d_%s" % (cin, "x".join(map(str, shape))), err_over_max=worst)
 
 
+@pytest.mark.parametrize("shape", [(1, 14, 64), (2, 21, 45), (1, 37, 130), (3, 5, 7), (5, 128, 160), (2, 100, 200), (1, 512, 640)])
+def test_narrow_pair_conv_against_fp64_and_two_launches(shape, monkeypatch):
+    """FPN conv0[0] -> conv0[1] in one launch (mvster_conv_narrow_pair: the 8-channel intermediate in LDS, zero outside the
+    image = the second layer's padding) against the fp64 composition of the two layers and against the two launches of the
+    shift-packed kernel: exact tiles, ragged tiles, maps smaller than one tile, several tiles per workgroup, ReLU on / off
+    per layer, one and two workgroups per CU; and FpnPlan._conv0 dispatches it from NARROW_PAIR_MIN_PIXELS."""
+    from mvster_amd import _lib
+    NB, H, W = shape
+    g = torch.Generator().manual_seed(7 * H + W)
+    w1 = torch.randn(8, 3, 1, 3, 3, generator=g) * 0.3
+    w2 = torch.randn(8, 8, 1, 3, 3, generator=g) * 0.2
+    x = torch.randn(NB, 1, H, W, 4, generator=g)
+    x[..., 3] = 0
+    x = x.to(DEV)
+    worst = 0.0
+    for relu1, relu2 in ((True, True), (False, True), (True, False)):
+        a = cp.ConvLayer(w1.to(DEV), False, (1, 1, 1), (0, 1, 1), bias=torch.randn(8, generator=g).to(DEV), relu=relu1, cin_pad=4)
+        b = cp.ConvLayer(w2.to(DEV), False, (1, 1, 1), (0, 1, 1), bias=torch.randn(8, generator=g).to(DEV), relu=relu2)
+        ref = x[..., :3].permute(0, 4, 1, 2, 3).double().cpu()
+        for l, w in ((a, w1), (b, w2)):
+            ref = torch.nn.functional.conv3d(ref, w.double(), padding=(0, 1, 1))
+            ref = ref * l.scale[:8].double().cpu().view(1, 8, 1, 1, 1) + l.shift[:8].double().cpu().view(1, 8, 1, 1, 1)
+            ref = ref.clamp_min(0) if l.relu else ref
+        ref = ref.permute(0, 2, 3, 4, 1)
+        two = b(a(x, tiles=(2, 0, 10)), tiles=(2, 0, 10))
+        scale = ref.abs().max().item()
+        for wpc in (1, 2):
+            got = torch.full((NB, 1, H, W, 8), float("nan"), device=DEV)
+            rc = _lib.load().mvster_conv_narrow_pair(x.data_ptr(), a.w_small.data_ptr(), a.scale.data_ptr(), a.shift.data_ptr(),
+                                                     b.w_small.data_ptr(), b.scale.data_ptr(), b.shift.data_ptr(), got.data_ptr(),
+                                                     NB, H, W, int(relu1), int(relu2), wpc, ops._stream())
+            _lib.check(rc, "conv_narrow_pair")
+            assert _lib.last_kernel() == "conv_narrow_pair_kernel"
+            e = (got.double().cpu() - ref).abs().max().item() / scale
+            e2 = (got - two).abs().max().item() / scale
+            worst = max(worst, e)
+            assert e < 2e-6 and e2 < 2e-6, (shape, relu1, relu2, wpc, e, e2)
+            # same MFMA chain per output as the two launches (the structural zeros of the shift packing are exact no-ops)
+            assert torch.equal(got, two), (shape, relu1, relu2, wpc)
+    note("conv_narrow_pair_%s" % "x".join(map(str, shape)), err_over_max=worst)
+
+    plan = cp.FpnPlan.__new__(cp.FpnPlan)                        # the plan's dispatch: same result either way
+    plan.conv0 = [a, b]
+    fused = plan._conv0(x)
+    fused_kernel = _lib.last_kernel()
+    monkeypatch.setattr(cp, "FUSE_CONV0", False)
+    plain = plan._conv0(x)
+    assert (fused_kernel == "conv_narrow_pair_kernel") == (NB * H * W >= cp.NARROW_PAIR_MIN_PIXELS), fused_kernel
+    assert _lib.last_kernel() != "conv_narrow_pair_kernel"
+    assert (fused - plain).abs().max().item() <= 2e-6 * scale
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 8, 32), (2, 3, 21, 45), (1, 4, 37, 130), (1, 2, 5, 7), (2, 4, 128, 160)])
 def test_narrow_mfma_conv_four_output_channels(shape):
     """The 8 -> 4 form of the shift-packed kernel (mvster_conv_narrow4: weights padded to eight output columns, the lanes of
