@@ -576,6 +576,8 @@ def train_measure(args, rank, local_rank, world, steps, warmup, min_total_s=0.5)
     if getattr(args, "train_side_stages", None):
         model.train_side_stages = tuple(int(v) for v in args.train_side_stages.lstrip("s").split(","))
         model.train_side_separate = args.train_side_stages.startswith("s")
+    if getattr(args, "no_fpn_tail_stream", False):
+        model.train_fpn_tail_stream = False
     params = [p for p in model.parameters() if p.requires_grad]
     H, W, N = args.height, args.width, args.views
     imgs, proj, dv = make_inputs(nviews=N, H=H, W=W, seed=100 + rank, device=dev, batch=B)      # every rank its own samples
@@ -735,6 +737,8 @@ def main():
                     help="train mode: 1 = weight-gradient kernels beside the backward chain on one side stream, 0 = after it (default: the class attribute)")
     ap.add_argument("--train-side-stages", default=None,
                     help="train mode (experiment): cascade stages (0-based, comma-separated) whose forward and backward run on a side stream")
+    ap.add_argument("--no-fpn-tail-stream", action="store_true",
+                    help="train mode (A/B): the FPN's two fine levels on the caller's stream instead of their own")
     ap.add_argument("--torch-adam", action="store_true",
                     help="train mode: torch.optim.Adam(fused=True) instead of mvster_amd.optim.FusedAdam (A/B)")
     ap.add_argument("--mode", choices=("eval", "train"), default="eval",

@@ -284,12 +284,9 @@ int launch_narrow(NarrowArgs& a, int wpc, hipStream_t s) {
 //   LDS: ring of two input patches (18 x 68 pixels x 16 B, LDS-DMA by the four loading waves) + the mid tile (33 KB) = 74 KB,
 //   two workgroups per CU.  Two barriers per tile: patch landed / mid free, mid complete / patch free.
 // (probe build: bits of `dbg` knock out parts of the kernel for timing -- 1 / 2: the MFMAs of phase 1 / 2, 4: the output stores,
-//  8: the input loads, 16: every tile, 32: the epilogues, 64: the form without pinned instruction order; scripts/conv_narrow_pair_bench.py)
-#ifdef MVSTER_PROBES
-#define PAIR_DBG a.dbg
-#else
-#define PAIR_DBG 0
-#endif
+//  8: the input loads, 16: every tile, 32: the epilogues -- a template argument, so that a switch costs nothing where it is off;
+//  scripts/conv_narrow_pair_bench.py)
+#define PAIR_DBG DBG
 struct NarrowPairArgs {
     const float* in;      // [NB, H, W, 4]
     const float* w1;      // [3][3][4][8]
@@ -316,7 +313,7 @@ struct PairGeom {
     static constexpr size_t LDS = (size_t)(R * STAGE + MID + 8) * 16;   // + scale / shift of both layers
 };
 
-template <int PIN>
+template <int DBG>
 __global__ void __launch_bounds__(512, 4) conv_narrow_pair_kernel(NarrowPairArgs a) {
     using G = PairGeom;
     constexpr int TY = G::TY, PW = G::PW, MW = G::MW, NIW = G::NIW;
@@ -387,10 +384,17 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_kernel(NarrowPairArgs
     }
 
     // ---- compute waves -------------------------------------------------------------------------------------------------
+    // Work split: wave w = (row group w >> 1, half w & 1).  Phase 1: mid rows 8 g .. 8 g + 7 of its 32-pixel half, two rows per
+    // pass; phase 2: output rows 7 g .. 7 g + 6 of its half, two rows per pass and a last single row.  The two rows of a pass
+    // share operand rows (4 instead of 6 row reads per pass), consecutive passes share two more, and the rows a pass adds are
+    // read while the pass before it computes.  A pass's epilogue (scale / shift / ReLU, mid or global store) is issued in the
+    // MFMA shadow of the NEXT pass -- measured with the probe build's knock-outs, the one-pass-at-a-time form spent 23 us in
+    // MFMAs at their full rate and 20 us beside them in epilogues, operand latency and barriers, nothing overlapping.
     const int delta = lm >> 3, co = lm & 7;
+    const int half = wave & 1, grp = wave >> 1;
     // layer 1 (four input channels): K step s = tap row ky, K slot = (channel j, tap column kx' = lq)
     f32x4v wf1[3];
-    const int p1 = 2 * lm + lq;                                 // operand slot of a unit's row: + tap row * PW
+    const int p1 = 32 * half + 2 * lm + lq;                     // operand slot in a patch row
     const int px1 = lm * PW + 64 + lq;                          // the extra unit: M index = mid row, pixel pair (64, 65)
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -402,14 +406,14 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_kernel(NarrowPairArgs
             wf1[s][j] = nz ? v : 0.0f;
         }
     }
-    // layer 2 (eight input channels): K step s = tap pair, K slot = (tap 2 s + (lq >> 1), channels (lq & 1) * 4 + j)
-    // (tap row = s >> 1, tap column kx' = 2 (s & 1) + (lq >> 1): two lane-dependent slots, the rest are immediates)
+    // layer 2 (eight input channels): K step s = (tap row s >> 1, tap-column pair e = s & 1); K slot = (tap column
+    // kx' = 2 e + (lq >> 1), channels (lq & 1) * 4 + j)
     f32x4v wf2[6];
-    int p2[2];
+    int p2[2];                                                  // operand slots in a mid row, e = 0, 1
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int pxl = 2 * lm + 2 * e + (lq >> 1);
-        p2[e] = (pxl ^ ((pxl >> 3) & 1)) * 2 + (lq & 1);
+        p2[e] = 64 * half + (pxl ^ ((pxl >> 3) & 1)) * 2 + (lq & 1);
     }
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
@@ -423,8 +427,7 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_kernel(NarrowPairArgs
             wf2[s][j] = nz ? v : 0.0f;
         }
     }
-    // scale / shift of both layers wait in LDS (eight float4 slots behind the mid tile) and are read in the epilogues: held in
-    // registers they are 16 VGPRs too many for two workgroups per CU
+    // scale / shift of both layers wait in LDS (eight float4 slots behind the mid tile), read once per pass
     f32x4v* const consts = mid + G::MID;
     if (wave == 0 && lane < 32) {
         const float* const src = lane < 8 ? a.scale1 : lane < 16 ? a.shift1 : lane < 24 ? a.scale2 : a.shift2;
@@ -432,122 +435,165 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_kernel(NarrowPairArgs
         __builtin_amdgcn_s_waitcnt(0xc07f);                     // (visible to the other waves after the first barrier)
     }
     const int hi = lq & 1;
+    const float floor1 = a.relu1 ? 0.0f : -__builtin_inff(), floor2 = a.relu2 ? 0.0f : -__builtin_inff();
     // accumulators are D^T: lane (lm, lq) holds channels (lq & 1) * 4 .. + 3 of pixel 2 lm + (lq >> 1) of its unit
-    const int col = 2 * lm + (lq >> 1);
-    const int mcol = (col ^ ((col >> 3) & 1)) * 2 + (lq & 1);   // its slot in a mid row (pair swap of the 8-channel layout)
+    const int col = 32 * half + 2 * lm + (lq >> 1);             // column in the tile (phase 2) / in the mid tile (phase 1)
+    const int pc = 2 * lm + (lq >> 1);
+    const int mcol = 64 * half + (pc ^ ((pc >> 3) & 1)) * 2 + hi;   // its slot in a mid row (pair swap of the 8-channel layout)
+    const unsigned ocol = (unsigned)((col * 8 + hi * 4) * 4);   // byte offset of its 16 bytes in an output row
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (int)a.out_bytes, 0x00020000);
     int st = 0;
-    for (; tile < a.ntiles; tile += nwg) {
+    unsigned turn = 0;                                          // the extra unit goes round the waves
+    for (; tile < a.ntiles; tile += nwg, ++turn) {
         int nb, y0, x0;
         decode(tile, nb, y0, x0);
         const f32x4v* const stage = lds + st * G::STAGE;
         st ^= 1;
+        const bool colok1 = (unsigned)(x0 - 1 + col) < (unsigned)a.W;       // this lane's mid pixel lies inside the image
+        const bool colok2 = x0 + col < a.W;
         __builtin_amdgcn_s_barrier();                           // (1) patch landed; everyone is done with the old mid tile
         // ---- phase 1: mid = ReLU(BN(conv(in))) on the halo tile, zero outside the image --------------------------------
         {
-            auto finish1 = [&](f32x4v v, int mrow, int mpix, int slot) {
-                if (PAIR_DBG & 32) return;
-                const f32x4v sc = consts[hi], sh = consts[2 + hi];
+            const int R0 = grp * 8;
+            const f32x4v* const xs = stage + R0 * PW + p1;
+            f32x4v* const ms = mid + R0 * MW * 2 + mcol;
+            f32x4v X[4], N[2], pend[2], sc, sh;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = fmaf(v[j], sc[j], sh[j]);
-                    if (a.relu1) v[j] = fmaxf(v[j], 0.0f);
+            for (int i = 0; i < 4; ++i) X[i] = xs[i * PW];
+            // one epilogue step per MFMA slot: q = 0 reads scale / shift, 2 .. 5 finish the pass's two rows (mid rows R0 + row ..)
+            auto epi1 = [&](int q, int row) {
+                if (PAIR_DBG & 32) return;
+                if (q == 0) { sc = consts[hi]; sh = consts[2 + hi]; }
+                if (q == 2 || q == 4) {
+                    f32x4v& v = pend[(q - 2) >> 1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), floor1);
                 }
-                const bool in_img = (unsigned)(y0 - 1 + mrow) < (unsigned)a.H && (unsigned)(x0 - 1 + mpix) < (unsigned)a.W;
-                if (!in_img) v = (f32x4v){0.f, 0.f, 0.f, 0.f};
-                mid[mrow * MW * 2 + slot] = v;
+                if (q == 3 || q == 5) {
+                    const int m = (q - 3) >> 1;
+                    const bool in_img = colok1 && (unsigned)(y0 - 1 + R0 + row + m) < (unsigned)a.H;
+                    ms[(row + m) * MW * 2] = in_img ? pend[m] : (f32x4v){0.f, 0.f, 0.f, 0.f};
+                }
             };
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int r = wave * 4 + rr;
-                f32x4v A[2][3], acc[2];
-#pragma unroll
-                for (int s = 0; s < 3; ++s)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) A[m][s] = stage[(r + s) * PW + 32 * m + p1];
+            for (int k = 0; k < 4; ++k) {
+                if (k < 3) {
+                    N[0] = xs[(2 * k + 4) * PW];
+                    N[1] = xs[(2 * k + 5) * PW];
+                }
+                f32x4v acc[2];
                 acc[0] = acc[1] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-                if (PIN) __builtin_amdgcn_sched_barrier(0);
-                if (!(PAIR_DBG & 1))
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                        for (int m = 0; m < 2; ++m)
-                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[s][j], A[m][s][j], acc[m], 0, 0, 0);
-                        if (PIN) __builtin_amdgcn_sched_barrier(0);
+                        if (!(PAIR_DBG & 1)) {
+                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[s][j], X[s][j], acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[s][j], X[s + 1][j], acc[1], 0, 0, 0);
+                        }
+                        if (k > 0) epi1(s * 4 + j, 2 * (k - 1));
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-#pragma unroll
-                for (int m = 0; m < 2; ++m) finish1(acc[m], r, 32 * m + col, 64 * m + mcol);
+                pend[0] = acc[0];
+                pend[1] = acc[1];
+                X[0] = X[2];
+                X[1] = X[3];
+                X[2] = N[0];
+                X[3] = N[1];
             }
-            if (wave == 0) {
-                f32x4v A[3], acc = (f32x4v){0.f, 0.f, 0.f, 0.f};
+            if (wave == (int)(turn & 3)) {
+                // the 33rd unit (pixel pair (64, 65) of all 16 mid rows) with the last pass's epilogue in its shadow
+                f32x4v E[3], acc = (f32x4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 3; ++s) A[s] = stage[s * PW + px1];
+                for (int s = 0; s < 3; ++s) E[s] = stage[s * PW + px1];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[s][j], A[s][j], acc, 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) {
+                        if (!(PAIR_DBG & 1)) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[s][j], E[s][j], acc, 0, 0, 0);
+                        epi1(s * 4 + j, 6);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 // lane (lm, lq): channels (lq & 1) * 4 .. of pixel 64 + (lq >> 1) of mid row lm
-                finish1(acc, lm, 64 + (lq >> 1), (64 + (lq >> 1)) * 2 + (lq & 1));
+                if (!(PAIR_DBG & 32)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaxf(fmaf(acc[j], sc[j], sh[j]), floor1);
+                    const bool in_img = (unsigned)(y0 - 1 + lm) < (unsigned)a.H && (unsigned)(x0 + 63 + (lq >> 1)) < (unsigned)a.W;
+                    mid[lm * MW * 2 + (64 + (lq >> 1)) * 2 + hi] = in_img ? acc : (f32x4v){0.f, 0.f, 0.f, 0.f};
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) epi1(q, 6);
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): mid written, patch read
         __builtin_amdgcn_s_barrier();                           // (2)
         // ---- phase 2: out = ReLU(BN(conv(mid))) ------------------------------------------------------------------------
         {
-            const unsigned oorigin = (unsigned)((((nb * a.H + y0) * a.W) + x0) * 32);
-            auto finish2 = [&](f32x4v v, int u) {
+            const int Q0 = grp * 7;
+            const f32x4v* const ys = mid + Q0 * MW * 2;
+            const unsigned oorigin = (unsigned)((((nb * a.H + y0 + Q0) * a.W) + x0) * 32) + ocol;
+            f32x4v Y[4][2], N[2][2], pend[2], sc, sh;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) Y[i][e] = ys[i * MW * 2 + p2[e]];
+            auto epi2 = [&](int q, int row, int nrows) {
                 if (PAIR_DBG & 32) return;
-                const int r = u >> 1, x = 32 * (u & 1) + col;
-                const f32x4v sc = consts[4 + hi], sh = consts[6 + hi];
+                if (q == 0) { sc = consts[4 + hi]; sh = consts[6 + hi]; }
+                if (q == 2 || (q == 4 && nrows == 2)) {
+                    f32x4v& v = pend[(q - 2) >> 1];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = fmaf(v[j], sc[j], sh[j]);
-                    if (a.relu2) v[j] = fmaxf(v[j], 0.0f);
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), floor2);
                 }
-                const bool ok = y0 + r < a.H && x0 + x < a.W;
-                const unsigned off = ok && !(PAIR_DBG & 4) ? oorigin + (unsigned)(((r * a.W + x) * 8 + (lq & 1) * 4) * 4) : 0x80000000u;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), out_rsrc, off, 0, MV_STORE_AUX);
+                if (q == 3 || (q == 5 && nrows == 2)) {
+                    const int m = (q - 3) >> 1;
+                    const bool ok = colok2 && y0 + Q0 + row + m < a.H && !(PAIR_DBG & 4);
+                    const unsigned off = ok ? oorigin + (unsigned)((row + m) * a.W * 32) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, pend[m]), out_rsrc, off, 0, MV_STORE_AUX);
+                }
             };
-            const int u0 = wave * 7;                            // 28 units (row, half), seven per wave
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const int ua = u0 + 2 * p, ub = ua + 1;
-                const int ba = ((ua >> 1) * MW + 32 * (ua & 1)) * 2, bb = ((ub >> 1) * MW + 32 * (ub & 1)) * 2;
-                f32x4v A[2][6], acc[2];
+            for (int k = 0; k < 4; ++k) {
+                // rows 2 k, 2 k + 1 (k = 3: the single row 6): mid rows Q0 + 2 k .. + 3 are in Y; read what the next pass adds
+                if (k < 2) {
 #pragma unroll
-                for (int s = 0; s < 6; ++s) {
-                    A[0][s] = mid[ba + (s >> 1) * MW * 2 + p2[s & 1]];
-                    A[1][s] = mid[bb + (s >> 1) * MW * 2 + p2[s & 1]];
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) N[i][e] = ys[(2 * k + 4 + i) * MW * 2 + p2[e]];
+                } else if (k == 2) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) N[0][e] = ys[8 * MW * 2 + p2[e]];
                 }
+                f32x4v acc[2];
                 acc[0] = acc[1] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-                if (PIN) __builtin_amdgcn_sched_barrier(0);
-                if (!(PAIR_DBG & 2))
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < 6; ++s)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                        for (int m = 0; m < 2; ++m)
-                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf2[s][j], A[m][s][j], acc[m], 0, 0, 0);
-                        if (PIN) __builtin_amdgcn_sched_barrier(0);
+                        if (!(PAIR_DBG & 2)) {
+                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf2[s][j], Y[s >> 1][s & 1][j], acc[0], 0, 0, 0);
+                            if (k < 3)
+                                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf2[s][j], Y[(s >> 1) + 1][s & 1][j], acc[1], 0, 0, 0);
+                        }
+                        if (k > 0) epi2(s * 4 + j, 2 * (k - 1), 2);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                finish2(acc[0], ua);
-                finish2(acc[1], ub);
+                pend[0] = acc[0];
+                pend[1] = acc[1];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    Y[0][e] = Y[2][e];
+                    Y[1][e] = Y[3][e];
+                    Y[2][e] = N[0][e];
+                    Y[3][e] = N[1][e];
+                }
             }
-            {
-                const int u = u0 + 6;
-                const int b = ((u >> 1) * MW + 32 * (u & 1)) * 2;
-                f32x4v A[6], acc = (f32x4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 6; ++s) A[s] = mid[b + (s >> 1) * MW * 2 + p2[s & 1]];
-#pragma unroll
-                for (int s = 0; s < 6; ++s)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf2[s][j], A[s][j], acc, 0, 0, 0);
-                finish2(acc, u);
-            }
+            for (int q = 0; q < 4; ++q) epi2(q, 6, 1);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): done reading the mid tile
     }
@@ -555,14 +601,20 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_kernel(NarrowPairArgs
 
 int launch_narrow_pair(NarrowPairArgs& a, int wpc, hipStream_t s) {
     using G = PairGeom;
+    auto kern = conv_narrow_pair_kernel<0>;
+    int slot = 0;
 #ifdef MVSTER_PROBES
-    auto kern = (a.dbg & 64) ? conv_narrow_pair_kernel<0> : conv_narrow_pair_kernel<1>;
-    static unsigned long attr_done0 = 0, attr_done1 = 0;
-    unsigned long& attr_done = (a.dbg & 64) ? attr_done0 : attr_done1;
-#else
-    auto kern = conv_narrow_pair_kernel<1>;
-    static unsigned long attr_done = 0;
+    switch (a.dbg) {
+#define PAIR_CASE(n, m) case m: kern = conv_narrow_pair_kernel<m>; slot = n; break;
+        PAIR_CASE(1, 1) PAIR_CASE(2, 2) PAIR_CASE(3, 3) PAIR_CASE(4, 4) PAIR_CASE(5, 8) PAIR_CASE(6, 12) PAIR_CASE(7, 15)
+        PAIR_CASE(8, 16) PAIR_CASE(9, 32) PAIR_CASE(10, 35) PAIR_CASE(11, 47) PAIR_CASE(12, 44)
+#undef PAIR_CASE
+        case 0: break;
+        default: return MVSTER_ERR_UNSUPPORTED;
+    }
 #endif
+    static unsigned long attr_done_all[13] = {0};
+    unsigned long& attr_done = attr_done_all[slot];
     if (G::LDS > 64 * 1024 && !mvconv::allow_big_lds(reinterpret_cast<const void*>(kern), attr_done)) return MVSTER_ERR_LAUNCH;
     const int ncu = mvconv::num_cus();
     if (ncu <= 0) return MVSTER_ERR_LAUNCH;

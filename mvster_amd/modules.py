@@ -13,6 +13,8 @@ folded-BatchNorm plans of ``mvster_amd.conv_plan``.
 Reference: models/mvs4net_utils.py:116-123 (ConvBnReLU3D), :224-251 (Conv2d), :419-502 (FPN4),
 :833-868 (mono_depth_decoder), :870-912 (reg2d), :914-965 (reg3d).
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -202,6 +204,8 @@ class FPN4(nn.Module):
         self.out3 = nn.Conv2d(f, c * 2, 3, padding=1, bias=False)
         self.out4 = nn.Conv2d(f, c, 3, padding=1, bias=False)
         self.out_channels = [c * 8, c * 4, c * 2, c]
+        self.tail_stream = None        # a HIP stream for the two fine levels' forward and backward (set per call by MVS4net)
+        self.tail_pending = None       # ... the stream the last forward_cl left un-joined, for the caller to wait on
 
     def forward(self, x):
         """[B,3,H,W] -> {"stage1".."stage4": [B,C,h,w]} (the reference's signature; views of channels-last maps)."""
@@ -234,10 +238,18 @@ class FPN4(nn.Module):
         out["stage1"], c3 = plain(self.out1, c3, tap=True)
         f = plain(self.inner1, c2, up=c3)
         out["stage2"], f = plain(self.out2, f, tap=True)
-        f = plain(self.inner2, c1, up=f)
-        out["stage3"], f = plain(self.out3, f, tap=True)
-        # finest level: re-associated, the full-resolution 64-channel map is never formed (train_ops.fpn_fine_level)
-        out["stage4"] = T.fpn_fine_level(c0, f, self.inner3, self.out4)
+        # The two fine levels on `tail_stream` when the caller set one (MVS4net._forward_train): nothing before cascade stage 3
+        # reads them, so they run beside stages 1 and 2 (small, latency-bound launches); the caller joins the stream before
+        # stage 3 (`tail_pending`).  Autograd runs their backward on the same stream.
+        side = self.tail_stream if x.is_cuda else None
+        self.tail_pending = side
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(x.device))
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            f = plain(self.inner2, c1, up=f)
+            out["stage3"], f = plain(self.out3, f, tap=True)
+            # finest level: re-associated, the full-resolution 64-channel map is never formed (train_ops.fpn_fine_level)
+            out["stage4"] = T.fpn_fine_level(c0, f, self.inner3, self.out4)
         return out
 
 

@@ -173,6 +173,8 @@ class MVS4net(nn.Module):
         # only 11.33, each stage on its own stream 11.13, one of them alone: no gain).  () = everything on the caller's stream.
         self.train_side_stages = (0, 1, 2)
         self.train_side_separate = False   # each side stage on a stream of its own (measured slower)
+        # training: the FPN's two fine levels (forward and backward) on their own stream, beside cascade stages 1-2
+        self.train_fpn_tail_stream = True
         self._side_streams = {}
         self.warp_variant = 0          # mvster_warp_agg_fwd variant (0 = per-shape default)
         # hypothesis scheduling inside the warp launch (mvster_warp_agg_fwd_sched: bit-identical, one launch less per stage).
@@ -430,6 +432,16 @@ class MVS4net(nn.Module):
             st["inverse_max_depth"] = 1 / depth - self.depth_interals_ratio[s] * itv
         return st
 
+    @staticmethod
+    def _no_stream_warning():
+        if not MVS4net._stream_warning_off:
+            # (DistributedDataParallel creates its AccumulateGrad nodes on the stream of its construction; gradients of the
+            #  side streams' nodes reach them from those streams -- intended here, the engine synchronises the two)
+            off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if off is not None:
+                off(False)
+            MVS4net._stream_warning_off = True
+
     def _forward_train(self, imgs, proj_matrices, depth_values, teacher=None):
         """Differentiable forward with every convolution pass (forward, input and weight gradients) and the
         fused warp/correlation/aggregation on the gfx950 kernels.  The FPN runs once over all views (view-major
@@ -445,12 +457,27 @@ class MVS4net(nn.Module):
             x = torch.cat([img.permute(0, 2, 3, 1).unsqueeze(1) for img in imgs], 0)
         else:
             x = ops.pack_images([img.to(dev, torch.float32) for img in imgs])        # [N*B,1,H,W,4] RGB0, one launch
+        # train_fpn_tail_stream: the FPN's two fine levels (needed from stage 3 on) on a stream of their own, beside stages 1-2
+        tail = None
+        if self.train_fpn_tail_stream and x.is_cuda and isinstance(self.feature, FPN4) and self.num_stage >= 3:
+            tail = self._side_streams.get(("fpn_tail", dev))
+            if tail is None:
+                tail = self._side_streams[("fpn_tail", dev)] = torch.cuda.Stream(device=dev)
+            self._no_stream_warning()
+        if isinstance(self.feature, FPN4):
+            self.feature.tail_stream = tail
         pyramid = self.feature.forward_cl(x, groups=nv)
+        tail = getattr(self.feature, "tail_pending", None)
+        if isinstance(self.feature, FPN4):
+            self.feature.tail_stream = self.feature.tail_pending = None      # (direct callers of the module get one stream)
         outputs = {}
         prev = None
         ref_feats = []
         for s in range(self.num_stage):
             name = "stage%d" % (s + 1)
+            if tail is not None and s >= 2:
+                torch.cuda.current_stream(dev).wait_stream(tail)     # the fine levels are read from here on
+                tail = None
             pyr = pyramid[name]                                      # [N*B,1,h,w,C], view-major
             _, _, h, w, C = pyr.shape
             G = self.group_cor_dim[s] if self.group_cor else C
@@ -459,13 +486,7 @@ class MVS4net(nn.Module):
             # stages' (the next stage detaches what it takes from this one: the stages' backward passes are independent)
             side = cur = None
             if s in self.train_side_stages and pyr.is_cuda:
-                if not MVS4net._stream_warning_off:
-                    # (DistributedDataParallel creates its AccumulateGrad nodes on the stream of its construction; gradients of
-                    #  the side stages reach them from the side stream -- intended here, the engine synchronises the two)
-                    off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-                    if off is not None:
-                        off(False)
-                    MVS4net._stream_warning_off = True
+                self._no_stream_warning()
                 cur = torch.cuda.current_stream(dev)
                 key = ("train", dev, s if self.train_side_separate else 0)
                 side = self._side_streams.get(key)

@@ -63,6 +63,6 @@ for cold in (False, True):
 
 if os.environ.get("PAIR_DBG"):
     for name, mask in (("all", 0), ("no phase-1 MFMA", 1), ("no phase-2 MFMA", 2), ("no MFMA", 3), ("no stores", 4), ("no loads", 8),
-                       ("no memory", 12), ("no MFMA no memory", 15), ("unpinned", 64), ("unpinned no MFMA", 67), ("no tiles", 16), ("no epilogues", 32), ("no epilogues no MFMA", 35),
-                       ("no epilogues no MFMA no memory", 47)):
+                       ("no memory", 12), ("no MFMA no memory", 15), ("no tiles", 16), ("no epilogues", 32), ("no epilogues no MFMA", 35),
+                       ("no epilogues no MFMA no memory", 47), ("no epilogues no memory", 44)):
         print("  %-20s wpc 2: %.1f us   wpc 1: %.1f us" % (name, timed(lambda: pair(2 | mask << 4), True), timed(lambda: pair(1 | mask << 4), True)))

@@ -788,12 +788,14 @@ def test_graphed_step_gradients_equal_eager_gradients(monkeypatch):
 def test_side_stream_stages_give_the_main_stream_step():
     """MVS4net.train_side_stages: the coarse stages' forward (and, through autograd's stream rule, backward) on a side stream
     launches the same kernels on the same operands in the same per-tensor order: loss, every stage output and every
-    gradient equal the single-stream step bit for bit -- one shared side stream and one stream per stage alike."""
+    gradient equal the single-stream step bit for bit -- one shared side stream and one stream per stage alike, with and
+    without the FPN's two fine levels on their own stream (MVS4net.train_fpn_tail_stream)."""
     build, loss_fn, (imgs, proj, dv, gt, mask) = _small_train_setup()
     runs = []
-    for stages, separate in (((), False), ((0, 1, 2), False), ((0, 1, 2), True), ((1, 3), False)):
+    for stages, separate, tail in (((), False, False), ((0, 1, 2), False, True), ((0, 1, 2), True, False), ((1, 3), False, True),
+                                   ((), False, True)):
         m = build()
-        m.train_side_stages, m.train_side_separate = stages, separate
+        m.train_side_stages, m.train_side_separate, m.train_fpn_tail_stream = stages, separate, tail
         out = m(imgs, proj, dv)
         loss = loss_fn(out, gt, mask)[0]
         loss.backward()
