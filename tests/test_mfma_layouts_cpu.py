@@ -264,3 +264,124 @@ def test_lds_staged_stride2_patch_rows_split_by_column_parity(KW, MT):
                         addrs[lane] = abase + ky * PW * 2 + ((kx & 1) * PWH + (kx >> 1)) * 2
                         assert held[int(addrs[lane])] == (row * sh + ky, (xs * 16 + lm) * sw + kx, lq)
                     assert _conflicts(addrs) == 0
+
+
+@pytest.mark.parametrize("H,W", [(17, 70), (14, 64), (5, 7)])
+def test_narrow_pair_layout(H, W):
+    """conv_narrow_pair_kernel (FPN conv0[0] -> conv0[1] in one launch) re-walked: the loaders' slot decode of the 18 x 68 patch,
+    the work split wave = (row group, half), the rolling operand rows of both phases (two rows of a pass share reads), the
+    33rd unit (pixel pair (64, 65) of all sixteen mid rows on one MFMA tile), the mid tile's pair-swapped 8-channel layout with
+    its zero fill outside the image, the second layer's operand slots and the output assignment -- against the two layers
+    applied one after the other with zero padding; every operand read is bank-conflict free."""
+    rng = np.random.default_rng(H * 100 + W)
+    TY, TX = 14, 64
+    MH, MW, PH, PW = TY + 2, TX + 2, TY + 4, TX + 4
+    PSLOTS = PH * PW
+    x = rng.standard_normal((H, W, 4))
+    w1 = rng.standard_normal((3, 3, 4, 8))
+    w2 = rng.standard_normal((3, 3, 8, 8))
+    s1, b1, s2, b2 = (rng.standard_normal(8) for _ in range(4))
+
+    def conv(t, w):
+        tp = np.zeros((H + 2, W + 2, t.shape[2]))
+        tp[1:-1, 1:-1] = t
+        return sum(np.einsum("hwi,io->hwo", tp[ky:ky + H, kx:kx + W], w[ky, kx]) for ky in range(3) for kx in range(3))
+    m_want = np.maximum(conv(x, w1) * s1 + b1, 0.0)
+    want = np.maximum(conv(m_want, w2) * s2 + b2, 0.0)
+    got = np.full((H, W, 8), np.nan)
+    lanes = np.arange(64)
+    lm, lq = lanes & 15, lanes >> 4
+    delta, co, hi = lm >> 3, lm & 7, lq & 1
+
+    def mfma(Arow, Bcol):
+        """D[i, n] += sum_k A[i, k] B[k, n]; lane l holds A[l & 15, l >> 4], B[l >> 4, l & 15]."""
+        A, Bm = np.zeros((16, 4)), np.zeros((4, 16))
+        A[lm, lq] = Arow
+        Bm[lq, lm] = Bcol
+        return A @ Bm
+
+    def acc_of(D):                                               # lane (lm, lq) holds D[4 lq + r, lm], r = 0..3
+        return np.stack([D[4 * lq + r, lm] for r in range(4)], 1)
+    turn = 0
+    for y0 in range(0, H, TY):
+        for x0 in range(0, W, TX):
+            stage = np.zeros((5 * 4 * 64, 4))
+            for s in range(PSLOTS):                              # the loading waves' DMA decode
+                prow, pl = s // PW, s % PW
+                iy, ix = y0 - 2 + prow, x0 - 2 + pl
+                if 0 <= iy < H and 0 <= ix < W:
+                    stage[s] = x[iy, ix]
+            mid = np.full((MH * MW * 2, 4), np.nan)
+            # ---- phase 1
+            for wave in range(4):
+                half, grp = wave & 1, wave >> 1
+                p1 = 32 * half + 2 * lm + lq
+                pc = 2 * lm + (lq >> 1)
+                col = 32 * half + pc
+                mcol = 64 * half + (pc ^ ((pc >> 3) & 1)) * 2 + hi
+                R0 = grp * 8
+                for k in range(4):
+                    X = []
+                    for i in range(4):
+                        addrs = (R0 + 2 * k + i) * PW + p1
+                        assert _conflicts(addrs) == 0
+                        X.append(stage[addrs])
+                    for m in range(2):                           # mid rows R0 + 2 k + m
+                        D = np.zeros((16, 16))
+                        for s in range(3):
+                            kx = lq - delta
+                            for j in range(4):
+                                Aw = np.where((kx >= 0) & (kx <= 2), w1[s, np.clip(kx, 0, 2), j, co], 0.0)
+                                D += mfma(Aw, X[s + m][:, j])
+                        v = np.maximum(acc_of(D) * s1[hi[:, None] * 4 + np.arange(4)] + b1[hi[:, None] * 4 + np.arange(4)], 0.0)
+                        mrow = R0 + 2 * k + m
+                        ok = (0 <= y0 - 1 + mrow < H) & (x0 - 1 + col >= 0) & (x0 - 1 + col < W)
+                        mid[mrow * MW * 2 + mcol] = np.where(ok[:, None], v, 0.0)
+                if wave == turn & 3:                             # the 33rd unit
+                    px1 = lm * PW + 64 + lq
+                    D = np.zeros((16, 16))
+                    for s in range(3):
+                        kx = lq - delta
+                        for j in range(4):
+                            Aw = np.where((kx >= 0) & (kx <= 2), w1[s, np.clip(kx, 0, 2), j, co], 0.0)
+                            D += mfma(Aw, stage[s * PW + px1][:, j])
+                    v = np.maximum(acc_of(D) * s1[hi[:, None] * 4 + np.arange(4)] + b1[hi[:, None] * 4 + np.arange(4)], 0.0)
+                    ok = (y0 - 1 + lm >= 0) & (y0 - 1 + lm < H) & (x0 + 63 + (lq >> 1) < W)
+                    mid[lm * MW * 2 + (64 + (lq >> 1)) * 2 + hi] = np.where(ok[:, None], v, 0.0)
+            assert not np.isnan(mid).any()                       # every mid slot written exactly by construction
+            for r in range(MH):                                  # ... and it is the first layer's output, zero outside the image
+                for mpx in range(MW):
+                    iy, ix = y0 - 1 + r, x0 - 1 + mpx
+                    ref = m_want[iy, ix] if 0 <= iy < H and 0 <= ix < W else np.zeros(8)
+                    pos = mpx ^ ((mpx >> 3) & 1)
+                    assert np.abs(mid[(r * MW + pos) * 2:(r * MW + pos) * 2 + 2].reshape(8) - ref).max() < 1e-12
+            # ---- phase 2
+            for wave in range(4):
+                half, grp = wave & 1, wave >> 1
+                pc = 2 * lm + (lq >> 1)
+                col = 32 * half + pc
+                p2 = []
+                for e in range(2):
+                    pxl = 2 * lm + 2 * e + (lq >> 1)
+                    p2.append(64 * half + (pxl ^ ((pxl >> 3) & 1)) * 2 + hi)
+                Q0 = grp * 7
+                for row in range(7):
+                    D = np.zeros((16, 16))
+                    for s in range(6):
+                        t = 2 * s + (lq >> 1)
+                        ky, kxp, c0 = t >> 2, t & 3, hi * 4
+                        assert (ky == s >> 1).all() and (kxp == 2 * (s & 1) + (lq >> 1)).all()
+                        addrs = (Q0 + row + (s >> 1)) * MW * 2 + p2[s & 1]
+                        assert _conflicts(addrs) == 0
+                        kx = kxp - delta
+                        for j in range(4):
+                            Aw = np.where((kx >= 0) & (kx <= 2), w2[ky, np.clip(kx, 0, 2), c0 + j, co], 0.0)
+                            D += mfma(Aw, mid[addrs][:, j])
+                    v = np.maximum(acc_of(D) * s2[hi[:, None] * 4 + np.arange(4)] + b2[hi[:, None] * 4 + np.arange(4)], 0.0)
+                    for lane in range(64):
+                        yy, xx = y0 + Q0 + row, x0 + col[lane]
+                        if yy < H and xx < W:
+                            assert np.isnan(got[yy, xx, hi[lane] * 4])          # every output is written once
+                            got[yy, xx, hi[lane] * 4:hi[lane] * 4 + 4] = v[lane]
+            turn += 1
+    assert np.abs(got - want).max() < 1e-11
