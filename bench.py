@@ -724,6 +724,8 @@ def main():
                     help="A/B switch: hypothesis scheduling as its own launch per stage (as before round 5)")
     ap.add_argument("--no-fuse-conv0", action="store_true",
                     help="A/B switch: FPN conv0[0] and conv0[1] as two launches (as before the one-launch form of round 6)")
+    ap.add_argument("--pair-wpc", type=int, default=0,
+                    help="A/B switch: workgroups per CU of the one-launch conv0 pair (0 = the kernel's default)")
     ap.add_argument("--no-merge-launches", action="store_true",
                     help="A/B switch: the forward's first three launches and the three confidence up-samplings separately")
     ap.add_argument("--no-api-call", action="store_true",
@@ -782,6 +784,9 @@ def main():
     if args.no_fuse_conv0:
         from mvster_amd import conv_plan as _cp
         _cp.FUSE_CONV0 = False
+    if args.pair_wpc:
+        from mvster_amd import conv_plan as _cp
+        _cp.NARROW_PAIR_WPC = args.pair_wpc
     # every rank works on its own depth maps: disjoint seeds = disjoint units of the shard
     units = shard.shard_units(world * (args.steps + args.warmup), rank, world)
     imgs, proj, dv = make_inputs(nviews=args.views, H=args.height, W=args.width, seed=units[0], device=dev, batch=args.batch)

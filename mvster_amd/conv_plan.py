@@ -124,6 +124,7 @@ LDS_BUDGET = 12 * 256 * 16      # bytes of staged patch the LDS variant accepts 
 FORCE_VARIANT = None            # None = choose per layer; 0 / 1 pin the kernel variant (experiments, tests)
 TPERS16_MIN_VOXELS = 40960      # 16 -> 8 transposed layers take the persistent MFMA kernel from this many input voxels
 FUSE_CONV0 = True               # FPN conv0[0] -> conv0[1] in one launch (FpnPlan._conv0)
+NARROW_PAIR_WPC = 1             # ... workgroups per CU of that launch (0 = the kernel's default, 2): alone 46-48 against 45 us, but with two depth maps in flight 1 169 against 1 156 depth-maps/s -- half of the LDS stays free for the other forward's kernels
 NARROW_PAIR_MIN_PIXELS = 512 * 14 * 64   # ... from two 14 x 64 tiles per CU (below: the two layers' own launches)
 NARROW_MIN_VOXELS = 64 * 256    # untuned narrow layers take the MFMA kernel from this many output voxels (one 8 x 32 tile per CU)
 
@@ -847,7 +848,7 @@ class FpnPlan:
             out = torch.empty((N, 1, H, W, 8), device=x.device, dtype=torch.float32)
             rc = _lib.load().mvster_conv_narrow_pair(
                 x.data_ptr(), a.w_small.data_ptr(), a.scale.data_ptr(), a.shift.data_ptr(), b.w_small.data_ptr(),
-                b.scale.data_ptr(), b.shift.data_ptr(), out.data_ptr(), N, H, W, int(a.relu), int(b.relu), 0, ops._stream())
+                b.scale.data_ptr(), b.shift.data_ptr(), out.data_ptr(), N, H, W, int(a.relu), int(b.relu), NARROW_PAIR_WPC, ops._stream())
             _lib.check(rc, "conv_narrow_pair")
             return out
         return self._seq(self.conv0, x)

@@ -1336,6 +1336,12 @@ int num_cus() {
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
         n = prop.multiProcessorCount;
+        // (probe build: MVSTER_CUS = the CU count the persistent grids are sized for -- fewer workgroups per launch leave room
+        //  for the kernels of the other depth map in flight; the product library reads no environment)
+        if (const char* e = MV_PROBE_ENV("MVSTER_CUS")) {
+            const int v = atoi(e);
+            if (v > 0 && v <= n) n = v;
+        }
     }
     return n;
 }

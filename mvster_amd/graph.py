@@ -212,7 +212,7 @@ class ForwardCache:
         # (the attributes of the model that pick kernels or streams: flipping one between two calls is a different graph)
         from . import conv_plan, ops
         # (+ the module-level switches that pick kernels: flipped between two calls they are a different launch sequence)
-        glob = (conv_plan.FORCE_VARIANT, conv_plan.FUSE_TAIL, conv_plan.FUSE_CONV0, conv_plan.FUSE_SELECT, conv_plan.LDS_BUDGET, conv_plan.NARROW_MIN_VOXELS,
+        glob = (conv_plan.FORCE_VARIANT, conv_plan.FUSE_TAIL, conv_plan.FUSE_CONV0, conv_plan.NARROW_PAIR_WPC, conv_plan.FUSE_SELECT, conv_plan.LDS_BUDGET, conv_plan.NARROW_MIN_VOXELS,
                 id(conv_plan._TUNING), ops.WGRAD_MAX_SLOTS)
         cfg = (glob, model.warp_variant, getattr(model, "fuse_hypotheses", None), getattr(model, "merge_launches", None), model.overlap_streams, float(model.attn_temp), model.attn_fuse_d, model.num_stage,
                tuple(model.stage_splits), tuple(model.depth_interals_ratio), tuple(model.group_cor_dim))
