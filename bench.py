@@ -610,6 +610,10 @@ def train_measure(args, rank, local_rank, world, steps, warmup, min_total_s=0.5)
     else:
         if getattr(args, "wgrad_streams", None):
             GraphedTrainStep.wgrad_streams = args.wgrad_streams
+        if getattr(args, "wgrad_early", None) is not None:
+            GraphedTrainStep.wgrad_early = bool(args.wgrad_early)
+        if getattr(args, "wgrad_policy", None):
+            GraphedTrainStep.wgrad_policy = args.wgrad_policy
         if getattr(args, "wgrad_overlap", None) is not None:
             GraphedTrainStep.wgrad_overlap = bool(args.wgrad_overlap)
         graphed = GraphedTrainStep(model, opt, loss_fn, imgs, proj, dv, gt, mask, warmup=3, grad_sync=bucket)
@@ -735,6 +739,10 @@ def main():
                     help="eval mode, N = 1: skip the embedded training measurement (line['train']: ten captured steps of config 4)")
     ap.add_argument("--wgrad-streams", type=int, default=0,
                     help="train mode: streams the postponed weight-gradient kernels are spread over (0 = the default, 2)")
+    ap.add_argument("--wgrad-early", type=int, default=None,
+                    help="train mode: 1 = the weight gradients collected before the FPN's backward are launched there, 0 = all at the end")
+    ap.add_argument("--wgrad-policy", choices=("rr", "lpt"), default=None,
+                    help="train mode: how the postponed weight-gradient kernels are dealt to their streams")
     ap.add_argument("--wgrad-overlap", type=int, default=None,
                     help="train mode: 1 = weight-gradient kernels beside the backward chain on one side stream, 0 = after it (default: the class attribute)")
     ap.add_argument("--train-side-stages", default=None,

@@ -345,8 +345,12 @@ class GraphedTrainStep:
     # grids sized for an empty chip: beside each other (or beside the backward chain: wgrad_overlap) they lose more than the
     # overlap gives.  Measured on the config-4 step at the end of round 6: 1 stream 11.85 ms, 2 11.95, 3 12.90, 4 14.13; on one
     # side stream beside the backward chain instead of after it 12.69 (mid-round, before the kernels' rewrite: 13.25 / 13.12 /
-    # 13.61 for 1 / 2 / 4).
-    wgrad_streams = 1
+    # 13.61 for 1 / 2 / 4).  With the cascade stages' backward on a side stream (MVS4net.train_side_stages) the balance moved:
+    # 1 stream 10.87 ms, 2 10.60, 3 10.69, 4 10.82 (same box, alternating) -- two is the default.  Dealing the kernels by
+    # estimated duration (wgrad_policy = "lpt") instead of round-robin in autograd's order: the same 10.6.
+    wgrad_streams = 2
+    wgrad_policy = "rr"
+    wgrad_early = True              # the kernels collected before the FPN's backward begins are launched there (train_ops.wgrad_flush_point)
     wgrad_overlap = False           # True: the kernels run on one side stream beside the backward chain, not after it
 
     def __init__(self, model, optimizer, loss_fn, imgs, proj_matrices, depth_values, depth_gt_ms, mask_ms, warmup=3,
@@ -424,7 +428,7 @@ class GraphedTrainStep:
             # (nothing reads a weight gradient before the backward pass is over -- the bucketed all-reduce and the optimizer
             #  come after it -- so the 64 finishing launches of the weight-gradient kernels are issued as one)
             from .train_ops import deferred_wgrad_finish
-            with deferred_wgrad_finish(streams=self.wgrad_streams, overlap=self.wgrad_overlap):
+            with deferred_wgrad_finish(streams=self.wgrad_streams, overlap=self.wgrad_overlap, policy=self.wgrad_policy, early=self.wgrad_early):
                 loss.backward()
         finally:
             if batched:

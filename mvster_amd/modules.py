@@ -249,7 +249,9 @@ class FPN4(nn.Module):
             f = plain(self.inner2, c1, up=f)
             out["stage3"], f = plain(self.out3, f, tap=True)
             # finest level: re-associated, the full-resolution 64-channel map is never formed (train_ops.fpn_fine_level)
-            out["stage4"] = T.fpn_fine_level(c0, f, self.inner3, self.out4)
+            # (autograd reaches this output when every cascade stage's backward has been issued and before the FPN's begins:
+            #  the point where a deferred_wgrad_finish(early=True) launches the weight gradients collected so far)
+            out["stage4"] = T.wgrad_flush_point(T.fpn_fine_level(c0, f, self.inner3, self.out4))
         return out
 
 

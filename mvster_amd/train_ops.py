@@ -331,7 +331,7 @@ class _ConvCL(torch.autograd.Function):
                 # deferred_wgrad_finish: nothing reads this gradient before the backward pass is over, so the kernel itself
                 # waits for the end of the pass and runs there beside the other layers' (see the context manager)
                 dw = torch.empty(ops.conv_wgrad_shape(wargs[0], wargs[1], kernel, **wkw), device=gy.device, dtype=torch.float32)
-                _WGRAD_JOBS.append((wargs, wkw, dw))
+                _WGRAD_JOBS.append((wargs, wkw, dw, torch.cuda.current_stream(gy.device) if gy.is_cuda else None))
                 if _WGRAD_EAGER is not None:
                     _WGRAD_EAGER.launch(wargs, wkw, dw)
                 gw = dw.view(dw.shape)           # (an alias: AccumulateGrad adopts a tensor only if nobody else holds it)
@@ -602,6 +602,29 @@ def mono_depth_cl(z, d_min, d_max):
 _WGRAD_JOBS = None           # a list while deferred_wgrad_finish is active: (args, kwargs, dw) of the postponed kernels
 _WGRAD_EAGER = None          # the active deferred_wgrad_finish(overlap=True): kernels go to its side stream where autograd reaches them
 _WGRAD_STREAMS = {}
+_WGRAD_CTX = None            # the active deferred_wgrad_finish (for wgrad_flush_point)
+
+
+class _FlushPoint(torch.autograd.Function):
+    """Identity; its backward tells the active ``deferred_wgrad_finish(early=True)`` to launch what it has collected."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        if _WGRAD_CTX is not None and _WGRAD_CTX.early:
+            _WGRAD_CTX.flush_now()
+        return g
+
+
+def wgrad_flush_point(t):
+    """Mark a point of the backward pass at which ``deferred_wgrad_finish(early=True)`` launches the weight-gradient kernels
+    postponed so far: FPN4 puts it on its finest output, which autograd reaches when every cascade stage's backward has been
+    issued and before the FPN's begins -- the regularisation networks' weight gradients then run beside the FPN's backward
+    chain instead of after it (one fork in the captured step, not one per layer)."""
+    return _FlushPoint.apply(t) if t.requires_grad else t
 
 
 class deferred_wgrad_finish:
@@ -611,14 +634,17 @@ class deferred_wgrad_finish:
     from the current one and joined back; every stream finishes its layers' partial sums with ONE batched launch (64
     finishing launches of 5 us otherwise).  ``overlap=True`` launches each kernel on one side stream where autograd reaches
     its layer instead (beside the rest of the backward chain; the finishes stay batched at the end).  Measured on the
-    config-4 step: one stream after the chain is the fastest form -- the kernels are persistent grids sized
-    for an empty chip, and every cross-stream edge of the captured graph costs ~10 us.  The activations and output
+    config-4 step: after the chain on two streams is the fastest form (one until the cascade stages' backward
+    moved to a side stream) -- the kernels are persistent grids sized for an empty chip, and every cross-stream edge of the
+    captured graph costs ~10 us.  The activations and output
     gradients the kernels read are kept alive until the join.  Plain ``loss.backward()`` outside the context runs every
     layer on the spot."""
 
-    def __init__(self, streams=1, overlap=False):
+    def __init__(self, streams=1, overlap=False, policy="rr", early=False):
         self.nstreams = max(1, int(streams))
         self.overlap = bool(overlap)
+        self.early = bool(early) and not self.overlap    # launch in two batches: at wgrad_flush_point and on exit
+        self.policy = policy             # "rr": round-robin in autograd's order; "lpt": longest estimated job to the least loaded stream
         self._side = None
         self._pend = []
 
@@ -626,10 +652,63 @@ class deferred_wgrad_finish:
         global _WGRAD_JOBS, _WGRAD_EAGER
         if _WGRAD_JOBS is not None:
             raise RuntimeError("deferred_wgrad_finish does not nest")
+        global _WGRAD_CTX
         _WGRAD_JOBS = []
         _WGRAD_EAGER = self if self.overlap else None
+        _WGRAD_CTX = self
         self._side, self._pend = None, []
+        self._launched, self._sides, self._pends = 0, None, None
         return self
+
+    def _streams(self, dev):
+        if self._sides is None:
+            pool = _WGRAD_STREAMS.setdefault(dev, [])
+            while len(pool) < self.nstreams:
+                pool.append(torch.cuda.Stream(device=dev))
+            self._sides = pool[:self.nstreams]
+            self._pends = [[] for _ in self._sides]
+        return self._sides
+
+    def flush_now(self):
+        """Launch the jobs collected since the last call on the side streams (forked from the streams the jobs were queued
+        on); their finishes stay for the batched launch on exit."""
+        jobs = _WGRAD_JOBS[self._launched:] if _WGRAD_JOBS else []
+        if not jobs:
+            return
+        dev = jobs[0][2].device
+        side = self._streams(dev)
+        first = self._launched
+        self._launched += len(jobs)
+        sources = []
+        for j in jobs:
+            if j[3] is not None and all(j[3] != q for q in sources):
+                sources.append(j[3])
+        cur = torch.cuda.current_stream(dev)
+        if all(cur != q for q in sources):
+            sources.append(cur)
+        for s_ in side:
+            for q in sources:
+                s_.wait_stream(q)                                        # fork: every input of these jobs is ready
+        where = [(first + i) % len(side) for i in range(len(jobs))]
+        if self.policy == "lpt" and len(side) > 1:
+            def cost(job):
+                x_, gy_, kern = job[0][0], job[0][1], job[0][2]
+                flops = 2.0 * gy_.numel() * x_.shape[-1] * kern[0] * kern[1] * kern[2]
+                return max(flops / 40e12, 4.0 * (x_.numel() + gy_.numel()) / 3e12) + 4e-6
+            load = [0.0] * len(side)
+            for i, job in sorted(enumerate(jobs), key=lambda t: -cost(t[1])):
+                k = load.index(min(load))
+                where[i] = k
+                load[k] += cost(job)
+        prev = ops.WGRAD_PENDING
+        try:
+            for i, (wargs, wkw, dw, _) in enumerate(jobs):
+                k = where[i]
+                ops.WGRAD_PENDING = self._pends[k]
+                with torch.cuda.stream(side[k]):
+                    ops.conv_wgrad(*wargs, may_defer=True, dw=dw, **wkw)
+        finally:
+            ops.WGRAD_PENDING = prev
 
     def launch(self, wargs, wkw, dw):
         """overlap=True: the kernel goes to ONE side stream the moment autograd reaches the layer (its inputs are ready on the
@@ -651,10 +730,21 @@ class deferred_wgrad_finish:
             ops.WGRAD_PENDING = prev
 
     def __exit__(self, exc_type, exc, tb):
-        global _WGRAD_JOBS, _WGRAD_EAGER
-        jobs, _WGRAD_JOBS = _WGRAD_JOBS, None
+        global _WGRAD_JOBS, _WGRAD_EAGER, _WGRAD_CTX
+        jobs = _WGRAD_JOBS
         eager, _WGRAD_EAGER = _WGRAD_EAGER, None
+        _WGRAD_CTX = None
+        try:
+            return self._finish(exc_type, jobs, eager)
+        finally:
+            _WGRAD_JOBS = None
+
+    def _finish(self, exc_type, jobs, eager):
         if exc_type is not None or not jobs:
+            if self._sides:                                              # (an early batch is in flight: join it)
+                main = torch.cuda.current_stream(self._sides[0].device)
+                for s_ in self._sides:
+                    main.wait_stream(s_)
             return False
         dev = jobs[0][2].device
         main = torch.cuda.current_stream(dev)
@@ -668,25 +758,16 @@ class deferred_wgrad_finish:
                 main.wait_stream(self._side)                             # join (the kernels' inputs are released after it)
                 self._pend = []
             return False
-        pool = _WGRAD_STREAMS.setdefault(dev, [])
-        while len(pool) < self.nstreams:
-            pool.append(torch.cuda.Stream(device=dev))
-        side = pool[:self.nstreams]
-        pend = [[] for _ in side]
         try:
-            for s_ in side:
-                s_.wait_stream(main)                                     # fork: every input of the jobs is ready
-            for i, (wargs, wkw, dw) in enumerate(jobs):
-                k = i % len(side)
-                ops.WGRAD_PENDING = pend[k]
-                with torch.cuda.stream(side[k]):
-                    ops.conv_wgrad(*wargs, may_defer=True, dw=dw, **wkw)
+            self.flush_now()                                             # (everything, or what came after the flush point)
+            side = self._streams(dev)
             for k, s_ in enumerate(side):
-                ops.WGRAD_PENDING = pend[k]
+                ops.WGRAD_PENDING = self._pends[k]
                 with torch.cuda.stream(s_):
                     ops.conv_wgrad_flush()
         finally:
             ops.WGRAD_PENDING = None
-            for s_ in side:
+            for s_ in (self._sides or []):
                 main.wait_stream(s_)                                     # join (the inputs are released after it)
+            self._sides = self._pends = None
         return False

@@ -958,7 +958,8 @@ def test_conv_cl_tap_adds_the_second_consumers_gradient_in_the_kernel():
 def test_deferred_weight_gradients_equal_the_inline_ones():
     """deferred_wgrad_finish: leaf-parameter weight-gradient kernels run at the end of the backward pass on side streams (one
     batched finish per stream), or with overlap=True on one side stream where autograd reaches them.  Same kernels on the
-    same operands: every gradient equals the plain backward's bit for bit, for 1 / 2 / 3 streams and the overlap form."""
+    same operands: every gradient equals the plain backward's bit for bit, for 1 / 2 / 3 streams, the overlap form and the
+    two-batch form (early=True: what was collected when autograd reaches a wgrad_flush_point is launched there)."""
     g = torch.Generator().manual_seed(5)
     ws = [(0.2 * torch.randn(16, 8, 1, 3, 3, generator=g)).to(DEV), (0.2 * torch.randn(32, 16, 1, 5, 5, generator=g)).to(DEV),
           (0.2 * torch.randn(32, 32, 3, 3, 3, generator=g)).to(DEV), (0.2 * torch.randn(16, 32, 1, 1, 1, generator=g)).to(DEV)]
@@ -969,6 +970,7 @@ def test_deferred_weight_gradients_equal_the_inline_ones():
         x = x0.clone().requires_grad_(True)
         y = T.conv_cl(x, params[0], None, 1, (0, 1, 1))
         y = T.conv_cl(y, params[1], None, (1, 2, 2), (0, 2, 2))
+        y = T.wgrad_flush_point(y)                 # (early=True: the two layers above it in the backward pass launch here)
         y = T.conv_cl(y, params[2], None, 1, (1, 1, 1))
         y = T.conv_cl(y, params[3], None, 1, 0)
         loss = y.square().sum()
@@ -982,11 +984,12 @@ def test_deferred_weight_gradients_equal_the_inline_ones():
 
     want = run(None)
     for ctx in (T.deferred_wgrad_finish(streams=1), T.deferred_wgrad_finish(streams=2), T.deferred_wgrad_finish(streams=3),
-                T.deferred_wgrad_finish(overlap=True)):
+                T.deferred_wgrad_finish(overlap=True), T.deferred_wgrad_finish(streams=2, early=True),
+                T.deferred_wgrad_finish(streams=1, early=True), T.deferred_wgrad_finish(streams=3, early=True, policy="lpt")):
         got = run(ctx)
         for a, b in zip(want, got):
             assert torch.equal(a, b)
-    assert T._WGRAD_JOBS is None and T._WGRAD_EAGER is None and ops.WGRAD_PENDING is None
+    assert T._WGRAD_JOBS is None and T._WGRAD_EAGER is None and T._WGRAD_CTX is None and ops.WGRAD_PENDING is None
 
 
 @pytest.mark.parametrize("lw,l1ot", [([1, 1, 1, 1], [0, 1]), ([0.5, 1.0, 1.5, 2.0], [0.3, 0.7])])
