@@ -987,7 +987,10 @@ extern "C" int mvster_fpn_tail_gather(const float* G, const float* vb, float* P,
             hipLaunchKernelGGL(fpn_tail_gather_lds_kernel<8>, dim3(tiles_x * tiles_y * NB), block, 0, s, G, vb, P, NB, H, W,
                                mv_fastdiv(tiles_x), mv_fastdiv(tiles_y), mv::lerp_scale(H / 2, H), mv::lerp_scale(W / 2, W));
         else
-            hipLaunchKernelGGL(fpn_tail_gather_lds_kernel<16>, dim3(tiles_x * tiles_y * NB, 2), block, 0, s, G, vb, P, NB, H,
+            // (probe build: MVSTER_GATHER_PAD = bytes of unused dynamic LDS per workgroup -- fewer workgroups per CU, room for the
+            //  other depth map's kernels; measured neutral, profiles/r06_k_inflight_tune.txt)
+            hipLaunchKernelGGL(fpn_tail_gather_lds_kernel<16>, dim3(tiles_x * tiles_y * NB, 2), block,
+                               (size_t)(MV_PROBE_ENV("MVSTER_GATHER_PAD") ? atoi(MV_PROBE_ENV("MVSTER_GATHER_PAD")) : 0), s, G, vb, P, NB, H,
                                W, mv_fastdiv(tiles_x), mv_fastdiv(tiles_y), mv::lerp_scale(H / 2, H), mv::lerp_scale(W / 2, W));
         return mv_check_launch();
     }
@@ -1080,7 +1083,13 @@ extern "C" int mvster_fpn_tail_fused(const float* x, const float* A, const float
         return mv_check_launch();
     }
 #endif
-    constexpr size_t lds = (size_t)(11 * 19 * 19 + 8 * 11 * 10) * 16 + 9 * 8 * 4;        // 77 904 B
+    // 77 904 B of tile + 8 KB that nobody touches: ONE workgroup (eight waves) per CU instead of two.  Alone the kernel is no
+    // slower for it (VALU-bound: the second workgroup added contention, not throughput), and with two depth maps in flight the
+    // other forward's kernels find half of the LDS free: 1 179.9 against 1 174.9 depth-maps/s over six alternating runs on one
+    // box (profiles/r06_k_inflight_tune.txt).  (probe build: MVSTER_FUSED_PAD = the padding in bytes, 0 = two workgroups)
+    size_t pad = 8192;
+    if (const char* e = MV_PROBE_ENV("MVSTER_FUSED_PAD")) pad = (size_t)atoi(e);
+    const size_t lds = (size_t)(11 * 19 * 19 + 8 * 11 * 10) * 16 + 9 * 8 * 4 + pad;
     static unsigned long done = 0;
     if (!big_lds(reinterpret_cast<const void*>(fpn_tail_fused_kernel<16, 16>), lds, done)) return MVSTER_ERR_LAUNCH;
     MV_NOTE_KERNEL("fpn_tail_fused_kernel<16, 16>");
