@@ -1083,11 +1083,11 @@ extern "C" int mvster_fpn_tail_fused(const float* x, const float* A, const float
         return mv_check_launch();
     }
 #endif
-    // 77 904 B of tile + 8 KB that nobody touches: ONE workgroup (eight waves) per CU instead of two.  Alone the kernel is no
-    // slower for it (VALU-bound: the second workgroup added contention, not throughput), and with two depth maps in flight the
-    // other forward's kernels find half of the LDS free: 1 179.9 against 1 174.9 depth-maps/s over six alternating runs on one
-    // box (profiles/r06_k_inflight_tune.txt).  (probe build: MVSTER_FUSED_PAD = the padding in bytes, 0 = two workgroups)
-    size_t pad = 8192;
+    // 77 904 B: two workgroups (sixteen waves) per CU.  With 8 KB of padding (ONE workgroup per CU) the other depth map's kernels
+    // find half of the LDS free and the two-in-flight rate gains 0.4 % (1 179.9 against 1 174.9 depth-maps/s over six alternating
+    // runs) -- but the kernel itself takes 107 instead of 80 us: not adopted (profiles/r06_k_inflight_tune.txt).
+    // (probe build: MVSTER_FUSED_PAD = bytes of such padding)
+    size_t pad = 0;
     if (const char* e = MV_PROBE_ENV("MVSTER_FUSED_PAD")) pad = (size_t)atoi(e);
     const size_t lds = (size_t)(11 * 19 * 19 + 8 * 11 * 10) * 16 + 9 * 8 * 4 + pad;
     static unsigned long done = 0;
