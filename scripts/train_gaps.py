@@ -33,3 +33,37 @@ hist = defaultdict(int)
 for g, _ in gaps:
     hist[min(int(g / 1000), 20)] += 1
 print("gap histogram (us: count):", dict(sorted(hist.items())))
+
+# concurrency profile of the same replay: time with k kernels running, and which kernels run ALONE for how long (the captured
+# step runs on several streams since round 6: a kernel that runs alone is on the step's critical path, one that always has
+# company is hidden)
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0][:70]
+
+
+pts = []
+for i, (s, e, n) in enumerate(ev):
+    pts.append((s, 1, i))
+    pts.append((e, -1, i))
+pts.sort(key=lambda p: (p[0], p[1]))
+live, last = set(), pts[0][0]
+conc = defaultdict(int)
+alone = defaultdict(int)
+for t, d, i in pts:
+    if t > last:
+        conc[min(len(live), 4)] += t - last
+        if len(live) == 1:
+            alone[short(ev[next(iter(live))][2])] += t - last
+        last = t
+    if d > 0:
+        live.add(i)
+    else:
+        live.discard(i)
+print("kernels running at once (ms):", {k: round(v / 1e6, 2) for k, v in sorted(conc.items())})
+print("time running ALONE, by kernel:")
+tot = defaultdict(int)
+for s_, e_, n_ in ev:
+    tot[short(n_)] += e_ - s_
+for n, v in sorted(alone.items(), key=lambda kv: -kv[1])[:40]:
+    print("%8.1f us alone of %8.1f  %s" % (v / 1e3, tot[n] / 1e3, n))
